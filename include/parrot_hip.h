@@ -1,0 +1,228 @@
+/*
+ * parrot_hip.h -- C ABI of libparrot_hip.so, the MI355X (gfx950) implementation of the
+ * acoustic-frame generation hot path of sotelo/parrot (Char2Wav).
+ *
+ * The reference has no FFI boundary of its own: the hot path sits behind Python brick/operator
+ * calls that Theano compiles at run time.  Each entry point below names
+ * the reference call it replaces (file:line relative to the reference checkout).  The Python host
+ * layer (parrot_amd/) binds these symbols with ctypes; INTEGRATION.md shows the stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - matrices are row-major float32 with explicit leading dimensions, "x . W" convention of the
+ *     reference (W is [in, out]);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, the
+ *     library never synchronises and never allocates device memory;
+ *   - return value 0 = success; otherwise a hipError_t value, or PARROT_ERR_* for bad arguments.
+ *     Plans additionally keep the first error (parrot_plan_last_error).
+ */
+#ifndef PARROT_HIP_H
+#define PARROT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARROT_ERR_BADARG 10001
+#define PARROT_ERR_UNSUPPORTED 10002
+
+#define PARROT_MAX_LAYERS 3
+
+/* Library / build identification ("parrot_hip <ver> gfx950"). */
+const char* parrot_hip_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense projections (Blocks Linear / Fork applies, model.py:580-627, 739-755; lib.ops.Linear,
+ * sampleRNN/lib/ops.py:32-128).  C[M,N] (+)= alpha * opA(A) * opB(B) + bias, f32 MFMA.
+ *   transA = 0: A is [M,K] (lda), 1: A is stored [K,M] (lda)      (same for B / transB, [K,N])
+ *   batched with element strides; split_k > 1 combines partial products with f32 atomics
+ *   (then C must be pre-initialised and is always accumulated into).
+ * M <= 64 with transA = 0 dispatches to the weight-streaming recurrent-step kernel.
+ * ------------------------------------------------------------------------------------------ */
+int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
+                long long strideA, long long strideB, long long strideC, int split_k, void* stream);
+
+/* out[n] (+)= sum_m x[m, n]  -- bias gradients. */
+int parrot_colsum(const float* x, long long M, int N, int ld, float* out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One GatedRecurrent step (Blocks GatedRecurrent.apply(inputs, gate_inputs, states,
+ * iterate=False), model.py:659-662, 707-710, 719-722; same algebra ops.py:364-393):
+ *   g = sigmoid(h . Wg + gate_inputs); z = g[:, :H]; r = g[:, H:]
+ *   c = tanh((r*h) . Wc + inputs);     h' = z*c + (1-z)*h;  h' = m*h' + (1-m)*h if mask
+ * Wg = state_to_gates [H,2H], Wc = state_to_state [H,H].  z, r, rh, c ([B,H] each) are the saved
+ * activations the backward step needs.
+ * ------------------------------------------------------------------------------------------ */
+int parrot_gru_step_fwd(const float* h, const float* inputs, const float* gate_inputs, const float* mask,
+                        const float* Wg, const float* Wc, float* h_out, float* z, float* r, float* rh,
+                        float* c, int B, int H, void* stream);
+
+/* Backward of the step: given dh_out [B,H] produces d_inputs (=dC) [B,H], d_gate_inputs (=dG)
+ * [B,2H] and dh [B,H] (overwritten).  Weight gradients are left to the caller:
+ * dWg += h^T dG, dWc += rh^T dC (parrot_gemm with transA = 1). */
+int parrot_gru_step_bwd(const float* dh_out, const float* h, const float* mask, const float* Wg,
+                        const float* Wc, const float* z, const float* r, const float* c, float* dh,
+                        float* d_inputs, float* d_gate_inputs, int B, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plain GRU scans (Blocks GatedRecurrent.apply over a sequence -- the bidirectional encoder,
+ * model.py:226-231, 245; lib.ops.LowMemGRU / stackedGRU, ops.py:395-440, 612-777).
+ * Up to 4 independent chains (e.g. forward + backward direction) advance in the same launches.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ParrotGruSeqDesc {
+    int T, B, H, nchain, use_graph, reserved;
+    int reverse[4];              /* chain consumes its inputs from t = T-1 down to 0 */
+    const float* Wg[4];          /* [H,2H] */
+    const float* Wc[4];          /* [H,H]  */
+    const float* inputs[4];      /* [T,B,H]  pre-projected candidate inputs (biases included) */
+    const float* gate_inputs[4]; /* [T,B,2H] */
+    const float* mask;           /* [T,B] or NULL (shared by all chains) */
+    float* h[4];                 /* [T+1,B,H]; slot 0 = initial state (caller), slot s+1 = state after
+                                    the chain's s-th processed step */
+    float* z[4]; float* r[4]; float* rh[4]; float* c[4]; /* [T,B,H] saved activations (per step s) */
+    /* backward */
+    float* dh[4];                /* [T+1,B,H] in: dL/dh[slot] from consumers (slots 1..T), slot 0 zero;
+                                    out: total gradient per slot (slot 0 = grad of the initial state) */
+    float* dG[4];                /* [T,B,2H] out: gradient wrt gate_inputs (per step s) */
+    float* dC[4];                /* [T,B,H]  out: gradient wrt inputs      (per step s) */
+} ParrotGruSeqDesc;
+
+int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan);
+int parrot_gru_seq_fwd(void* plan, void* stream);
+int parrot_gru_seq_bwd(void* plan, void* stream);
+int parrot_gru_seq_destroy(void* plan);
+
+/* ------------------------------------------------------------------------------------------
+ * GMM-window attention step (model.py:664-690; sampling variant :931-958).
+ * att_type 0 = graves, 1 = softmax.  Watt = [h1_to_att alpha|beta|kappa] packed [H,3A].
+ * ------------------------------------------------------------------------------------------ */
+int parrot_gmm_attention_fwd(const float* h1, const float* Watt, const float* batt, const float* kappa_prev,
+                             const float* ctx, float* a, float* b, float* kappa, float* phi, float* w, int B,
+                             int H, int A, int U, int E, int att_type, float eps, float alignment,
+                             float sharpening, float timing, void* stream);
+
+/* dw [B,E] in; dkappa [B,A] in/out carry; dp [B,3A] out; dh1 [B,H] accumulated. */
+int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, const float* b,
+                             const float* kappa, const float* kappa_prev, const float* Watt, float* dkappa,
+                             float* dp, float* dh1, int B, int H, int A, int U, int E, int att_type, float eps,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-window decoder scan for training: the theano.scan over `step` of Parrot.compute_cost
+ * (model.py:651-737) and its reverse-mode gradient.  L in {1,2,3} GRU layers with the reference's
+ * dense skip topology (h_j -> h_l for j < l), attention after layer 1 (0-based layer 0).
+ *
+ * Packed per-layer weights, rows in this order (K_l = H + E + l*H, l 0-based):
+ *     [ h_l (recurrent) ; w (attention context) ; h_0 .. h_{l-1} ]
+ *   Wg[l] [K_l, 2H]: rnn{l+1}.state_to_gates ; inp_to_h{l+1}.gates ; h{j+1}_to_h{l+1}.gates
+ *   Wc[l] [K_l,  H]: rnn{l+1}.state_to_state ; inp_to_h{l+1}.inputs ; h{j+1}_to_h{l+1}.inputs
+ *   bg[l] [2H], bc[l] [H]: sums of the biases of the Forks feeding the layer.
+ * Layer 0 consumes w_{t-1}; layers >= 1 consume w_t (model.py:655, 692-693).
+ * History buffers have T+1 slots: slot 0 = state entering the window (learned initial state or the
+ * carried last_* state, model.py:633-643), slot t+1 = value after step t.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ParrotDecoderDesc {
+    int T, B, H, E, A, U, L, att_type, use_graph, reserved;
+    float eps, alignment, sharpening, timing;
+    const float* Wg[PARROT_MAX_LAYERS];
+    const float* Wc[PARROT_MAX_LAYERS];
+    const float* bg[PARROT_MAX_LAYERS];
+    const float* bc[PARROT_MAX_LAYERS];
+    const float* Watt;  /* [H,3A] */
+    const float* batt;  /* [3A]   */
+    const float* ctx;   /* [B,U,E] encoder output * labels_mask (model.py:645-646) */
+    const float* seq_c[PARROT_MAX_LAYERS]; /* [T,B,H]  per-step additive cell inputs or NULL (model.py:562-627) */
+    const float* seq_g[PARROT_MAX_LAYERS]; /* [T,B,2H] per-step additive gate inputs or NULL */
+    /* forward state / saved activations */
+    float* h[PARROT_MAX_LAYERS];   /* [T+1,B,H] */
+    float* w;                      /* [T+1,B,E] */
+    float* kappa;                  /* [T+1,B,A] */
+    float* z[PARROT_MAX_LAYERS]; float* r[PARROT_MAX_LAYERS];
+    float* rh[PARROT_MAX_LAYERS]; float* c[PARROT_MAX_LAYERS]; /* [T,B,H] */
+    float* a; float* b;            /* [T,B,A] */
+    float* phi;                    /* [T,B,U] */
+    /* backward */
+    float* dh[PARROT_MAX_LAYERS];  /* [T+1,B,H] in: gradient from the readouts per slot; out: total */
+    float* dw;                     /* [T+1,B,E] in: gradient from att_to_readout per slot; out: total */
+    float* dkappa;                 /* [B,A] in: gradient wrt final kappa (0); out: wrt initial kappa */
+    float* dG[PARROT_MAX_LAYERS];  /* [T,B,2H] out: gradient wrt gate pre-activations */
+    float* dC[PARROT_MAX_LAYERS];  /* [T,B,H]  out: gradient wrt candidate pre-activations */
+    float* dp;                     /* [T,B,3A] out: gradient wrt attention projection */
+} ParrotDecoderDesc;
+
+int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
+int parrot_decoder_seq_fwd(void* plan, void* stream);
+int parrot_decoder_seq_bwd(void* plan, void* stream);
+int parrot_decoder_destroy(void* plan);
+
+/* ------------------------------------------------------------------------------------------
+ * Autoregressive decode: the theano.scan over `sample_step` of Parrot.sample_model_fun
+ * (model.py:882-1057) for the MSE ("greedy") head: x_t = readout_to_output(readouts_t).
+ * Same packed weights as above plus, per layer, the fed-back-output rows (out_to_h*, present
+ * when weak/full feedback is on; Wfg[l] [O,2H], Wfc[l] [O,H], NULL otherwise), and the readout
+ * stack Wr = [h1_to_readout ; .. ; hL_to_readout ; att_to_readout] [L*H+E, R], br = summed bias,
+ * Wo [R,O], bo [O].  x is stored with leading dimension ldx >= O (padded rows are zero).
+ * Whole sequences are captured into one hipGraph when use_graph = 1.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ParrotSampleDesc {
+    int S, B, H, E, A, U, L, O, R, ldx, att_type, use_graph;
+    float eps, alignment, sharpening, timing;
+    const float* Wg[PARROT_MAX_LAYERS];
+    const float* Wc[PARROT_MAX_LAYERS];
+    const float* bg[PARROT_MAX_LAYERS];
+    const float* bc[PARROT_MAX_LAYERS];
+    const float* Wfg[PARROT_MAX_LAYERS];
+    const float* Wfc[PARROT_MAX_LAYERS];
+    const float* seq_c[PARROT_MAX_LAYERS]; /* [B,H]  constant additive inputs (speaker) or NULL */
+    const float* seq_g[PARROT_MAX_LAYERS]; /* [B,2H] */
+    const float* Watt; const float* batt;
+    const float* Wr; const float* br;      /* [L*H+E, R], [R] (+ speaker readout folded in by caller) */
+    const float* radd;                     /* [B,R] constant additive readout term or NULL */
+    const float* Wo; const float* bo;      /* [R,O], [O] */
+    const float* oadd;                     /* [B,O] constant additive output term or NULL */
+    const float* ctx;                      /* [B,U,E] */
+    float* x;      /* [S+1,B,ldx] slot 0 = initial_x (zeros, model.py:834-835) */
+    float* h[PARROT_MAX_LAYERS]; /* [2,B,H] ping-pong, slot 0 = initial state */
+    float* w;      /* [S+1,B,E]  */
+    float* kappa;  /* [S+1,B,A]  */
+    float* a;      /* [S,B,A] (pi_att) */
+    float* bwork;  /* [B,A] scratch */
+    float* phi;    /* [S,B,U] */
+    float* zwork; float* rwork; float* rhwork; float* readout; /* [B,H],[B,H],[B,H],[B,R] scratch */
+} ParrotSampleDesc;
+
+int parrot_sample_create(const ParrotSampleDesc* desc, void** plan);
+int parrot_sample_run(void* plan, void* stream);
+int parrot_sample_destroy(void* plan);
+
+int parrot_plan_last_error(void* plan);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser step next to the path (train.py:100-108): StepClipping(threshold) o Adam on the flat
+ * parameter buffer.  gnorm_sq is a device scalar filled by parrot_sumsq (after the gradient
+ * all-reduce in data-parallel runs); grad_scale rescales the raw gradient first (1/world_size).
+ * ------------------------------------------------------------------------------------------ */
+int parrot_sumsq(const float* x, size_t n, float* out, void* stream);
+int parrot_adam_clip_step(float* param, const float* grad, float* m, float* v, size_t n,
+                          const float* gnorm_sq, float grad_scale, float clip_threshold, float lr,
+                          float beta1, float beta2, float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Audio quantisers (quantize.py:14-99).  x is [rows, n] float32; every row is min-max normalised
+ * in float64 exactly as quantize.__batch_quantize does.  mode 0: mu-law -> int16 out,
+ * mode 1: linear(q_levels) -> int32 out.  ws = device scratch of 2*rows doubles.
+ * parrot_mu2linear: int32 class indices -> float32 amplitudes (quantize.py:68-78).
+ * ------------------------------------------------------------------------------------------ */
+int parrot_batch_quantize(const float* x, int rows, int n, int ld, double* ws, void* out, int ldo, int mode,
+                          int q_levels, void* stream);
+int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARROT_HIP_H */

@@ -1,0 +1,414 @@
+"""torch-CPU restatement of reference model.py (test infrastructure, see oracle/__init__.py).
+
+PARITY UNPINNED: no reference test / golden vector exists for this path and Theano/Blocks cannot
+run here.  Every function cites the reference lines it restates.  Row-vector convention
+``y = x . W + b`` with ``W [in, out]`` (Blocks Linear).  Default dtype float64 (the checker);
+``dtype=torch.float32`` is used when this code is timed as the CPU baseline.
+
+Parameters live in a flat dict keyed by Blocks-style brick paths (sample.py:83 shows the style:
+``/parrot/lookuptable.W``), see ``init_params``.  Generalisation beyond the reference: the number
+of decoder layers L may be 1, 2 or 3 (the reference hard-wires 3, model.py:312-314).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+SQRT_INV_2PI = 0.3989422917366028  # model.py:682
+
+
+# ----------------------------------------------------------------------------- config / params
+def default_config(**kw):
+    """Parrot.__init__ keyword defaults (model.py:251-277) plus `num_layers` and
+    `encoder_literal` (the reference scans the encoder GRU over the BATCH axis)."""
+    cfg = dict(
+        input_dim=420, output_dim=63, rnn_h_dim=1024, readouts_dim=1024,
+        weak_feedback=False, full_feedback=False, feedback_noise_level=None, layer_norm=False,
+        use_speaker=False, num_speakers=21, speaker_dim=128, which_cost='MSE', k_gmm=20,
+        sampling_bias=0., epsilon=1e-5, num_characters=43, attention_type='graves',
+        attention_size=10, attention_alignment=1., sharpening_coeff=1., timing_coeff=1.,
+        encoder_type=None, encoder_dim=128, raw_output=False,
+        num_layers=3, encoder_literal=True)
+    cfg.update(kw)
+    if cfg['full_feedback']:
+        cfg['weak_feedback'] = True  # model.py:485
+    cfg['encoded_input_dim'] = (2 * cfg['encoder_dim'] if cfg['encoder_type'] == 'bidirectional'
+                                else cfg['input_dim'])  # model.py:302-307
+    return cfg
+
+
+def param_shapes(cfg):
+    """name -> shape for every parameter of the configured model (Blocks brick paths)."""
+    H, R, O, E = cfg['rnn_h_dim'], cfg['readouts_dim'], cfg['output_dim'], cfg['encoded_input_dim']
+    A, L = cfg['attention_size'], cfg['num_layers']
+    s = {}
+
+    def fork(name, din, outs):
+        for oname, od in outs:
+            s[f'/parrot/{name}/fork_{oname}.W'] = (din, od)
+            s[f'/parrot/{name}/fork_{oname}.b'] = (od,)
+
+    def linear(name, din, dout):
+        s[f'/parrot/{name}.W'] = (din, dout)
+        s[f'/parrot/{name}.b'] = (dout,)
+
+    if cfg['encoder_type'] == 'bidirectional':
+        D, ED = cfg['input_dim'], cfg['encoder_dim']
+        s['/parrot/encoder/embed_label.W'] = (cfg['num_characters'], D)
+        for d in ('forward', 'backward'):
+            p = f'/parrot/encoder/encoder/{d}'
+            s[f'{p}/fork/fork_inputs.W'] = (D, ED)
+            s[f'{p}/fork/fork_inputs.b'] = (ED,)
+            s[f'{p}/fork/fork_gate_inputs.W'] = (D, 2 * ED)
+            s[f'{p}/fork/fork_gate_inputs.b'] = (2 * ED,)
+            s[f'{p}/gatedrecurrent.state_to_state'] = (ED, ED)
+            s[f'{p}/gatedrecurrent.state_to_gates'] = (ED, 2 * ED)
+            s[f'{p}/gatedrecurrent.initial_state'] = (ED,)
+    for l in range(1, L + 1):
+        s[f'/parrot/rnn{l}.state_to_state'] = (H, H)
+        s[f'/parrot/rnn{l}.state_to_gates'] = (H, 2 * H)
+        s[f'/parrot/rnn{l}.initial_state'] = (H,)
+        linear(f'h{l}_to_readout', H, R)
+        fork(f'inp_to_h{l}', E, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+        for j in range(1, l):
+            fork(f'h{j}_to_h{l}', H, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+    fork('h1_to_att', H, [('alpha', A), ('beta', A), ('kappa', A)])
+    linear('att_to_readout', E, R)
+    if cfg['which_cost'] == 'MSE':
+        linear('readout_to_output', R, O)
+    else:
+        K = cfg['k_gmm']
+        fork('readout_to_output', R, [('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K)])
+    if cfg['use_speaker']:
+        SD = cfg['speaker_dim']
+        s['/parrot/lookuptable.W'] = (cfg['num_speakers'], SD)
+        for l in range(1, L + 1):
+            fork(f'speaker_to_h{l}', SD, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+        linear('speaker_to_readout', SD, R)
+        if cfg['which_cost'] == 'MSE':
+            linear('speaker_to_output', SD, O)
+        else:
+            K = cfg['k_gmm']
+            fork('speaker_to_output', SD, [('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K)])
+    if cfg['weak_feedback']:
+        fork('out_to_h1', O, [('rnn1_inputs', H), ('rnn1_gates', 2 * H)])
+    if cfg['full_feedback']:
+        for l in range(2, L + 1):
+            fork(f'out_to_h{l}', O, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+    s['/parrot.initial_w'] = (E,)
+    return s
+
+
+def init_params(cfg, seed=1234, std=0.01, dtype=torch.float64, scale_by_fan_in=False):
+    """train.py:30-31: weights ~ N(0, 0.01^2), biases 0, initial states 0 (model.py:502-506).
+    scale_by_fan_in=True draws N(0, 1/fan_in) instead so gates/attention leave the linear regime
+    (SURVEY 8d second parameter set)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for name, shape in param_shapes(cfg).items():
+        is_w = (name.endswith('.W') or name.endswith('state_to_state') or name.endswith('state_to_gates'))
+        if is_w:
+            sd = (1.0 / math.sqrt(shape[0])) if scale_by_fan_in else std
+            p[name] = (torch.randn(shape, generator=g, dtype=torch.float64) * sd).to(dtype)
+        else:
+            if scale_by_fan_in:
+                p[name] = (torch.randn(shape, generator=g, dtype=torch.float64) * 0.1).to(dtype)
+            else:
+                p[name] = torch.zeros(shape, dtype=dtype)
+    return p
+
+
+# ----------------------------------------------------------------------------- bricks
+def simple_norm(x, eps=1e-5):
+    """model.py:24-27: (x - mean) / (eps + std), population std, no affine."""
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, unbiased=False, keepdim=True)
+    return (x - mean) / (eps + std)
+
+
+def apply_norm(x, layer_norm):
+    """model.py:30-34."""
+    return simple_norm(x) if layer_norm else x
+
+
+def linear(p, name, x):
+    """Blocks Linear.apply: x . W + b."""
+    return x @ p[f'/parrot/{name}.W'] + p[f'/parrot/{name}.b']
+
+
+def fork(p, name, x, outs):
+    """Blocks Fork.apply: one independent Linear per output name, in output_names order."""
+    return [x @ p[f'/parrot/{name}/fork_{o}.W'] + p[f'/parrot/{name}/fork_{o}.b'] for o in outs]
+
+
+def gru_step(inputs, gate_inputs, h, W_ss, W_sg, mask=None):
+    """Blocks GatedRecurrent.apply(iterate=False) (call sites model.py:659-662); twin algebra
+    sampleRNN/lib/ops.py:364-393.  z = update (first half), r = reset (second half)."""
+    H = h.shape[-1]
+    g = torch.sigmoid(h @ W_sg + gate_inputs)
+    z, r = g[..., :H], g[..., H:]
+    c = torch.tanh((h * r) @ W_ss + inputs)
+    hn = c * z + h * (1 - z)
+    if mask is not None:
+        hn = mask[..., None] * hn + (1 - mask[..., None]) * h
+    return hn
+
+
+def gru_scan(inputs, gate_inputs, h0, W_ss, W_sg, mask=None):
+    """GatedRecurrent.apply over axis 0 (Blocks recurrent bricks iterate axis 0)."""
+    hs = []
+    h = h0
+    for t in range(inputs.shape[0]):
+        h = gru_step(inputs[t], gate_inputs[t], h, W_ss, W_sg, None if mask is None else mask[t])
+        hs.append(h)
+    return torch.stack(hs, 0)
+
+
+def encoder_apply(p, cfg, labels):
+    """Encoder.apply (model.py:233-247): LookupTable -> Bidirectional(RecurrentWithFork(GRU)).
+    Literal mode reproduces the reference quirk: the input is batch-major [B,U,D] and Blocks
+    recurrents iterate axis 0, so the scan runs over the batch axis with U as the batch
+    (model.py:645 passes no mask)."""
+    if cfg['encoder_type'] is None:
+        return labels  # model.py:235-236
+    emb = p['/parrot/encoder/embed_label.W'][labels]  # [B,U,D]
+    seq = emb if cfg['encoder_literal'] else emb.transpose(0, 1)
+    outs = []
+    for d in ('forward', 'backward'):
+        pre = f'/parrot/encoder/encoder/{d}'
+        x = seq if d == 'forward' else seq.flip(0)
+        inp = x @ p[f'{pre}/fork/fork_inputs.W'] + p[f'{pre}/fork/fork_inputs.b']
+        gat = x @ p[f'{pre}/fork/fork_gate_inputs.W'] + p[f'{pre}/fork/fork_gate_inputs.b']
+        h0 = p[f'{pre}/gatedrecurrent.initial_state'].expand(x.shape[1], -1)
+        hs = gru_scan(inp, gat, h0, p[f'{pre}/gatedrecurrent.state_to_state'],
+                      p[f'{pre}/gatedrecurrent.state_to_gates'])
+        outs.append(hs if d == 'forward' else hs.flip(0))
+    out = torch.cat(outs, -1)
+    return out if cfg['encoder_literal'] else out.transpose(0, 1)
+
+
+def attention_step(cfg, a_hat, b_hat, k_hat, k_tm1, ctx, sampling=False):
+    """model.py:664-690 (training) / :931-958 (sampling: sharpening, timing)."""
+    eps = cfg['epsilon']
+    if cfg['attention_type'] == 'softmax':
+        a = torch.softmax(a_hat, -1) + eps
+    else:
+        a = torch.exp(a_hat) + eps
+    sharp = cfg['sharpening_coeff'] if sampling else 1.
+    timing = cfg['timing_coeff'] if sampling else 1.
+    b = torch.exp(b_hat) * sharp + eps
+    k = k_tm1 + cfg['attention_alignment'] * torch.exp(k_hat) / timing
+    U = ctx.shape[1]
+    u = torch.arange(U, dtype=ctx.dtype)[None, None, :]
+    a_, b_, k_ = a[..., None], b[..., None], k[..., None]
+    if cfg['attention_type'] == 'softmax':
+        phi = SQRT_INV_2PI * (a_ * torch.sqrt(b_) * torch.exp(-0.5 * b_ * (k_ - u) ** 2)).sum(1)
+    else:
+        phi = (a_ * torch.exp(-b_ * (k_ - u) ** 2)).sum(1)
+    w = (phi[..., None] * ctx).sum(1)
+    return a, k, phi, w
+
+
+def decoder_step(p, cfg, seq_in, h_tm1, k_tm1, w_tm1, ctx, sampling=False):
+    """One `step` of the training scan (model.py:651-724) for L layers.
+    seq_in: list of (cell_l, gate_l) additive inputs for this timestep."""
+    L, ln = cfg['num_layers'], cfg['layer_norm']
+    hs = []
+    # layer 1: context of the previous step
+    ci, gi = fork(p, 'inp_to_h1', w_tm1, ['rnn1_inputs', 'rnn1_gates'])
+    h1 = gru_step(seq_in[0][0] + ci, seq_in[0][1] + gi, h_tm1[0],
+                  p['/parrot/rnn1.state_to_state'], p['/parrot/rnn1.state_to_gates'])
+    hs.append(h1)
+    a_hat, b_hat, k_hat = fork(p, 'h1_to_att', h1, ['alpha', 'beta', 'kappa'])
+    a, k, phi, w = attention_step(cfg, a_hat, b_hat, k_hat, k_tm1, ctx, sampling)
+    for l in range(2, L + 1):
+        ci, gi = fork(p, f'inp_to_h{l}', w, [f'rnn{l}_inputs', f'rnn{l}_gates'])
+        c_in = seq_in[l - 1][0] + ci
+        g_in = seq_in[l - 1][1] + gi
+        for j in range(1, l):
+            cj, gj = fork(p, f'h{j}_to_h{l}', hs[j - 1], [f'rnn{l}_inputs', f'rnn{l}_gates'])
+            c_in = c_in + apply_norm(cj, ln)
+            g_in = g_in + apply_norm(gj, ln)
+        hl = gru_step(c_in, g_in, h_tm1[l - 1],
+                      p[f'/parrot/rnn{l}.state_to_state'], p[f'/parrot/rnn{l}.state_to_gates'])
+        hs.append(hl)
+    return hs, k, w, phi, a
+
+
+def logsumexp(x, axis):
+    """model.py:37-41."""
+    x_max = x.max(axis, keepdim=True)[0]
+    z = torch.log(torch.exp(x - x_max).sum(axis, keepdim=True)) + x_max
+    return z.sum(axis)
+
+
+def cost_gmm(y, mu, sig, weight):
+    """model.py:65-91."""
+    shape_y = y.shape
+    k = weight.shape[-1]
+    y2 = y.reshape(-1, shape_y[-1])[..., None]
+    mu = mu.reshape(-1, shape_y[-1], k)
+    sig = sig.reshape(-1, shape_y[-1], k)
+    weight = weight.reshape(-1, k)
+    diff = (y2 - mu) ** 2
+    inner = -0.5 * (diff / sig ** 2 + 2 * torch.log(sig) + math.log(2 * math.pi)).sum(-2)
+    nll = -logsumexp(torch.log(weight) + inner, -1)
+    return nll.reshape(shape_y[:-1])
+
+
+def initial_carry(p, cfg, batch):
+    """Parrot.initial_states (model.py:529-549): learned initial h, learned initial_w, zero k."""
+    dt = p['/parrot.initial_w'].dtype
+    hs = [p[f'/parrot/rnn{l}.initial_state'].expand(batch, -1) for l in range(1, cfg['num_layers'] + 1)]
+    w = p['/parrot.initial_w'].expand(batch, -1)
+    k = torch.zeros(batch, cfg['attention_size'], dtype=dt)
+    return dict(h=hs, w=w, k=k)
+
+
+def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=None, start_flag=1,
+                 carry=None, feedback_noise=None):
+    """Parrot.compute_cost (model.py:551-824), MSE or GMM-NLL head, without the raw_output branch.
+
+    features [T+1,B,O], features_mask [T+1,B] (time-major), labels [B,U] int64, labels_mask [B,U],
+    speaker [B,1] int64 or None.  carry = state left by the previous TBPTT window (used when
+    start_flag == 0, model.py:633-643).  Returns (cost, new_carry, attention_vars, extras)."""
+    L, H, ln = cfg['num_layers'], cfg['rnn_h_dim'], cfg['layer_norm']
+    dt = p['/parrot.initial_w'].dtype
+    target = features[1:]
+    mask = features_mask[1:]
+    T, B = mask.shape
+    seq = [[torch.zeros(T, B, H, dtype=dt), torch.zeros(T, B, 2 * H, dtype=dt)] for _ in range(L)]
+
+    if cfg['weak_feedback']:  # model.py:571-588
+        inp = features[:-1]
+        if feedback_noise is not None:
+            inp = inp + feedback_noise
+        oc, og = fork(p, 'out_to_h1', inp, ['rnn1_inputs', 'rnn1_gates'])
+        seq[0][0] = seq[0][0] + apply_norm(oc, ln)
+        seq[0][1] = seq[0][1] + apply_norm(og, ln)
+    if cfg['full_feedback']:  # model.py:590-603
+        for l in range(2, L + 1):
+            oc, og = fork(p, f'out_to_h{l}', inp, [f'rnn{l}_inputs', f'rnn{l}_gates'])
+            seq[l - 1][0] = seq[l - 1][0] + apply_norm(oc, ln)
+            seq[l - 1][1] = seq[l - 1][1] + apply_norm(og, ln)
+    emb_speaker = None
+    if cfg['use_speaker']:  # model.py:605-627
+        emb_speaker = p['/parrot/lookuptable.W'][speaker[:, 0]][None]
+        for l in range(1, L + 1):
+            sc, sg = fork(p, f'speaker_to_h{l}', emb_speaker, [f'rnn{l}_inputs', f'rnn{l}_gates'])
+            seq[l - 1][0] = apply_norm(sc, ln) + seq[l - 1][0]
+            seq[l - 1][1] = apply_norm(sg, ln) + seq[l - 1][1]
+
+    init = initial_carry(p, cfg, B)
+    if start_flag or carry is None:  # model.py:633-643
+        h, w, k = init['h'], init['w'], init['k']
+    else:
+        h, w, k = carry['h'], carry['w'], carry['k']
+
+    ctx = encoder_apply(p, cfg, labels) * labels_mask[..., None]  # model.py:645-646
+
+    hs_all = [[] for _ in range(L)]
+    ks, ws, phis, pis = [], [], [], []
+    for t in range(T):  # theano.scan, model.py:726-737
+        h, k, w, phi, a = decoder_step(p, cfg, [(s[0][t], s[1][t]) for s in seq], h, k, w, ctx)
+        for l in range(L):
+            hs_all[l].append(h[l])
+        ks.append(k); ws.append(w); phis.append(phi); pis.append(a)
+    hs_all = [torch.stack(x, 0) for x in hs_all]
+    k_all, w_all, phi_all, pi_all = (torch.stack(x, 0) for x in (ks, ws, phis, pis))
+
+    readouts = 0  # model.py:739-753
+    for l in range(1, L + 1):
+        readouts = readouts + apply_norm(linear(p, f'h{l}_to_readout', hs_all[l - 1]), ln)
+    if cfg['use_speaker']:
+        readouts = readouts + linear(p, 'speaker_to_readout', emb_speaker)
+    readouts = readouts + linear(p, 'att_to_readout', w_all)
+
+    extras = {}
+    if cfg['which_cost'] == 'MSE':  # model.py:757-764
+        predicted = linear(p, 'readout_to_output', readouts)
+        if cfg['use_speaker']:
+            predicted = predicted + linear(p, 'speaker_to_output', emb_speaker)
+        cost = ((predicted - target) ** 2).sum(-1)
+        next_x, coeff = predicted, predicted
+    else:  # model.py:765-782 (NLL only; the sampled next_x is stochastic in the reference)
+        mu, sigma, coeff = fork(p, 'readout_to_output', readouts, ['gmm_mu', 'gmm_sigma', 'gmm_coeff'])
+        if cfg['use_speaker']:
+            smu, ssig, sco = fork(p, 'speaker_to_output', emb_speaker, ['gmm_mu', 'gmm_sigma', 'gmm_coeff'])
+            mu, sigma, coeff = mu + smu, sigma + ssig, coeff + sco
+        sigma = torch.exp(sigma) + cfg['epsilon']
+        coeff = torch.softmax(coeff, -1) + cfg['epsilon']
+        cost = cost_gmm(target, mu, sigma, coeff)
+        next_x = mu
+        extras.update(mu=mu, sigma=sigma)
+    cost = (cost * mask).sum() / (mask.sum() + 1e-5)  # model.py:784
+
+    new_carry = dict(h=[x[-1] for x in hs_all], k=k_all[-1], w=w_all[-1])  # model.py:786-791
+    attention_vars = [next_x, k_all, w_all, coeff, phi_all, pi_all]
+    extras.update(h=hs_all, ctx=ctx, readouts=readouts)
+    return cost, new_carry, attention_vars, extras
+
+
+def sample_model(p, cfg, labels, labels_mask, speaker, num_steps):
+    """Parrot.sample_model / sample_model_fun (model.py:826-1083) for the MSE head:
+    x_t = readout_to_output(readouts_t) is fed back deterministically (model.py:1010-1016).
+    Returns [sample_x [S,N,O], k, w, pi(=x for MSE), phi, pi_att] like the reference."""
+    assert cfg['which_cost'] == 'MSE', 'stochastic GMM sampling has no deterministic oracle'
+    L, H, ln = cfg['num_layers'], cfg['rnn_h_dim'], cfg['layer_norm']
+    N = labels.shape[0]
+    dt = p['/parrot.initial_w'].dtype
+    const = [[torch.zeros(N, H, dtype=dt), torch.zeros(N, 2 * H, dtype=dt)] for _ in range(L)]
+    spk_readout = spk_output = None
+    if cfg['use_speaker']:  # model.py:846-874
+        emb = p['/parrot/lookuptable.W'][speaker[:, 0]]
+        spk_readout = linear(p, 'speaker_to_readout', emb)
+        spk_output = linear(p, 'speaker_to_output', emb)
+        for l in range(1, L + 1):
+            sc, sg = fork(p, f'speaker_to_h{l}', emb[None], [f'rnn{l}_inputs', f'rnn{l}_gates'])
+            const[l - 1][0] = const[l - 1][0] + apply_norm(sc, ln)[0]
+            const[l - 1][1] = const[l - 1][1] + apply_norm(sg, ln)[0]
+    ctx = encoder_apply(p, cfg, labels) * labels_mask[..., None]  # model.py:876-877
+    init = initial_carry(p, cfg, N)  # always the learned initial states (model.py:1049-1054)
+    h, w, k = init['h'], init['w'], init['k']
+    x = torch.zeros(N, cfg['output_dim'], dtype=dt)  # model.py:834-835
+    xs, ks, ws, phis, pis = [], [], [], [], []
+    for _ in range(num_steps):
+        seq_in = [[c[0].clone(), c[1].clone()] for c in const]
+        if cfg['weak_feedback']:  # model.py:899-908
+            oc, og = fork(p, 'out_to_h1', x, ['rnn1_inputs', 'rnn1_gates'])
+            seq_in[0][0] = seq_in[0][0] + apply_norm(oc, ln)
+            seq_in[0][1] = seq_in[0][1] + apply_norm(og, ln)
+        if cfg['full_feedback']:  # model.py:910-924
+            for l in range(2, L + 1):
+                oc, og = fork(p, f'out_to_h{l}', x, [f'rnn{l}_inputs', f'rnn{l}_gates'])
+                seq_in[l - 1][0] = seq_in[l - 1][0] + apply_norm(oc, ln)
+                seq_in[l - 1][1] = seq_in[l - 1][1] + apply_norm(og, ln)
+        h, k, w, phi, a = decoder_step(p, cfg, seq_in, h, k, w, ctx, sampling=True)
+        readout = 0  # model.py:992-1006
+        for l in range(1, L + 1):
+            readout = readout + apply_norm(linear(p, f'h{l}_to_readout', h[l - 1]), ln)
+        readout = readout + linear(p, 'att_to_readout', w)
+        if cfg['use_speaker']:
+            readout = readout + spk_readout
+        x = linear(p, 'readout_to_output', readout)  # model.py:1008-1013
+        if cfg['use_speaker']:
+            x = x + spk_output
+        xs.append(x); ks.append(k); ws.append(w); phis.append(phi); pis.append(a)
+    sx, kk, ww, ph, pa = (torch.stack(v, 0) for v in (xs, ks, ws, phis, pis))
+    return [sx, kk, ww, sx, ph, pa]
+
+
+# ----------------------------------------------------------------------------- optimiser
+def clip_adam_step(params, grads, m, v, step, lr=1e-4, clip=9.0, b1=0.9, b2=0.999, eps=1e-8):
+    """train.py:100-108: StepClipping(10*grad_clip) then Adam (Blocks defaults).
+    All arguments are dicts name -> tensor; updates in place."""
+    tot = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    scale = clip / tot if tot > clip else 1.0
+    lr_t = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    for n in params:
+        g = grads[n] * scale
+        m[n].mul_(b1).add_(g, alpha=1 - b1)
+        v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
+        params[n].sub_(lr_t * m[n] / (v[n].sqrt() + eps))
+    return tot

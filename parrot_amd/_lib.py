@@ -1,0 +1,139 @@
+"""ctypes binding of libparrot_hip.so (see include/parrot_hip.h).
+
+The HIP library is the product path.  There is deliberately no CPU fallback here: if the shared
+object is missing or a call fails, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparrot_hip.so")
+
+MAX_LAYERS = 3
+
+c_float_p = C.c_void_p  # device pointers are passed as integers
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+class GruSeqDesc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("nchain", C.c_int),
+        ("use_graph", C.c_int), ("reserved", C.c_int),
+        ("reverse", C.c_int * 4),
+        ("Wg", C.c_void_p * 4), ("Wc", C.c_void_p * 4),
+        ("inputs", C.c_void_p * 4), ("gate_inputs", C.c_void_p * 4),
+        ("mask", C.c_void_p),
+        ("h", C.c_void_p * 4),
+        ("z", C.c_void_p * 4), ("r", C.c_void_p * 4), ("rh", C.c_void_p * 4), ("c", C.c_void_p * 4),
+        ("dh", C.c_void_p * 4), ("dG", C.c_void_p * 4), ("dC", C.c_void_p * 4),
+    ]
+
+
+class DecoderDesc(C.Structure):
+    _fields_ = [
+        ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("E", C.c_int), ("A", C.c_int),
+        ("U", C.c_int), ("L", C.c_int), ("att_type", C.c_int), ("use_graph", C.c_int),
+        ("reserved", C.c_int),
+        ("eps", C.c_float), ("alignment", C.c_float), ("sharpening", C.c_float), ("timing", C.c_float),
+        ("Wg", C.c_void_p * MAX_LAYERS), ("Wc", C.c_void_p * MAX_LAYERS),
+        ("bg", C.c_void_p * MAX_LAYERS), ("bc", C.c_void_p * MAX_LAYERS),
+        ("Watt", C.c_void_p), ("batt", C.c_void_p), ("ctx", C.c_void_p),
+        ("seq_c", C.c_void_p * MAX_LAYERS), ("seq_g", C.c_void_p * MAX_LAYERS),
+        ("h", C.c_void_p * MAX_LAYERS), ("w", C.c_void_p), ("kappa", C.c_void_p),
+        ("z", C.c_void_p * MAX_LAYERS), ("r", C.c_void_p * MAX_LAYERS),
+        ("rh", C.c_void_p * MAX_LAYERS), ("c", C.c_void_p * MAX_LAYERS),
+        ("a", C.c_void_p), ("b", C.c_void_p), ("phi", C.c_void_p),
+        ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dkappa", C.c_void_p),
+        ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
+    ]
+
+
+class SampleDesc(C.Structure):
+    _fields_ = [
+        ("S", C.c_int), ("B", C.c_int), ("H", C.c_int), ("E", C.c_int), ("A", C.c_int),
+        ("U", C.c_int), ("L", C.c_int), ("O", C.c_int), ("R", C.c_int), ("ldx", C.c_int),
+        ("att_type", C.c_int), ("use_graph", C.c_int),
+        ("eps", C.c_float), ("alignment", C.c_float), ("sharpening", C.c_float), ("timing", C.c_float),
+        ("Wg", C.c_void_p * MAX_LAYERS), ("Wc", C.c_void_p * MAX_LAYERS),
+        ("bg", C.c_void_p * MAX_LAYERS), ("bc", C.c_void_p * MAX_LAYERS),
+        ("Wfg", C.c_void_p * MAX_LAYERS), ("Wfc", C.c_void_p * MAX_LAYERS),
+        ("seq_c", C.c_void_p * MAX_LAYERS), ("seq_g", C.c_void_p * MAX_LAYERS),
+        ("Watt", C.c_void_p), ("batt", C.c_void_p),
+        ("Wr", C.c_void_p), ("br", C.c_void_p), ("radd", C.c_void_p),
+        ("Wo", C.c_void_p), ("bo", C.c_void_p), ("oadd", C.c_void_p),
+        ("ctx", C.c_void_p),
+        ("x", C.c_void_p), ("h", C.c_void_p * MAX_LAYERS), ("w", C.c_void_p), ("kappa", C.c_void_p),
+        ("a", C.c_void_p), ("bwork", C.c_void_p), ("phi", C.c_void_p),
+        ("zwork", C.c_void_p), ("rwork", C.c_void_p), ("rhwork", C.c_void_p), ("readout", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/parrot_hip.h declares must be listed here
+# (tests/test_capi_symbols.py cross-checks this table against the header).
+_vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+SIGNATURES = {
+    "parrot_hip_version": (C.c_char_p, []),
+    "parrot_gemm": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
+    "parrot_colsum": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp]),
+    "parrot_gru_step_fwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
+    "parrot_gru_step_bwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
+    "parrot_gru_seq_create": (_i, [C.POINTER(GruSeqDesc), C.POINTER(C.c_void_p)]),
+    "parrot_gru_seq_fwd": (_i, [_vp, _vp]),
+    "parrot_gru_seq_bwd": (_i, [_vp, _vp]),
+    "parrot_gru_seq_destroy": (_i, [_vp]),
+    "parrot_gmm_attention_fwd": (_i, [_vp] * 10 + [_i] * 6 + [_f] * 4 + [_vp]),
+    "parrot_gmm_attention_bwd": (_i, [_vp] * 10 + [_i] * 6 + [_f, _vp]),
+    "parrot_decoder_create": (_i, [C.POINTER(DecoderDesc), C.POINTER(C.c_void_p)]),
+    "parrot_decoder_seq_fwd": (_i, [_vp, _vp]),
+    "parrot_decoder_seq_bwd": (_i, [_vp, _vp]),
+    "parrot_decoder_destroy": (_i, [_vp]),
+    "parrot_sample_create": (_i, [C.POINTER(SampleDesc), C.POINTER(C.c_void_p)]),
+    "parrot_sample_run": (_i, [_vp, _vp]),
+    "parrot_sample_destroy": (_i, [_vp]),
+    "parrot_plan_last_error": (_i, [_vp]),
+    "parrot_sumsq": (_i, [_vp, _sz, _vp, _vp]),
+    "parrot_adam_clip_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
+    "parrot_batch_quantize": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "parrot_mu2linear": (_i, [_vp, _sz, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m parrot_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str, plan=None):
+    if rc != 0:
+        raise HipCallError(f"{what} failed with code {rc}")
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    check(rc, name)
+    return rc

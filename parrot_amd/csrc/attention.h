@@ -1,0 +1,32 @@
+// Internal interface of the GMM-window attention step kernels (reference model.py:664-690, 931-958).
+#pragma once
+#include "common.h"
+
+struct AttFwdArgs {
+    const float* h1;  int ldh;     // [B,H] layer-1 state of this step
+    const float* Watt;             // [H,3A] (alpha | beta | kappa columns)
+    const float* batt;             // [3A] or null
+    const float* kappa_prev;       // [B,A]
+    const float* ctx;              // [B,U,E] encoder output * labels_mask
+    float* a_out; float* b_out; float* kappa_out;  // [B,A]
+    float* phi_out;                // [B,U]
+    float* w_out; int ldw;         // [B,E]
+    int B, H, A, U, E, esplit, att_type;
+    float eps, alignment, sharpening, timing;
+};
+
+struct AttBwdArgs {
+    const float* dw; int lddw;     // [B,E] total gradient wrt w_t
+    const float* ctx;              // [B,U,E]
+    const float* a; const float* b; const float* kappa; const float* kappa_prev;  // [B,A]
+    const float* Watt;             // [H,3A]
+    float* dkappa;                 // [B,A] in: carry from step t+1, out: carry to step t-1
+    float* dp_out;                 // [B,3A] gradient wrt the projection (for deferred dWatt)
+    float* dh1; int lddh;          // [B,H] accumulated (+=)
+    int B, H, A, U, E, att_type;
+    float eps;
+};
+
+int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream);
+int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream);
+int att_default_esplit(int B, int E);

@@ -1,0 +1,269 @@
+// Graves GMM-window location attention, forward and backward, one decoder timestep per launch.
+// Restates reference model.py:664-690 (training) and :931-958 (sampling: sharpening / timing
+// coefficients).  attention_type 0 = "graves", 1 = "softmax" (model.py:666-669, 680-687).
+//
+//   p = h1 @ Watt + batt                 p = [alpha_hat | beta_hat | kappa_hat], each [A]
+//   a = exp(alpha_hat) + eps   (graves)  |  softmax(alpha_hat) + eps   (softmax)
+//   b = exp(beta_hat) * sharpening + eps
+//   kappa = kappa_prev + alignment * exp(kappa_hat) / timing
+//   phi[u] = sum_A a * exp(-b (kappa - u)^2)                               (graves)
+//          = 0.3989422917366028 * sum_A a * sqrt(b) * exp(-b/2 (kappa - u)^2)   (softmax)
+//   w[e]   = sum_u phi[u] * ctx[b, u, e]
+//
+// HBM-bound part: the per-step read of ctx[B,U,E] (13.1 MB at B=64,U=200,E=256).  Forward runs
+// ESPLIT workgroups per batch row, each reducing over all U for a slice of E with coalesced
+// row-segment reads; the tiny projection and the window are recomputed per slice (L2-resident
+// inputs).  Reductions over A happen in-lane, reductions over U / H use wave shuffles + LDS.
+#include "attention.h"
+
+namespace {
+
+constexpr int ATT_THREADS = 256;
+constexpr int ATT_MAXA = 32;  // attention_size limit (reference default 10)
+
+// Block-wide sum of `n` per-thread partial vectors (n <= 3*ATT_MAXA); result in out[0..n).
+// part: per-thread array in registers is awkward for runtime n, so partials are staged in LDS:
+// scratch[t * n + j].  Simple tree over threads per j done by the first n threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    // red: >= 4 floats
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int A = g.A, U = g.U, E = g.E, H = g.H;
+    float* s_p = sm;                 // [3A] projection
+    float* s_a = s_p + 3 * ATT_MAXA; // [A]
+    float* s_b = s_a + ATT_MAXA;
+    float* s_k = s_b + ATT_MAXA;
+    float* s_red = s_k + ATT_MAXA;   // [8]
+    float* s_phi = s_red + 8;        // [U]
+    float* s_acc = s_phi + ((U + 3) & ~3);  // [ATT_THREADS] (+ column loop reuse)
+
+    const int b = blockIdx.x, es = blockIdx.y, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const float* h = g.h1 + (size_t)b * g.ldh;
+
+    // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
+    for (int j = wave; j < 3 * A; j += 4) {
+        float acc = 0.f;
+        for (int k = lane; k < H; k += 64) acc += h[k] * g.Watt[(size_t)k * 3 * A + j];
+        acc = wave_sum(acc);
+        if (lane == 0) s_p[j] = acc + (g.batt ? g.batt[j] : 0.f);
+    }
+    __syncthreads();
+
+    // 2) window parameters
+    if (g.att_type == 1) {
+        if (t == 0) {
+            float mx = -INFINITY;
+            for (int j = 0; j < A; ++j) mx = fmaxf(mx, s_p[j]);
+            float s = 0.f;
+            for (int j = 0; j < A; ++j) s += expf(s_p[j] - mx);
+            s_red[4] = mx;
+            s_red[5] = s;
+        }
+        __syncthreads();
+    }
+    if (t < A) {
+        float av;
+        if (g.att_type == 1) av = expf(s_p[t] - s_red[4]) / s_red[5] + g.eps;
+        else av = expf(s_p[t]) + g.eps;
+        const float bv = expf(s_p[A + t]) * g.sharpening + g.eps;
+        const float kv = g.kappa_prev[(size_t)b * A + t] + g.alignment * expf(s_p[2 * A + t]) / g.timing;
+        s_a[t] = av;
+        s_b[t] = bv;
+        s_k[t] = kv;
+        if (es == 0) {
+            g.a_out[(size_t)b * A + t] = av;
+            g.b_out[(size_t)b * A + t] = bv;
+            g.kappa_out[(size_t)b * A + t] = kv;
+        }
+    }
+    __syncthreads();
+
+    // 3) phi[u]
+    for (int u = t; u < U; u += ATT_THREADS) {
+        float ph = 0.f;
+        const float uf = (float)u;
+        if (g.att_type == 1) {
+            for (int j = 0; j < A; ++j) {
+                const float d = s_k[j] - uf;
+                ph += s_a[j] * sqrtf(s_b[j]) * expf(-0.5f * s_b[j] * d * d);
+            }
+            ph *= 0.3989422917366028f;
+        } else {
+            for (int j = 0; j < A; ++j) {
+                const float d = s_k[j] - uf;
+                ph += s_a[j] * expf(-s_b[j] * d * d);
+            }
+        }
+        s_phi[u] = ph;
+        if (es == 0) g.phi_out[(size_t)b * U + u] = ph;
+    }
+    __syncthreads();
+
+    // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
+    const int EW = (E + g.esplit - 1) / g.esplit;
+    const int e0 = es * EW, e1 = min(E, e0 + EW);
+    int CW = 1;
+    while (CW < EW && CW < ATT_THREADS) CW <<= 1;  // columns handled per pass (power of two)
+    const int G = ATT_THREADS / CW;                // u-groups
+    const int c = t % CW, ug = t / CW;
+    const float* ctx = g.ctx + (size_t)b * U * E;
+    for (int eb = e0; eb < e1; eb += CW) {
+        const int e = eb + c;
+        float acc = 0.f;
+        if (e < e1)
+            for (int u = ug; u < U; u += G) acc += s_phi[u] * ctx[(size_t)u * E + e];
+        __syncthreads();
+        s_acc[t] = acc;
+        __syncthreads();
+        if (ug == 0 && e < e1) {
+            float s = 0.f;
+            for (int q = 0; q < G; ++q) s += s_acc[q * CW + c];
+            g.w_out[(size_t)b * g.ldw + e] = s;
+        }
+    }
+}
+
+// Backward of one step for batch row b (one workgroup per row).
+__global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int A = g.A, U = g.U, E = g.E, H = g.H;
+    float* s_a = sm;                  // [A]
+    float* s_b = s_a + ATT_MAXA;
+    float* s_k = s_b + ATT_MAXA;
+    float* s_dp = s_k + ATT_MAXA;     // [3A]
+    float* s_red = s_dp + 3 * ATT_MAXA;  // [8]
+    float* s_dw = s_red + 8;          // [E]
+    float* s_dphi = s_dw + ((E + 3) & ~3);  // [U]
+
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const float* ctx = g.ctx + (size_t)b * U * E;
+
+    for (int e = t; e < E; e += ATT_THREADS) s_dw[e] = g.dw[(size_t)b * g.lddw + e];
+    if (t < A) {
+        s_a[t] = g.a[(size_t)b * A + t];
+        s_b[t] = g.b[(size_t)b * A + t];
+        s_k[t] = g.kappa[(size_t)b * A + t];
+    }
+    __syncthreads();
+
+    // dphi[u] = sum_e dw[e] ctx[u][e]: one wave per u, lanes over e (coalesced row reads).
+    for (int u = wave; u < U; u += 4) {
+        float acc = 0.f;
+        for (int e = lane; e < E; e += 64) acc += s_dw[e] * ctx[(size_t)u * E + e];
+        acc = wave_sum(acc);
+        if (lane == 0) s_dphi[u] = acc;
+    }
+    __syncthreads();
+
+    // da, db, dkappa: for each mixture j reduce over u.
+    for (int j = 0; j < A; ++j) {
+        const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
+        float da = 0.f, db = 0.f, dk = 0.f;
+        for (int u = t; u < U; u += ATT_THREADS) {
+            const float d = kj - (float)u;
+            const float dph = s_dphi[u];
+            if (g.att_type == 1) {
+                const float sq = sqrtf(bj);
+                const float ex = 0.3989422917366028f * expf(-0.5f * bj * d * d);
+                da += dph * sq * ex;
+                // d/db [a sqrt(b) exp(-b d^2/2)] = a ex (1/(2 sqrt b) - sqrt(b) d^2 / 2)
+                db += dph * aj * ex * (0.5f / sq - 0.5f * sq * d * d);
+                dk += dph * aj * sq * ex * (-bj * d);
+            } else {
+                const float ex = expf(-bj * d * d);
+                da += dph * ex;
+                db += dph * aj * ex * (-d * d);
+                dk += dph * aj * ex * (-2.f * bj * d);
+            }
+        }
+        da = block_sum(da, s_red);
+        db = block_sum(db, s_red);
+        dk = block_sum(dk, s_red);
+        if (t == 0) {
+            s_dp[j] = da;           // temporarily da
+            s_dp[A + j] = db;       // db
+            s_dp[2 * A + j] = dk;   // dkappa (without carry)
+        }
+    }
+    __syncthreads();
+
+    // chain through the window parameterisation.
+    if (g.att_type == 1) {
+        if (t == 0) {
+            // a = softmax(p) + eps : dp = s * (da - sum(da * s)), s = a - eps
+            float dot = 0.f;
+            for (int j = 0; j < A; ++j) dot += s_dp[j] * (s_a[j] - g.eps);
+            s_red[4] = dot;
+        }
+        __syncthreads();
+    }
+    float dpa = 0.f, dpb = 0.f, dpk = 0.f;
+    if (t < A) {
+        const float sa = s_a[t] - g.eps;
+        if (g.att_type == 1) dpa = sa * (s_dp[t] - s_red[4]);
+        else dpa = s_dp[t] * sa;
+        dpb = s_dp[A + t] * (s_b[t] - g.eps);
+        const float dkt = s_dp[2 * A + t] + g.dkappa[(size_t)b * A + t];  // + carry from step t+1
+        dpk = dkt * (s_k[t] - g.kappa_prev[(size_t)b * A + t]);
+        g.dkappa[(size_t)b * A + t] = dkt;  // kappa_t = kappa_{t-1} + ... : carry to step t-1
+    }
+    __syncthreads();
+    if (t < A) {
+        s_dp[t] = dpa;
+        s_dp[A + t] = dpb;
+        s_dp[2 * A + t] = dpk;
+        g.dp_out[(size_t)b * 3 * A + t] = dpa;
+        g.dp_out[(size_t)b * 3 * A + A + t] = dpb;
+        g.dp_out[(size_t)b * 3 * A + 2 * A + t] = dpk;
+    }
+    __syncthreads();
+
+    // dh1[b][k] += sum_j dp[j] Watt[k][j]
+    float* dh = g.dh1 + (size_t)b * g.lddh;
+    for (int k = t; k < H; k += ATT_THREADS) {
+        const float* wr = g.Watt + (size_t)k * 3 * A;
+        float acc = 0.f;
+        for (int j = 0; j < 3 * A; ++j) acc += s_dp[j] * wr[j];
+        dh[k] += acc;
+    }
+}
+
+}  // namespace
+
+static size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + ATT_THREADS); }
+static size_t att_bwd_lds(int U, int E) {
+    return sizeof(float) * (6 * ATT_MAXA + 8 + ((E + 3) & ~3) + ((U + 3) & ~3));
+}
+
+int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream) {
+    if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.esplit < 1) return PH_ERR_BADARG;
+    const size_t lds = att_fwd_lds(g.U);
+    if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(att_fwd_kernel, dim3(g.B, g.esplit), dim3(ATT_THREADS), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
+int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream) {
+    if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1) return PH_ERR_BADARG;
+    const size_t lds = att_bwd_lds(g.U, g.E);
+    if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(att_bwd_kernel, dim3(g.B), dim3(ATT_THREADS), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
+int att_default_esplit(int B, int E) {
+    // aim for >= 256 workgroups while keeping slices >= 32 columns
+    int es = 1;
+    while (B * es < 256 && E / (es * 2) >= 32) es *= 2;
+    return es;
+}

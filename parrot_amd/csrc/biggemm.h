@@ -1,0 +1,24 @@
+// Internal interface of the LDS-tiled f32 MFMA GEMM used for everything that is batched over
+// time: readouts / output projection (reference model.py:739-755), teacher-forcing feedback and
+// speaker projections (model.py:580-627), the deferred weight gradients of the scan, and the
+// SampleRNN training MLP (three_tier.py:452-515).
+#pragma once
+#include "common.h"
+
+struct BgArgs {
+    const float* A;  // element (m,k) at A[m*sam + k*sak]; one of sam/sak must be 1
+    const float* B;  // element (k,n) at B[k*sbk + n*sbn]; one of sbk/sbn must be 1
+    float* C;        // row-major [M,N], leading dimension ldc
+    const float* bias;  // [N] or null, added once
+    int M, N, K;
+    long long sam, sak, sbk, sbn;
+    int ldc;
+    long long batchA, batchB, batchC;  // element strides between batch entries
+    int nbatch;
+    int splitk;      // >1: K is split over grid.z and results are combined with f32 atomics
+    int accumulate;  // C += result (C must hold valid data; with splitk>1 always accumulates)
+    float alpha;
+    int act;         // SkAct-compatible activation, only when splitk == 1
+};
+
+int bg_launch(const BgArgs& a, hipStream_t stream);

@@ -1,0 +1,203 @@
+// LDS-tiled f32 GEMM on the CDNA4 f32-input matrix cores (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// C[M,N] (+)= alpha * A(M,K) * B(K,N) (+ bias) with arbitrary "one stride is 1" operand layouts, so
+// the same kernel serves NN (x*W), NT (dy*W^T) and TN (x^T*dy, the deferred weight gradients of
+// the decoder scan) without transposed copies in HBM.
+//
+// Tiling: 128x128x16 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32
+// blocks, 64 accumulator VGPRs).  Operands are staged global -> VGPR -> LDS in [k][m] / [k][n]
+// images (row pitch 132 floats) so that an MFMA fragment read is 32 consecutive floats per half
+// wave (conflict-free ds_read_b32); the next K-tile is prefetched into registers while the
+// current one is consumed (double-buffered LDS, one barrier per K-tile).  Workgroup ids are
+// remapped so that each XCD (private 4 MiB L2) walks a contiguous band of tiles.
+#include "biggemm.h"
+
+#include <hip/hip_runtime.h>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, PITCH = 132;
+
+// Loads the 128 x 16 slab of an operand whose element (x, k) sits at p[x*sx + k*sk].
+// XC = true : x is the contiguous index (sx == 1).  thread -> (xq = t&31, kr = t>>5), 2 passes.
+// XC = false: k is the contiguous index (sk == 1).  thread -> (x = t>>1, kq = t&1), 2 vectors.
+template <bool XC>
+__device__ __forceinline__ void bg_load(const float* __restrict__ p, int x0, int X, int k0, int kend,
+                                        long long sx, long long sk, bool vec, int t, f32x4 (&v)[2]) {
+    if (XC) {
+        const int xq = t & 31, kr = t >> 5;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int k = k0 + kr + 8 * ps;
+            const int x = x0 + 4 * xq;
+            v[ps] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k < kend) {
+                const float* q = p + (long long)k * sk + x;
+                if (vec && x + 3 < X) {
+                    v[ps] = *reinterpret_cast<const f32x4*>(q);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (x + u < X) v[ps][u] = q[u];
+                }
+            }
+        }
+    } else {
+        const int x = x0 + (t >> 1), kq = t & 1;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int k = k0 + 8 * kq + 4 * ps;
+            v[ps] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (x < X) {
+                const float* q = p + (long long)x * sx + k;
+                if (vec && k + 3 < kend) {
+                    v[ps] = *reinterpret_cast<const f32x4*>(q);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (k + u < kend) v[ps][u] = q[u];
+                }
+            }
+        }
+    }
+}
+
+template <bool XC>
+__device__ __forceinline__ void bg_store(float* __restrict__ s, int t, const f32x4 (&v)[2]) {
+    if (XC) {
+        const int xq = t & 31, kr = t >> 5;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            *reinterpret_cast<f32x4*>(s + (kr + 8 * ps) * PITCH + 4 * xq) = v[ps];
+    } else {
+        const int x = t >> 1, kq = t & 1;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[(8 * kq + 4 * ps + u) * PITCH + x] = v[ps][u];
+    }
+}
+
+template <bool AXC, bool BXC>
+__global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * PITCH];
+
+    // XCD-aware remap (8 XCDs; block b runs on XCD b % 8): give each XCD a contiguous band.
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8;
+        const int xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int batch = z / a.splitk, ks = z % a.splitk;
+    int kchunk = (a.K + a.splitk - 1) / a.splitk;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    const int kbeg = ks * kchunk;
+    const int kend = min(a.K, kbeg + kchunk);
+    if (kbeg >= kend && ks > 0) return;
+
+    const float* A = a.A + (long long)batch * a.batchA;
+    const float* B = a.B + (long long)batch * a.batchB;
+    float* C = a.C + (long long)batch * a.batchC;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kk = lane >> 5, li = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        bg_load<AXC>(A, m0, a.M, kbeg, kend, a.sam, a.sak, vecA, t, ra);
+        bg_load<BXC>(B, n0, a.N, kbeg, kend, a.sbn, a.sbk, vecB, t, rb);
+        bg_store<AXC>(As[0], t, ra);
+        bg_store<BXC>(Bs[0], t, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            bg_load<AXC>(A, m0, a.M, kbeg + (kt + 1) * BK, kend, a.sam, a.sak, vecA, t, ra);
+            bg_load<BXC>(B, n0, a.N, kbeg + (kt + 1) * BK, kend, a.sbn, a.sbk, vecB, t, rb);
+        }
+        const float* as = As[cur] + wm * 64 + li;
+        const float* bs = Bs[cur] + wn * 64 + li;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const int row = (2 * kp + kk) * PITCH;
+            const float a0 = as[row], a1 = as[row + 32];
+            const float b0 = bs[row], b1 = bs[row + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            bg_store<AXC>(As[cur ^ 1], t, ra);
+            bg_store<BXC>(Bs[cur ^ 1], t, rb);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  32x32 C/D layout: col = lane & 31, row = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            if (n >= a.N) continue;
+            const float bias = (a.bias && ks == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+                if (m >= a.M) continue;
+                float v = a.alpha * acc[i][j][q] + bias;
+                float* c = C + (long long)m * a.ldc + n;
+                if (a.splitk > 1) {
+                    unsafeAtomicAdd(c, v);
+                } else {
+                    if (a.accumulate) v += *c;
+                    if (a.act == 1) v = fmaxf(v, 0.f);
+                    else if (a.act == 2) v = tanhf(v);
+                    else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+                    *c = v;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+int bg_launch(const BgArgs& a, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch < 1 || a.splitk < 1) return PH_ERR_BADARG;
+    const bool axc = (a.sam == 1), bxc = (a.sbn == 1);
+    if (!axc && a.sak != 1) return PH_ERR_BADARG;
+    if (!bxc && a.sbk != 1) return PH_ERR_BADARG;
+    // vector loads need 16-byte aligned addresses for every (tile, k) start.
+    auto al = [](const float* p, long long stride, long long batch) {
+        return (((uintptr_t)p & 15) == 0) && (stride % 4 == 0) && (batch % 4 == 0);
+    };
+    const int vecA = axc ? al(a.A, a.sak, a.batchA) : al(a.A, a.sam, a.batchA);
+    const int vecB = bxc ? al(a.B, a.sbk, a.batchB) : al(a.B, a.sbn, a.batchB);
+    const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
+    dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
+    dim3 block(256);
+    if (axc && bxc) hipLaunchKernelGGL((bg_kernel<true, true>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+    else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel<true, false>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+    else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel<false, true>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((bg_kernel<false, false>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+    return (int)hipGetLastError();
+}

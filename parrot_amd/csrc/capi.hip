@@ -1,0 +1,167 @@
+// extern "C" entry points that are single operations (the scan plans live in plans.hip).
+#include "../../include/parrot_hip.h"
+#include "attention.h"
+#include "biggemm.h"
+#include "elementwise.h"
+#include "quantize.h"
+#include "skinny.h"
+
+#include <math.h>
+
+extern "C" {
+
+const char* parrot_hip_version(void) { return "parrot_hip 0.1.0 gfx950"; }
+
+int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
+                long long strideA, long long strideB, long long strideC, int split_k, void* stream) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1 || nbatch < 1) return PARROT_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (M <= 64 && !transA && nbatch == 1 && split_k <= 1 && alpha == 1.0f) {
+        SkJob j;
+        sk_job_init(j);
+        j.nseg = 1;
+        j.seg[0] = sk_seg(A, lda, B, ldb, K, transB ? 1 : 0);
+        j.M = M; j.N = N; j.H = N; j.epi = SK_EPI_LINEAR; j.act = act; j.accumulate = accumulate;
+        j.bias = bias;
+        j.out = C; j.ldo = ldc;
+        SkLaunch L;
+        int rc = sk_make_launch(L, &j, 1);
+        if (rc) return rc;
+        return sk_launch(L, st);
+    }
+    BgArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias;
+    a.M = M; a.N = N; a.K = K;
+    a.sam = transA ? 1 : lda; a.sak = transA ? lda : 1;
+    a.sbk = transB ? 1 : ldb; a.sbn = transB ? ldb : 1;
+    a.ldc = ldc;
+    a.batchA = strideA; a.batchB = strideB; a.batchC = strideC;
+    a.nbatch = nbatch; a.splitk = split_k < 1 ? 1 : split_k;
+    a.accumulate = accumulate; a.alpha = alpha; a.act = act;
+    if (a.splitk > 1 && act != 0) return PARROT_ERR_BADARG;
+    return bg_launch(a, st);
+}
+
+int parrot_colsum(const float* x, long long M, int N, int ld, float* out, int accumulate, void* stream) {
+    return colsum_launch(x, M, N, ld, out, accumulate, (hipStream_t)stream);
+}
+
+int parrot_gru_step_fwd(const float* h, const float* inputs, const float* gate_inputs, const float* mask,
+                        const float* Wg, const float* Wc, float* h_out, float* z, float* r, float* rh,
+                        float* c, int B, int H, void* stream) {
+    if (!h || !Wg || !Wc || !h_out || !z || !r || !rh || B < 1 || H < 1) return PARROT_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    SkJob j;
+    SkLaunch L;
+    sk_job_init(j);
+    j.nseg = 1;
+    j.seg[0] = sk_seg(h, H, Wg, 2 * H, H, 0);
+    j.M = B; j.N = 2 * H; j.H = H; j.epi = SK_EPI_GRU_GATES;
+    j.add = gate_inputs; j.ld_add = 2 * H;
+    j.e0 = h; j.lde0 = H;
+    j.o1 = z; j.ldo1 = H; j.o2 = r; j.ldo2 = H; j.out = rh; j.ldo = H;
+    int rc = sk_make_launch(L, &j, 1);
+    if (rc) return rc;
+    rc = sk_launch(L, st);
+    if (rc) return rc;
+    sk_job_init(j);
+    j.nseg = 1;
+    j.seg[0] = sk_seg(rh, H, Wc, H, H, 0);
+    j.M = B; j.N = H; j.H = H; j.epi = SK_EPI_GRU_CAND;
+    j.add = inputs; j.ld_add = H;
+    j.e0 = h; j.lde0 = H; j.e1 = z; j.lde1 = H;
+    j.o1 = c; j.ldo1 = H; j.out = h_out; j.ldo = H; j.mask = mask;
+    rc = sk_make_launch(L, &j, 1);
+    if (rc) return rc;
+    return sk_launch(L, st);
+}
+
+int parrot_gru_step_bwd(const float* dh_out, const float* h, const float* mask, const float* Wg,
+                        const float* Wc, const float* z, const float* r, const float* c, float* dh,
+                        float* d_inputs, float* d_gate_inputs, int B, int H, void* stream) {
+    if (!dh_out || !h || !Wg || !Wc || !z || !r || !c || !dh || !d_inputs || !d_gate_inputs)
+        return PARROT_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dh, 0, sizeof(float) * (size_t)B * H, st);
+    if (e != hipSuccess) return (int)e;
+    GruStateBwdArgs ga;
+    ga.nchain = 1; ga.B = B; ga.H = H;
+    ga.chain[0].dh = dh_out; ga.chain[0].hprev = h; ga.chain[0].z = z; ga.chain[0].c = c;
+    ga.chain[0].mask = mask; ga.chain[0].dC = d_inputs; ga.chain[0].dG = d_gate_inputs; ga.chain[0].dhprev = dh;
+    int rc = gru_state_bwd_launch(ga, st);
+    if (rc) return rc;
+    SkJob j;
+    SkLaunch L;
+    sk_job_init(j);
+    j.nseg = 1;
+    j.seg[0] = sk_seg(d_inputs, H, Wc, H, H, 1);
+    j.M = B; j.N = H; j.H = H; j.epi = SK_EPI_BWD_RH;
+    j.e0 = h; j.lde0 = H; j.e1 = r; j.lde1 = H;
+    j.out = d_gate_inputs + H; j.ldo = 2 * H; j.o1 = dh; j.ldo1 = H;
+    rc = sk_make_launch(L, &j, 1);
+    if (rc) return rc;
+    rc = sk_launch(L, st);
+    if (rc) return rc;
+    sk_job_init(j);
+    j.nseg = 1;
+    j.seg[0] = sk_seg(d_gate_inputs, 2 * H, Wg, 2 * H, 2 * H, 1);
+    j.M = B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+    j.out = dh; j.ldo = H;
+    rc = sk_make_launch(L, &j, 1);
+    if (rc) return rc;
+    return sk_launch(L, st);
+}
+
+int parrot_gmm_attention_fwd(const float* h1, const float* Watt, const float* batt, const float* kappa_prev,
+                             const float* ctx, float* a, float* b, float* kappa, float* phi, float* w, int B,
+                             int H, int A, int U, int E, int att_type, float eps, float alignment,
+                             float sharpening, float timing, void* stream) {
+    if (!h1 || !Watt || !kappa_prev || !ctx || !a || !b || !kappa || !phi || !w) return PARROT_ERR_BADARG;
+    AttFwdArgs g;
+    g.h1 = h1; g.ldh = H; g.Watt = Watt; g.batt = batt; g.kappa_prev = kappa_prev; g.ctx = ctx;
+    g.a_out = a; g.b_out = b; g.kappa_out = kappa; g.phi_out = phi; g.w_out = w; g.ldw = E;
+    g.B = B; g.H = H; g.A = A; g.U = U; g.E = E; g.esplit = att_default_esplit(B, E);
+    g.att_type = att_type; g.eps = eps; g.alignment = alignment; g.sharpening = sharpening; g.timing = timing;
+    return att_fwd_launch(g, (hipStream_t)stream);
+}
+
+int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, const float* b,
+                             const float* kappa, const float* kappa_prev, const float* Watt, float* dkappa,
+                             float* dp, float* dh1, int B, int H, int A, int U, int E, int att_type, float eps,
+                             void* stream) {
+    if (!dw || !ctx || !a || !b || !kappa || !kappa_prev || !Watt || !dkappa || !dp || !dh1)
+        return PARROT_ERR_BADARG;
+    AttBwdArgs g;
+    g.dw = dw; g.lddw = E; g.ctx = ctx; g.a = a; g.b = b; g.kappa = kappa; g.kappa_prev = kappa_prev;
+    g.Watt = Watt; g.dkappa = dkappa; g.dp_out = dp; g.dh1 = dh1; g.lddh = H;
+    g.B = B; g.H = H; g.A = A; g.U = U; g.E = E; g.att_type = att_type; g.eps = eps;
+    return att_bwd_launch(g, (hipStream_t)stream);
+}
+
+int parrot_sumsq(const float* x, size_t n, float* out, void* stream) {
+    return sumsq_launch(x, n, out, (hipStream_t)stream);
+}
+
+int parrot_adam_clip_step(float* param, const float* grad, float* m, float* v, size_t n,
+                          const float* gnorm_sq, float grad_scale, float clip_threshold, float lr,
+                          float beta1, float beta2, float eps, int step, void* stream) {
+    if (!param || !grad || !m || !v || step < 1) return PARROT_ERR_BADARG;
+    if (clip_threshold > 0.f && !gnorm_sq) return PARROT_ERR_BADARG;
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    return adam_clip_launch(param, grad, m, v, n, gnorm_sq, grad_scale, clip_threshold, (float)lr_t, beta1,
+                            beta2, eps, (hipStream_t)stream);
+}
+
+int parrot_batch_quantize(const float* x, int rows, int n, int ld, double* ws, void* out, int ldo, int mode,
+                          int q_levels, void* stream) {
+    if (!x || !ws || !out) return PARROT_ERR_BADARG;
+    return quantize_launch(x, rows, n, ld, ws, out, ldo, mode, q_levels, (hipStream_t)stream);
+}
+
+int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream) {
+    if (!q || !out) return PARROT_ERR_BADARG;
+    return mu2linear_launch(q, n, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

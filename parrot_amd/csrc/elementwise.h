@@ -1,0 +1,25 @@
+// Internal interface of the elementwise / reduction kernels.
+#pragma once
+#include "common.h"
+
+struct GruStateBwdChain {
+    const float* dh;     // [B,H] total gradient wrt h_t
+    const float* hprev;  // [B,H]
+    const float* z;      // [B,H]
+    const float* c;      // [B,H]
+    const float* mask;   // [B] or null
+    float* dC;           // [B,H]
+    float* dG;           // [B,2H]; only columns [0,H) (update gate) are written here
+    float* dhprev;       // [B,H] accumulated (+=)
+};
+struct GruStateBwdArgs {
+    GruStateBwdChain chain[4];
+    int nchain, B, H;
+};
+
+int gru_state_bwd_launch(const GruStateBwdArgs& g, hipStream_t stream);
+int colsum_launch(const float* x, long long M, int N, int ld, float* out, int accumulate, hipStream_t stream);
+int sumsq_launch(const float* x, size_t n, float* out, hipStream_t stream);
+int adam_clip_launch(float* p, const float* g, float* m, float* v, size_t n, const float* gnorm_sq,
+                     float grad_scale, float threshold, float lr_t, float b1, float b2, float eps,
+                     hipStream_t stream);

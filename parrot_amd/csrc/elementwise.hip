@@ -1,0 +1,142 @@
+// HBM-bound elementwise / reduction kernels around the recurrent step (gfx950).
+//  * GRU state backward (the elementwise half of the GatedRecurrent backward step)
+//  * column sums (bias gradients), sum of squares (global-norm StepClipping, train.py:100-101)
+//  * fused global-norm clip + Adam over the flat parameter buffer (train.py:100-108,
+//    Blocks StepClipping -> Adam, Appendix A.1 of SURVEY.md)
+#include "elementwise.h"
+
+namespace {
+
+// dh: total gradient wrt h_t. Emits dC = dh*z*(1-c^2), dGz = dh*(c-hp)*z*(1-z),
+// and accumulates dh_prev += dh*(1-z).   (h_t = z*c + (1-z)*hp)
+__global__ __launch_bounds__(256) void gru_state_bwd_kernel(const GruStateBwdArgs g) {
+    const int ch = blockIdx.y;
+    const GruStateBwdChain& c = g.chain[ch];
+    const size_t n = (size_t)g.B * g.H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / g.H), k = (int)(i % g.H);
+        float dh = c.dh[(size_t)m * g.H + k];
+        const float hp = c.hprev[(size_t)m * g.H + k];
+        float dhp_direct = 0.f;
+        if (c.mask) {
+            const float mk = c.mask[m];
+            dhp_direct = dh * (1.f - mk);
+            dh *= mk;
+        }
+        const float z = c.z[(size_t)m * g.H + k];
+        const float cc = c.c[(size_t)m * g.H + k];
+        c.dC[(size_t)m * g.H + k] = dh * z * (1.f - cc * cc);
+        c.dG[(size_t)m * 2 * g.H + k] = dh * (cc - hp) * z * (1.f - z);
+        c.dhprev[(size_t)m * g.H + k] += dh * (1.f - z) + dhp_direct;
+    }
+}
+
+// out[n] (+)= sum_m x[m*ld + n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long M, int N, int ld,
+                                                     float* __restrict__ out, int accumulate) {
+    // block handles 64 columns; 4 row-groups of 64 lanes
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (n < N) {
+        const long long per = (M + gridDim.y - 1) / gridDim.y;
+        const long long mb = (long long)blockIdx.y * per, me = min(M, mb + per);
+        for (long long m = mb + rg; m < me; m += 4) acc += x[m * ld + n];
+    }
+    red[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (gridDim.y > 1) unsafeAtomicAdd(out + n, s);
+        else if (accumulate) out[n] += s;
+        else out[n] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const size_t n4 = n / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += x[i] * x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// StepClipping(threshold) then Adam (Blocks 0.2 semantics):
+//   g' = g * min(1, threshold / ||g||)      (global norm over all parameters, gnorm_sq = ||g||^2)
+//   m = b1 m + (1-b1) g' ;  v = b2 v + (1-b2) g'^2
+//   lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) ;  p -= lr_t * m / (sqrt(v) + eps)
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                        const float* __restrict__ gnorm_sq, float grad_scale,
+                                                        float threshold, float lr_t, float b1, float b2, float eps) {
+    float scale = grad_scale;
+    if (threshold > 0.f) {
+        const float nrm = sqrtf(*gnorm_sq) * grad_scale;
+        if (nrm > threshold) scale *= threshold / nrm;
+        if (!(nrm == nrm) || nrm > 3.0e38f) scale = 0.f;  // NaN / inf guard: skip the step
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * scale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace
+
+int gru_state_bwd_launch(const GruStateBwdArgs& g, hipStream_t stream) {
+    if (g.nchain < 1 || g.nchain > 4) return PH_ERR_BADARG;
+    const size_t n = (size_t)g.B * g.H;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(gru_state_bwd_kernel, dim3(bx, g.nchain), dim3(256), 0, stream, g);
+    return (int)hipGetLastError();
+}
+
+int colsum_launch(const float* x, long long M, int N, int ld, float* out, int accumulate, hipStream_t stream) {
+    if (M < 0 || N < 1) return PH_ERR_BADARG;
+    int ysplit = 1;
+    const int bx = ceil_div(N, 64);
+    while (bx * ysplit < 512 && M / (ysplit * 2) >= 256) ysplit *= 2;
+    if (ysplit > 1 && !accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(bx, ysplit), dim3(256), 0, stream, x, M, N, ld, out, accumulate);
+    return (int)hipGetLastError();
+}
+
+int sumsq_launch(const float* x, size_t n, float* out, hipStream_t stream) {
+    if (((uintptr_t)x & 15) != 0) return PH_ERR_BADARG;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
+    if (e != hipSuccess) return (int)e;
+    int bx = (int)((n / 4 + 255) / 256);
+    if (bx < 1) bx = 1;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(bx), dim3(256), 0, stream, x, n, out);
+    return (int)hipGetLastError();
+}
+
+int adam_clip_launch(float* p, const float* g, float* m, float* v, size_t n, const float* gnorm_sq,
+                     float grad_scale, float threshold, float lr_t, float b1, float b2, float eps,
+                     hipStream_t stream) {
+    int bx = (int)((n + 255) / 256);
+    if (bx < 1) bx = 1;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(bx), dim3(256), 0, stream, p, g, m, v, n, gnorm_sq, grad_scale,
+                       threshold, lr_t, b1, b2, eps);
+    return (int)hipGetLastError();
+}

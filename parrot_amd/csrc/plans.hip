@@ -1,0 +1,454 @@
+// Host-side scan orchestration: the loops that theano.scan ran inside one theano.function call in
+// the reference (model.py:726-737, 1038-1057; ops.py:299-327) become fixed launch sequences of the
+// fused step kernels, captured once into a hipGraph and replayed per window (all pointers in a
+// plan are fixed, so a replay costs one hipGraphLaunch instead of thousands of host launches).
+#include <new>
+#include <vector>
+
+#include "../../include/parrot_hip.h"
+#include "attention.h"
+#include "elementwise.h"
+#include "skinny.h"
+
+namespace {
+
+struct PlanBase {
+    int last_error = 0;
+    int use_graph = 0;
+    hipGraphExec_t exec[2] = {nullptr, nullptr};
+    hipStream_t cap_stream = nullptr;
+    virtual ~PlanBase() {
+        for (int i = 0; i < 2; ++i)
+            if (exec[i]) hipGraphExecDestroy(exec[i]);
+        if (cap_stream) hipStreamDestroy(cap_stream);
+    }
+    virtual int enqueue(int which, hipStream_t s) = 0;
+
+    int run(int which, hipStream_t s) {
+        if (!use_graph) return note(enqueue(which, s));
+        if (!exec[which]) {
+            if (!cap_stream) {
+                hipError_t e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
+                if (e != hipSuccess) return note((int)e);
+            }
+            hipError_t e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed);
+            if (e != hipSuccess) return note((int)e);
+            const int rc = enqueue(which, cap_stream);
+            hipGraph_t graph = nullptr;
+            e = hipStreamEndCapture(cap_stream, &graph);
+            if (rc != 0) {
+                if (graph) hipGraphDestroy(graph);
+                return note(rc);
+            }
+            if (e != hipSuccess) return note((int)e);
+            e = hipGraphInstantiate(&exec[which], graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                exec[which] = nullptr;
+                return note((int)e);
+            }
+        }
+        return note((int)hipGraphLaunch(exec[which], s));
+    }
+    int note(int rc) {
+        if (rc != 0 && last_error == 0) last_error = rc;
+        return rc;
+    }
+};
+
+#define PL_TRY(x)                \
+    do {                         \
+        const int rc__ = (x);    \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+int launch_jobs(const SkJob* jobs, int n, hipStream_t s) {
+    SkLaunch L;
+    PL_TRY(sk_make_launch(L, jobs, n));
+    return sk_launch(L, s);
+}
+
+// ----------------------------------------------------------------------------- GRU scan
+struct GruSeqPlan : PlanBase {
+    ParrotGruSeqDesc d;
+
+    int enqueue(int which, hipStream_t s) override { return which == 0 ? fwd(s) : bwd(s); }
+
+    int fwd(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H;
+        for (int s = 0; s < d.T; ++s) {
+            SkJob jobs[4];
+            for (int ch = 0; ch < d.nchain; ++ch) {
+                const int t = d.reverse[ch] ? d.T - 1 - s : s;
+                SkJob& j = jobs[ch];
+                sk_job_init(j);
+                j.nseg = 1;
+                j.seg[0] = sk_seg(d.h[ch] + s * BH, d.H, d.Wg[ch], 2 * d.H, d.H, 0);
+                j.M = d.B; j.N = 2 * d.H; j.H = d.H; j.epi = SK_EPI_GRU_GATES;
+                j.add = d.gate_inputs[ch] ? d.gate_inputs[ch] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
+                j.e0 = d.h[ch] + s * BH; j.lde0 = d.H;
+                j.o1 = d.z[ch] + t * BH; j.ldo1 = d.H;
+                j.o2 = d.r[ch] + t * BH; j.ldo2 = d.H;
+                j.out = d.rh[ch] + t * BH; j.ldo = d.H;
+            }
+            PL_TRY(launch_jobs(jobs, d.nchain, st));
+            for (int ch = 0; ch < d.nchain; ++ch) {
+                const int t = d.reverse[ch] ? d.T - 1 - s : s;
+                SkJob& j = jobs[ch];
+                sk_job_init(j);
+                j.nseg = 1;
+                j.seg[0] = sk_seg(d.rh[ch] + t * BH, d.H, d.Wc[ch], d.H, d.H, 0);
+                j.M = d.B; j.N = d.H; j.H = d.H; j.epi = SK_EPI_GRU_CAND;
+                j.add = d.inputs[ch] ? d.inputs[ch] + t * BH : nullptr; j.ld_add = d.H;
+                j.e0 = d.h[ch] + s * BH; j.lde0 = d.H;
+                j.e1 = d.z[ch] + t * BH; j.lde1 = d.H;
+                j.o1 = d.c[ch] + t * BH; j.ldo1 = d.H;
+                j.out = d.h[ch] + (s + 1) * BH; j.ldo = d.H;
+                j.mask = d.mask ? d.mask + (size_t)t * d.B : nullptr;
+            }
+            PL_TRY(launch_jobs(jobs, d.nchain, st));
+        }
+        return 0;
+    }
+
+    int bwd(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H;
+        for (int s = d.T - 1; s >= 0; --s) {
+            GruStateBwdArgs ga;
+            ga.nchain = d.nchain; ga.B = d.B; ga.H = d.H;
+            SkJob jx[4], jy[4];
+            for (int ch = 0; ch < d.nchain; ++ch) {
+                const int t = d.reverse[ch] ? d.T - 1 - s : s;
+                GruStateBwdChain& c = ga.chain[ch];
+                c.dh = d.dh[ch] + (s + 1) * BH;
+                c.hprev = d.h[ch] + s * BH;
+                c.z = d.z[ch] + t * BH;
+                c.c = d.c[ch] + t * BH;
+                c.mask = d.mask ? d.mask + (size_t)t * d.B : nullptr;
+                c.dC = d.dC[ch] + t * BH;
+                c.dG = d.dG[ch] + t * 2 * BH;
+                c.dhprev = d.dh[ch] + s * BH;
+
+                SkJob& x = jx[ch];
+                sk_job_init(x);
+                x.nseg = 1;
+                x.seg[0] = sk_seg(d.dC[ch] + t * BH, d.H, d.Wc[ch], d.H, d.H, 1);
+                x.M = d.B; x.N = d.H; x.H = d.H; x.epi = SK_EPI_BWD_RH;
+                x.e0 = d.h[ch] + s * BH; x.lde0 = d.H;
+                x.e1 = d.r[ch] + t * BH; x.lde1 = d.H;
+                x.out = d.dG[ch] + t * 2 * BH + d.H; x.ldo = 2 * d.H;
+                x.o1 = d.dh[ch] + s * BH; x.ldo1 = d.H;
+
+                SkJob& y = jy[ch];
+                sk_job_init(y);
+                y.nseg = 1;
+                y.seg[0] = sk_seg(d.dG[ch] + t * 2 * BH, 2 * d.H, d.Wg[ch], 2 * d.H, 2 * d.H, 1);
+                y.M = d.B; y.N = d.H; y.H = d.H; y.epi = SK_EPI_LINEAR; y.accumulate = 1;
+                y.out = d.dh[ch] + s * BH; y.ldo = d.H;
+            }
+            PL_TRY(gru_state_bwd_launch(ga, st));
+            PL_TRY(launch_jobs(jx, d.nchain, st));
+            PL_TRY(launch_jobs(jy, d.nchain, st));
+        }
+        return 0;
+    }
+};
+
+// ----------------------------------------------------------------------------- decoder (training)
+struct DecoderPlan : PlanBase {
+    ParrotDecoderDesc d;
+    int esplit = 1;
+
+    int enqueue(int which, hipStream_t s) override { return which == 0 ? fwd(s) : bwd(s); }
+
+    // Adds the K-segments [h_l ; w ; h_0..h_{l-1}] against weight W (row-major [K_l, ldw]).
+    void layer_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw) const {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        int n = 0;
+        j.seg[n++] = sk_seg(first, d.H, W, ldw, d.H, 0);
+        const float* wsrc = d.w + (size_t)(l == 0 ? t : t + 1) * BE;
+        j.seg[n++] = sk_seg(wsrc, d.E, W + (size_t)d.H * ldw, ldw, d.E, 0);
+        for (int q = 0; q < l; ++q)
+            j.seg[n++] = sk_seg(d.h[q] + (size_t)(t + 1) * BH, d.H, W + (size_t)(d.H + d.E + q * d.H) * ldw, ldw,
+                                d.H, 0);
+        j.nseg = n;
+    }
+
+    int fwd(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+        for (int t = 0; t < d.T; ++t) {
+            for (int l = 0; l < d.L; ++l) {
+                SkJob j;
+                sk_job_init(j);
+                layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
+                j.M = d.B; j.N = 2 * d.H; j.H = d.H; j.epi = SK_EPI_GRU_GATES;
+                j.bias = d.bg[l];
+                j.add = d.seq_g[l] ? d.seq_g[l] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
+                j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
+                j.o1 = d.z[l] + t * BH; j.ldo1 = d.H;
+                j.o2 = d.r[l] + t * BH; j.ldo2 = d.H;
+                j.out = d.rh[l] + t * BH; j.ldo = d.H;
+                PL_TRY(launch_jobs(&j, 1, st));
+
+                sk_job_init(j);
+                layer_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
+                j.M = d.B; j.N = d.H; j.H = d.H; j.epi = SK_EPI_GRU_CAND;
+                j.bias = d.bc[l];
+                j.add = d.seq_c[l] ? d.seq_c[l] + t * BH : nullptr; j.ld_add = d.H;
+                j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
+                j.e1 = d.z[l] + t * BH; j.lde1 = d.H;
+                j.o1 = d.c[l] + t * BH; j.ldo1 = d.H;
+                j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
+                PL_TRY(launch_jobs(&j, 1, st));
+
+                if (l == 0) {
+                    AttFwdArgs g;
+                    g.h1 = d.h[0] + (t + 1) * BH; g.ldh = d.H;
+                    g.Watt = d.Watt; g.batt = d.batt;
+                    g.kappa_prev = d.kappa + t * BA;
+                    g.ctx = d.ctx;
+                    g.a_out = d.a + t * BA; g.b_out = d.b + t * BA; g.kappa_out = d.kappa + (t + 1) * BA;
+                    g.phi_out = d.phi + (size_t)t * d.B * d.U;
+                    g.w_out = d.w + (t + 1) * BE; g.ldw = d.E;
+                    g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.esplit = esplit;
+                    g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
+                    g.sharpening = d.sharpening; g.timing = d.timing;
+                    PL_TRY(att_fwd_launch(g, st));
+                }
+            }
+        }
+        return 0;
+    }
+
+    int layer_bwd(int l, int t, hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        const int H = d.H, E = d.E;
+        GruStateBwdArgs ga;
+        ga.nchain = 1; ga.B = d.B; ga.H = H;
+        GruStateBwdChain& c = ga.chain[0];
+        c.dh = d.dh[l] + (t + 1) * BH;
+        c.hprev = d.h[l] + t * BH;
+        c.z = d.z[l] + t * BH;
+        c.c = d.c[l] + t * BH;
+        c.mask = nullptr;
+        c.dC = d.dC[l] + t * BH;
+        c.dG = d.dG[l] + t * 2 * BH;
+        c.dhprev = d.dh[l] + t * BH;
+        PL_TRY(gru_state_bwd_launch(ga, st));
+
+        // X: d(r*h_prev) = dC . Wc[0:H,:]^T ; epilogue -> dG_r, dh_prev += d(rh) * r
+        SkJob x;
+        sk_job_init(x);
+        x.nseg = 1;
+        x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+        x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
+        x.e0 = d.h[l] + t * BH; x.lde0 = H;
+        x.e1 = d.r[l] + t * BH; x.lde1 = H;
+        x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
+        x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
+        PL_TRY(launch_jobs(&x, 1, st));
+
+        // Y: gradients flowing to the layer's inputs, one job per destination.
+        SkJob y[4];
+        int n = 0;
+        const float* dG = d.dG[l] + t * 2 * BH;
+        const float* dC = d.dC[l] + t * BH;
+        {   // previous state of this layer: only the gate GEMM (rh part handled by X)
+            SkJob& j = y[n++];
+            sk_job_init(j);
+            j.nseg = 1;
+            j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+            j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+            j.out = d.dh[l] + t * BH; j.ldo = H;
+        }
+        {   // attention context
+            SkJob& j = y[n++];
+            sk_job_init(j);
+            j.nseg = 2;
+            j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
+            j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)H * H, H, H, 1);
+            j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+            j.out = d.dw + (size_t)(l == 0 ? t : t + 1) * BE; j.ldo = E;
+        }
+        for (int q = 0; q < l; ++q) {  // lower layers' states of the same step
+            SkJob& j = y[n++];
+            sk_job_init(j);
+            j.nseg = 2;
+            j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + q * H) * 2 * H, 2 * H, 2 * H, 1);
+            j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + q * H) * H, H, H, 1);
+            j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+            j.out = d.dh[q] + (t + 1) * BH; j.ldo = H;
+        }
+        return launch_jobs(y, n, st);
+    }
+
+    int bwd(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+        for (int t = d.T - 1; t >= 0; --t) {
+            for (int l = d.L - 1; l >= 1; --l) PL_TRY(layer_bwd(l, t, st));
+            AttBwdArgs g;
+            g.dw = d.dw + (t + 1) * BE; g.lddw = d.E;
+            g.ctx = d.ctx;
+            g.a = d.a + t * BA; g.b = d.b + t * BA;
+            g.kappa = d.kappa + (t + 1) * BA; g.kappa_prev = d.kappa + t * BA;
+            g.Watt = d.Watt;
+            g.dkappa = d.dkappa;
+            g.dp_out = d.dp + (size_t)t * d.B * 3 * d.A;
+            g.dh1 = d.dh[0] + (t + 1) * BH; g.lddh = d.H;
+            g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
+            PL_TRY(att_bwd_launch(g, st));
+            PL_TRY(layer_bwd(0, t, st));
+        }
+        return 0;
+    }
+};
+
+// ----------------------------------------------------------------------------- decoder (sampling)
+struct SamplePlan : PlanBase {
+    ParrotSampleDesc d;
+    int esplit = 1;
+
+    int enqueue(int, hipStream_t s) override { return run_all(s); }
+
+    void layer_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw, const float* Wf) const {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        const int nxt = (t + 1) & 1;
+        int n = 0;
+        j.seg[n++] = sk_seg(first, d.H, W, ldw, d.H, 0);
+        const float* wsrc = d.w + (size_t)(l == 0 ? t : t + 1) * BE;
+        j.seg[n++] = sk_seg(wsrc, d.E, W + (size_t)d.H * ldw, ldw, d.E, 0);
+        for (int q = 0; q < l; ++q)
+            j.seg[n++] = sk_seg(d.h[q] + nxt * BH, d.H, W + (size_t)(d.H + d.E + q * d.H) * ldw, ldw, d.H, 0);
+        if (Wf) j.seg[n++] = sk_seg(d.x + (size_t)t * d.B * d.ldx, d.ldx, Wf, ldw, d.O, 0);
+        j.nseg = n;
+    }
+
+    int run_all(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+        const int H = d.H;
+        for (int t = 0; t < d.S; ++t) {
+            const int cur = t & 1, nxt = (t + 1) & 1;
+            for (int l = 0; l < d.L; ++l) {
+                SkJob j;
+                sk_job_init(j);
+                layer_segs(j, l, t, d.h[l] + cur * BH, d.Wg[l], 2 * H, d.Wfg[l]);
+                j.M = d.B; j.N = 2 * H; j.H = H; j.epi = SK_EPI_GRU_GATES;
+                j.bias = d.bg[l];
+                j.add = d.seq_g[l]; j.ld_add = 2 * H;
+                j.e0 = d.h[l] + cur * BH; j.lde0 = H;
+                j.o1 = d.zwork; j.ldo1 = H;
+                j.o2 = d.rwork; j.ldo2 = H;
+                j.out = d.rhwork; j.ldo = H;
+                PL_TRY(launch_jobs(&j, 1, st));
+
+                sk_job_init(j);
+                layer_segs(j, l, t, d.rhwork, d.Wc[l], H, d.Wfc[l]);
+                j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_GRU_CAND;
+                j.bias = d.bc[l];
+                j.add = d.seq_c[l]; j.ld_add = H;
+                j.e0 = d.h[l] + cur * BH; j.lde0 = H;
+                j.e1 = d.zwork; j.lde1 = H;
+                j.o1 = nullptr;
+                j.out = d.h[l] + nxt * BH; j.ldo = H;
+                PL_TRY(launch_jobs(&j, 1, st));
+
+                if (l == 0) {
+                    AttFwdArgs g;
+                    g.h1 = d.h[0] + nxt * BH; g.ldh = H;
+                    g.Watt = d.Watt; g.batt = d.batt;
+                    g.kappa_prev = d.kappa + t * BA;
+                    g.ctx = d.ctx;
+                    g.a_out = d.a + t * BA; g.b_out = d.bwork; g.kappa_out = d.kappa + (t + 1) * BA;
+                    g.phi_out = d.phi + (size_t)t * d.B * d.U;
+                    g.w_out = d.w + (t + 1) * BE; g.ldw = d.E;
+                    g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = d.E; g.esplit = esplit;
+                    g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
+                    g.sharpening = d.sharpening; g.timing = d.timing;
+                    PL_TRY(att_fwd_launch(g, st));
+                }
+            }
+            // readouts (model.py:992-1006) and output (model.py:1008-1013)
+            SkJob j;
+            sk_job_init(j);
+            int n = 0;
+            for (int l = 0; l < d.L; ++l)
+                j.seg[n++] = sk_seg(d.h[l] + nxt * BH, H, d.Wr + (size_t)l * H * d.R, d.R, H, 0);
+            j.seg[n++] = sk_seg(d.w + (t + 1) * BE, d.E, d.Wr + (size_t)d.L * H * d.R, d.R, d.E, 0);
+            j.nseg = n;
+            j.M = d.B; j.N = d.R; j.H = H; j.epi = SK_EPI_LINEAR;
+            j.bias = d.br; j.add = d.radd; j.ld_add = d.R;
+            j.out = d.readout; j.ldo = d.R;
+            PL_TRY(launch_jobs(&j, 1, st));
+
+            sk_job_init(j);
+            j.nseg = 1;
+            j.seg[0] = sk_seg(d.readout, d.R, d.Wo, d.O, d.R, 0);
+            j.M = d.B; j.N = d.O; j.H = H; j.epi = SK_EPI_LINEAR;
+            j.bias = d.bo; j.add = d.oadd; j.ld_add = d.O;
+            j.out = d.x + (size_t)(t + 1) * d.B * d.ldx; j.ldo = d.ldx;
+            PL_TRY(launch_jobs(&j, 1, st));
+        }
+        return 0;
+    }
+};
+
+bool bad_dims(int L) { return L < 1 || L > PARROT_MAX_LAYERS; }
+
+}  // namespace
+
+extern "C" {
+
+int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan) {
+    if (!desc || !plan || desc->T < 1 || desc->B < 1 || desc->H < 1 || desc->nchain < 1 || desc->nchain > 4)
+        return PARROT_ERR_BADARG;
+    GruSeqPlan* p = new (std::nothrow) GruSeqPlan();
+    if (!p) return PARROT_ERR_BADARG;
+    p->d = *desc;
+    p->use_graph = desc->use_graph;
+    *plan = p;
+    return 0;
+}
+int parrot_gru_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_gru_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_gru_seq_destroy(void* plan) {
+    delete static_cast<PlanBase*>(plan);
+    return 0;
+}
+
+int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
+    if (!desc || !plan || desc->T < 1 || desc->B < 1 || bad_dims(desc->L)) return PARROT_ERR_BADARG;
+    DecoderPlan* p = new (std::nothrow) DecoderPlan();
+    if (!p) return PARROT_ERR_BADARG;
+    p->d = *desc;
+    p->use_graph = desc->use_graph;
+    p->esplit = att_default_esplit(desc->B, desc->E);
+    *plan = p;
+    return 0;
+}
+int parrot_decoder_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_decoder_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_decoder_destroy(void* plan) {
+    delete static_cast<PlanBase*>(plan);
+    return 0;
+}
+
+int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) {
+    if (!desc || !plan || desc->S < 1 || desc->B < 1 || bad_dims(desc->L) || desc->ldx < desc->O)
+        return PARROT_ERR_BADARG;
+    SamplePlan* p = new (std::nothrow) SamplePlan();
+    if (!p) return PARROT_ERR_BADARG;
+    p->d = *desc;
+    p->use_graph = desc->use_graph;
+    p->esplit = att_default_esplit(desc->B, desc->E);
+    *plan = p;
+    return 0;
+}
+int parrot_sample_run(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_sample_destroy(void* plan) {
+    delete static_cast<PlanBase*>(plan);
+    return 0;
+}
+
+int parrot_plan_last_error(void* plan) { return plan ? static_cast<PlanBase*>(plan)->last_error : PARROT_ERR_BADARG; }
+
+}  // extern "C"

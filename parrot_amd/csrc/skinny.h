@@ -1,0 +1,61 @@
+// Internal interface of the "skinny" recurrent-step GEMM: out[M<=64.., N] = sum over K-segments
+// of A_s[M,K_s] * B_s, with the GRU/LSTM gate math fused into the epilogue.
+//
+// This is the kernel that runs once per (layer, phase, timestep) inside the decoder scan, i.e. the
+// replacement for one Blocks GatedRecurrent.apply(..., iterate=False) call
+// (reference model.py:659-662, 707-710, 719-722) plus the Fork/Linear applies that feed it
+// (model.py:655, 692-700, 712).
+#pragma once
+#include "common.h"
+
+enum { SK_MAXSEG = 5, SK_MAXJOB = 4, SK_NW = 8, SK_THREADS = SK_NW * 64 };
+
+enum SkEpi {
+    SK_EPI_LINEAR = 0,     // out = act(acc + bias + add) (optionally accumulated into out)
+    SK_EPI_GRU_GATES = 1,  // N = 2H: z -> o1, r -> o2, r*h_prev -> out
+    SK_EPI_GRU_CAND = 2,   // N = H : c = tanh(pre) -> o1, h' = z*c + (1-z)*h_prev -> out
+    SK_EPI_BWD_RH = 3,     // N = H : acc = d(r*h_prev); writes dG_r and accumulates dh_prev
+    SK_EPI_LSTM = 4,       // N = 4H with gate-interleaved columns (see lstm notes in skinny.hip)
+};
+
+enum SkAct { SK_ACT_NONE = 0, SK_ACT_RELU = 1, SK_ACT_TANH = 2, SK_ACT_SIGMOID = 3 };
+
+struct SkSeg {
+    const float* A;  // [M, K] row-major, leading dimension lda (K contiguous)
+    const float* B;  // b_kcontig ? B[n * ldb + k] : B[k * ldb + n]
+    int lda, ldb, K, b_kcontig;
+};
+
+struct SkJob {
+    SkSeg seg[SK_MAXSEG];
+    int nseg, M, N, epi;
+    int act, accumulate, H, aligned;  // aligned: all segment pointers/strides allow 16-byte loads
+    const float* bias;  // [N] or null
+    const float* add;   // [M, N] additive pre-activation input or null
+    float* out;
+    const float* e0;  // epilogue input 0 (h_prev)
+    const float* e1;  // epilogue input 1 (z for CAND, r for BWD_RH, c_prev for LSTM)
+    float* o1;
+    float* o2;
+    const float* mask;  // [M] optional step mask (GRU_CAND): h' = m*h' + (1-m)*h_prev
+    int ld_add, ldo, lde0, lde1, ldo1, ldo2, pad0, pad1;
+};
+
+struct SkLaunch {
+    SkJob job[SK_MAXJOB];
+    int njobs;
+    int tile_end[SK_MAXJOB];  // exclusive prefix of 16-column tiles per job
+};
+
+// Enqueue one launch on `stream`. Returns hipError_t / PH_ERR_*.
+int sk_launch(const SkLaunch& L, hipStream_t stream);
+
+// Helpers to build jobs.
+static inline SkSeg sk_seg(const float* A, int lda, const float* B, int ldb, int K, int b_kcontig) {
+    SkSeg s;
+    s.A = A; s.B = B; s.lda = lda; s.ldb = ldb; s.K = K; s.b_kcontig = b_kcontig;
+    return s;
+}
+void sk_job_init(SkJob& j);
+void sk_finalize_job(SkJob& j);  // computes `aligned`
+int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs);

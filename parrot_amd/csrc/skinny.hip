@@ -1,0 +1,281 @@
+// Recurrent-step GEMM with fused gate epilogues, hand-written for gfx950 (CDNA4).
+//
+// Shape regime: M = batch rows of one timestep (<= 64 per workgroup row-chunk), N = 2H / H / 4H
+// gate columns, K = concatenation of up to four operand segments (previous state, attention
+// context w, lower-layer states, fed-back output frame).  Each weight element is used by only M
+// MACs, so the kernel is a weight-streaming kernel: weights go HBM/L2 -> VGPR exactly once per
+// launch, no LDS staging (nothing is shared between waves), f32 MFMA 16x16x4 does the math
+// (exact f32, the reference computes in floatX = float32, model.py:21).
+//
+// Decomposition (wave64, 8 waves = 512 threads per workgroup):
+//   * one workgroup owns a 64(M) x 16(N) output tile; grid.x enumerates the 16-column tiles of
+//     up to four independent jobs (e.g. the gate GEMMs of different layers), grid.y the 64-row
+//     chunks of the batch;
+//   * the K range is split round-robin in 16-deep chunks over the 8 waves (intra-workgroup
+//     split-K); every wave keeps MB (<=4) 16x16 accumulators = all 64 rows of the tile;
+//   * per chunk a lane (kk = lane>>4, i = lane&15) loads one 16-byte vector of A per 16-row block
+//     (row i, k = kc+4kk..+3) and the matching B values, then issues 4*MB MFMAs, using vector
+//     component u as the k = kc+4kk+u step.  Any bijection k <-> (step, kk) is legal because the
+//     MFMA sums over kk and we sum over steps;
+//   * partial tiles are reduced through LDS (32 KiB), then 256 threads run the fused epilogue:
+//     sigmoid / tanh / state blend of the GRU (Blocks GatedRecurrent; twin in
+//     sampleRNN/lib/ops.py:364-393), its backward counterpart, or the LSTM cell (ops.py:505-553).
+#include "skinny.h"
+
+#include <string.h>
+
+template <bool AL>
+__device__ __forceinline__ f32x4 ld4k(const float* __restrict__ p, int k, int K) {
+    // p already points at element k; returns elements k..k+3 with zero fill beyond K.
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (AL) {
+        if (k < K) v = *reinterpret_cast<const f32x4*>(p);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u < K) v[u] = p[u];
+    }
+    return v;
+}
+
+// Column mapping of MFMA column jj (0..15) of tile `tile` to a real output column.
+__device__ __forceinline__ int sk_col(int epi, int H, int tile, int jj) {
+    if (epi == SK_EPI_LSTM) return (jj >> 2) * H + tile * 4 + (jj & 3);  // gate-major columns
+    return tile * 16 + jj;
+}
+
+template <int MB, bool AL>
+__device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M, int ncol, bool ncol_ok,
+                                         int kk, int i, f32x4 (&a)[MB], f32x4& b) {
+    const int k = kc + 4 * kk;
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) {
+        const int m = m0 + rb * 16 + i;
+        a[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (m < M) a[rb] = ld4k<AL>(sg.A + (size_t)m * sg.lda + k, k, sg.K);
+    }
+    b = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ncol_ok) {
+        if (sg.b_kcontig) {
+            b = ld4k<AL>(sg.B + (size_t)ncol * sg.ldb + k, k, sg.K);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < sg.K) b[u] = sg.B[(size_t)(k + u) * sg.ldb + ncol];
+        }
+    }
+}
+
+template <int MB>
+__device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32x4 (&acc)[MB]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb)
+            acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[u], acc[rb], 0, 0, 0);
+}
+
+template <int MB, bool AL>
+__device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 4, i = lane & 15;
+    const int m0 = blockIdx.y * 64;
+    const int M = job.M, N = job.N;
+    if (m0 >= M) return;
+
+    const int ncol = sk_col(job.epi, job.H, tile, i);
+    const bool ncol_ok = ncol < N;
+
+    f32x4 acc[MB];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Round-robin 16-deep K chunks over the waves, across the concatenated segments.
+    int base = 0;
+    for (int s = 0; s < job.nseg; ++s) {
+        const SkSeg sg = job.seg[s];
+        const int nch = (sg.K + 15) >> 4;
+        int c = (wave - (base % SK_NW) + SK_NW) % SK_NW;
+        f32x4 a_cur[MB], b_cur;
+        if (c < nch) sk_fetch<MB, AL>(sg, c * 16, m0, M, ncol, ncol_ok, kk, i, a_cur, b_cur);
+        while (c < nch) {
+            const int cn = c + SK_NW;
+            f32x4 a_nxt[MB], b_nxt;
+            if (cn < nch) sk_fetch<MB, AL>(sg, cn * 16, m0, M, ncol, ncol_ok, kk, i, a_nxt, b_nxt);
+            sk_mma<MB>(a_cur, b_cur, acc);
+            if (cn < nch) {
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) a_cur[rb] = a_nxt[rb];
+                b_cur = b_nxt;
+            }
+            c = cn;
+        }
+        base += nch;
+    }
+
+    // Intra-workgroup split-K reduction through LDS.
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
+    __syncthreads();
+    if (tid >= MB * 64) return;
+    const int rb = tid >> 6;
+    f32x4 v = red[rb * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < SK_NW; ++w) v += red[(w * MB + rb) * 64 + lane];
+
+    // Fused epilogue.  MFMA C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg.
+    const int g = lane >> 4, jj = lane & 15;
+    const int n = sk_col(job.epi, job.H, tile, jj);
+    const bool n_ok = n < N;
+    const float bias = (job.bias && n_ok) ? job.bias[n] : 0.f;
+    const int H = job.H;
+
+    if (job.epi == SK_EPI_LSTM) {
+        // Gates of hidden unit j live in lanes jj = q*4 + (j&3), q = 0..3 (i, f, o, g order,
+        // ops.py:523-541).  Gather them with wave shuffles; lanes with q == 0 do the cell update.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + rb * 16 + 4 * g + r;
+            const bool ok = (m < M) && n_ok;
+            float pre = v[r] + bias;
+            if (job.add && ok) pre += job.add[(size_t)m * job.ld_add + n];
+            const int q = jj >> 2;
+            const float gate = (q == 3) ? tanhf(pre) : ph_sigmoid(pre);
+            if (job.o2 && ok) job.o2[(size_t)m * job.ldo2 + n] = gate;  // saved activations [M,4H]
+            const int src = (lane & ~12);
+            const float gi = __shfl(gate, src | 0, 64);
+            const float gf = __shfl(gate, src | 4, 64);
+            const float go = __shfl(gate, src | 8, 64);
+            const float gg = __shfl(gate, src | 12, 64);
+            if (q == 0 && ok) {
+                const int j = n;  // q == 0 -> n = hidden index
+                const float cp = job.e1[(size_t)m * job.lde1 + j];
+                const float cn = cp * gf + gg * gi;
+                job.o1[(size_t)m * job.ldo1 + j] = cn;
+                job.out[(size_t)m * job.ldo + j] = tanhf(cn) * go;
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + rb * 16 + 4 * g + r;
+        if (m >= M || !n_ok) continue;
+        float x = v[r];
+        switch (job.epi) {
+            case SK_EPI_LINEAR: {
+                x += bias;
+                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (job.act == SK_ACT_TANH) x = tanhf(x);
+                else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
+                float* o = job.out + (size_t)m * job.ldo + n;
+                if (job.accumulate) x += *o;
+                *o = x;
+            } break;
+            case SK_EPI_GRU_GATES: {
+                x += bias;
+                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                const float gt = ph_sigmoid(x);
+                if (n < H) {
+                    job.o1[(size_t)m * job.ldo1 + n] = gt;  // update gate z
+                } else {
+                    const int j = n - H;
+                    job.o2[(size_t)m * job.ldo2 + j] = gt;  // reset gate r
+                    job.out[(size_t)m * job.ldo + j] = gt * job.e0[(size_t)m * job.lde0 + j];
+                }
+            } break;
+            case SK_EPI_GRU_CAND: {
+                x += bias;
+                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                const float c = tanhf(x);
+                const float z = job.e1[(size_t)m * job.lde1 + n];
+                const float hp = job.e0[(size_t)m * job.lde0 + n];
+                float hn = z * c + (1.f - z) * hp;
+                if (job.mask) {
+                    const float mk = job.mask[m];
+                    hn = mk * hn + (1.f - mk) * hp;
+                }
+                if (job.o1) job.o1[(size_t)m * job.ldo1 + n] = c;
+                job.out[(size_t)m * job.ldo + n] = hn;
+            } break;
+            case SK_EPI_BWD_RH: {
+                // x = d(r*h_prev)[m][n]
+                const float r_ = job.e1[(size_t)m * job.lde1 + n];
+                const float hp = job.e0[(size_t)m * job.lde0 + n];
+                job.out[(size_t)m * job.ldo + n] = x * hp * r_ * (1.f - r_);  // dG_r
+                job.o1[(size_t)m * job.ldo1 + n] += x * r_;                   // dh_prev +=
+            } break;
+            default: break;
+        }
+    }
+}
+
+template <int MB>
+__global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);
+    const int bx = blockIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < SK_MAXJOB - 1; ++q)
+        if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
+    const int tile = bx - (j > 0 ? L.tile_end[j - 1] : 0);
+    const SkJob& job = L.job[j];
+    if (job.aligned) sk_body<MB, true>(job, tile, red);
+    else sk_body<MB, false>(job, tile, red);
+}
+
+void sk_job_init(SkJob& j) { memset(&j, 0, sizeof(j)); }
+
+void sk_finalize_job(SkJob& j) {
+    int al = 1;
+    for (int s = 0; s < j.nseg; ++s) {
+        const SkSeg& g = j.seg[s];
+        if (((uintptr_t)g.A & 15) || (g.lda & 3) || (g.K & 3)) al = 0;
+        if (g.b_kcontig && (((uintptr_t)g.B & 15) || (g.ldb & 3))) al = 0;
+    }
+    j.aligned = al;
+}
+
+int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
+    if (njobs < 1 || njobs > SK_MAXJOB) return PH_ERR_BADARG;
+    memset(&L, 0, sizeof(L));
+    int t = 0;
+    for (int q = 0; q < njobs; ++q) {
+        L.job[q] = jobs[q];
+        sk_finalize_job(L.job[q]);
+        const SkJob& j = L.job[q];
+        if (j.nseg < 1 || j.nseg > SK_MAXSEG || j.M < 1 || j.N < 1) return PH_ERR_BADARG;
+        int tiles;
+        if (j.epi == SK_EPI_LSTM) {
+            if (j.N != 4 * j.H || (j.H & 3)) return PH_ERR_BADARG;
+            tiles = j.H / 4;
+        } else {
+            tiles = ceil_div(j.N, 16);
+        }
+        t += tiles;
+        L.tile_end[q] = t;
+    }
+    L.njobs = njobs;
+    return 0;
+}
+
+int sk_launch(const SkLaunch& L, hipStream_t stream) {
+    int maxM = 0;
+    for (int q = 0; q < L.njobs; ++q) maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
+    const int tiles = L.tile_end[L.njobs - 1];
+    const int mb = maxM >= 49 ? 4 : (maxM + 15) / 16;
+    dim3 grid(tiles, ceil_div(maxM, 64));
+    const size_t lds = (size_t)SK_NW * mb * 64 * sizeof(f32x4);
+    switch (mb) {
+        case 1: hipLaunchKernelGGL(sk_kernel<1>, grid, dim3(SK_THREADS), lds, stream, L); break;
+        case 2: hipLaunchKernelGGL(sk_kernel<2>, grid, dim3(SK_THREADS), lds, stream, L); break;
+        case 3: hipLaunchKernelGGL(sk_kernel<3>, grid, dim3(SK_THREADS), lds, stream, L); break;
+        default: hipLaunchKernelGGL(sk_kernel<4>, grid, dim3(SK_THREADS), lds, stream, L); break;
+    }
+    return (int)hipGetLastError();
+}
