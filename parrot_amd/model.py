@@ -1,0 +1,864 @@
+"""Parrot: the attention-GRU encoder-decoder that emits vocoder feature frames.
+
+Host-side mirror of reference model.py (``Parrot``, ``Encoder``, ``RecurrentWithFork``) with the
+same constructor keywords, method names and return conventions (model.py:250-277, 508-554,
+1061-1083).  Where the reference builds a Theano graph and lets Blocks/Theano run it, this class
+drives the HIP library directly:
+
+  * ``compute_cost``    -> encoder GRU scan plan + batched MFMA GEMMs + decoder scan plan
+                           (parrot_decoder_seq_fwd/bwd, include/parrot_hip.h) + masked cost;
+                           the returned cost is a torch scalar whose ``backward()`` runs the
+                           hand-written reverse pass and fills the flat gradient buffer;
+  * ``sample_model``    -> parrot_sample_run (whole autoregressive loop in one hipGraph);
+  * parameters          -> one flat float32 buffer, exposed under the Blocks brick paths
+                           (``/parrot/rnn1.state_to_state`` ...) as views.
+
+Generalisations beyond the reference (flagged in SURVEY.md 8a): ``num_layers`` in {1,2,3} (the
+reference hard-wires 3) and ``encoder_literal`` (True reproduces the reference's encoder scan over
+the batch axis).  Not built yet on the HIP path and therefore rejected loudly: ``layer_norm=True``,
+GMM *sampling*, ``raw_output=True`` inside compute_cost (the SampleRNN head is driven separately).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy
+import torch
+
+from . import _lib, ops
+from .bricks import Brick, Constant, IsotropicGaussian
+from .params import ParamStore
+
+floatX = "float32"
+
+
+def _simple_norm(x, eps=1e-5):
+    """model.py:24-27."""
+    return (x - x.mean(-1, keepdim=True)) / (eps + x.std(-1, unbiased=False, keepdim=True))
+
+
+def logsumexp(x, axis=None):
+    """model.py:37-41."""
+    x_max = x.max(axis, keepdim=True)[0]
+    z = torch.log(torch.exp(x - x_max).sum(axis, keepdim=True)) + x_max
+    return z.sum(axis)
+
+
+def cost_gmm(y, mu, sig, weight):
+    """model.py:65-91 (Gaussian-mixture negative log-likelihood)."""
+    shape_y = y.shape
+    k = weight.shape[-1]
+    y2 = y.reshape(-1, shape_y[-1])[..., None]
+    mu = mu.reshape(-1, shape_y[-1], k)
+    sig = sig.reshape(-1, shape_y[-1], k)
+    weight = weight.reshape(-1, k)
+    inner = -0.5 * ((y2 - mu) ** 2 / sig ** 2 + 2 * torch.log(sig) + float(numpy.log(2 * numpy.pi))).sum(-2)
+    nll = -logsumexp(torch.log(weight) + inner, -1)
+    return nll.reshape(shape_y[:-1])
+
+
+class _CostFn(torch.autograd.Function):
+    """Ties the hand-written backward pass of one compute_cost call to ``cost.backward()``."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, token, cost_value):
+        ctx.engine, ctx.token = engine, token
+        return cost_value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.engine._backward(ctx.token, g)
+        return None, None, None, None
+
+
+class Parrot(Brick):
+    def __init__(
+            self,
+            input_dim=420, output_dim=63, rnn_h_dim=1024, readouts_dim=1024,
+            weak_feedback=False, full_feedback=False, feedback_noise_level=None,
+            layer_norm=False, use_speaker=False, num_speakers=21, speaker_dim=128,
+            which_cost='MSE', k_gmm=20, sampling_bias=0, epsilon=1e-5, num_characters=43,
+            attention_type='graves', attention_size=10, attention_alignment=1.,
+            sharpening_coeff=1., timing_coeff=1., encoder_type=None, encoder_dim=128,
+            raw_output=False,
+            # --- extensions (not in the reference) ---
+            num_layers=3, encoder_literal=True, use_graph=True, seed=1234,
+            **kwargs):
+        kwargs.setdefault('name', 'parrot')
+        kwargs.setdefault('weights_init', IsotropicGaussian(0.01))  # train.py:30
+        kwargs.setdefault('biases_init', Constant(0.))              # train.py:31
+        super().__init__(seed=seed, **kwargs)
+        assert which_cost in ('MSE', 'GMM')
+        assert attention_type in ('graves', 'softmax')
+        assert encoder_type in (None, 'bidirectional')  # model.py:209
+        assert 1 <= num_layers <= _lib.MAX_LAYERS
+        if layer_norm:
+            raise NotImplementedError(
+                "layer_norm=True (model.py:24-34) is not built on the HIP path yet")
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.rnn_h_dim, self.readouts_dim = rnn_h_dim, readouts_dim
+        self.layer_norm, self.which_cost, self.use_speaker = layer_norm, which_cost, use_speaker
+        self.full_feedback = full_feedback
+        self.weak_feedback = bool(weak_feedback or full_feedback)  # model.py:485
+        self.feedback_noise_level = feedback_noise_level
+        self.epsilon = epsilon
+        self.num_characters, self.attention_type = num_characters, attention_type
+        self.attention_alignment, self.attention_size = attention_alignment, attention_size
+        self.sharpening_coeff, self.timing_coeff = sharpening_coeff, timing_coeff
+        self.encoder_type, self.encoder_dim = encoder_type, encoder_dim
+        self.encoded_input_dim = 2 * encoder_dim if encoder_type == 'bidirectional' else input_dim
+        self.raw_output = raw_output
+        self.num_speakers, self.speaker_dim = num_speakers, speaker_dim
+        self.k_gmm, self.sampling_bias = k_gmm, sampling_bias
+        self.num_layers, self.encoder_literal, self.use_graph = num_layers, encoder_literal, use_graph
+
+        self.store = ParamStore()
+        self._declare_parameters()
+        self._allocated = False
+        self._train_ws = {}
+        self._sample_ws = {}
+        self._carry = {}
+        self._token = 0
+        self._saved = None
+        if raw_output:
+            from .sampleRNN.models.conditional import three_tier  # noqa: F401  (import check only)
+            self.sampleRnn = SampleRnn(name='samplernn', device=self.device)
+
+    # ------------------------------------------------------------------ parameters
+    def _declare_parameters(self):
+        s = self.store
+        H, R, O, E = self.rnn_h_dim, self.readouts_dim, self.output_dim, self.encoded_input_dim
+        A, L = self.attention_size, self.num_layers
+        P = '/' + self.name
+
+        def fork_separate(name, din, outs):
+            for on, od in outs:
+                s.add(f'{P}/{name}/fork_{on}.W', (din, od), 'weight')
+                s.add(f'{P}/{name}/fork_{on}.b', (od,), 'bias')
+
+        if self.encoder_type == 'bidirectional':
+            D, ED = self.input_dim, self.encoder_dim
+            s.add(f'{P}/encoder/embed_label.W', (self.num_characters, D), 'weight')
+            for d in ('forward', 'backward'):
+                q = f'{P}/encoder/encoder/{d}'
+                s.add(f'{q}/fork/fork_inputs.W', (D, ED), 'weight')
+                s.add(f'{q}/fork/fork_inputs.b', (ED,), 'bias')
+                s.add(f'{q}/fork/fork_gate_inputs.W', (D, 2 * ED), 'weight')
+                s.add(f'{q}/fork/fork_gate_inputs.b', (2 * ED,), 'bias')
+                s.add(f'{q}/gatedrecurrent.state_to_state', (ED, ED), 'weight')
+                s.add(f'{q}/gatedrecurrent.state_to_gates', (ED, 2 * ED), 'weight')
+                s.add(f'{q}/gatedrecurrent.initial_state', (ED,), 'initial_state')
+        # decoder layers: packed [h_l ; w ; h_1..h_{l-1}] weight matrices (include/parrot_hip.h)
+        for l in range(1, L + 1):
+            K = H + E + (l - 1) * H
+            s.add(f'dec.Wg{l}', (K, 2 * H), 'weight', alias=False)
+            s.add(f'dec.Wc{l}', (K, H), 'weight', alias=False)
+            s.alias(f'{P}/rnn{l}.state_to_state', f'dec.Wc{l}', rows=(0, H))
+            s.alias(f'{P}/rnn{l}.state_to_gates', f'dec.Wg{l}', rows=(0, H))
+            s.add(f'{P}/rnn{l}.initial_state', (H,), 'initial_state')
+            s.alias(f'{P}/inp_to_h{l}/fork_rnn{l}_inputs.W', f'dec.Wc{l}', rows=(H, H + E))
+            s.add(f'{P}/inp_to_h{l}/fork_rnn{l}_inputs.b', (H,), 'bias')
+            s.alias(f'{P}/inp_to_h{l}/fork_rnn{l}_gates.W', f'dec.Wg{l}', rows=(H, H + E))
+            s.add(f'{P}/inp_to_h{l}/fork_rnn{l}_gates.b', (2 * H,), 'bias')
+            for j in range(1, l):
+                r0 = H + E + (j - 1) * H
+                s.alias(f'{P}/h{j}_to_h{l}/fork_rnn{l}_inputs.W', f'dec.Wc{l}', rows=(r0, r0 + H))
+                s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_inputs.b', (H,), 'bias')
+                s.alias(f'{P}/h{j}_to_h{l}/fork_rnn{l}_gates.W', f'dec.Wg{l}', rows=(r0, r0 + H))
+                s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_gates.b', (2 * H,), 'bias')
+        s.add('dec.Watt', (H, 3 * A), 'weight', alias=False)
+        s.add('dec.batt', (3 * A,), 'bias', alias=False)
+        for i, n in enumerate(('alpha', 'beta', 'kappa')):
+            s.alias(f'{P}/h1_to_att/fork_{n}.W', 'dec.Watt', cols=(i * A, (i + 1) * A))
+            s.alias(f'{P}/h1_to_att/fork_{n}.b', 'dec.batt', rows=(i * A, (i + 1) * A), role='bias')
+        s.add('dec.Wr', (L * H + E, R), 'weight', alias=False)
+        for l in range(1, L + 1):
+            s.alias(f'{P}/h{l}_to_readout.W', 'dec.Wr', rows=((l - 1) * H, l * H))
+            s.add(f'{P}/h{l}_to_readout.b', (R,), 'bias')
+        s.alias(f'{P}/att_to_readout.W', 'dec.Wr', rows=(L * H, L * H + E))
+        s.add(f'{P}/att_to_readout.b', (R,), 'bias')
+        if self.which_cost == 'MSE':
+            s.add(f'{P}/readout_to_output.W', (R, O), 'weight')
+            s.add(f'{P}/readout_to_output.b', (O,), 'bias')
+            self._out_names = [(f'{P}/readout_to_output.W', f'{P}/readout_to_output.b', O)]
+        else:
+            K = self.k_gmm
+            fork_separate('readout_to_output', R, [('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K)])
+            self._out_names = [(f'{P}/readout_to_output/fork_{n}.W', f'{P}/readout_to_output/fork_{n}.b', d)
+                               for n, d in (('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K))]
+        if self.use_speaker:
+            SD = self.speaker_dim
+            s.add(f'{P}/lookuptable.W', (self.num_speakers, SD), 'weight')  # sample.py:83
+            for l in range(1, L + 1):
+                fork_separate(f'speaker_to_h{l}', SD, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+            s.add(f'{P}/speaker_to_readout.W', (SD, R), 'weight')
+            s.add(f'{P}/speaker_to_readout.b', (R,), 'bias')
+            if self.which_cost == 'MSE':
+                s.add(f'{P}/speaker_to_output.W', (SD, O), 'weight')
+                s.add(f'{P}/speaker_to_output.b', (O,), 'bias')
+                self._spk_out_names = [(f'{P}/speaker_to_output.W', f'{P}/speaker_to_output.b', O)]
+            else:
+                K = self.k_gmm
+                fork_separate('speaker_to_output', SD,
+                              [('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K)])
+                self._spk_out_names = [
+                    (f'{P}/speaker_to_output/fork_{n}.W', f'{P}/speaker_to_output/fork_{n}.b', d)
+                    for n, d in (('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K))]
+        self._fb_layers = []
+        if self.weak_feedback:
+            self._fb_layers = [1]
+        if self.full_feedback:
+            self._fb_layers = list(range(1, L + 1))
+        for l in self._fb_layers:
+            fork_separate(f'out_to_h{l}', O, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+        s.add(f'{P}.initial_w', (E,), 'initial_state')
+
+    def allocate(self):
+        if not self._allocated:
+            self.store.allocate(self._dev())
+            self._allocated = True
+        return self
+
+    def initialize(self, gen=None):
+        """Initializable.initialize (train.py:79-80): weights ~ weights_init, biases ~ biases_init,
+        initial states zero (model.py:502-506)."""
+        self.allocate()
+        if gen is None:
+            gen = torch.Generator().manual_seed(int(self.seed))
+        with torch.no_grad():
+            for name in self.store.names():
+                t = self.store.param(name)
+                role = self.store.role(name)
+                if role == 'weight':
+                    t.copy_(self.weights_init.generate(gen, tuple(t.shape)).to(t.device))
+                elif role == 'bias':
+                    t.copy_(self.biases_init.generate(gen, tuple(t.shape)).to(t.device))
+                else:
+                    t.zero_()
+        self.initialized = True
+        return self
+
+    # Blocks Model-like accessors -------------------------------------------------
+    def get_parameter_dict(self, prefix=""):
+        self.allocate()
+        return self.store.named_parameters()
+
+    def get_parameter_values(self):
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.get_parameter_dict().items())
+
+    def set_parameter_values(self, values):
+        """Model.set_parameter_values (sample.py:127): name -> ndarray / tensor."""
+        self.allocate()
+        with torch.no_grad():
+            for k, v in values.items():
+                if k not in self.store._aliases:
+                    raise KeyError(f'unknown parameter {k}')
+                t = self.store.param(k)
+                v = torch.as_tensor(numpy.asarray(v) if not isinstance(v, torch.Tensor) else v)
+                if tuple(v.shape) != tuple(t.shape):
+                    raise ValueError(f'{k}: shape {tuple(v.shape)} != {tuple(t.shape)}')
+                t.copy_(v.to(t.device, torch.float32))
+
+    def get_gradient_dict(self):
+        return self.store.named_gradients()
+
+    @property
+    def flat_parameters(self):
+        return self.allocate().store.flat
+
+    @property
+    def flat_gradients(self):
+        return self.allocate().store.flat_grad
+
+    def zero_grad(self):
+        self.store.zero_grad()
+
+    def _p(self, short):
+        return self.store.param(f'/{self.name}{short}')
+
+    def _g(self, short):
+        return self.store.grad(f'/{self.name}{short}')
+
+    # ------------------------------------------------------------------ reference surface
+    def symbolic_input_variables(self):
+        """model.py:508-527.  There is no symbolic graph here; the names are returned in the
+        reference order so callers can bind batch sources by name (Blocks does, model.py:509-522)."""
+        speaker = 'speaker_index' if self.use_speaker else None
+        raw = 'raw_audio' if self.raw_output else None
+        return 'features', 'features_mask', 'labels', 'labels_mask', speaker, 'start_flag', raw
+
+    def initial_states(self, batch_size):
+        """model.py:529-549: (initial_h1, last_h1, ..., initial_w, last_w, initial_k, last_k).
+        For num_layers < 3 the missing layers are returned as None."""
+        dev = self._dev()
+        f = dict(device=dev, dtype=torch.float32)
+        out = []
+        carry = self._get_carry(batch_size)
+        for l in range(1, 4):
+            if l <= self.num_layers:
+                out += [self._p(f'/rnn{l}.initial_state').unsqueeze(0).expand(batch_size, -1), carry['h'][l - 1]]
+            else:
+                out += [None, None]
+        out += [self._p('.initial_w').unsqueeze(0).expand(batch_size, -1), carry['w'],
+                torch.zeros(batch_size, self.attention_size, **f), carry['k']]
+        return tuple(out)
+
+    def _get_carry(self, B):
+        c = self._carry.get(B)
+        if c is None:
+            f = dict(device=self._dev(), dtype=torch.float32)
+            c = dict(h=[torch.zeros(B, self.rnn_h_dim, **f) for _ in range(self.num_layers)],
+                     w=torch.zeros(B, self.encoded_input_dim, **f),
+                     k=torch.zeros(B, self.attention_size, **f))
+            self._carry[B] = c
+        return c
+
+    def apply_updates(self, updates):
+        """Applies the (shared variable, new value) pairs compute_cost returns -- what Blocks'
+        GradientDescent.add_updates(extra_updates) did implicitly (train.py:108, model.py:786-791)."""
+        with torch.no_grad():
+            for dst, src in updates:
+                dst.copy_(src)
+
+    # ------------------------------------------------------------------ encoder
+    def _encoder_dims(self, B, U):
+        return (B, U) if self.encoder_literal else (U, B)
+
+    def _enc_runner(self, B, U):
+        key = ('enc', B, U)
+        ws = self._train_ws.get(key)
+        if ws is None:
+            Te, Be = self._encoder_dims(B, U)
+            run = ops.GruSeqRunner(Te, Be, self.encoder_dim, 2, [0, 1], self._dev(), use_graph=self.use_graph)
+            ws = dict(run=run)
+            self._train_ws[key] = ws
+        return ws
+
+    def _encoder_forward(self, labels, labels_mask, save):
+        """Encoder.apply (model.py:233-247) * labels_mask (model.py:645-646)."""
+        if self.encoder_type is None:
+            ctx = labels.to(torch.float32) * labels_mask[..., None]
+            return ctx.contiguous()
+        B, U = labels.shape
+        P = '/encoder/encoder'
+        emb = self._p('/encoder/embed_label.W')[labels.long()]  # LookupTable gather [B,U,D]
+        x = emb if self.encoder_literal else emb.transpose(0, 1)
+        x = x.contiguous()
+        Te, Be, D = x.shape
+        ws = self._enc_runner(B, U)
+        run = ws['run']
+        x2 = x.reshape(Te * Be, D)
+        Wg, Wc = [], []
+        for i, d in enumerate(('forward', 'backward')):
+            ops.gemm(x2, self._p(f'{P}/{d}/fork/fork_inputs.W'), bias=self._p(f'{P}/{d}/fork/fork_inputs.b'),
+                     out=run.inputs[i].view(Te * Be, -1))
+            ops.gemm(x2, self._p(f'{P}/{d}/fork/fork_gate_inputs.W'),
+                     bias=self._p(f'{P}/{d}/fork/fork_gate_inputs.b'), out=run.gate_inputs[i].view(Te * Be, -1))
+            run.h[i][0].copy_(self._p(f'{P}/{d}/gatedrecurrent.initial_state').unsqueeze(0).expand(Be, -1))
+            Wg.append(self._p(f'{P}/{d}/gatedrecurrent.state_to_gates'))
+            Wc.append(self._p(f'{P}/{d}/gatedrecurrent.state_to_state'))
+        run.bind(Wg, Wc)
+        run.forward()
+        out = torch.cat([run.h[0][1:], run.h[1][1:].flip(0)], dim=-1)  # [Te,Be,2*enc]
+        if not self.encoder_literal:
+            out = out.transpose(0, 1)
+        ctx = (out * labels_mask[..., None]).contiguous()
+        if save is not None:
+            save.update(enc_x2=x2, enc_labels=labels, enc_mask=labels_mask)
+        return ctx
+
+    def _encoder_backward(self, dctx, save):
+        if self.encoder_type is None:
+            return
+        labels, mask, x2 = save['enc_labels'], save['enc_mask'], save['enc_x2']
+        B, U = labels.shape
+        P = '/encoder/encoder'
+        ED = self.encoder_dim
+        run = self._enc_runner(B, U)['run']
+        Te, Be = run.T, run.B
+        d_out = dctx * mask[..., None]
+        if not self.encoder_literal:
+            d_out = d_out.transpose(0, 1)
+        for i in range(2):
+            run.dh[i].zero_()
+        run.dh[0][1:].copy_(d_out[..., :ED])
+        run.dh[1][1:].copy_(d_out[..., ED:].flip(0))
+        run.backward()
+        dx = torch.zeros_like(x2)
+        for i, d in enumerate(('forward', 'backward')):
+            dC = run.dC[i].view(Te * Be, ED)
+            dG = run.dG[i].view(Te * Be, 2 * ED)
+            hprev = run.h[i][:Te] if i == 0 else run.h[i][:Te].flip(0)
+            hprev = hprev.reshape(Te * Be, ED)
+            ops.gemm(x2.t(), dC, out=self._g(f'{P}/{d}/fork/fork_inputs.W'), accumulate=True)
+            ops.gemm(x2.t(), dG, out=self._g(f'{P}/{d}/fork/fork_gate_inputs.W'), accumulate=True)
+            ops.colsum(dC, out=self._g(f'{P}/{d}/fork/fork_inputs.b'), accumulate=True)
+            ops.colsum(dG, out=self._g(f'{P}/{d}/fork/fork_gate_inputs.b'), accumulate=True)
+            ops.gemm(run.rh[i].view(Te * Be, ED).t(), dC,
+                     out=self._g(f'{P}/{d}/gatedrecurrent.state_to_state'), accumulate=True)
+            ops.gemm(hprev.t(), dG, out=self._g(f'{P}/{d}/gatedrecurrent.state_to_gates'), accumulate=True)
+            ops.colsum(run.dh[i][0], out=self._g(f'{P}/{d}/gatedrecurrent.initial_state'), accumulate=True)
+            ops.gemm(dC, self._p(f'{P}/{d}/fork/fork_inputs.W').t(), out=dx, accumulate=True)
+            ops.gemm(dG, self._p(f'{P}/{d}/fork/fork_gate_inputs.W').t(), out=dx, accumulate=True)
+        demb = dx.view(Te, Be, -1)
+        if not self.encoder_literal:
+            demb = demb.transpose(0, 1)
+        self._g('/encoder/embed_label.W').index_add_(0, labels.long().reshape(-1),
+                                                     demb.reshape(-1, demb.shape[-1]))
+
+    # ------------------------------------------------------------------ training workspace
+    def _train_workspace(self, T, B, U):
+        key = ('dec', T, B, U)
+        ws = self._train_ws.get(key)
+        if ws is not None:
+            return ws
+        H, E, A, L, R = self.rnn_h_dim, self.encoded_input_dim, self.attention_size, self.num_layers, self.readouts_dim
+        f = dict(device=self._dev(), dtype=torch.float32)
+        ws = dict(
+            h=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
+            w=torch.zeros(T + 1, B, E, **f), kappa=torch.zeros(T + 1, B, A, **f),
+            z=[torch.empty(T, B, H, **f) for _ in range(L)], r=[torch.empty(T, B, H, **f) for _ in range(L)],
+            rh=[torch.empty(T, B, H, **f) for _ in range(L)], c=[torch.empty(T, B, H, **f) for _ in range(L)],
+            a=torch.empty(T, B, A, **f), b=torch.empty(T, B, A, **f), phi=torch.empty(T, B, U, **f),
+            dh=[torch.zeros(T + 1, B, H, **f) for _ in range(L)], dw=torch.zeros(T + 1, B, E, **f),
+            dkappa=torch.zeros(B, A, **f),
+            dG=[torch.empty(T, B, 2 * H, **f) for _ in range(L)], dC=[torch.empty(T, B, H, **f) for _ in range(L)],
+            dp=torch.empty(T, B, 3 * A, **f),
+            ctx=torch.zeros(B, U, E, **f),
+            bg=[torch.zeros(2 * H, **f) for _ in range(L)], bc=[torch.zeros(H, **f) for _ in range(L)],
+            readouts=torch.empty(T * B, R, **f),
+        )
+        ws['seq_c'] = [None] * L
+        ws['seq_g'] = [None] * L
+        for l in range(1, L + 1):
+            if l in self._fb_layers or self.use_speaker:
+                ws['seq_c'][l - 1] = torch.zeros(T, B, H, **f)
+                ws['seq_g'][l - 1] = torch.zeros(T, B, 2 * H, **f)
+        d = _lib.DecoderDesc()
+        d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, L
+        d.att_type = 1 if self.attention_type == 'softmax' else 0
+        d.use_graph = int(self.use_graph)
+        d.eps, d.alignment, d.sharpening, d.timing = self.epsilon, self.attention_alignment, 1.0, 1.0
+        st = self.store.storage
+        for l in range(L):
+            d.Wg[l], d.Wc[l] = st[f'dec.Wg{l + 1}'].data_ptr(), st[f'dec.Wc{l + 1}'].data_ptr()
+            d.bg[l], d.bc[l] = ws['bg'][l].data_ptr(), ws['bc'][l].data_ptr()
+            d.seq_c[l] = ws['seq_c'][l].data_ptr() if ws['seq_c'][l] is not None else None
+            d.seq_g[l] = ws['seq_g'][l].data_ptr() if ws['seq_g'][l] is not None else None
+            for n in ('h', 'z', 'r', 'rh', 'c', 'dh', 'dG', 'dC'):
+                getattr(d, n)[l] = ws[n][l].data_ptr()
+        d.Watt, d.batt, d.ctx = st['dec.Watt'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
+        for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dkappa', 'dp'):
+            setattr(d, n, ws[n].data_ptr())
+        plan = C.c_void_p()
+        _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
+        ws['plan'], ws['desc'] = plan, d
+        self._train_ws[key] = ws
+        return ws
+
+    def _layer_bias_names(self, l):
+        """Names of the bias parameters that add into layer l's pre-activations (cell, gates)."""
+        names = [(f'/inp_to_h{l}/fork_rnn{l}_inputs.b', f'/inp_to_h{l}/fork_rnn{l}_gates.b')]
+        for j in range(1, l):
+            names.append((f'/h{j}_to_h{l}/fork_rnn{l}_inputs.b', f'/h{j}_to_h{l}/fork_rnn{l}_gates.b'))
+        return names
+
+    # ------------------------------------------------------------------ compute_cost
+    def compute_cost(self, features, features_mask, labels, labels_mask, speaker, start_flag,
+                     batch_size, raw_audio=None, feedback_noise=None):
+        """Parrot.compute_cost (model.py:551-824).
+
+        features [T+1,B,O], features_mask [T+1,B] (time-major), labels [B,U] int, labels_mask [B,U],
+        speaker [B,1] int or None, start_flag 0/1.  Returns (cost, updates, attention_vars, cost_raw)
+        like the reference; ``cost.backward()`` fills ``flat_gradients`` (accumulating), and
+        ``apply_updates(updates)`` carries the final scan state into the next TBPTT window."""
+        self.allocate()
+        if speaker is None:
+            assert not self.use_speaker  # model.py:556-557
+        if self.raw_output or raw_audio is not None:
+            raise NotImplementedError("raw_output inside compute_cost: drive SampleRnn separately")
+        dev = self._dev()
+        features = features.to(dev, torch.float32)
+        features_mask = features_mask.to(dev, torch.float32)
+        labels_mask = labels_mask.to(dev, torch.float32)
+        labels = labels.to(dev)
+        target = features[1:]
+        mask = features_mask[1:].contiguous()
+        T, B = mask.shape
+        assert B == batch_size
+        U = labels.shape[1]
+        H, E, L, R, O = self.rnn_h_dim, self.encoded_input_dim, self.num_layers, self.readouts_dim, self.output_dim
+        ws = self._train_workspace(T, B, U)
+        save = dict(T=T, B=B, U=U, ws=ws, start_flag=int(bool(start_flag)))
+
+        # --- per-step additive inputs: feedback (model.py:571-603) and speaker (model.py:605-627)
+        inp = None
+        if self.weak_feedback:
+            inp = features[:-1]
+            if self.feedback_noise_level:
+                if feedback_noise is None:
+                    feedback_noise = self.feedback_noise_level * torch.randn_like(inp)
+                inp = inp + feedback_noise
+            inp = inp.reshape(T * B, O).contiguous()
+            save['fb_inp'] = inp
+        emb_spk = None
+        if self.use_speaker:
+            emb_spk = self._p('/lookuptable.W')[speaker[:, 0].long()].contiguous()  # [B,SD]
+            save['spk_idx'], save['emb_spk'] = speaker[:, 0].long(), emb_spk
+        for l in range(1, L + 1):
+            sc, sg = ws['seq_c'][l - 1], ws['seq_g'][l - 1]
+            if sc is None:
+                continue
+            have = False
+            if l in self._fb_layers:
+                ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_inputs.W'),
+                         bias=self._p(f'/out_to_h{l}/fork_rnn{l}_inputs.b'), out=sc.view(T * B, H))
+                ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_gates.W'),
+                         bias=self._p(f'/out_to_h{l}/fork_rnn{l}_gates.b'), out=sg.view(T * B, 2 * H))
+                have = True
+            if self.use_speaker:
+                spc = ops.gemm(emb_spk, self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.W'),
+                               bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.b'))
+                spg = ops.gemm(emb_spk, self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.W'),
+                               bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.b'))
+                if have:
+                    sc.add_(spc.unsqueeze(0)); sg.add_(spg.unsqueeze(0))
+                else:
+                    sc.copy_(spc.unsqueeze(0).expand(T, -1, -1)); sg.copy_(spg.unsqueeze(0).expand(T, -1, -1))
+
+        # --- initial state of the window (model.py:629-643)
+        carry = self._get_carry(B)
+        for l in range(L):
+            if start_flag:
+                ws['h'][l][0].copy_(self._p(f'/rnn{l + 1}.initial_state').unsqueeze(0).expand(B, -1))
+            else:
+                ws['h'][l][0].copy_(carry['h'][l])
+        if start_flag:
+            ws['w'][0].copy_(self._p('.initial_w').unsqueeze(0).expand(B, -1))
+            ws['kappa'][0].zero_()
+        else:
+            ws['w'][0].copy_(carry['w'])
+            ws['kappa'][0].copy_(carry['k'])
+
+        # --- encoder (model.py:645-646) and summed layer biases
+        ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, save))
+        for l in range(1, L + 1):
+            bc, bg = ws['bc'][l - 1], ws['bg'][l - 1]
+            bc.zero_(); bg.zero_()
+            for nc, ng in self._layer_bias_names(l):
+                bc.add_(self._p(nc)); bg.add_(self._p(ng))
+
+        # --- the scan (model.py:651-737)
+        _lib.call('parrot_decoder_seq_fwd', ws['plan'], ops._stream())
+
+        # --- readouts and output (model.py:739-755)
+        readouts = ws['readouts']
+        Wr = self.store.storage['dec.Wr']
+        rb = self._p('/att_to_readout.b').clone()
+        for l in range(1, L + 1):
+            rb.add_(self._p(f'/h{l}_to_readout.b'))
+        ops.gemm(ws['h'][0][1:].view(T * B, H), Wr[0:H], bias=rb, out=readouts)
+        for l in range(1, L):
+            ops.gemm(ws['h'][l][1:].view(T * B, H), Wr[l * H:(l + 1) * H], out=readouts, accumulate=True)
+        ops.gemm(ws['w'][1:].view(T * B, E), Wr[L * H:], out=readouts, accumulate=True)
+        if self.use_speaker:
+            spr = ops.gemm(emb_spk, self._p('/speaker_to_readout.W'), bias=self._p('/speaker_to_readout.b'))
+            readouts.view(T, B, R).add_(spr.unsqueeze(0))
+        preds = []
+        for i, (wn, bn, dim) in enumerate(self._out_names):
+            pr = ops.gemm(readouts, self.store.param(wn), bias=self.store.param(bn)).view(T, B, dim)
+            if self.use_speaker:
+                swn, sbn, _ = self._spk_out_names[i]
+                pr.add_(ops.gemm(emb_spk, self.store.param(swn), bias=self.store.param(sbn)).unsqueeze(0))
+            preds.append(pr)
+
+        # --- masked cost (model.py:757-784); small [T,B,O] elementwise math with local autograd
+        leafs = [p.detach().requires_grad_(True) for p in preds]
+        with torch.enable_grad():
+            if self.which_cost == 'MSE':
+                cost_tb = ((leafs[0] - target) ** 2).sum(-1)
+                next_x, coeff = preds[0], preds[0]
+            else:
+                sigma = torch.exp(leafs[1]) + self.epsilon
+                coeff_ = torch.softmax(leafs[2], -1) + self.epsilon
+                cost_tb = cost_gmm(target, leafs[0], sigma, coeff_)
+                next_x, coeff = preds[0], coeff_.detach()  # sampled next_x is stochastic in the reference
+            cost_val = (cost_tb * mask).sum() / (mask.sum() + 1e-5)
+        dpreds = torch.autograd.grad(cost_val, leafs)
+        save['dpreds'] = [d.reshape(T * B, -1).contiguous() for d in dpreds]
+
+        # --- carried state (model.py:786-791)
+        updates = [(carry['h'][l], ws['h'][l][T].clone()) for l in range(L)]
+        updates += [(carry['k'], ws['kappa'][T].clone()), (carry['w'], ws['w'][T].clone())]
+
+        attention_vars = [next_x, ws['kappa'][1:], ws['w'][1:], coeff, ws['phi'], ws['a']]
+        self._token += 1
+        self._saved = (self._token, save)
+        anchor = torch.zeros((), device=dev, requires_grad=True)
+        cost = _CostFn.apply(anchor, self, self._token, cost_val.detach())
+        return cost, updates, attention_vars, None
+
+    # ------------------------------------------------------------------ backward
+    def _backward(self, token, gscale):
+        if self._saved is None or self._saved[0] != token:
+            raise RuntimeError("backward() must follow the compute_cost() call that produced this cost "
+                               "(workspaces are reused between calls)")
+        save = self._saved[1]
+        ws, T, B, U = save['ws'], save['T'], save['B'], save['U']
+        H, E, L, R, O, A = (self.rnn_h_dim, self.encoded_input_dim, self.num_layers, self.readouts_dim,
+                            self.output_dim, self.attention_size)
+        readouts = ws['readouts']
+        emb_spk = save.get('emb_spk')
+        demb_spk = torch.zeros_like(emb_spk) if emb_spk is not None else None
+
+        # output layer
+        dread = torch.zeros(T * B, R, device=readouts.device, dtype=torch.float32)
+        for i, (wn, bn, dim) in enumerate(self._out_names):
+            dp = save['dpreds'][i] * gscale
+            ops.gemm(readouts.t(), dp, out=self.store.grad(wn), accumulate=True, split_k=self._split(T * B))
+            ops.colsum(dp, out=self.store.grad(bn), accumulate=True)
+            ops.gemm(dp, self.store.param(wn).t(), out=dread, accumulate=True)
+            if self.use_speaker:
+                swn, sbn, _ = self._spk_out_names[i]
+                dsum = dp.view(T, B, dim).sum(0)
+                ops.gemm(emb_spk.t(), dsum, out=self.store.grad(swn), accumulate=True)
+                ops.colsum(dsum, out=self.store.grad(sbn), accumulate=True)
+                ops.gemm(dsum, self.store.param(swn).t(), out=demb_spk, accumulate=True)
+        # readouts
+        gWr = self.store.storage_grad['dec.Wr']
+        Wr = self.store.storage['dec.Wr']
+        sp = self._split(T * B)
+        for l in range(L):
+            ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dread, out=gWr[l * H:(l + 1) * H], accumulate=True, split_k=sp)
+        ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True, split_k=sp)
+        db = ops.colsum(dread)
+        for l in range(1, L + 1):
+            self._g(f'/h{l}_to_readout.b').add_(db)
+        self._g('/att_to_readout.b').add_(db)
+        if self.use_speaker:
+            dsum = dread.view(T, B, R).sum(0)
+            ops.gemm(emb_spk.t(), dsum, out=self._g('/speaker_to_readout.W'), accumulate=True)
+            ops.colsum(dsum, out=self._g('/speaker_to_readout.b'), accumulate=True)
+            ops.gemm(dsum, self._p('/speaker_to_readout.W').t(), out=demb_spk, accumulate=True)
+        # gradients entering the scan through the readouts
+        for l in range(L):
+            ws['dh'][l][0].zero_()
+            ops.gemm(dread, Wr[l * H:(l + 1) * H].t(), out=ws['dh'][l][1:].view(T * B, H))
+        ws['dw'][0].zero_()
+        ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
+        ws['dkappa'].zero_()
+
+        _lib.call('parrot_decoder_seq_bwd', ws['plan'], ops._stream())
+
+        # deferred weight gradients of the scan: dW = X^T dPre over all (t, b) rows
+        sg_, sc_ = self.store.storage_grad, self.store.storage
+        for l in range(L):
+            dG = ws['dG'][l].view(T * B, 2 * H)
+            dC = ws['dC'][l].view(T * B, H)
+            gWg, gWc = sg_[f'dec.Wg{l + 1}'], sg_[f'dec.Wc{l + 1}']
+            hprev = ws['h'][l][:T].view(T * B, H)
+            wsrc = (ws['w'][:T] if l == 0 else ws['w'][1:]).view(T * B, E)
+            ops.gemm(hprev.t(), dG, out=gWg[0:H], accumulate=True, split_k=sp)
+            ops.gemm(ws['rh'][l].view(T * B, H).t(), dC, out=gWc[0:H], accumulate=True, split_k=sp)
+            ops.gemm(wsrc.t(), dG, out=gWg[H:H + E], accumulate=True, split_k=sp)
+            ops.gemm(wsrc.t(), dC, out=gWc[H:H + E], accumulate=True, split_k=sp)
+            for j in range(l):
+                r0 = H + E + j * H
+                hj = ws['h'][j][1:].view(T * B, H)
+                ops.gemm(hj.t(), dG, out=gWg[r0:r0 + H], accumulate=True, split_k=sp)
+                ops.gemm(hj.t(), dC, out=gWc[r0:r0 + H], accumulate=True, split_k=sp)
+            dbg, dbc = ops.colsum(dG), ops.colsum(dC)
+            for nc, ng in self._layer_bias_names(l + 1):
+                self._g(nc).add_(dbc); self._g(ng).add_(dbg)
+            # per-step additive inputs
+            ll = l + 1
+            if ll in self._fb_layers:
+                inp = save['fb_inp']
+                ops.gemm(inp.t(), dC, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.W'), accumulate=True, split_k=sp)
+                ops.gemm(inp.t(), dG, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.W'), accumulate=True, split_k=sp)
+                self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.b').add_(dbc)
+                self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.b').add_(dbg)
+            if self.use_speaker:
+                dCs, dGs = dC.view(T, B, H).sum(0), dG.view(T, B, 2 * H).sum(0)
+                ops.gemm(emb_spk.t(), dCs, out=self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_inputs.W'), accumulate=True)
+                ops.gemm(emb_spk.t(), dGs, out=self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_gates.W'), accumulate=True)
+                self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_inputs.b').add_(dbc)
+                self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_gates.b').add_(dbg)
+                ops.gemm(dCs, self._p(f'/speaker_to_h{ll}/fork_rnn{ll}_inputs.W').t(), out=demb_spk, accumulate=True)
+                ops.gemm(dGs, self._p(f'/speaker_to_h{ll}/fork_rnn{ll}_gates.W').t(), out=demb_spk, accumulate=True)
+            if save['start_flag']:
+                ops.colsum(ws['dh'][l][0], out=self._g(f'/rnn{ll}.initial_state'), accumulate=True)
+        if save['start_flag']:
+            ops.colsum(ws['dw'][0], out=self._g('.initial_w'), accumulate=True)
+        # attention projection
+        dpj = ws['dp'].view(T * B, 3 * A)
+        ops.gemm(ws['h'][0][1:].view(T * B, H).t(), dpj, out=sg_['dec.Watt'], accumulate=True, split_k=sp)
+        ops.colsum(dpj, out=sg_['dec.batt'], accumulate=True)
+        # encoder output: dctx[b] = phi[:, b, :]^T . dw_total[1:, b, :]   (batched over b)
+        dctx = torch.empty(B, U, E, device=readouts.device, dtype=torch.float32)
+        _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
+                  dctx.data_ptr(), E, U, E, T, None, 1.0, 0, 0, B, U, E, U * E, 1, ops._stream())
+        if self.use_speaker:
+            self._g('/lookuptable.W').index_add_(0, save['spk_idx'], demb_spk)
+        self._encoder_backward(dctx, save)
+        self._saved = None
+
+    @staticmethod
+    def _split(rows):
+        s = 1
+        while s < 8 and rows // (s * 2) >= 2048:
+            s *= 2
+        return s
+
+    # ------------------------------------------------------------------ sampling
+    def _sample_workspace(self, S, N, U):
+        key = (S, N, U)
+        ws = self._sample_ws.get(key)
+        if ws is not None:
+            return ws
+        H, E, A, L, R, O = (self.rnn_h_dim, self.encoded_input_dim, self.attention_size, self.num_layers,
+                            self.readouts_dim, self.output_dim)
+        ldx = (O + 3) // 4 * 4
+        f = dict(device=self._dev(), dtype=torch.float32)
+        ws = dict(
+            x=torch.zeros(S + 1, N, ldx, **f), h=[torch.zeros(2, N, H, **f) for _ in range(L)],
+            w=torch.zeros(S + 1, N, E, **f), kappa=torch.zeros(S + 1, N, A, **f),
+            a=torch.empty(S, N, A, **f), bwork=torch.empty(N, A, **f), phi=torch.empty(S, N, U, **f),
+            zwork=torch.empty(N, H, **f), rwork=torch.empty(N, H, **f), rhwork=torch.empty(N, H, **f),
+            readout=torch.empty(N, R, **f), ctx=torch.zeros(N, U, E, **f),
+            bg=[torch.zeros(2 * H, **f) for _ in range(L)], bc=[torch.zeros(H, **f) for _ in range(L)],
+            br=torch.zeros(R, **f), ldx=ldx,
+            seq_c=[torch.zeros(N, H, **f) if self.use_speaker else None for _ in range(L)],
+            seq_g=[torch.zeros(N, 2 * H, **f) if self.use_speaker else None for _ in range(L)],
+            radd=torch.zeros(N, R, **f) if self.use_speaker else None,
+            oadd=torch.zeros(N, O, **f) if self.use_speaker else None,
+        )
+        d = _lib.SampleDesc()
+        d.S, d.B, d.H, d.E, d.A, d.U, d.L, d.O, d.R, d.ldx = S, N, H, E, A, U, L, O, R, ldx
+        d.att_type = 1 if self.attention_type == 'softmax' else 0
+        d.use_graph = int(self.use_graph)
+        d.eps, d.alignment = self.epsilon, self.attention_alignment
+        d.sharpening, d.timing = self.sharpening_coeff, self.timing_coeff
+        st = self.store.storage
+        for l in range(L):
+            d.Wg[l], d.Wc[l] = st[f'dec.Wg{l + 1}'].data_ptr(), st[f'dec.Wc{l + 1}'].data_ptr()
+            d.bg[l], d.bc[l] = ws['bg'][l].data_ptr(), ws['bc'][l].data_ptr()
+            if (l + 1) in self._fb_layers:
+                d.Wfg[l] = self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_gates.W').data_ptr()
+                d.Wfc[l] = self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_inputs.W').data_ptr()
+            if self.use_speaker:
+                d.seq_c[l], d.seq_g[l] = ws['seq_c'][l].data_ptr(), ws['seq_g'][l].data_ptr()
+            d.h[l] = ws['h'][l].data_ptr()
+        d.Watt, d.batt = st['dec.Watt'].data_ptr(), st['dec.batt'].data_ptr()
+        d.Wr, d.br = st['dec.Wr'].data_ptr(), ws['br'].data_ptr()
+        d.radd = ws['radd'].data_ptr() if ws['radd'] is not None else None
+        d.Wo, d.bo = self._p('/readout_to_output.W').data_ptr(), self._p('/readout_to_output.b').data_ptr()
+        d.oadd = ws['oadd'].data_ptr() if ws['oadd'] is not None else None
+        d.ctx = ws['ctx'].data_ptr()
+        for n in ('x', 'w', 'kappa', 'a', 'bwork', 'phi', 'zwork', 'rwork', 'rhwork', 'readout'):
+            setattr(d, n, ws[n].data_ptr())
+        plan = C.c_void_p()
+        _lib.call('parrot_sample_create', C.byref(d), C.byref(plan))
+        ws['plan'], ws['desc'] = plan, d
+        self._sample_ws[key] = ws
+        return ws
+
+    def sample_model_device(self, labels, labels_mask, speaker, num_samples, num_steps):
+        """Device-resident version of sample_model: returns torch tensors
+        [sample_x [S,N,O], k [S,N,A], w [S,N,E], pi, phi [S,N,U], pi_att [S,N,A]]."""
+        self.allocate()
+        if self.which_cost != 'MSE':
+            raise NotImplementedError("GMM sampling (model.py:1017-1033) needs the reference's Theano RNG "
+                                      "stream; only the deterministic MSE head is built")
+        dev = self._dev()
+        labels = torch.as_tensor(labels).to(dev)
+        labels_mask = torch.as_tensor(labels_mask).to(dev, torch.float32)
+        N, U = labels.shape[0], labels.shape[1]
+        assert N == num_samples
+        S, L, H, O = num_steps, self.num_layers, self.rnn_h_dim, self.output_dim
+        ws = self._sample_workspace(S, N, U)
+        ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, None))
+        for l in range(1, L + 1):
+            bc, bg = ws['bc'][l - 1], ws['bg'][l - 1]
+            bc.zero_(); bg.zero_()
+            for nc, ng in self._layer_bias_names(l):
+                bc.add_(self._p(nc)); bg.add_(self._p(ng))
+            if l in self._fb_layers:
+                bc.add_(self._p(f'/out_to_h{l}/fork_rnn{l}_inputs.b'))
+                bg.add_(self._p(f'/out_to_h{l}/fork_rnn{l}_gates.b'))
+            ws['h'][l - 1][0].copy_(self._p(f'/rnn{l}.initial_state').unsqueeze(0).expand(N, -1))
+        ws['br'].copy_(self._p('/att_to_readout.b'))
+        for l in range(1, L + 1):
+            ws['br'].add_(self._p(f'/h{l}_to_readout.b'))
+        if self.use_speaker:
+            speaker = torch.as_tensor(speaker).to(dev)
+            emb = self._p('/lookuptable.W')[speaker[:, 0].long()].contiguous()
+            for l in range(1, L + 1):
+                ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.W'),
+                         bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.b'), out=ws['seq_c'][l - 1])
+                ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.W'),
+                         bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.b'), out=ws['seq_g'][l - 1])
+            ops.gemm(emb, self._p('/speaker_to_readout.W'), bias=self._p('/speaker_to_readout.b'), out=ws['radd'])
+            ops.gemm(emb, self._p('/speaker_to_output.W'), bias=self._p('/speaker_to_output.b'), out=ws['oadd'])
+        ws['x'][0].zero_()  # initial_x, model.py:834-835
+        ws['w'][0].copy_(self._p('.initial_w').unsqueeze(0).expand(N, -1))
+        ws['kappa'][0].zero_()
+        _lib.call('parrot_sample_run', ws['plan'], ops._stream())
+        sx = ws['x'][1:, :, :O]
+        return [sx, ws['kappa'][1:], ws['w'][1:], sx, ws['phi'], ws['a']]
+
+    def sample_model(self, labels_tr, labels_mask_tr, features_mask_tr, speaker_tr, num_samples, num_steps):
+        """Parrot.sample_model (model.py:1061-1083): numpy in, list of numpy arrays out
+        [sample_x, k, w, pi, phi, pi_att], all time-major (the caller swaps axes, sample.py:142-143)."""
+        outs = self.sample_model_device(labels_tr, labels_mask_tr, speaker_tr, num_samples, num_steps)
+        return [o.detach().cpu().numpy().copy() for o in outs]
+
+    def sample_using_input(self, data_tr, num_samples):
+        """model.py:1085-1111: teacher-forced pass on a batch dict; returns
+        [sample_x, k, w, pi, phi, pi_att] as numpy arrays."""
+        dev = self._dev()
+        t = lambda k: torch.as_tensor(data_tr[k]).to(dev) if data_tr.get(k) is not None else None
+        with torch.no_grad():
+            _, _, av, _ = self.compute_cost(t('features'), t('features_mask'), t('labels'), t('labels_mask'),
+                                            t('speaker_index'), data_tr.get('start_flag', 1), num_samples)
+        return [a.detach().cpu().numpy().copy() for a in av]
+
+    def close(self):
+        lib = _lib.load()
+        for ws in self._train_ws.values():
+            if 'plan' in ws:
+                lib.parrot_decoder_destroy(ws['plan'])
+            if 'run' in ws:
+                ws['run'].close()
+        for ws in self._sample_ws.values():
+            lib.parrot_sample_destroy(ws['plan'])
+        self._train_ws, self._sample_ws = {}, {}
+
+
+class SampleRnn(Brick):
+    """model.py:121-169: adapter brick around the conditional three-tier SampleRNN."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        from .sampleRNN.models.conditional import three_tier
+        self.three_tier = three_tier
+        self.N_RNN = three_tier.N_RNN
+
+    def initial_states(self, batch_size):
+        tt = self.three_tier
+        dev = self._dev()
+        last_big_h0 = torch.zeros(batch_size, tt.N_RNN, tt.H0_MULT * tt.BIG_DIM, device=dev)
+        last_h0 = torch.zeros(batch_size, tt.N_RNN, tt.H0_MULT * tt.DIM, device=dev)
+        return last_h0, last_big_h0
+
+    def apply(self, sequences, features, h0, big_h0, reset, mask):
+        return self.three_tier.compute_cost(sequences, features, h0, big_h0, reset, mask)
+
+    def sample_raw(self, test_feats, features_length, tag, path_to_save):
+        tt = self.three_tier
+        fns = tt.getting_generation_functions(None, None, None, None, None)
+        return tt.generate_and_save_samples(
+            tag, path_to_save=path_to_save, features=test_feats, features_length=features_length,
+            noise_level=0., big_frame_level_generate_fn=fns[0], frame_level_generate_fn=fns[1],
+            sample_level_generate_fn=fns[2], npy_address=None)

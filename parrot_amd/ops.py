@@ -151,3 +151,228 @@ class _LinearFn(torch.autograd.Function):
 
 def linear(x, W, b=None, act=ACT_NONE):
     return _LinearFn.apply(x, W, b, act)
+
+
+# ----------------------------------------------------------------------------- GRU step / scan
+def gru_step_fwd(h, inputs, gate_inputs, Wg, Wc, mask=None):
+    """One GatedRecurrent step; returns (h_new, saved) with saved = (z, r, rh, c)."""
+    B, H = h.shape
+    z, r, rh, c, out = (torch.empty((B, H), device=h.device, dtype=torch.float32) for _ in range(5))
+    _lib.call("parrot_gru_step_fwd", ptr(h, "h"), ptr(inputs, "inputs"), ptr(gate_inputs, "gate_inputs"),
+              ptr(mask, "mask"), ptr(Wg, "Wg"), ptr(Wc, "Wc"), ptr(out), ptr(z), ptr(r), ptr(rh), ptr(c),
+              B, H, _stream())
+    return out, (z, r, rh, c)
+
+
+def gru_step_bwd(dh_out, h, Wg, Wc, saved, mask=None):
+    """Returns (dh, d_inputs, d_gate_inputs)."""
+    z, r, rh, c = saved
+    B, H = h.shape
+    dh = torch.empty((B, H), device=h.device, dtype=torch.float32)
+    dC = torch.empty((B, H), device=h.device, dtype=torch.float32)
+    dG = torch.empty((B, 2 * H), device=h.device, dtype=torch.float32)
+    _lib.call("parrot_gru_step_bwd", ptr(dh_out, "dh_out"), ptr(h, "h"), ptr(mask, "mask"), ptr(Wg), ptr(Wc),
+              ptr(z), ptr(r), ptr(c), ptr(dh), ptr(dC), ptr(dG), B, H, _stream())
+    return dh, dC, dG
+
+
+class _GruStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, gate_inputs, h, Wc, Wg, mask):
+        inputs, gate_inputs, h = inputs.contiguous(), gate_inputs.contiguous(), h.contiguous()
+        out, saved = gru_step_fwd(h, inputs, gate_inputs, Wg, Wc, mask)
+        ctx.save_for_backward(h, Wc, Wg, mask, *saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, Wc, Wg, mask, z, r, rh, c = ctx.saved_tensors
+        dh, dC, dG = gru_step_bwd(dout.contiguous(), h, Wg, Wc, (z, r, rh, c), mask)
+        dWc = gemm(rh.t(), dC) if ctx.needs_input_grad[3] else None
+        dWg = gemm(h.t(), dG) if ctx.needs_input_grad[4] else None
+        return dC, dG, dh, dWc, dWg, None
+
+
+def gru_step(inputs, gate_inputs, h, Wc, Wg, mask=None):
+    """Differentiable single GatedRecurrent step (Wc = state_to_state, Wg = state_to_gates)."""
+    return _GruStepFn.apply(inputs, gate_inputs, h, Wc, Wg, mask)
+
+
+class GruSeqRunner:
+    """Owns the workspaces + plan of a GRU scan with up to 4 independent chains (include/parrot_hip.h,
+    ParrotGruSeqDesc).  Buffers are allocated once, so the plan's hipGraph can be replayed."""
+
+    def __init__(self, T, B, H, nchain, reverse, device, use_graph=False, with_backward=True):
+        import ctypes as C
+        self.T, self.B, self.H, self.nchain = T, B, H, nchain
+        self.reverse = list(reverse)
+        f = dict(device=device, dtype=torch.float32)
+        self.h = [torch.zeros((T + 1, B, H), **f) for _ in range(nchain)]
+        self.z, self.r, self.rh, self.c = ([torch.empty((T, B, H), **f) for _ in range(nchain)] for _ in range(4))
+        self.inputs = [torch.zeros((T, B, H), **f) for _ in range(nchain)]
+        self.gate_inputs = [torch.zeros((T, B, 2 * H), **f) for _ in range(nchain)]
+        self.mask = None
+        self.with_backward = with_backward
+        if with_backward:
+            self.dh = [torch.zeros((T + 1, B, H), **f) for _ in range(nchain)]
+            self.dG = [torch.empty((T, B, 2 * H), **f) for _ in range(nchain)]
+            self.dC = [torch.empty((T, B, H), **f) for _ in range(nchain)]
+        self.use_graph = use_graph
+        self._plan = None
+        self._weights = None
+
+    def bind(self, Wg, Wc, mask=None):
+        """(Re)creates the plan for these weight tensors (list per chain) / mask [T,B]."""
+        import ctypes as C
+        key = tuple(w.data_ptr() for w in list(Wg) + list(Wc)) + ((mask.data_ptr(),) if mask is not None else ())
+        if self._plan is not None and key == self._weights:
+            return
+        self.close()
+        d = _lib.GruSeqDesc()
+        d.T, d.B, d.H, d.nchain, d.use_graph = self.T, self.B, self.H, self.nchain, int(self.use_graph)
+        for i in range(self.nchain):
+            d.reverse[i] = int(self.reverse[i])
+            d.Wg[i], d.Wc[i] = ptr(Wg[i], "Wg"), ptr(Wc[i], "Wc")
+            d.inputs[i], d.gate_inputs[i] = self.inputs[i].data_ptr(), self.gate_inputs[i].data_ptr()
+            d.h[i] = self.h[i].data_ptr()
+            d.z[i], d.r[i], d.rh[i], d.c[i] = (x[i].data_ptr() for x in (self.z, self.r, self.rh, self.c))
+            if self.with_backward:
+                d.dh[i], d.dG[i], d.dC[i] = self.dh[i].data_ptr(), self.dG[i].data_ptr(), self.dC[i].data_ptr()
+        d.mask = ptr(mask, "mask") if mask is not None else None
+        self.mask = mask
+        plan = C.c_void_p()
+        _lib.call("parrot_gru_seq_create", C.byref(d), C.byref(plan))
+        self._plan, self._weights = plan, key
+        self._keep = (list(Wg), list(Wc), mask)
+
+    def forward(self):
+        _lib.call("parrot_gru_seq_fwd", self._plan, _stream())
+
+    def backward(self):
+        _lib.call("parrot_gru_seq_bwd", self._plan, _stream())
+
+    def close(self):
+        if self._plan is not None:
+            _lib.load().parrot_gru_seq_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _GruSeqFn(torch.autograd.Function):
+    """GatedRecurrent.apply over a sequence: inputs [T,B,H], gate_inputs [T,B,2H], h0 [B,H]."""
+
+    @staticmethod
+    def forward(ctx, inputs, gate_inputs, h0, Wc, Wg, mask, reverse):
+        T, B, H = inputs.shape
+        run = GruSeqRunner(T, B, H, 1, [reverse], inputs.device, use_graph=False)
+        run.inputs[0].copy_(inputs)
+        run.gate_inputs[0].copy_(gate_inputs)
+        run.h[0][0].copy_(h0)
+        run.bind([Wg], [Wc], mask.contiguous() if mask is not None else None)
+        run.forward()
+        ctx.run = run
+        ctx.reverse = reverse
+        ctx.save_for_backward(Wc, Wg)
+        hs = run.h[0][1:]
+        return hs.flip(0) if reverse else hs.clone()
+
+    @staticmethod
+    def backward(ctx, dhs):
+        run = ctx.run
+        Wc, Wg = ctx.saved_tensors
+        T, B, H = run.T, run.B, run.H
+        run.dh[0].zero_()
+        run.dh[0][1:].copy_(dhs.flip(0) if ctx.reverse else dhs)
+        run.backward()
+        dC, dG = run.dC[0], run.dG[0]
+        # saved activations are time-indexed; the state that fed time t is slot s (s = step index)
+        hprev = run.h[0][:T]
+        if ctx.reverse:
+            hprev = hprev.flip(0)  # step s handled time T-1-s
+        dWc = gemm(run.rh[0].reshape(T * B, H).t(), dC.reshape(T * B, H)) if ctx.needs_input_grad[3] else None
+        dWg = gemm(hprev.reshape(T * B, H).t(), dG.reshape(T * B, 2 * H)) if ctx.needs_input_grad[4] else None
+        return dC, dG, run.dh[0][0].clone(), dWc, dWg, None, None
+
+
+def gru_seq(inputs, gate_inputs, h0, Wc, Wg, mask=None, reverse=False):
+    """Differentiable GRU scan; returns states [T,B,H] indexed by time."""
+    return _GruSeqFn.apply(inputs.contiguous(), gate_inputs.contiguous(), h0.contiguous(), Wc, Wg, mask, reverse)
+
+
+# ----------------------------------------------------------------------------- attention step
+def gmm_attention_fwd(h1, Watt, batt, kappa_prev, ctx, att_type=0, eps=1e-5, alignment=1.0,
+                      sharpening=1.0, timing=1.0):
+    B, H = h1.shape
+    A = kappa_prev.shape[1]
+    _, U, E = ctx.shape
+    f = dict(device=h1.device, dtype=torch.float32)
+    a, b, k = (torch.empty((B, A), **f) for _ in range(3))
+    phi = torch.empty((B, U), **f)
+    w = torch.empty((B, E), **f)
+    _lib.call("parrot_gmm_attention_fwd", ptr(h1, "h1"), ptr(Watt, "Watt"), ptr(batt, "batt"),
+              ptr(kappa_prev, "kappa_prev"), ptr(ctx, "ctx"), ptr(a), ptr(b), ptr(k), ptr(phi), ptr(w),
+              B, H, A, U, E, int(att_type), float(eps), float(alignment), float(sharpening), float(timing),
+              _stream())
+    return a, b, k, phi, w
+
+
+def gmm_attention_bwd(dw, ctx, a, b, kappa, kappa_prev, Watt, dkappa, dh1, att_type=0, eps=1e-5):
+    """dkappa [B,A] is updated in place (carry); dh1 [B,H] is accumulated; returns dp [B,3A]."""
+    B, H = dh1.shape
+    A = kappa.shape[1]
+    _, U, E = ctx.shape
+    dp = torch.empty((B, 3 * A), device=dw.device, dtype=torch.float32)
+    _lib.call("parrot_gmm_attention_bwd", ptr(dw, "dw"), ptr(ctx, "ctx"), ptr(a), ptr(b), ptr(kappa),
+              ptr(kappa_prev), ptr(Watt), ptr(dkappa), ptr(dp), ptr(dh1), B, H, A, U, E, int(att_type),
+              float(eps), _stream())
+    return dp
+
+
+# ----------------------------------------------------------------------------- optimiser
+def sumsq(x, out=None):
+    if out is None:
+        out = torch.empty((1,), device=x.device, dtype=torch.float32)
+    _lib.call("parrot_sumsq", ptr(x, "x"), x.numel(), ptr(out), _stream())
+    return out
+
+
+def adam_clip_step(param, grad, m, v, gnorm_sq, step, lr=1e-4, clip=9.0, grad_scale=1.0,
+                   beta1=0.9, beta2=0.999, eps=1e-8):
+    _lib.call("parrot_adam_clip_step", ptr(param, "param"), ptr(grad, "grad"), ptr(m), ptr(v), param.numel(),
+              ptr(gnorm_sq) if gnorm_sq is not None else None, float(grad_scale), float(clip), float(lr),
+              float(beta1), float(beta2), float(eps), int(step), _stream())
+
+
+# ----------------------------------------------------------------------------- quantisers
+def batch_quantize(x, q_levels=256, q_type="mu-law"):
+    """quantize.__batch_quantize on the GPU: x [rows, n] float32 -> int16 (mu-law) / int32 (linear)."""
+    _chk(x, "x")
+    if x.dim() != 2:
+        raise ValueError("batch_quantize expects a 2-D tensor")
+    x = x.contiguous()
+    rows, n = x.shape
+    if q_type == "mu-law":
+        mode, out = 0, torch.empty((rows, n), device=x.device, dtype=torch.int16)
+    elif q_type == "linear":
+        mode, out = 1, torch.empty((rows, n), device=x.device, dtype=torch.int32)
+    else:
+        raise NotImplementedError(q_type)  # quantize.py:38-42: a-law raises NotImplementedError
+    ws = torch.empty((2 * rows,), device=x.device, dtype=torch.float64)
+    _lib.call("parrot_batch_quantize", x.data_ptr(), rows, n, x.stride(0), ws.data_ptr(), out.data_ptr(), n,
+              mode, int(q_levels), _stream())
+    return out
+
+
+def mu2linear(q):
+    """quantize.mu2linear on the GPU: integer class indices -> float32 amplitudes."""
+    if not q.is_cuda:
+        raise _lib.HipCallError("mu2linear needs a GPU tensor; there is no CPU fallback")
+    q32 = q.to(torch.int32).contiguous()
+    out = torch.empty(q32.shape, device=q.device, dtype=torch.float32)
+    _lib.call("parrot_mu2linear", q32.data_ptr(), q32.numel(), out.data_ptr(), _stream())
+    return out

@@ -1,0 +1,152 @@
+"""Parity of the HIP decoder path (Parrot.compute_cost / sample_model through the C ABI) against
+the fp64 oracle restatement of model.py on the same seeded inputs.
+
+Tolerance: the north star asks for feature frames within 1e-4 relative in fp32; gradients are
+compared norm-wise per parameter at 1e-3 (fp32 accumulation over T*B rows vs an fp64 oracle)."""
+import pytest
+import torch
+
+from tests.util import assert_close, make_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(rnn_h_dim=64, readouts_dim=48, encoder_dim=16, input_dim=24, speaker_dim=8, num_speakers=5)
+
+
+def _build(dev, use_graph=False, **kw):
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    base = dict(SMALL)
+    base.update(kw)
+    cfg = R.default_config(**base)
+    p = R.init_params(cfg, seed=7, scale_by_fan_in=True)
+    kw2 = {k: v for k, v in base.items()}
+    m = Parrot(device=dev, use_graph=use_graph, **kw2).allocate()
+    m.set_parameter_values(p)
+    return cfg, p, m
+
+
+def _check_cost_and_grads(dev, T, B, U, ragged=False, tol_out=1e-4, tol_grad=1e-3, **kw):
+    from oracle import parrot_ref as R
+    cfg, p, m = _build(dev, **kw)
+    feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=3, ragged=ragged, speaker=cfg['use_speaker'])
+    for v in p.values():
+        v.requires_grad_()
+    rc, rcarry, rav, rex = R.compute_cost(p, cfg, feat, fm, lab, lm, spk, 1)
+    rc.backward()
+    m.zero_grad()
+    cost, updates, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev),
+                                          None if spk is None else spk.to(dev), 1, B)
+    cost.backward()
+    assert_close(cost, rc, tol_out, "cost")
+    if cfg['which_cost'] == 'MSE':
+        assert_close(av[0], rav[0], tol_out, "predicted frames")
+    assert_close(av[1], rav[1], tol_out, "kappa")
+    assert_close(av[2], rav[2], tol_out, "w")
+    assert_close(av[4], rav[4], tol_out, "phi")
+    assert_close(av[5], rav[5], tol_out, "pi_att")
+    grads = m.get_gradient_dict()
+    worst = 0.0
+    for name, ref in p.items():
+        if ref.grad is None:
+            continue
+        e = rel_err(grads[name], ref.grad)
+        scale = float(ref.grad.abs().max())
+        if scale < 1e-12:
+            assert float(grads[name].abs().max()) < 1e-6, name
+            continue
+        assert e <= tol_grad, f"grad {name}: rel err {e:.3e}"
+        worst = max(worst, e)
+    m.close()
+    return worst
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_cost_and_grads_layers(dev, L):
+    _check_cost_and_grads(dev, T=6, B=4, U=9, num_layers=L, encoder_type='bidirectional')
+
+
+def test_cost_and_grads_feedback_speaker_ragged(dev):
+    _check_cost_and_grads(dev, T=7, B=5, U=11, ragged=True, num_layers=3, encoder_type='bidirectional',
+                          full_feedback=True, use_speaker=True)
+
+
+def test_cost_and_grads_softmax_attention_nonliteral_encoder(dev):
+    _check_cost_and_grads(dev, T=5, B=3, U=8, num_layers=2, encoder_type='bidirectional',
+                          attention_type='softmax', encoder_literal=False, weak_feedback=True)
+
+
+def test_cost_and_grads_gmm_head(dev):
+    _check_cost_and_grads(dev, T=5, B=4, U=7, num_layers=2, encoder_type='bidirectional', which_cost='GMM',
+                          k_gmm=3, tol_grad=2e-3)
+
+
+def test_larger_batch_multi_chunk(dev):
+    """B > 64 exercises the 64-row chunking of the step kernels; odd sizes exercise the masks."""
+    _check_cost_and_grads(dev, T=4, B=70, U=13, num_layers=2, encoder_type='bidirectional', weak_feedback=True)
+
+
+def test_graph_replay_equals_eager_and_tbptt_carry(dev):
+    """hipGraph replay == eager launches (bitwise), and one long window == two windows with the
+    carried state (start_flag=0; model.py:633-643, datasets.py:107-133)."""
+    from oracle import parrot_ref as R
+    T, B, U = 8, 4, 6
+    outs = {}
+    for use_graph in (False, True):
+        cfg, p, m = _build(dev, use_graph=use_graph, num_layers=2, encoder_type='bidirectional', weak_feedback=True)
+        feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=5)
+        args = [t.to(dev) for t in (feat.float(), fm.float(), lab, lm.float())]
+        for rep in range(2):  # second call replays the captured graph
+            m.zero_grad()
+            c, upd, av, _ = m.compute_cost(args[0], args[1], args[2], args[3], None, 1, B)
+            c.backward()
+        outs[use_graph] = (c.detach().clone(), av[0].clone(), m.flat_gradients.clone())
+        if use_graph:
+            c1, u1, av1, _ = m.compute_cost(args[0][:5], args[1][:5], args[2], args[3], None, 1, B)
+            m.apply_updates(u1)
+            c2, u2, av2, _ = m.compute_cost(args[0][4:], args[1][4:], args[2], args[3], None, 0, B)
+            both = torch.cat([av1[0], av2[0]], 0)
+            assert_close(both, av[0], 1e-5, "TBPTT carry")
+        m.close()
+    assert torch.equal(outs[False][0], outs[True][0])
+    assert torch.equal(outs[False][1], outs[True][1])
+    assert_close(outs[True][2], outs[False][2], 1e-6, "graph grads")
+
+
+@pytest.mark.parametrize("kw", [dict(num_layers=3, full_feedback=True, use_speaker=True),
+                                dict(num_layers=2, weak_feedback=True, sharpening_coeff=1.2, timing_coeff=0.9),
+                                dict(num_layers=1)])
+def test_sample_model_parity(dev, kw):
+    from oracle import parrot_ref as R
+    cfg, p, m = _build(dev, use_graph=True, encoder_type='bidirectional', **kw)
+    N, U, S = 4, 9, 12
+    _, _, lab, lm, spk = make_batch(cfg, 2, N, U, seed=9, speaker=cfg['use_speaker'])
+    with torch.no_grad():
+        ref = R.sample_model(p, cfg, lab, lm, spk, S)
+    outs = m.sample_model(lab.numpy(), lm.float().numpy(), None, None if spk is None else spk.numpy(), N, S)
+    for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+        assert o.shape == tuple(r.shape), n
+        assert_close(torch.from_numpy(o), r, 1e-4, n)
+    m.close()
+
+
+def test_full_width_short_window(dev):
+    """BASELINE cfg2 widths (H=1024, B=64, U=200, E=256) on a short window: parity on frames/cost."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=2, encoder_type='bidirectional', rnn_h_dim=1024, readouts_dim=1024)
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=11, scale_by_fan_in=True, dtype=torch.float32)
+    m = Parrot(device=dev, use_graph=True, **kw).allocate()
+    m.set_parameter_values(p)
+    T, B, U = 6, 64, 200
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=13, ragged=True, dtype=torch.float32)
+    with torch.no_grad():
+        rc, _, rav, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
+    cost, _, av, _ = m.compute_cost(feat.to(dev), fm.to(dev), lab.to(dev), lm.to(dev), None, 1, B)
+    assert_close(cost, rc, 1e-4, "cost")
+    assert_close(av[0], rav[0], 1e-4, "frames")
+    cost.backward()
+    g = m.flat_gradients
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    m.close()
