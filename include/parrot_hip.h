@@ -39,8 +39,9 @@ const char* parrot_hip_version(void);
  * Dense projections (Blocks Linear / Fork applies, model.py:580-627, 739-755; lib.ops.Linear,
  * sampleRNN/lib/ops.py:32-128).  C[M,N] (+)= alpha * opA(A) * opB(B) + bias, f32 MFMA.
  *   transA = 0: A is [M,K] (lda), 1: A is stored [K,M] (lda)      (same for B / transB, [K,N])
- *   batched with element strides; split_k > 1 combines partial products with f32 atomics
- *   (then C must be pre-initialised and is always accumulated into).
+ *   batched with element strides; split_k > 1 splits K over workgroups and combines the partial
+ *   products with f32 atomics (C is cleared first unless accumulate); split_k = 0 picks a split
+ *   automatically (long reductions with few output tiles, e.g. deferred weight gradients).
  * M <= 64 with transA = 0 dispatches to the weight-streaming recurrent-step kernel.
  * ------------------------------------------------------------------------------------------ */
 int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
@@ -99,16 +100,17 @@ int parrot_gru_seq_destroy(void* plan);
 
 /* ------------------------------------------------------------------------------------------
  * GMM-window attention step (model.py:664-690; sampling variant :931-958).
- * att_type 0 = graves, 1 = softmax.  Watt = [h1_to_att alpha|beta|kappa] packed [H,3A].
+ * att_type 0 = graves, 1 = softmax.  WattT = h1_to_att [alpha;beta;kappa] weights stored
+ * TRANSPOSED, [3A,H] (row j = output j), so the per-row dot products read contiguous memory.
  * ------------------------------------------------------------------------------------------ */
-int parrot_gmm_attention_fwd(const float* h1, const float* Watt, const float* batt, const float* kappa_prev,
+int parrot_gmm_attention_fwd(const float* h1, const float* WattT, const float* batt, const float* kappa_prev,
                              const float* ctx, float* a, float* b, float* kappa, float* phi, float* w, int B,
                              int H, int A, int U, int E, int att_type, float eps, float alignment,
                              float sharpening, float timing, void* stream);
 
 /* dw [B,E] in; dkappa [B,A] in/out carry; dp [B,3A] out; dh1 [B,H] accumulated. */
 int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, const float* b,
-                             const float* kappa, const float* kappa_prev, const float* Watt, float* dkappa,
+                             const float* kappa, const float* kappa_prev, const float* WattT, float* dkappa,
                              float* dp, float* dh1, int B, int H, int A, int U, int E, int att_type, float eps,
                              void* stream);
 
@@ -133,7 +135,7 @@ typedef struct ParrotDecoderDesc {
     const float* Wc[PARROT_MAX_LAYERS];
     const float* bg[PARROT_MAX_LAYERS];
     const float* bc[PARROT_MAX_LAYERS];
-    const float* Watt;  /* [H,3A] */
+    const float* WattT; /* [3A,H] */
     const float* batt;  /* [3A]   */
     const float* ctx;   /* [B,U,E] encoder output * labels_mask (model.py:645-646) */
     const float* seq_c[PARROT_MAX_LAYERS]; /* [T,B,H]  per-step additive cell inputs or NULL (model.py:562-627) */
@@ -149,6 +151,7 @@ typedef struct ParrotDecoderDesc {
     /* backward */
     float* dh[PARROT_MAX_LAYERS];  /* [T+1,B,H] in: gradient from the readouts per slot; out: total */
     float* dw;                     /* [T+1,B,E] in: gradient from att_to_readout per slot; out: total */
+    float* dw0;                    /* [T+1,B,E] scratch, zero-filled by the caller: layer-0 share of dw */
     float* dkappa;                 /* [B,A] in: gradient wrt final kappa (0); out: wrt initial kappa */
     float* dG[PARROT_MAX_LAYERS];  /* [T,B,2H] out: gradient wrt gate pre-activations */
     float* dC[PARROT_MAX_LAYERS];  /* [T,B,H]  out: gradient wrt candidate pre-activations */
@@ -180,7 +183,7 @@ typedef struct ParrotSampleDesc {
     const float* Wfc[PARROT_MAX_LAYERS];
     const float* seq_c[PARROT_MAX_LAYERS]; /* [B,H]  constant additive inputs (speaker) or NULL */
     const float* seq_g[PARROT_MAX_LAYERS]; /* [B,2H] */
-    const float* Watt; const float* batt;
+    const float* WattT; const float* batt;
     const float* Wr; const float* br;      /* [L*H+E, R], [R] (+ speaker readout folded in by caller) */
     const float* radd;                     /* [B,R] constant additive readout term or NULL */
     const float* Wo; const float* bo;      /* [R,O], [O] */

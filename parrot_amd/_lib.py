@@ -46,13 +46,13 @@ class DecoderDesc(C.Structure):
         ("eps", C.c_float), ("alignment", C.c_float), ("sharpening", C.c_float), ("timing", C.c_float),
         ("Wg", C.c_void_p * MAX_LAYERS), ("Wc", C.c_void_p * MAX_LAYERS),
         ("bg", C.c_void_p * MAX_LAYERS), ("bc", C.c_void_p * MAX_LAYERS),
-        ("Watt", C.c_void_p), ("batt", C.c_void_p), ("ctx", C.c_void_p),
+        ("WattT", C.c_void_p), ("batt", C.c_void_p), ("ctx", C.c_void_p),
         ("seq_c", C.c_void_p * MAX_LAYERS), ("seq_g", C.c_void_p * MAX_LAYERS),
         ("h", C.c_void_p * MAX_LAYERS), ("w", C.c_void_p), ("kappa", C.c_void_p),
         ("z", C.c_void_p * MAX_LAYERS), ("r", C.c_void_p * MAX_LAYERS),
         ("rh", C.c_void_p * MAX_LAYERS), ("c", C.c_void_p * MAX_LAYERS),
         ("a", C.c_void_p), ("b", C.c_void_p), ("phi", C.c_void_p),
-        ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dkappa", C.c_void_p),
+        ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dw0", C.c_void_p), ("dkappa", C.c_void_p),
         ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
     ]
 
@@ -67,7 +67,7 @@ class SampleDesc(C.Structure):
         ("bg", C.c_void_p * MAX_LAYERS), ("bc", C.c_void_p * MAX_LAYERS),
         ("Wfg", C.c_void_p * MAX_LAYERS), ("Wfc", C.c_void_p * MAX_LAYERS),
         ("seq_c", C.c_void_p * MAX_LAYERS), ("seq_g", C.c_void_p * MAX_LAYERS),
-        ("Watt", C.c_void_p), ("batt", C.c_void_p),
+        ("WattT", C.c_void_p), ("batt", C.c_void_p),
         ("Wr", C.c_void_p), ("br", C.c_void_p), ("radd", C.c_void_p),
         ("Wo", C.c_void_p), ("bo", C.c_void_p), ("oadd", C.c_void_p),
         ("ctx", C.c_void_p),

@@ -4,7 +4,7 @@
 
 struct AttFwdArgs {
     const float* h1;  int ldh;     // [B,H] layer-1 state of this step
-    const float* Watt;             // [H,3A] (alpha | beta | kappa columns)
+    const float* WattT;            // [3A,H] (alpha | beta | kappa rows): h1_to_att weights, transposed
     const float* batt;             // [3A] or null
     const float* kappa_prev;       // [B,A]
     const float* ctx;              // [B,U,E] encoder output * labels_mask
@@ -16,10 +16,11 @@ struct AttFwdArgs {
 };
 
 struct AttBwdArgs {
-    const float* dw; int lddw;     // [B,E] total gradient wrt w_t
+    float* dw; int lddw;           // [B,E] gradient wrt w_t (in; the total is written back when dw2 != null)
+    const float* dw2;              // [B,E] optional second share of the gradient (layer-0 path) or null
     const float* ctx;              // [B,U,E]
     const float* a; const float* b; const float* kappa; const float* kappa_prev;  // [B,A]
-    const float* Watt;             // [H,3A]
+    const float* WattT;            // [3A,H]
     float* dkappa;                 // [B,A] in: carry from step t+1, out: carry to step t-1
     float* dp_out;                 // [B,3A] gradient wrt the projection (for deferred dWatt)
     float* dh1; int lddh;          // [B,H] accumulated (+=)

@@ -2,7 +2,9 @@
 // Restates reference model.py:664-690 (training) and :931-958 (sampling: sharpening / timing
 // coefficients).  attention_type 0 = "graves", 1 = "softmax" (model.py:666-669, 680-687).
 //
-//   p = h1 @ Watt + batt                 p = [alpha_hat | beta_hat | kappa_hat], each [A]
+//   p = h1 @ Watt + batt  (Watt is stored transposed, WattT [3A,H], so both dot-product operands are
+//                            contiguous along H)
+//                  p = [alpha_hat | beta_hat | kappa_hat], each [A]
 //   a = exp(alpha_hat) + eps   (graves)  |  softmax(alpha_hat) + eps   (softmax)
 //   b = exp(beta_hat) * sharpening + eps
 //   kappa = kappa_prev + alignment * exp(kappa_hat) / timing
@@ -19,6 +21,7 @@
 namespace {
 
 constexpr int ATT_THREADS = 256;
+constexpr int ATTB_THREADS = 512;  // backward: one workgroup per batch row, 8 waves
 constexpr int ATT_MAXA = 32;  // attention_size limit (reference default 10)
 
 // Block-wide sum of `n` per-thread partial vectors (n <= 3*ATT_MAXA); result in out[0..n).
@@ -32,6 +35,15 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     if (lane == 0) red[wave] = v;
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float block_sum8(float v, float* red) {  // 512-thread variant, red >= 8 floats
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7];
 }
 
 __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g) {
@@ -51,8 +63,15 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
 
     // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
     for (int j = wave; j < 3 * A; j += 4) {
+        const float* wr = g.WattT + (size_t)j * H;
         float acc = 0.f;
-        for (int k = lane; k < H; k += 64) acc += h[k] * g.Watt[(size_t)k * 3 * A + j];
+        int k = lane;
+        for (; k + 192 < H; k += 256) {  // 8 independent loads in flight per lane
+            const float h0 = h[k], h1 = h[k + 64], h2 = h[k + 128], h3 = h[k + 192];
+            const float w0 = wr[k], w1 = wr[k + 64], w2 = wr[k + 128], w3 = wr[k + 192];
+            acc += h0 * w0 + h1 * w1 + h2 * w2 + h3 * w3;
+        }
+        for (; k < H; k += 64) acc += h[k] * wr[k];
         acc = wave_sum(acc);
         if (lane == 0) s_p[j] = acc + (g.batt ? g.batt[j] : 0.f);
     }
@@ -119,8 +138,17 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     for (int eb = e0; eb < e1; eb += CW) {
         const int e = eb + c;
         float acc = 0.f;
-        if (e < e1)
-            for (int u = ug; u < U; u += G) acc += s_phi[u] * ctx[(size_t)u * E + e];
+        if (e < e1) {
+            int u = ug;
+            for (; u + 7 * G < U; u += 8 * G) {  // 8 independent row reads in flight
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += s_phi[u + q * G] * v[q];
+            }
+            for (; u < U; u += G) acc += s_phi[u] * ctx[(size_t)u * E + e];
+        }
         __syncthreads();
         s_acc[t] = acc;
         __syncthreads();
@@ -133,22 +161,29 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
 }
 
 // Backward of one step for batch row b (one workgroup per row).
-__global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g) {
+__global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_a = sm;                  // [A]
     float* s_b = s_a + ATT_MAXA;
     float* s_k = s_b + ATT_MAXA;
     float* s_dp = s_k + ATT_MAXA;     // [3A]
-    float* s_red = s_dp + 3 * ATT_MAXA;  // [8]
-    float* s_dw = s_red + 8;          // [E]
+    float* s_red = s_dp + 3 * ATT_MAXA;  // [16]
+    float* s_dw = s_red + 16;          // [E]
     float* s_dphi = s_dw + ((E + 3) & ~3);  // [U]
 
     const int b = blockIdx.x, t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const float* ctx = g.ctx + (size_t)b * U * E;
 
-    for (int e = t; e < E; e += ATT_THREADS) s_dw[e] = g.dw[(size_t)b * g.lddw + e];
+    for (int e = t; e < E; e += ATTB_THREADS) {
+        float v = g.dw[(size_t)b * g.lddw + e];
+        if (g.dw2) {
+            v += g.dw2[(size_t)b * g.lddw + e];
+            g.dw[(size_t)b * g.lddw + e] = v;  // total, needed later for the deferred d(ctx) GEMM
+        }
+        s_dw[e] = v;
+    }
     if (t < A) {
         s_a[t] = g.a[(size_t)b * A + t];
         s_b[t] = g.b[(size_t)b * A + t];
@@ -157,11 +192,22 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g
     __syncthreads();
 
     // dphi[u] = sum_e dw[e] ctx[u][e]: one wave per u, lanes over e (coalesced row reads).
-    for (int u = wave; u < U; u += 4) {
-        float acc = 0.f;
-        for (int e = lane; e < E; e += 64) acc += s_dw[e] * ctx[(size_t)u * E + e];
-        acc = wave_sum(acc);
-        if (lane == 0) s_dphi[u] = acc;
+    constexpr int NWB = ATTB_THREADS / 64;
+    for (int u0 = wave * 4; u0 < U; u0 += NWB * 4) {  // 4 context rows in flight per wave
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = lane; e < E; e += 64) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (u0 + q < U) ? ctx[(size_t)(u0 + q) * E + e] : 0.f;
+            const float d = s_dw[e];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += d * v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float r = wave_sum(acc[q]);
+            if (lane == 0 && u0 + q < U) s_dphi[u0 + q] = r;
+        }
     }
     __syncthreads();
 
@@ -169,7 +215,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g
     for (int j = 0; j < A; ++j) {
         const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
         float da = 0.f, db = 0.f, dk = 0.f;
-        for (int u = t; u < U; u += ATT_THREADS) {
+        for (int u = t; u < U; u += ATTB_THREADS) {
             const float d = kj - (float)u;
             const float dph = s_dphi[u];
             if (g.att_type == 1) {
@@ -186,9 +232,9 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g
                 dk += dph * aj * ex * (-2.f * bj * d);
             }
         }
-        da = block_sum(da, s_red);
-        db = block_sum(db, s_red);
-        dk = block_sum(dk, s_red);
+        da = block_sum8(da, s_red);
+        db = block_sum8(db, s_red);
+        dk = block_sum8(dk, s_red);
         if (t == 0) {
             s_dp[j] = da;           // temporarily da
             s_dp[A + j] = db;       // db
@@ -203,14 +249,14 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g
             // a = softmax(p) + eps : dp = s * (da - sum(da * s)), s = a - eps
             float dot = 0.f;
             for (int j = 0; j < A; ++j) dot += s_dp[j] * (s_a[j] - g.eps);
-            s_red[4] = dot;
+            s_red[8] = dot;
         }
         __syncthreads();
     }
     float dpa = 0.f, dpb = 0.f, dpk = 0.f;
     if (t < A) {
         const float sa = s_a[t] - g.eps;
-        if (g.att_type == 1) dpa = sa * (s_dp[t] - s_red[4]);
+        if (g.att_type == 1) dpa = sa * (s_dp[t] - s_red[8]);
         else dpa = s_dp[t] * sa;
         dpb = s_dp[A + t] * (s_b[t] - g.eps);
         const float dkt = s_dp[2 * A + t] + g.dkappa[(size_t)b * A + t];  // + carry from step t+1
@@ -230,10 +276,10 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g
 
     // dh1[b][k] += sum_j dp[j] Watt[k][j]
     float* dh = g.dh1 + (size_t)b * g.lddh;
-    for (int k = t; k < H; k += ATT_THREADS) {
-        const float* wr = g.Watt + (size_t)k * 3 * A;
+    for (int k = t; k < H; k += ATTB_THREADS) {
         float acc = 0.f;
-        for (int j = 0; j < 3 * A; ++j) acc += s_dp[j] * wr[j];
+#pragma unroll 6
+        for (int j = 0; j < 3 * A; ++j) acc += s_dp[j] * g.WattT[(size_t)j * H + k];
         dh[k] += acc;
     }
 }
@@ -242,7 +288,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_bwd_kernel(const AttBwdArgs g
 
 static size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + ATT_THREADS); }
 static size_t att_bwd_lds(int U, int E) {
-    return sizeof(float) * (6 * ATT_MAXA + 8 + ((E + 3) & ~3) + ((U + 3) & ~3));
+    return sizeof(float) * (6 * ATT_MAXA + 16 + ((E + 3) & ~3) + ((U + 3) & ~3));
 }
 
 int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream) {
@@ -257,13 +303,13 @@ int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream) {
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1) return PH_ERR_BADARG;
     const size_t lds = att_bwd_lds(g.U, g.E);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(att_bwd_kernel, dim3(g.B), dim3(ATT_THREADS), lds, stream, g);
+    hipLaunchKernelGGL(att_bwd_kernel, dim3(g.B), dim3(ATTB_THREADS), lds, stream, g);
     return (int)hipGetLastError();
 }
 
 int att_default_esplit(int B, int E) {
     // aim for >= 256 workgroups while keeping slices >= 32 columns
     int es = 1;
-    while (B * es < 256 && E / (es * 2) >= 32) es *= 2;
+    while (B * es < 512 && E / (es * 2) >= 32) es *= 2;
     return es;
 }

@@ -37,9 +37,32 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     a.sbk = transB ? 1 : ldb; a.sbn = transB ? ldb : 1;
     a.ldc = ldc;
     a.batchA = strideA; a.batchB = strideB; a.batchC = strideC;
-    a.nbatch = nbatch; a.splitk = split_k < 1 ? 1 : split_k;
+    a.nbatch = nbatch;
     a.accumulate = accumulate; a.alpha = alpha; a.act = act;
-    if (a.splitk > 1 && act != 0) return PARROT_ERR_BADARG;
+    int split = split_k;
+    if (split <= 0) {
+        // auto: few output tiles but a long reduction (deferred weight gradients: K = T*B rows)
+        // -> spread K over enough workgroups to fill 256 CUs.
+        const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
+        split = 1;
+        if (act == 0 && tiles < 256 && K >= 512) {
+            split = (int)((512 + tiles - 1) / tiles);
+            const int maxs = K / 256 > 0 ? K / 256 : 1;
+            if (split > maxs) split = maxs;
+            if (split > 64) split = 64;
+        }
+    }
+    a.splitk = split;
+    if (a.splitk > 1) {
+        if (act != 0) return PARROT_ERR_BADARG;
+        if (!accumulate) {  // atomics accumulate into C: clear it first
+            for (int b = 0; b < nbatch; ++b) {
+                hipError_t e = hipMemset2DAsync(C + (long long)b * strideC, sizeof(float) * (size_t)ldc, 0,
+                                                sizeof(float) * (size_t)N, (size_t)M, st);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+    }
     return bg_launch(a, st);
 }
 
@@ -113,13 +136,13 @@ int parrot_gru_step_bwd(const float* dh_out, const float* h, const float* mask, 
     return sk_launch(L, st);
 }
 
-int parrot_gmm_attention_fwd(const float* h1, const float* Watt, const float* batt, const float* kappa_prev,
+int parrot_gmm_attention_fwd(const float* h1, const float* WattT, const float* batt, const float* kappa_prev,
                              const float* ctx, float* a, float* b, float* kappa, float* phi, float* w, int B,
                              int H, int A, int U, int E, int att_type, float eps, float alignment,
                              float sharpening, float timing, void* stream) {
-    if (!h1 || !Watt || !kappa_prev || !ctx || !a || !b || !kappa || !phi || !w) return PARROT_ERR_BADARG;
+    if (!h1 || !WattT || !kappa_prev || !ctx || !a || !b || !kappa || !phi || !w) return PARROT_ERR_BADARG;
     AttFwdArgs g;
-    g.h1 = h1; g.ldh = H; g.Watt = Watt; g.batt = batt; g.kappa_prev = kappa_prev; g.ctx = ctx;
+    g.h1 = h1; g.ldh = H; g.WattT = WattT; g.batt = batt; g.kappa_prev = kappa_prev; g.ctx = ctx;
     g.a_out = a; g.b_out = b; g.kappa_out = kappa; g.phi_out = phi; g.w_out = w; g.ldw = E;
     g.B = B; g.H = H; g.A = A; g.U = U; g.E = E; g.esplit = att_default_esplit(B, E);
     g.att_type = att_type; g.eps = eps; g.alignment = alignment; g.sharpening = sharpening; g.timing = timing;
@@ -127,14 +150,14 @@ int parrot_gmm_attention_fwd(const float* h1, const float* Watt, const float* ba
 }
 
 int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, const float* b,
-                             const float* kappa, const float* kappa_prev, const float* Watt, float* dkappa,
+                             const float* kappa, const float* kappa_prev, const float* WattT, float* dkappa,
                              float* dp, float* dh1, int B, int H, int A, int U, int E, int att_type, float eps,
                              void* stream) {
-    if (!dw || !ctx || !a || !b || !kappa || !kappa_prev || !Watt || !dkappa || !dp || !dh1)
+    if (!dw || !ctx || !a || !b || !kappa || !kappa_prev || !WattT || !dkappa || !dp || !dh1)
         return PARROT_ERR_BADARG;
     AttBwdArgs g;
-    g.dw = dw; g.lddw = E; g.ctx = ctx; g.a = a; g.b = b; g.kappa = kappa; g.kappa_prev = kappa_prev;
-    g.Watt = Watt; g.dkappa = dkappa; g.dp_out = dp; g.dh1 = dh1; g.lddh = H;
+    g.dw = const_cast<float*>(dw); g.dw2 = nullptr; g.lddw = E; g.ctx = ctx; g.a = a; g.b = b; g.kappa = kappa; g.kappa_prev = kappa_prev;
+    g.WattT = WattT; g.dkappa = dkappa; g.dp_out = dp; g.dh1 = dh1; g.lddh = H;
     g.B = B; g.H = H; g.A = A; g.U = U; g.E = E; g.att_type = att_type; g.eps = eps;
     return att_bwd_launch(g, (hipStream_t)stream);
 }

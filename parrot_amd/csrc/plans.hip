@@ -174,130 +174,159 @@ struct DecoderPlan : PlanBase {
         j.nseg = n;
     }
 
-    int fwd(hipStream_t st) {
+    void gates_job(SkJob& j, int l, int t) const {
+        const size_t BH = (size_t)d.B * d.H;
+        sk_job_init(j);
+        layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
+        j.M = d.B; j.N = 2 * d.H; j.H = d.H; j.epi = SK_EPI_GRU_GATES;
+        j.bias = d.bg[l];
+        j.add = d.seq_g[l] ? d.seq_g[l] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
+        j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
+        j.o1 = d.z[l] + t * BH; j.ldo1 = d.H;
+        j.o2 = d.r[l] + t * BH; j.ldo2 = d.H;
+        j.out = d.rh[l] + t * BH; j.ldo = d.H;
+    }
+
+    void cand_job(SkJob& j, int l, int t) const {
+        const size_t BH = (size_t)d.B * d.H;
+        sk_job_init(j);
+        layer_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
+        j.M = d.B; j.N = d.H; j.H = d.H; j.epi = SK_EPI_GRU_CAND;
+        j.bias = d.bc[l];
+        j.add = d.seq_c[l] ? d.seq_c[l] + t * BH : nullptr; j.ld_add = d.H;
+        j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
+        j.e1 = d.z[l] + t * BH; j.lde1 = d.H;
+        j.o1 = d.c[l] + t * BH; j.ldo1 = d.H;
+        j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
+    }
+
+    int att_fwd_step(int t, hipStream_t st) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
-        for (int t = 0; t < d.T; ++t) {
+        AttFwdArgs g;
+        g.h1 = d.h[0] + (t + 1) * BH; g.ldh = d.H;
+        g.WattT = d.WattT; g.batt = d.batt;
+        g.kappa_prev = d.kappa + t * BA;
+        g.ctx = d.ctx;
+        g.a_out = d.a + t * BA; g.b_out = d.b + t * BA; g.kappa_out = d.kappa + (t + 1) * BA;
+        g.phi_out = d.phi + (size_t)t * d.B * d.U;
+        g.w_out = d.w + (t + 1) * BE; g.ldw = d.E;
+        g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.esplit = esplit;
+        g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
+        g.sharpening = d.sharpening; g.timing = d.timing;
+        return att_fwd_launch(g, st);
+    }
+
+    // Forward wavefront: at tick q layer l advances step t = q - l, so the gate GEMMs of all layers share
+    // one launch, the candidate GEMMs a second one, and the attention of step q is the third.  Layer
+    // l >= 1 needs h_j(t) (j < l) and w_t, both produced in earlier ticks; layer 0 needs w_{t-1}.
+    int fwd(hipStream_t st) {
+        for (int q = 0; q < d.T + d.L - 1; ++q) {
+            SkJob jobs[PARROT_MAX_LAYERS];
+            int n = 0;
             for (int l = 0; l < d.L; ++l) {
-                SkJob j;
-                sk_job_init(j);
-                layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
-                j.M = d.B; j.N = 2 * d.H; j.H = d.H; j.epi = SK_EPI_GRU_GATES;
-                j.bias = d.bg[l];
-                j.add = d.seq_g[l] ? d.seq_g[l] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
-                j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
-                j.o1 = d.z[l] + t * BH; j.ldo1 = d.H;
-                j.o2 = d.r[l] + t * BH; j.ldo2 = d.H;
-                j.out = d.rh[l] + t * BH; j.ldo = d.H;
-                PL_TRY(launch_jobs(&j, 1, st));
-
-                sk_job_init(j);
-                layer_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
-                j.M = d.B; j.N = d.H; j.H = d.H; j.epi = SK_EPI_GRU_CAND;
-                j.bias = d.bc[l];
-                j.add = d.seq_c[l] ? d.seq_c[l] + t * BH : nullptr; j.ld_add = d.H;
-                j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
-                j.e1 = d.z[l] + t * BH; j.lde1 = d.H;
-                j.o1 = d.c[l] + t * BH; j.ldo1 = d.H;
-                j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
-                PL_TRY(launch_jobs(&j, 1, st));
-
-                if (l == 0) {
-                    AttFwdArgs g;
-                    g.h1 = d.h[0] + (t + 1) * BH; g.ldh = d.H;
-                    g.Watt = d.Watt; g.batt = d.batt;
-                    g.kappa_prev = d.kappa + t * BA;
-                    g.ctx = d.ctx;
-                    g.a_out = d.a + t * BA; g.b_out = d.b + t * BA; g.kappa_out = d.kappa + (t + 1) * BA;
-                    g.phi_out = d.phi + (size_t)t * d.B * d.U;
-                    g.w_out = d.w + (t + 1) * BE; g.ldw = d.E;
-                    g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.esplit = esplit;
-                    g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
-                    g.sharpening = d.sharpening; g.timing = d.timing;
-                    PL_TRY(att_fwd_launch(g, st));
-                }
+                const int t = q - l;
+                if (t >= 0 && t < d.T) gates_job(jobs[n++], l, t);
             }
+            PL_TRY(launch_jobs(jobs, n, st));
+            n = 0;
+            for (int l = 0; l < d.L; ++l) {
+                const int t = q - l;
+                if (t >= 0 && t < d.T) cand_job(jobs[n++], l, t);
+            }
+            PL_TRY(launch_jobs(jobs, n, st));
+            if (q < d.T) PL_TRY(att_fwd_step(q, st));
         }
         return 0;
     }
 
-    int layer_bwd(int l, int t, hipStream_t st) {
-        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
-        const int H = d.H, E = d.E;
-        GruStateBwdArgs ga;
-        ga.nchain = 1; ga.B = d.B; ga.H = H;
-        GruStateBwdChain& c = ga.chain[0];
-        c.dh = d.dh[l] + (t + 1) * BH;
-        c.hprev = d.h[l] + t * BH;
-        c.z = d.z[l] + t * BH;
-        c.c = d.c[l] + t * BH;
-        c.mask = nullptr;
-        c.dC = d.dC[l] + t * BH;
-        c.dG = d.dG[l] + t * 2 * BH;
-        c.dhprev = d.dh[l] + t * BH;
-        PL_TRY(gru_state_bwd_launch(ga, st));
-
-        // X: d(r*h_prev) = dC . Wc[0:H,:]^T ; epilogue -> dG_r, dh_prev += d(rh) * r
-        SkJob x;
-        sk_job_init(x);
-        x.nseg = 1;
-        x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
-        x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
-        x.e0 = d.h[l] + t * BH; x.lde0 = H;
-        x.e1 = d.r[l] + t * BH; x.lde1 = H;
-        x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
-        x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
-        PL_TRY(launch_jobs(&x, 1, st));
-
-        // Y: gradients flowing to the layer's inputs, one job per destination.
-        SkJob y[4];
-        int n = 0;
-        const float* dG = d.dG[l] + t * 2 * BH;
-        const float* dC = d.dC[l] + t * BH;
-        {   // previous state of this layer: only the gate GEMM (rh part handled by X)
-            SkJob& j = y[n++];
-            sk_job_init(j);
-            j.nseg = 1;
-            j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
-            j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-            j.out = d.dh[l] + t * BH; j.ldo = H;
-        }
-        {   // attention context
-            SkJob& j = y[n++];
-            sk_job_init(j);
-            j.nseg = 2;
-            j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
-            j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)H * H, H, H, 1);
-            j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-            j.out = d.dw + (size_t)(l == 0 ? t : t + 1) * BE; j.ldo = E;
-        }
-        for (int q = 0; q < l; ++q) {  // lower layers' states of the same step
-            SkJob& j = y[n++];
-            sk_job_init(j);
-            j.nseg = 2;
-            j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + q * H) * 2 * H, 2 * H, 2 * H, 1);
-            j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + q * H) * H, H, H, 1);
-            j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-            j.out = d.dh[q] + (t + 1) * BH; j.ldo = H;
-        }
-        return launch_jobs(y, n, st);
-    }
-
+    // Backward wavefront: at tick q layer l (upper layers first) handles step t = T-1-(q-(L-1-l)).
+    // Per tick: attention backward of layer 0's step, then one elementwise launch, one launch of the
+    // d(r*h) GEMMs and one launch of the input-gradient GEMMs for all active layers.
+    // Layer 0 sends its w-gradient to dw0 (slot t) because in the same launch layer 1 writes
+    // dw slot t; the attention backward of step t-1 adds the two.
     int bwd(hipStream_t st) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
-        for (int t = d.T - 1; t >= 0; --t) {
-            for (int l = d.L - 1; l >= 1; --l) PL_TRY(layer_bwd(l, t, st));
-            AttBwdArgs g;
-            g.dw = d.dw + (t + 1) * BE; g.lddw = d.E;
-            g.ctx = d.ctx;
-            g.a = d.a + t * BA; g.b = d.b + t * BA;
-            g.kappa = d.kappa + (t + 1) * BA; g.kappa_prev = d.kappa + t * BA;
-            g.Watt = d.Watt;
-            g.dkappa = d.dkappa;
-            g.dp_out = d.dp + (size_t)t * d.B * 3 * d.A;
-            g.dh1 = d.dh[0] + (t + 1) * BH; g.lddh = d.H;
-            g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
-            PL_TRY(att_bwd_launch(g, st));
-            PL_TRY(layer_bwd(0, t, st));
+        const int H = d.H, E = d.E;
+        for (int q = 0; q < d.T + d.L - 1; ++q) {
+            int tl[PARROT_MAX_LAYERS];
+            for (int l = 0; l < d.L; ++l) tl[l] = d.T - 1 - (q - (d.L - 1 - l));
+            const int t0 = tl[0];
+            if (t0 >= 0 && t0 < d.T) {
+                AttBwdArgs g;
+                g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
+                g.ctx = d.ctx;
+                g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
+                g.kappa = d.kappa + (t0 + 1) * BA; g.kappa_prev = d.kappa + t0 * BA;
+                g.WattT = d.WattT;
+                g.dkappa = d.dkappa;
+                g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
+                g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
+                g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
+                PL_TRY(att_bwd_launch(g, st));
+            }
+            GruStateBwdArgs ga;
+            ga.nchain = 0; ga.B = d.B; ga.H = H;
+            SkJob jx[PARROT_MAX_LAYERS], jy[SK_MAXJOB];
+            int nx = 0, ny = 0;
+            for (int l = d.L - 1; l >= 0; --l) {
+                const int t = tl[l];
+                if (t < 0 || t >= d.T) continue;
+                GruStateBwdChain& c = ga.chain[ga.nchain++];
+                c.dh = d.dh[l] + (t + 1) * BH;
+                c.hprev = d.h[l] + t * BH;
+                c.z = d.z[l] + t * BH;
+                c.c = d.c[l] + t * BH;
+                c.mask = nullptr;
+                c.dC = d.dC[l] + t * BH;
+                c.dG = d.dG[l] + t * 2 * BH;
+                c.dhprev = d.dh[l] + t * BH;
+
+                // X: d(r*h_prev) = dC . Wc[0:H,:]^T ; epilogue -> dG_r, dh_prev += d(rh) * r
+                SkJob& x = jx[nx++];
+                sk_job_init(x);
+                x.nseg = 1;
+                x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+                x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
+                x.e0 = d.h[l] + t * BH; x.lde0 = H;
+                x.e1 = d.r[l] + t * BH; x.lde1 = H;
+                x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
+                x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
+
+                // Y: gradients flowing to the layer's inputs, one job per destination.
+                const float* dG = d.dG[l] + t * 2 * BH;
+                const float* dC = d.dC[l] + t * BH;
+                {   // previous state of this layer: only the gate GEMM (rh part handled by X)
+                    SkJob& j = jy[ny++];
+                    sk_job_init(j);
+                    j.nseg = 1;
+                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+                    // layer l+1 (one step ahead in reverse time) adds into the same slot in this launch
+                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 2;
+                    j.out = d.dh[l] + t * BH; j.ldo = H;
+                }
+                {   // attention context
+                    SkJob& j = jy[ny++];
+                    sk_job_init(j);
+                    j.nseg = 2;
+                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
+                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)H * H, H, H, 1);
+                    j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                    j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
+                }
+                for (int p = 0; p < l; ++p) {  // lower layers' states of the same step
+                    SkJob& j = jy[ny++];
+                    sk_job_init(j);
+                    j.nseg = 2;
+                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + p * H) * 2 * H, 2 * H, 2 * H, 1);
+                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + p * H) * H, H, H, 1);
+                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 2;
+                    j.out = d.dh[p] + (t + 1) * BH; j.ldo = H;
+                }
+            }
+            if (ga.nchain == 0) continue;
+            PL_TRY(gru_state_bwd_launch(ga, st));
+            PL_TRY(launch_jobs(jx, nx, st));
+            PL_TRY(launch_jobs(jy, ny, st));
         }
         return 0;
     }
@@ -355,7 +384,7 @@ struct SamplePlan : PlanBase {
                 if (l == 0) {
                     AttFwdArgs g;
                     g.h1 = d.h[0] + nxt * BH; g.ldh = H;
-                    g.Watt = d.Watt; g.batt = d.batt;
+                    g.WattT = d.WattT; g.batt = d.batt;
                     g.kappa_prev = d.kappa + t * BA;
                     g.ctx = d.ctx;
                     g.a_out = d.a + t * BA; g.b_out = d.bwork; g.kappa_out = d.kappa + (t + 1) * BA;

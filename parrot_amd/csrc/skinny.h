@@ -8,7 +8,7 @@
 #pragma once
 #include "common.h"
 
-enum { SK_MAXSEG = 5, SK_MAXJOB = 4, SK_NW = 8, SK_THREADS = SK_NW * 64 };
+enum { SK_MAXSEG = 5, SK_MAXJOB = 9, SK_NW = 8, SK_THREADS = SK_NW * 64 };
 
 enum SkEpi {
     SK_EPI_LINEAR = 0,     // out = act(acc + bias + add) (optionally accumulated into out)
@@ -29,7 +29,8 @@ struct SkSeg {
 struct SkJob {
     SkSeg seg[SK_MAXSEG];
     int nseg, M, N, epi;
-    int act, accumulate, H, aligned;  // aligned: all segment pointers/strides allow 16-byte loads
+    int act, accumulate, H, aligned;  // accumulate: 0 store, 1 out += (exclusive owner), 2 atomic add
+                                      // aligned: every segment allows the branch-free 16-byte fetch
     const float* bias;  // [N] or null
     const float* add;   // [M, N] additive pre-activation input or null
     float* out;

@@ -52,10 +52,19 @@ __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M,
     for (int rb = 0; rb < MB; ++rb) {
         const int m = m0 + rb * 16 + i;
         a[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifndef SK_DBG_NO_A
         if (m < M) a[rb] = ld4k<AL>(sg.A + (size_t)m * sg.lda + k, k, sg.K);
+#else
+        a[rb][0] = (float)m;
+#endif
     }
     b = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef SK_DBG_NO_B
+    b[0] = (float)ncol;
+    if (false) {
+#else
     if (ncol_ok) {
+#endif
         if (sg.b_kcontig) {
             b = ld4k<AL>(sg.B + (size_t)ncol * sg.ldb + k, k, sg.K);
         } else {
@@ -72,16 +81,38 @@ __device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb)
+#ifndef SK_DBG_NO_MMA
             acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[u], acc[rb], 0, 0, 0);
+#else
+            acc[rb][u] += a[rb][u] * b[u];
+#endif
 }
 
-template <int MB, bool AL>
+// Branch-free operand fetch of the fast path: every segment has K % 16 == 0 and 16-byte aligned
+// rows, out-of-range rows / columns are clamped (their results are discarded by the epilogue).
+template <int MB>
+__device__ __forceinline__ void sk_fetch_fast(const SkSeg& sg, int kc, const int (&mrow)[MB], int ncol, int kk,
+                                              f32x4 (&a)[MB], f32x4& b) {
+    const int k = kc + 4 * kk;
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb)
+        a[rb] = *reinterpret_cast<const f32x4*>(sg.A + (size_t)mrow[rb] * sg.lda + k);
+    if (sg.b_kcontig) {
+        b = *reinterpret_cast<const f32x4*>(sg.B + (size_t)ncol * sg.ldb + k);
+    } else {
+        const float* bp = sg.B + (size_t)k * sg.ldb + ncol;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = bp[(size_t)u * sg.ldb];
+    }
+}
+
+template <int MB, bool FAST>
 __device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 4, i = lane & 15;
-    const int m0 = blockIdx.y * 64;
+    const int m0 = blockIdx.y * (16 * MB);  // the launch picks MB = row blocks per workgroup
     const int M = job.M, N = job.N;
     if (m0 >= M) return;
 
@@ -92,27 +123,72 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) 
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Round-robin 16-deep K chunks over the waves, across the concatenated segments.
-    int base = 0;
-    for (int s = 0; s < job.nseg; ++s) {
-        const SkSeg sg = job.seg[s];
-        const int nch = (sg.K + 15) >> 4;
-        int c = (wave - (base % SK_NW) + SK_NW) % SK_NW;
-        f32x4 a_cur[MB], b_cur;
-        if (c < nch) sk_fetch<MB, AL>(sg, c * 16, m0, M, ncol, ncol_ok, kk, i, a_cur, b_cur);
-        while (c < nch) {
-            const int cn = c + SK_NW;
-            f32x4 a_nxt[MB], b_nxt;
-            if (cn < nch) sk_fetch<MB, AL>(sg, cn * 16, m0, M, ncol, ncol_ok, kk, i, a_nxt, b_nxt);
-            sk_mma<MB>(a_cur, b_cur, acc);
-            if (cn < nch) {
+    if (FAST) {
+        // One flat sequence of 16-deep chunks over all segments, dealt round-robin to the waves, with
+        // the next chunk's loads in flight while the current one feeds the matrix cores.
+        int cend[SK_MAXSEG];
+        int total = 0;
 #pragma unroll
-                for (int rb = 0; rb < MB; ++rb) a_cur[rb] = a_nxt[rb];
-                b_cur = b_nxt;
-            }
-            c = cn;
+        for (int s = 0; s < SK_MAXSEG; ++s) {
+            if (s < job.nseg) total += job.seg[s].K >> 4;
+            cend[s] = total;
         }
-        base += nch;
+        int mrow[MB];
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + i, M - 1);
+        const int ncl = min(ncol, N - 1);
+        auto locate = [&](int g, int& sidx, int& kc) {
+            sidx = 0;
+            int beg = 0;
+#pragma unroll
+            for (int s = 0; s < SK_MAXSEG - 1; ++s)
+                if (g >= cend[s]) { sidx = s + 1; beg = cend[s]; }
+            kc = (g - beg) << 4;
+        };
+        f32x4 a_cur[MB], b_cur, a_nxt[MB], b_nxt;
+        int g = wave;
+        if (g < total) {
+            int sidx, kc;
+            locate(g, sidx, kc);
+            sk_fetch_fast<MB>(job.seg[sidx], kc, mrow, ncl, kk, a_cur, b_cur);
+        }
+        while (g < total) {
+            const int gn = g + SK_NW;
+            if (gn < total) {
+                int sidx, kc;
+                locate(gn, sidx, kc);
+                sk_fetch_fast<MB>(job.seg[sidx], kc, mrow, ncl, kk, a_nxt, b_nxt);
+            }
+            sk_mma<MB>(a_cur, b_cur, acc);
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) a_cur[rb] = a_nxt[rb];
+            b_cur = b_nxt;
+            g = gn;
+        }
+    } else {
+        // Generic path: per-element masks for K tails / unaligned operands (e.g. the 63-wide fed-back
+        // output frame).  Round-robin 16-deep K chunks over the waves, segment by segment.
+        int base = 0;
+        for (int s = 0; s < job.nseg; ++s) {
+            const SkSeg sg = job.seg[s];
+            const int nch = (sg.K + 15) >> 4;
+            int c = (wave - (base % SK_NW) + SK_NW) % SK_NW;
+            f32x4 a_cur[MB], b_cur;
+            if (c < nch) sk_fetch<MB, false>(sg, c * 16, m0, M, ncol, ncol_ok, kk, i, a_cur, b_cur);
+            while (c < nch) {
+                const int cn = c + SK_NW;
+                f32x4 a_nxt[MB], b_nxt;
+                if (cn < nch) sk_fetch<MB, false>(sg, cn * 16, m0, M, ncol, ncol_ok, kk, i, a_nxt, b_nxt);
+                sk_mma<MB>(a_cur, b_cur, acc);
+                if (cn < nch) {
+#pragma unroll
+                    for (int rb = 0; rb < MB; ++rb) a_cur[rb] = a_nxt[rb];
+                    b_cur = b_nxt;
+                }
+                c = cn;
+            }
+            base += nch;
+        }
     }
 
     // Intra-workgroup split-K reduction through LDS.
@@ -173,8 +249,12 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) 
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
                 float* o = job.out + (size_t)m * job.ldo + n;
-                if (job.accumulate) x += *o;
-                *o = x;
+                if (job.accumulate == 2) {
+                    unsafeAtomicAdd(o, x);  // another job of the same launch adds into this tile too
+                } else {
+                    if (job.accumulate) x += *o;
+                    *o = x;
+                }
             } break;
             case SK_EPI_GRU_GATES: {
                 x += bias;
@@ -225,7 +305,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
         if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
     const int tile = bx - (j > 0 ? L.tile_end[j - 1] : 0);
     const SkJob& job = L.job[j];
-    if (job.aligned) sk_body<MB, true>(job, tile, red);
+    if (job.aligned) sk_body<MB, true>(job, tile, red);   // fast path: branch-free operand fetch
     else sk_body<MB, false>(job, tile, red);
 }
 
@@ -235,7 +315,7 @@ void sk_finalize_job(SkJob& j) {
     int al = 1;
     for (int s = 0; s < j.nseg; ++s) {
         const SkSeg& g = j.seg[s];
-        if (((uintptr_t)g.A & 15) || (g.lda & 3) || (g.K & 3)) al = 0;
+        if (((uintptr_t)g.A & 15) || (g.lda & 3) || (g.K & 15)) al = 0;
         if (g.b_kcontig && (((uintptr_t)g.B & 15) || (g.ldb & 3))) al = 0;
     }
     j.aligned = al;
@@ -268,8 +348,13 @@ int sk_launch(const SkLaunch& L, hipStream_t stream) {
     int maxM = 0;
     for (int q = 0; q < L.njobs; ++q) maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
     const int tiles = L.tile_end[L.njobs - 1];
-    const int mb = maxM >= 49 ? 4 : (maxM + 15) / 16;
-    dim3 grid(tiles, ceil_div(maxM, 64));
+    // Rows per workgroup (16*mb).  Each weight element should ideally be streamed by one workgroup
+    // (mb = 4 covers 64 batch rows), but a launch with few column tiles would leave most of the 256
+    // CUs idle, so split the batch rows over more workgroups until the grid reaches ~256 (the
+    // duplicated weight reads are served by L2; measured 22 -> 13.5 us for the cfg2 gate GEMM).
+    int mb = maxM >= 49 ? 4 : (maxM + 15) / 16;
+    while (mb > 1 && tiles * ceil_div(maxM, 16 * mb) < 224) mb = (mb + 1) / 2;
+    dim3 grid(tiles, ceil_div(maxM, 16 * mb));
     const size_t lds = (size_t)SK_NW * mb * 64 * sizeof(f32x4);
     switch (mb) {
         case 1: hipLaunchKernelGGL(sk_kernel<1>, grid, dim3(SK_THREADS), lds, stream, L); break;

@@ -167,10 +167,10 @@ class Parrot(Brick):
                 s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_inputs.b', (H,), 'bias')
                 s.alias(f'{P}/h{j}_to_h{l}/fork_rnn{l}_gates.W', f'dec.Wg{l}', rows=(r0, r0 + H))
                 s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_gates.b', (2 * H,), 'bias')
-        s.add('dec.Watt', (H, 3 * A), 'weight', alias=False)
+        s.add('dec.WattT', (3 * A, H), 'weight', alias=False)  # h1_to_att weights, stored transposed
         s.add('dec.batt', (3 * A,), 'bias', alias=False)
         for i, n in enumerate(('alpha', 'beta', 'kappa')):
-            s.alias(f'{P}/h1_to_att/fork_{n}.W', 'dec.Watt', cols=(i * A, (i + 1) * A))
+            s.alias(f'{P}/h1_to_att/fork_{n}.W', 'dec.WattT', rows=(i * A, (i + 1) * A), transpose=True)
             s.alias(f'{P}/h1_to_att/fork_{n}.b', 'dec.batt', rows=(i * A, (i + 1) * A), role='bias')
         s.add('dec.Wr', (L * H + E, R), 'weight', alias=False)
         for l in range(1, L + 1):
@@ -422,6 +422,7 @@ class Parrot(Brick):
             rh=[torch.empty(T, B, H, **f) for _ in range(L)], c=[torch.empty(T, B, H, **f) for _ in range(L)],
             a=torch.empty(T, B, A, **f), b=torch.empty(T, B, A, **f), phi=torch.empty(T, B, U, **f),
             dh=[torch.zeros(T + 1, B, H, **f) for _ in range(L)], dw=torch.zeros(T + 1, B, E, **f),
+            dw0=torch.zeros(T + 1, B, E, **f),
             dkappa=torch.zeros(B, A, **f),
             dG=[torch.empty(T, B, 2 * H, **f) for _ in range(L)], dC=[torch.empty(T, B, H, **f) for _ in range(L)],
             dp=torch.empty(T, B, 3 * A, **f),
@@ -448,8 +449,8 @@ class Parrot(Brick):
             d.seq_g[l] = ws['seq_g'][l].data_ptr() if ws['seq_g'][l] is not None else None
             for n in ('h', 'z', 'r', 'rh', 'c', 'dh', 'dG', 'dC'):
                 getattr(d, n)[l] = ws[n][l].data_ptr()
-        d.Watt, d.batt, d.ctx = st['dec.Watt'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
-        for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dkappa', 'dp'):
+        d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
+        for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dw0', 'dkappa', 'dp'):
             setattr(d, n, ws[n].data_ptr())
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
@@ -616,7 +617,7 @@ class Parrot(Brick):
         dread = torch.zeros(T * B, R, device=readouts.device, dtype=torch.float32)
         for i, (wn, bn, dim) in enumerate(self._out_names):
             dp = save['dpreds'][i] * gscale
-            ops.gemm(readouts.t(), dp, out=self.store.grad(wn), accumulate=True, split_k=self._split(T * B))
+            ops.gemm(readouts.t(), dp, out=self.store.grad(wn), accumulate=True)
             ops.colsum(dp, out=self.store.grad(bn), accumulate=True)
             ops.gemm(dp, self.store.param(wn).t(), out=dread, accumulate=True)
             if self.use_speaker:
@@ -628,10 +629,9 @@ class Parrot(Brick):
         # readouts
         gWr = self.store.storage_grad['dec.Wr']
         Wr = self.store.storage['dec.Wr']
-        sp = self._split(T * B)
         for l in range(L):
-            ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dread, out=gWr[l * H:(l + 1) * H], accumulate=True, split_k=sp)
-        ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True, split_k=sp)
+            ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dread, out=gWr[l * H:(l + 1) * H], accumulate=True)
+        ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True)
         db = ops.colsum(dread)
         for l in range(1, L + 1):
             self._g(f'/h{l}_to_readout.b').add_(db)
@@ -648,6 +648,7 @@ class Parrot(Brick):
         ws['dw'][0].zero_()
         ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
+        ws['dw0'].zero_()
 
         _lib.call('parrot_decoder_seq_bwd', ws['plan'], ops._stream())
 
@@ -659,15 +660,15 @@ class Parrot(Brick):
             gWg, gWc = sg_[f'dec.Wg{l + 1}'], sg_[f'dec.Wc{l + 1}']
             hprev = ws['h'][l][:T].view(T * B, H)
             wsrc = (ws['w'][:T] if l == 0 else ws['w'][1:]).view(T * B, E)
-            ops.gemm(hprev.t(), dG, out=gWg[0:H], accumulate=True, split_k=sp)
-            ops.gemm(ws['rh'][l].view(T * B, H).t(), dC, out=gWc[0:H], accumulate=True, split_k=sp)
-            ops.gemm(wsrc.t(), dG, out=gWg[H:H + E], accumulate=True, split_k=sp)
-            ops.gemm(wsrc.t(), dC, out=gWc[H:H + E], accumulate=True, split_k=sp)
+            ops.gemm(hprev.t(), dG, out=gWg[0:H], accumulate=True)
+            ops.gemm(ws['rh'][l].view(T * B, H).t(), dC, out=gWc[0:H], accumulate=True)
+            ops.gemm(wsrc.t(), dG, out=gWg[H:H + E], accumulate=True)
+            ops.gemm(wsrc.t(), dC, out=gWc[H:H + E], accumulate=True)
             for j in range(l):
                 r0 = H + E + j * H
                 hj = ws['h'][j][1:].view(T * B, H)
-                ops.gemm(hj.t(), dG, out=gWg[r0:r0 + H], accumulate=True, split_k=sp)
-                ops.gemm(hj.t(), dC, out=gWc[r0:r0 + H], accumulate=True, split_k=sp)
+                ops.gemm(hj.t(), dG, out=gWg[r0:r0 + H], accumulate=True)
+                ops.gemm(hj.t(), dC, out=gWc[r0:r0 + H], accumulate=True)
             dbg, dbc = ops.colsum(dG), ops.colsum(dC)
             for nc, ng in self._layer_bias_names(l + 1):
                 self._g(nc).add_(dbc); self._g(ng).add_(dbg)
@@ -675,8 +676,8 @@ class Parrot(Brick):
             ll = l + 1
             if ll in self._fb_layers:
                 inp = save['fb_inp']
-                ops.gemm(inp.t(), dC, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.W'), accumulate=True, split_k=sp)
-                ops.gemm(inp.t(), dG, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.W'), accumulate=True, split_k=sp)
+                ops.gemm(inp.t(), dC, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.W'), accumulate=True)
+                ops.gemm(inp.t(), dG, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.W'), accumulate=True)
                 self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.b').add_(dbc)
                 self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.b').add_(dbg)
             if self.use_speaker:
@@ -691,9 +692,10 @@ class Parrot(Brick):
                 ops.colsum(ws['dh'][l][0], out=self._g(f'/rnn{ll}.initial_state'), accumulate=True)
         if save['start_flag']:
             ops.colsum(ws['dw'][0], out=self._g('.initial_w'), accumulate=True)
+            ops.colsum(ws['dw0'][0], out=self._g('.initial_w'), accumulate=True)
         # attention projection
         dpj = ws['dp'].view(T * B, 3 * A)
-        ops.gemm(ws['h'][0][1:].view(T * B, H).t(), dpj, out=sg_['dec.Watt'], accumulate=True, split_k=sp)
+        ops.gemm(dpj.t(), ws['h'][0][1:].view(T * B, H), out=sg_['dec.WattT'], accumulate=True)
         ops.colsum(dpj, out=sg_['dec.batt'], accumulate=True)
         # encoder output: dctx[b] = phi[:, b, :]^T . dw_total[1:, b, :]   (batched over b)
         dctx = torch.empty(B, U, E, device=readouts.device, dtype=torch.float32)
@@ -750,7 +752,7 @@ class Parrot(Brick):
             if self.use_speaker:
                 d.seq_c[l], d.seq_g[l] = ws['seq_c'][l].data_ptr(), ws['seq_g'][l].data_ptr()
             d.h[l] = ws['h'][l].data_ptr()
-        d.Watt, d.batt = st['dec.Watt'].data_ptr(), st['dec.batt'].data_ptr()
+        d.WattT, d.batt = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr()
         d.Wr, d.br = st['dec.Wr'].data_ptr(), ws['br'].data_ptr()
         d.radd = ws['radd'].data_ptr() if ws['radd'] is not None else None
         d.Wo, d.bo = self._p('/readout_to_output.W').data_ptr(), self._p('/readout_to_output.b').data_ptr()

@@ -50,14 +50,14 @@ def _mat(t: torch.Tensor, name: str):
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate=False, act=ACT_NONE,
-         alpha=1.0, split_k=1) -> torch.Tensor:
+         alpha=1.0, split_k=0) -> torch.Tensor:
     """out[M,N] (+)= alpha * a[M,K] @ b[K,N] + bias.  a / b may be transposed views (no copies)."""
     pa, M, K, lda, ta = _mat(a, "a")
     pb, K2, N, ldb, tb = _mat(b, "b")
     if K != K2:
         raise ValueError(f"gemm: inner dimensions differ ({K} vs {K2})")
     if out is None:
-        if accumulate or split_k > 1:
+        if accumulate:
             out = torch.zeros((M, N), device=a.device, dtype=torch.float32)
         else:
             out = torch.empty((M, N), device=a.device, dtype=torch.float32)
@@ -138,12 +138,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm(dy2, W.t()).reshape(ctx.xshape)
         if ctx.needs_input_grad[1]:
-            M = x2.shape[0]
-            split = 1
-            tiles = ((W.shape[0] + 127) // 128) * ((W.shape[1] + 127) // 128)
-            while tiles * split < 256 and M // (split * 2) >= 512:
-                split *= 2
-            dW = gemm(x2.t(), dy2, split_k=split)
+            dW = gemm(x2.t(), dy2)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dW, db, None
@@ -305,7 +300,7 @@ def gru_seq(inputs, gate_inputs, h0, Wc, Wg, mask=None, reverse=False):
 
 
 # ----------------------------------------------------------------------------- attention step
-def gmm_attention_fwd(h1, Watt, batt, kappa_prev, ctx, att_type=0, eps=1e-5, alignment=1.0,
+def gmm_attention_fwd(h1, WattT, batt, kappa_prev, ctx, att_type=0, eps=1e-5, alignment=1.0,
                       sharpening=1.0, timing=1.0):
     B, H = h1.shape
     A = kappa_prev.shape[1]
@@ -314,21 +309,21 @@ def gmm_attention_fwd(h1, Watt, batt, kappa_prev, ctx, att_type=0, eps=1e-5, ali
     a, b, k = (torch.empty((B, A), **f) for _ in range(3))
     phi = torch.empty((B, U), **f)
     w = torch.empty((B, E), **f)
-    _lib.call("parrot_gmm_attention_fwd", ptr(h1, "h1"), ptr(Watt, "Watt"), ptr(batt, "batt"),
+    _lib.call("parrot_gmm_attention_fwd", ptr(h1, "h1"), ptr(WattT, "WattT"), ptr(batt, "batt"),
               ptr(kappa_prev, "kappa_prev"), ptr(ctx, "ctx"), ptr(a), ptr(b), ptr(k), ptr(phi), ptr(w),
               B, H, A, U, E, int(att_type), float(eps), float(alignment), float(sharpening), float(timing),
               _stream())
     return a, b, k, phi, w
 
 
-def gmm_attention_bwd(dw, ctx, a, b, kappa, kappa_prev, Watt, dkappa, dh1, att_type=0, eps=1e-5):
+def gmm_attention_bwd(dw, ctx, a, b, kappa, kappa_prev, WattT, dkappa, dh1, att_type=0, eps=1e-5):
     """dkappa [B,A] is updated in place (carry); dh1 [B,H] is accumulated; returns dp [B,3A]."""
     B, H = dh1.shape
     A = kappa.shape[1]
     _, U, E = ctx.shape
     dp = torch.empty((B, 3 * A), device=dw.device, dtype=torch.float32)
     _lib.call("parrot_gmm_attention_bwd", ptr(dw, "dw"), ptr(ctx, "ctx"), ptr(a), ptr(b), ptr(kappa),
-              ptr(kappa_prev), ptr(Watt), ptr(dkappa), ptr(dp), ptr(dh1), B, H, A, U, E, int(att_type),
+              ptr(kappa_prev), ptr(WattT), ptr(dkappa), ptr(dp), ptr(dh1), B, H, A, U, E, int(att_type),
               float(eps), _stream())
     return dp
 

@@ -23,6 +23,7 @@ class ParamStore:
         self.storage = OrderedDict()    # storage name -> view of flat
         self.storage_grad = OrderedDict()
         self.offsets = {}
+        self._transposed = set()
 
     # -- declaration
     def add(self, name, shape, role="weight", alias=True):
@@ -31,9 +32,11 @@ class ParamStore:
         if alias:
             self._aliases[name] = (name, None, None, role)
 
-    def alias(self, refname, storage, rows=None, cols=None, role="weight"):
+    def alias(self, refname, storage, rows=None, cols=None, role="weight", transpose=False):
         assert refname not in self._aliases, refname
         self._aliases[refname] = (storage, rows, cols, role)
+        if transpose:
+            self._transposed.add(refname)
 
     # -- allocation
     def allocate(self, device):
@@ -60,6 +63,8 @@ class ParamStore:
             t = t[rows[0]:rows[1]]
         if cols is not None:
             t = t[..., cols[0]:cols[1]]
+        if refname in self._transposed:
+            t = t.t()
         return t
 
     def param(self, refname):

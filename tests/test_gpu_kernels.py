@@ -20,7 +20,7 @@ def _rand(shape, dev, seed, scale=1.0):
 @pytest.mark.parametrize("transB", [False, True])
 def test_skinny_gemm(dev, M, N, K, transB):
     from parrot_amd import ops
-    a = _rand((M, K), dev, 1)
+    a = _rand((M, K), dev, 1, 1.0 / math.sqrt(K))
     b = _rand((N, K) if transB else (K, N), dev, 2)
     bias = _rand((N,), dev, 3)
     bb = b.t() if transB else b
@@ -151,7 +151,8 @@ def test_attention_fwd_bwd(dev, att_type, B, H, A, U, E):
     kprev = _rand((B, A), dev, 4).abs() * 3
     ctx = _rand((B, U, E), dev, 5)
     at = 1 if att_type == "softmax" else 0
-    a, b, k, phi, w = ops.gmm_attention_fwd(h1, Watt, batt, kprev, ctx, at, 1e-5, 0.7, 1.3, 0.8)
+    WattT = Watt.t().contiguous()
+    a, b, k, phi, w = ops.gmm_attention_fwd(h1, WattT, batt, kprev, ctx, at, 1e-5, 0.7, 1.3, 0.8)
     rh1, rW, rb, rk, rctx = (t.double().cpu().requires_grad_() for t in (h1, Watt, batt, kprev, ctx))
     p = rh1 @ rW + rb
     ra, rkk, rphi, rw = R.attention_step(cfg, p[:, :A], p[:, A:2 * A], p[:, 2 * A:], rk, rctx, sampling=True)
@@ -165,7 +166,7 @@ def test_attention_fwd_bwd(dev, att_type, B, H, A, U, E):
     ((rw * gw.double().cpu()).sum() + (rkk * gk.double().cpu()).sum()).backward()
     dkappa = gk.clone()
     dh1 = torch.zeros(B, H, device=dev)
-    dp = ops.gmm_attention_bwd(gw, ctx, a, b, k, kprev, Watt, dkappa, dh1, at, 1e-5)
+    dp = ops.gmm_attention_bwd(gw, ctx, a, b, k, kprev, WattT, dkappa, dh1, at, 1e-5)
     assert_close(dh1, rh1.grad, 1e-4, "dh1")
     assert_close(dkappa, rk.grad, 1e-4, "dkappa_prev")
     assert_close(dp.sum(0), rb.grad, 1e-4, "dp (bias grad)")
