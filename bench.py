@@ -1,0 +1,252 @@
+"""Headline benchmark: acoustic feature frames/sec of one training step (fwd + bwd + gradient
+all-reduce + clip/Adam) of the attention-GRU decoder at BASELINE.json configs[1]:
+2-layer attention-GRU h=1024, batch=64 per GPU, T_enc=200, T_dec=800, fp32, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-reduce of the flat gradient)
+
+Prints ONE JSON line on rank 0 (see the driver contract).  Besides the contract fields it carries
+  roofline     -- the recurrent-step kernel family (sk_kernel): algorithmic flops of all its dispatches
+                  in one training step / summed dispatch time, measured with HIP events attached to
+                  every dispatch (hipExtLaunchKernelGGL) on the stream they run on, vs the f32 MFMA peak;
+  cpu_baseline -- the oracle restatement of the reference (torch-CPU fp32, all host cores) timed on
+                  a bounded sample of the same workload, on rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--T", type=int, default=800, help="decoder frames per window (T_dec)")
+    ap.add_argument("--B", type=int, default=64, help="batch per GPU")
+    ap.add_argument("--U", type=int, default=200, help="encoder timesteps (T_enc)")
+    ap.add_argument("--H", type=int, default=1024)
+    ap.add_argument("--L", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound on timed CPU-baseline work")
+    return ap.parse_args()
+
+
+def host_cores():
+    """Usable host cores: min(affinity, cgroup CPU quota).  The GPU boxes show 256 logical CPUs but
+    run the container under a 16-CPU quota; oversubscribing that stalls torch-CPU for minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def make_batch(a, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(a.T + 1, a.B, 63, generator=g).to(dev)
+    fmask = torch.ones(a.T + 1, a.B, device=dev)
+    labels = torch.randint(0, 43, (a.B, a.U), generator=g).to(dev)
+    lmask = torch.ones(a.B, a.U, device=dev)
+    return feat, fmask, labels, lmask
+
+
+def model_kwargs(a):
+    return dict(num_layers=a.L, rnn_h_dim=a.H, readouts_dim=a.H, encoder_type='bidirectional')
+
+
+def roofline_leg(a, dev, flat_params):
+    """One extra, untimed training step with eager launches, every recurrent-step dispatch timed."""
+    from parrot_amd import _lib, ops
+    from parrot_amd.model import Parrot
+    from parrot_amd.trainer import Trainer
+    m = Parrot(device=dev, use_graph=False, **model_kwargs(a)).initialize()
+    m.flat_parameters.copy_(flat_params)
+    tr = Trainer(m)
+    batch = make_batch(a, dev, 4321)
+    tr.step(*batch, None, 1)  # warm (allocations, caches)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    lib.parrot_profile_begin()
+    tr.step(*batch, None, 1)
+    torch.cuda.synchronize()
+    us, fl, by = C.c_double(), C.c_double(), C.c_double()
+    n = lib.parrot_profile_end(C.byref(us), C.byref(fl), C.byref(by))
+    m.close()
+    if n <= 0 or us.value <= 0:
+        return None
+    peak = 157.3  # f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+    ach = fl.value / us.value * 1e-6  # TFLOP/s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "kernel": "sk_kernel (fused GRU gate/candidate step GEMM, fwd + bwd)",
+        "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(ach / peak, 4), "traffic": traffic,
+        "launches_per_step": int(n), "avg_launch_us": round(us.value / n, 3),
+        "alg_flops_per_launch": round(fl.value / n), "alg_bytes_per_launch": round(by.value / n),
+        "alg_GBps": round(by.value / us.value * 1e-3, 1), "hbm_peak_GBps": 8000,
+        "kernel_time_ms_per_step": round(us.value * 1e-3, 3),
+    }
+
+
+def cpu_baseline_leg(a):
+    """Oracle (port of the reference equations, torch-CPU fp32, all cores): fwd + bwd + clip/Adam on
+    cfg2 shapes with a short T; frames/s is per-frame-linear in T so it is reported as is."""
+    from oracle import parrot_ref as R
+    nthreads = host_cores()
+    torch.set_num_threads(nthreads)
+    cfg = R.default_config(**model_kwargs(a))
+    p = R.init_params(cfg, seed=1234, dtype=torch.float32)
+    for v in p.values():
+        v.requires_grad_()
+    mom = {k: torch.zeros_like(v) for k, v in p.items()}
+    var = {k: torch.zeros_like(v) for k, v in p.items()}
+    g = torch.Generator().manual_seed(99)
+    lab = torch.randint(0, 43, (a.B, a.U), generator=g)
+    lm = torch.ones(a.B, a.U)
+    Ts = (4, 12)
+    data = {Tc: (torch.randn(Tc + 1, a.B, 63, generator=g), torch.ones(Tc + 1, a.B)) for Tc in Ts}
+    state = {"step": 0}
+
+    def one(Tc):
+        feat, fm = data[Tc]
+        for v in p.values():
+            v.grad = None
+        cost, _, _, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
+        cost.backward()
+        state["step"] += 1
+        with torch.no_grad():
+            R.clip_adam_step({k: v.data for k, v in p.items()}, {k: v.grad for k, v in p.items()}, mom, var,
+                             state["step"])
+
+    one(Ts[0])  # warm-up
+    times = {Tc: [] for Tc in Ts}
+    t_start = time.time()
+    while True:
+        for Tc in Ts:
+            t0 = time.time()
+            one(Tc)
+            times[Tc].append(time.time() - t0)
+        if time.time() - t_start >= a.cpu_seconds or len(times[Ts[0]]) >= 20:
+            break
+    el = time.time() - t_start
+    med = {Tc: sorted(v)[len(v) // 2] for Tc, v in times.items()}
+    per_frame_step = (med[Ts[1]] - med[Ts[0]]) / (Ts[1] - Ts[0])   # seconds per decoder timestep (B frames)
+    fixed = max(0.0, med[Ts[0]] - Ts[0] * per_frame_step)            # encoder + optimiser + overhead per window
+    window = fixed + a.T * per_frame_step
+    fps = a.B * a.T / window
+    return {"value": round(fps, 1), "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": f"{len(times[Ts[0]])} training steps each at T_dec={Ts[0]} and T_dec={Ts[1]} of the cfg2 shapes "
+                      f"(L={a.L}, H={a.H}, B={a.B}, T_enc={a.U}; {el:.1f} s of CPU work); per-timestep cost "
+                      f"{1e3 * per_frame_step:.1f} ms and per-window cost {1e3 * fixed:.0f} ms extrapolated "
+                      f"linearly to T_dec={a.T}; oracle/parrot_ref.py (torch-CPU fp32, autograd backward, "
+                      f"clip+Adam), {nthreads} threads"}
+
+
+def cpu_baseline_subprocess(a):
+    """Runs the CPU leg in a child process with a hard wall-clock limit so a mis-sized thread pool can
+    never stall the GPU job."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--T", str(a.T), "--B", str(a.B),
+           "--U", str(a.U), "--H", str(a.H), "--L", str(a.L), "--cpu-seconds", str(a.cpu_seconds)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "frames/s", "cores": host_cores(), "kind": "port",
+                "sample": "cpu leg produced no result: " + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/s", "cores": host_cores(), "kind": "port",
+                "sample": "cpu leg exceeded its 240 s limit"}
+
+
+def main():
+    a = parse()
+    torch.set_num_threads(host_cores())
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_leg(a)), flush=True)
+        return
+    from parrot_amd import dist as pdist
+    rank, local_rank, world = pdist.init_process_group()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from parrot_amd.model import Parrot
+    from parrot_amd.trainer import Trainer
+
+    model = Parrot(device=dev, use_graph=True, seed=1234, **model_kwargs(a)).initialize()
+    trainer = Trainer(model)
+    batch = make_batch(a, dev, 1234 + rank)
+
+    for _ in range(a.warmup):
+        trainer.step(*batch, None, 1)
+    pdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cost = trainer.step(*batch, None, 1)
+    torch.cuda.synchronize()
+    pdist.barrier()
+    el = time.perf_counter() - t0
+    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    el = float(tmax)
+    final_cost = float(cost)
+
+    roof = cpu = None
+    if rank == 0:
+        if not a.no_roofline:
+            roof = roofline_leg(a, dev, model.flat_parameters)
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline_subprocess(a)
+    model.close()
+    if world > 1:
+        pdist.barrier()
+    if rank == 0:
+        frames = world * a.B * a.T * a.steps
+        out = {
+            "metric": "acoustic feature frames/sec (train fwd+bwd+allreduce+clip/Adam)",
+            "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 2-layer attention-GRU decoder, h=1024, "
+                                   "batch=64 per GPU, T_enc=200, T_dec=800, fp32, N(0,0.01) init",
+                       "layers": a.L, "hidden": a.H, "batch_per_gpu": a.B, "global_batch": a.B * world,
+                       "T_enc": a.U, "T_dec": a.T, "parallelism": f"dp{world}",
+                       "params": int(model.store.numel)},
+            "final_cost": round(final_cost, 5),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

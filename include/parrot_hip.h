@@ -35,6 +35,14 @@ extern "C" {
 /* Library / build identification ("parrot_hip <ver> gfx950"). */
 const char* parrot_hip_version(void);
 
+/* Measurement aid (bench.py roofline leg): between begin and end every dispatch of the recurrent-step
+ * kernel is timed with HIP events attached to the dispatch (hipExtLaunchKernelGGL start/stop events)
+ * and its algorithmic flops / bytes are accumulated.  Use only with eager plans (use_graph = 0) and
+ * call parrot_profile_end after synchronising the stream; it returns the number of dispatches and the
+ * summed kernel time [us], flops and bytes. */
+int parrot_profile_begin(void);
+long long parrot_profile_end(double* total_us, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------------
  * Dense projections (Blocks Linear / Fork applies, model.py:580-627, 739-755; lib.ops.Linear,
  * sampleRNN/lib/ops.py:32-128).  C[M,N] (+)= alpha * opA(A) * opB(B) + bias, f32 MFMA.

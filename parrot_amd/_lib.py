@@ -82,6 +82,8 @@ class SampleDesc(C.Structure):
 _vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 SIGNATURES = {
     "parrot_hip_version": (C.c_char_p, []),
+    "parrot_profile_begin": (_i, []),
+    "parrot_profile_end": (C.c_longlong, [C.POINTER(C.c_double)] * 3),
     "parrot_gemm": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "parrot_colsum": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp]),
     "parrot_gru_step_fwd": (_i, [_vp] * 11 + [_i, _i, _vp]),

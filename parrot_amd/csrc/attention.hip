@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int ATT_THREADS = 256;
-constexpr int ATTB_THREADS = 512;  // backward: one workgroup per batch row, 8 waves
+constexpr int ATTB_THREADS = 1024;  // backward: one workgroup per batch row, 16 waves
 constexpr int ATT_MAXA = 32;  // attention_size limit (reference default 10)
 
 // Block-wide sum of `n` per-thread partial vectors (n <= 3*ATT_MAXA); result in out[0..n).
@@ -37,13 +37,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__device__ __forceinline__ float block_sum8(float v, float* red) {  // 512-thread variant, red >= 8 floats
+__device__ __forceinline__ float block_sum8(float v, float* red) {  // backward variant, red >= 16 floats
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3] + red[4] + red[5] + red[6] + red[7];
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATTB_THREADS / 64; ++w) s += red[w];
+    return s;
 }
 
 __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g) {
@@ -168,8 +171,8 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     float* s_b = s_a + ATT_MAXA;
     float* s_k = s_b + ATT_MAXA;
     float* s_dp = s_k + ATT_MAXA;     // [3A]
-    float* s_red = s_dp + 3 * ATT_MAXA;  // [16]
-    float* s_dw = s_red + 16;          // [E]
+    float* s_red = s_dp + 3 * ATT_MAXA;  // [24]
+    float* s_dw = s_red + 24;          // [E]
     float* s_dphi = s_dw + ((E + 3) & ~3);  // [U]
 
     const int b = blockIdx.x, t = threadIdx.x;
@@ -249,14 +252,14 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
             // a = softmax(p) + eps : dp = s * (da - sum(da * s)), s = a - eps
             float dot = 0.f;
             for (int j = 0; j < A; ++j) dot += s_dp[j] * (s_a[j] - g.eps);
-            s_red[8] = dot;
+            s_red[20] = dot;
         }
         __syncthreads();
     }
     float dpa = 0.f, dpb = 0.f, dpk = 0.f;
     if (t < A) {
         const float sa = s_a[t] - g.eps;
-        if (g.att_type == 1) dpa = sa * (s_dp[t] - s_red[8]);
+        if (g.att_type == 1) dpa = sa * (s_dp[t] - s_red[20]);
         else dpa = s_dp[t] * sa;
         dpb = s_dp[A + t] * (s_b[t] - g.eps);
         const float dkt = s_dp[2 * A + t] + g.dkappa[(size_t)b * A + t];  // + carry from step t+1
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
 
 static size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + ATT_THREADS); }
 static size_t att_bwd_lds(int U, int E) {
-    return sizeof(float) * (6 * ATT_MAXA + 16 + ((E + 3) & ~3) + ((U + 3) & ~3));
+    return sizeof(float) * (6 * ATT_MAXA + 24 + ((E + 3) & ~3) + ((U + 3) & ~3));
 }
 
 int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream) {

@@ -12,6 +12,15 @@ extern "C" {
 
 const char* parrot_hip_version(void) { return "parrot_hip 0.1.0 gfx950"; }
 
+int parrot_profile_begin(void) {
+    sk_profile_begin();
+    return 0;
+}
+
+long long parrot_profile_end(double* total_us, double* flops, double* bytes) {
+    return sk_profile_end(total_us, flops, bytes);
+}
+
 int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
                 int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
                 long long strideA, long long strideB, long long strideC, int split_k, void* stream) {

@@ -50,6 +50,8 @@ struct SkLaunch {
 
 // Enqueue one launch on `stream`. Returns hipError_t / PH_ERR_*.
 int sk_launch(const SkLaunch& L, hipStream_t stream);
+void sk_profile_begin();
+long long sk_profile_end(double* total_us, double* flops, double* bytes);
 
 // Helpers to build jobs.
 static inline SkSeg sk_seg(const float* A, int lda, const float* B, int ldb, int K, int b_kcontig) {

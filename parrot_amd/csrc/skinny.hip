@@ -22,7 +22,10 @@
 //     sampleRNN/lib/ops.py:364-393), its backward counterpart, or the LSTM cell (ops.py:505-553).
 #include "skinny.h"
 
+#include <hip/hip_ext.h>
+#include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 template <bool AL>
 __device__ __forceinline__ f32x4 ld4k(const float* __restrict__ p, int k, int K) {
@@ -344,6 +347,72 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
     return 0;
 }
 
+// ---- optional per-dispatch timing (bench.py roofline leg) ------------------------------------
+// When enabled, every launch is bracketed by HIP events attached to the dispatch itself
+// (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps), and the
+// algorithmic flops / bytes of its jobs are recorded next to them.
+namespace {
+struct SkProfRec { hipEvent_t e0, e1; double flops, bytes; };
+struct SkProf { bool on = false; std::vector<SkProfRec> recs; } g_prof;
+
+void sk_account(const SkLaunch& L, double& flops, double& bytes) {
+    flops = 0.0; bytes = 0.0;
+    for (int q = 0; q < L.njobs; ++q) {
+        const SkJob& j = L.job[q];
+        double ksum = 0.0;
+        for (int s = 0; s < j.nseg; ++s) ksum += j.seg[s].K;
+        flops += 2.0 * j.M * ksum * j.N;
+        double epi = 1.0;  // values moved per output element by the epilogue
+        switch (j.epi) {
+            case SK_EPI_GRU_GATES: epi = 2.0 + (j.add ? 1.0 : 0.0); break;          // z|r out, rh out + h_prev in (half width each)
+            case SK_EPI_GRU_CAND: epi = 4.0 + (j.add ? 1.0 : 0.0); break;           // c, h' out; z, h_prev in
+            case SK_EPI_BWD_RH: epi = 5.0; break;                                   // r, h_prev in; dG_r out; dh rmw
+            case SK_EPI_LSTM: epi = 2.0; break;
+            default: epi = 1.0 + (j.accumulate ? 1.0 : 0.0) + (j.add ? 1.0 : 0.0); break;
+        }
+        bytes += 4.0 * (ksum * j.N + (double)j.M * ksum + epi * j.M * j.N);
+    }
+}
+}  // namespace
+
+void sk_profile_begin() {
+    for (auto& r : g_prof.recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_prof.recs.clear();
+    g_prof.on = true;
+}
+
+// Must be called after the stream has been synchronised.  Returns the number of launches.
+long long sk_profile_end(double* total_us, double* flops, double* bytes) {
+    g_prof.on = false;
+    double us = 0.0, fl = 0.0, by = 0.0;
+    for (auto& r : g_prof.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) us += 1000.0 * ms;
+        fl += r.flops; by += r.bytes;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    const long long n = (long long)g_prof.recs.size();
+    g_prof.recs.clear();
+    if (total_us) *total_us = us;
+    if (flops) *flops = fl;
+    if (bytes) *bytes = by;
+    return n;
+}
+
+template <int MB>
+static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t stream) {
+    if (g_prof.on) {
+        SkProfRec r;
+        hipEventCreate(&r.e0);
+        hipEventCreate(&r.e1);
+        sk_account(L, r.flops, r.bytes);
+        hipExtLaunchKernelGGL(sk_kernel<MB>, grid, dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, L);
+        g_prof.recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL(sk_kernel<MB>, grid, dim3(SK_THREADS), lds, stream, L);
+    }
+}
+
 int sk_launch(const SkLaunch& L, hipStream_t stream) {
     int maxM = 0;
     for (int q = 0; q < L.njobs; ++q) maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
@@ -357,10 +426,10 @@ int sk_launch(const SkLaunch& L, hipStream_t stream) {
     dim3 grid(tiles, ceil_div(maxM, 16 * mb));
     const size_t lds = (size_t)SK_NW * mb * 64 * sizeof(f32x4);
     switch (mb) {
-        case 1: hipLaunchKernelGGL(sk_kernel<1>, grid, dim3(SK_THREADS), lds, stream, L); break;
-        case 2: hipLaunchKernelGGL(sk_kernel<2>, grid, dim3(SK_THREADS), lds, stream, L); break;
-        case 3: hipLaunchKernelGGL(sk_kernel<3>, grid, dim3(SK_THREADS), lds, stream, L); break;
-        default: hipLaunchKernelGGL(sk_kernel<4>, grid, dim3(SK_THREADS), lds, stream, L); break;
+        case 1: sk_dispatch<1>(L, grid, lds, stream); break;
+        case 2: sk_dispatch<2>(L, grid, lds, stream); break;
+        case 3: sk_dispatch<3>(L, grid, lds, stream); break;
+        default: sk_dispatch<4>(L, grid, lds, stream); break;
     }
     return (int)hipGetLastError();
 }

@@ -1,0 +1,88 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU for tests).
+
+The reference is single-device (no NCCL/MPI anywhere); data parallelism attaches
+at the gradient step (train.py:100-108).  The batch is sharded along B only (utterances are
+independent through the whole step); two things couple the shards and both are handled here:
+
+  * the masked-mean cost denominator (model.py:784) is over the GLOBAL batch, so every rank scales its
+    backward pass by (den_local + eps) / (den_global + eps) before the gradient all-reduce;
+  * StepClipping uses the global-norm of the SUMMED gradient (train.py:100-101), so the norm is
+    taken after the all-reduce.
+
+Gradients live in one flat float32 buffer (parrot_amd.params.ParamStore), so the exchange is a
+single all-reduce over one bucket: 55.7 MB for BASELINE cfg2, 100.8 MB for the 3-layer model.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+COST_EPS = 1e-5  # model.py:784
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process if absent)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_batch(batch_size, rank, world):
+    """Contiguous shard [lo, hi) of the global batch for this rank (remainder to the low ranks)."""
+    base, rem = divmod(batch_size, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_cost_scale(den_local: torch.Tensor, group=None):
+    """Returns (scale, den_global): scale = (den_local + eps) / (den_global + eps) turns the gradient of
+    the rank-local masked mean into this rank's share of the global masked mean's gradient."""
+    den_global = den_local.detach().clone().reshape(1).to(torch.float32)
+    if is_distributed():
+        dist.all_reduce(den_global, op=dist.ReduceOp.SUM, group=group)
+    scale = (den_local + COST_EPS) / (den_global + COST_EPS)
+    return scale.reshape(()), den_global.reshape(())
+
+
+def allreduce_flat_(flat: torch.Tensor, group=None, async_op=False):
+    """Sum-all-reduce of the flat gradient bucket, in place."""
+    if not is_distributed():
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def allreduce_cost(num_local: torch.Tensor, den_global: torch.Tensor, group=None):
+    """Global masked-mean cost from the rank-local numerators."""
+    num = num_local.detach().clone().reshape(1).to(torch.float32)
+    if is_distributed():
+        dist.all_reduce(num, op=dist.ReduceOp.SUM, group=group)
+    return (num / (den_global + COST_EPS)).reshape(())
+
+
+def broadcast_parameters_(flat: torch.Tensor, src=0, group=None):
+    if is_distributed():
+        dist.broadcast(flat, src=src, group=group)
+
+
+def barrier():
+    if is_distributed():
+        dist.barrier()

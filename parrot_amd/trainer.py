@@ -1,0 +1,66 @@
+"""Training step next to the hot path: StepClipping(10*grad_clip) o Adam(lr) on the flat buffers
+(reference train.py:100-108, Blocks defaults), with the data-parallel gradient exchange in between.
+
+Replaces Blocks' GradientDescent/MainLoop machinery (out of scope) with a
+plain loop; the optional patience / halve-LR schedule of extensions.py:83-152 is kept because it
+changes the arithmetic of the optimiser state."""
+from __future__ import annotations
+
+import torch
+
+from . import dist as pdist
+from . import ops
+
+
+class Trainer:
+    def __init__(self, parrot, learning_rate=1e-4, grad_clip=0.9, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.parrot = parrot.allocate()
+        self.lr = float(learning_rate)
+        self.clip = 10.0 * float(grad_clip)  # train.py:100-101: "for adam is 10x"
+        self.beta1, self.beta2, self.eps = beta1, beta2, eps
+        self.m = torch.zeros_like(parrot.flat_parameters)
+        self.v = torch.zeros_like(parrot.flat_parameters)
+        self.gnorm_sq = torch.zeros(1, device=parrot.flat_parameters.device, dtype=torch.float32)
+        self.step_count = 0
+        self.last_grad_norm = None
+        pdist.broadcast_parameters_(parrot.flat_parameters)
+
+    def step(self, features, features_mask, labels, labels_mask, speaker=None, start_flag=1,
+             feedback_noise=None):
+        """One training step on this rank's shard.  Returns the (global) cost as a 0-dim tensor."""
+        p = self.parrot
+        p.zero_grad()
+        B = features_mask.shape[1]
+        cost, updates, _, _ = p.compute_cost(features, features_mask, labels, labels_mask, speaker,
+                                             start_flag, B, feedback_noise=feedback_noise)
+        den_local = features_mask[1:].to(cost.device, torch.float32).sum()
+        if pdist.is_distributed():
+            scale, den_global = pdist.global_cost_scale(den_local)
+            cost.backward(gradient=scale.to(cost.dtype))
+            pdist.allreduce_flat_(p.flat_gradients)
+            gcost = pdist.allreduce_cost(cost.detach() * (den_local + pdist.COST_EPS), den_global)
+        else:
+            cost.backward()
+            gcost = cost.detach()
+        p.apply_updates(updates)  # TBPTT carry (model.py:786-791)
+        ops.sumsq(p.flat_gradients, out=self.gnorm_sq)
+        self.step_count += 1
+        ops.adam_clip_step(p.flat_parameters, p.flat_gradients, self.m, self.v, self.gnorm_sq,
+                           self.step_count, lr=self.lr, clip=self.clip, beta1=self.beta1, beta2=self.beta2,
+                           eps=self.eps)
+        self.last_grad_norm = self.gnorm_sq
+        return gcost
+
+    # -- extensions.py:83-152 (LearningRateSchedule) arithmetic: halve LR, zero Adam buffers
+    def cut_learning_rate(self, factor=0.5):
+        self.lr *= factor
+        self.m.zero_()
+        self.v.zero_()
+        self.step_count = 0
+
+    def state_dict(self):
+        return dict(m=self.m.clone(), v=self.v.clone(), step=self.step_count, lr=self.lr)
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd['m']); self.v.copy_(sd['v'])
+        self.step_count, self.lr = int(sd['step']), float(sd['lr'])
