@@ -1,0 +1,73 @@
+"""Host-side batch producer semantics (reference datasets.py) -- CPU only."""
+import numpy as np
+
+from oracle import quantize_ref as Q
+from parrot_amd.datasets import SegmentSequence, _chunk, get_raw_transformer, parrot_stream
+
+
+def test_segment_sequence_tbptt_windows():
+    """datasets.py:66-138, 286-292: windows of seq_size+1 with hop seq_size (overlap 1), trailing
+    partial window dropped (return_last=False -> min_size = 10 + window), flag 1 on the first window."""
+    T, B = 137, 3
+    feats = np.arange(T * B, dtype='float32').reshape(T, B)
+    lab = np.zeros((B, 5), dtype='int32')
+    seq_size = 50
+    seg = SegmentSequence([(feats, lab)], ('features', 'labels'), seq_size=seq_size + 1, share_value=1,
+                          return_last=False, add_flag=True, which_sources=('features',))
+    out = list(seg)
+    assert seg.sources == ('features', 'labels', 'start_flag')
+    # step sequence: 0, 50, 100 ... stop when step + (10 + 51) >= 137  -> after the window at 50 (100+61>=137)
+    assert [o[0].shape[0] for o in out] == [51, 51]
+    assert [o[2] for o in out] == [1, 0]
+    assert np.array_equal(out[0][0][-1], out[1][0][0])  # one-frame overlap (teacher-forcing shift)
+    assert out[0][1] is lab  # unsegmented sources pass through
+    # a batch shorter than one window still yields its first (short) window
+    short = SegmentSequence([(feats[:30], lab)], ('features', 'labels'), seq_size=51, share_value=1,
+                            return_last=False, add_flag=True, which_sources=('features',))
+    o = list(short)
+    assert len(o) == 1 and o[0][0].shape[0] == 30 and o[0][2] == 1
+
+
+def test_stream_layout_and_sorting():
+    s = parrot_stream('vctk', which_sets=('train',), batch_size=4, seq_size=20, labels_type='text',
+                      raw_data=False, num_examples=10, sorting_mult=2, use_speaker=True)
+    assert s.sources == ('features', 'features_mask', 'labels', 'labels_mask', 'speaker_index', 'start_flag')
+    items = list(s.get_epoch_iterator())
+    assert len(items) > 0
+    for f, fm, lab, lm, spk, flag in items:
+        assert f.ndim == 3 and f.shape[1] == 4 and f.shape[2] == 63 and f.dtype == np.float32  # time-major
+        assert fm.shape == f.shape[:2] and lab.shape == lm.shape and lab.shape[0] == 4
+        assert spk.shape == (4, 1) and flag in (0, 1)
+    # 10 examples, sorting window 8 -> batches of 4,4 (+ a dropped batch of 2): 2 padded batches
+    assert sum(i[-1] for i in items) == 2
+    # epochs reshuffle for the train set but are deterministic per construction
+    a = [i[0].shape for i in parrot_stream('vctk', batch_size=4, seq_size=20, labels_type='text', raw_data=False,
+                                           num_examples=10, sorting_mult=2).get_epoch_iterator()]
+    b = [i[0].shape for i in parrot_stream('vctk', batch_size=4, seq_size=20, labels_type='text', raw_data=False,
+                                           num_examples=10, sorting_mult=2).get_epoch_iterator()]
+    assert a == b
+
+
+def test_raw_audio_chunk_and_quantise_with_oracle_quantiser():
+    """datasets.py:194-203 with the oracle quantiser injected (the product default is the HIP kernel)."""
+    rng = np.random.RandomState(0)
+    B, T = 3, 7
+    raw = rng.randn(B, T * 80).astype('float32')
+    chunks = _chunk(raw)  # [T,B,80]
+    assert chunks.shape == (T, B, 80) and np.array_equal(chunks[2, 1], raw[1, 160:240])
+    tf = get_raw_transformer('mu-law', 256, quantizer=lambda x, ql, qt: Q.batch_quantize(x, ql, qt))
+    q = tf(chunks)
+    assert q.shape == (T, B, 80) and q.dtype == np.int16
+    ref = Q.batch_quantize(raw, 256, 'mu-law')
+    assert np.array_equal(q.transpose(1, 0, 2).reshape(B, -1), ref)
+
+
+def test_end_of_utterance_heuristic():
+    from parrot_amd.utils import end_of_utterance
+    S, U = 30, 6
+    phi = np.zeros((S, U + 1), dtype='float32')
+    for t in range(S):
+        phi[t, min(U, t // 4)] = 1.0  # the window walks over the text, reaches the end at t = 24
+    assert end_of_utterance(phi, U, 100) == 24 + 40
+    assert end_of_utterance(phi, U, 50) == 50
+    assert end_of_utterance(phi[:10], U, 77) == 77  # never reaches the end

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests of the data-parallel plumbing (CPU).  The gradient provider is the oracle:
+what is under test is parrot_amd.dist (sharding, global-denominator scaling, flat all-reduce)."""
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from oracle import parrot_ref as R
+    from parrot_amd import dist as pdist
+    from tests.util import make_batch
+    torch.set_num_threads(1)
+    r, lr, w = pdist.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world) and pdist.is_distributed()
+    cfg = R.default_config(rnn_h_dim=12, readouts_dim=10, encoder_type='bidirectional', encoder_dim=4, input_dim=6,
+                           num_layers=2, encoder_literal=False)
+    p = R.init_params(cfg, seed=3, scale_by_fan_in=True)
+    names = sorted(p)
+    T, B, U = 5, 6, 4
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=1, ragged=True)
+    lo, hi = pdist.shard_batch(B, rank, world)
+    for v in p.values():
+        v.requires_grad_()
+    cost, _, _, _ = R.compute_cost(p, cfg, feat[:, lo:hi], fm[:, lo:hi], lab[lo:hi], lm[lo:hi], None, 1)
+    den_local = fm[1:, lo:hi].sum()
+    scale, den_global = pdist.global_cost_scale(den_local)
+    cost.backward(gradient=scale.to(cost.dtype))
+    flat = torch.cat([p[n].grad.reshape(-1) for n in names]).float()
+    pdist.allreduce_flat_(flat)
+    gcost = pdist.allreduce_cost(cost.detach() * (den_local + pdist.COST_EPS), den_global)
+    pdist.barrier()
+    if rank == 0:
+        ret["flat"] = flat.clone()
+        ret["cost"] = float(gcost)
+        ret["den"] = float(den_global)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp2_gradients_equal_single_process():
+    from oracle import parrot_ref as R
+    from tests.util import make_batch
+    world, port = 2, 29517
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    cfg = R.default_config(rnn_h_dim=12, readouts_dim=10, encoder_type='bidirectional', encoder_dim=4, input_dim=6,
+                           num_layers=2, encoder_literal=False)
+    p = R.init_params(cfg, seed=3, scale_by_fan_in=True)
+    names = sorted(p)
+    feat, fm, lab, lm, _ = make_batch(cfg, 5, 6, 4, seed=1, ragged=True)
+    for v in p.values():
+        v.requires_grad_()
+    cost, _, _, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
+    cost.backward()
+    flat = torch.cat([p[n].grad.reshape(-1) for n in names]).float()
+    assert abs(ret["cost"] - float(cost)) < 1e-5 * abs(float(cost))
+    assert abs(ret["den"] - float(fm[1:].sum())) < 1e-6
+    assert torch.allclose(ret["flat"], flat, rtol=1e-4, atol=1e-7)
+
+
+def test_shard_batch_covers_batch():
+    from parrot_amd.dist import shard_batch
+    for B in (1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_batch(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
