@@ -233,6 +233,43 @@ int parrot_batch_quantize(const float* x, int rows, int n, int ld, double* ws, v
                           int q_levels, void* stream);
 int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Conditional three-tier SampleRNN generation: the per-sample loop of generate_and_save_samples
+ * (sampleRNN/models/conditional/three_tier.py:794-832) and the three Theano functions it calls
+ * (getting_generation_functions, :703-734) as one device-resident launch sequence per 80-sample
+ * period, replayed from a hipGraph.  All weights are the EFFECTIVE weights (weight norm,
+ * ops.py:101-110, folded by the caller), row-major [in, out].  emb_tbl = Embedding folded with
+ * SampleLevel.L1_PrevSamples: emb_tbl[pos][q][:] = Embedding[q] . W1[pos*EMB:(pos+1)*EMB, :].
+ * temperature = 0 -> argmax (softmax_and_argmax, ops.py:296-297; lowest index on ties);
+ * temperature > 0 -> multinomial draw from a seeded counter-based generator (not Theano's MRG stream).
+ * samples: [B, BFS*T] int32, first BFS entries = Q/2 set by the caller; big_h / frm_h hold the
+ * initial states (learned h0) on entry and the final states on return.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct SampleRnnGenDesc {
+    int B, D, T, Q, FS, BFS, feat_dim, use_graph;
+    float temperature; int reserved;
+    unsigned long long seed;
+    const float* big_Win_frames; const float* big_Win_feats; const float* big_bin; /* [BFS,D],[feat,D],[D] */
+    const float* big_U; const float* big_bU; const float* big_Wg; const float* big_Wc; /* [D,3D],[3D],[D,2D],[D,D] */
+    const float* big_Wout; const float* big_bout;                                  /* [D,(BFS/FS)*D] */
+    const float* frm_Win; const float* frm_bin;                                    /* [FS,D],[D] */
+    const float* frm_U; const float* frm_bU; const float* frm_Wg; const float* frm_Wc;
+    const float* frm_Wout; const float* frm_bout;                                  /* [D,FS*D] */
+    const float* emb_tbl;                                                          /* [FS,Q,D] */
+    const float* W2; const float* b2; const float* W3; const float* b3; const float* W4; const float* b4;
+    const float* features;   /* [T,B,feat_dim] time-major */
+    int* samples;            /* [B,BFS*T] */
+    float* big_h; float* frm_h;            /* [B,D] */
+    /* scratch */
+    float* xf_big; float* xf_frm; float* feat_cur; float* gru_in; float* P; float* z; float* r; float* rh;
+    float* big_out; float* frame_out; float* o1; float* o2; float* o3; float* logits;
+    int* tbase;
+} SampleRnnGenDesc;
+
+int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan);
+int samplernn_generate_run(void* plan, void* stream);
+int samplernn_generate_destroy(void* plan);
+
 #ifdef __cplusplus
 }
 #endif

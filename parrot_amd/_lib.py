@@ -77,6 +77,17 @@ class SampleDesc(C.Structure):
     ]
 
 
+class SampleRnnGenDesc(C.Structure):
+    _fields_ = ([(n, C.c_int) for n in ("B", "D", "T", "Q", "FS", "BFS", "feat_dim", "use_graph")] +
+                [("temperature", C.c_float), ("reserved", C.c_int), ("seed", C.c_ulonglong)] +
+                [(n, C.c_void_p) for n in (
+                    "big_Win_frames", "big_Win_feats", "big_bin", "big_U", "big_bU", "big_Wg", "big_Wc",
+                    "big_Wout", "big_bout", "frm_Win", "frm_bin", "frm_U", "frm_bU", "frm_Wg", "frm_Wc",
+                    "frm_Wout", "frm_bout", "emb_tbl", "W2", "b2", "W3", "b3", "W4", "b4", "features",
+                    "samples", "big_h", "frm_h", "xf_big", "xf_frm", "feat_cur", "gru_in", "P", "z", "r", "rh",
+                    "big_out", "frame_out", "o1", "o2", "o3", "logits", "tbase")])
+
+
 # name -> (restype, argtypes); every symbol include/parrot_hip.h declares must be listed here
 # (tests/test_capi_symbols.py cross-checks this table against the header).
 _vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
@@ -106,6 +117,9 @@ SIGNATURES = {
     "parrot_adam_clip_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
     "parrot_batch_quantize": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "parrot_mu2linear": (_i, [_vp, _sz, _vp, _vp]),
+    "samplernn_generate_create": (_i, [C.POINTER(SampleRnnGenDesc), C.POINTER(C.c_void_p)]),
+    "samplernn_generate_run": (_i, [_vp, _vp]),
+    "samplernn_generate_destroy": (_i, [_vp]),
 }
 
 _lib = None

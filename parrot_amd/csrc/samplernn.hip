@@ -1,0 +1,267 @@
+// Conditional three-tier SampleRNN generation loop on the device (gfx950).
+//
+// Replaces the per-sample Python loop of reference three_tier.py:809-832, which crosses the
+// host/device boundary three times per audio sample (big_frame_level_generate_fn every 80 samples,
+// frame_level_generate_fn every 10, sample_level_generate_fn every sample).  Here the whole loop is a
+// fixed launch sequence per 80-sample period (1 big-tier step, 8 frame-tier steps, 80 sample-MLP
+// steps) captured once into a hipGraph and replayed per period; the running sample index lives in
+// device memory, so no value ever returns to the host inside the loop.
+//
+// Arithmetic restated from sampleRNN/lib/ops.py:329-393 (GRU step with the Input linear inside the
+// step) and three_tier.py:291-515; weight norm (ops.py:101-110) is folded by the caller, and the
+// sample-level Embedding (ops.py:252-266) is folded with SampleLevel.L1_PrevSamples into a
+// [FS, Q, D] table, which turns the K = FS*EMB GEMM into a 10-row gather-sum.
+#include <new>
+
+#include "../../include/parrot_hip.h"
+#include "skinny.h"
+
+namespace {
+
+// xf[b][i] = (s / (Q/2) - 1) * 2 for the `n` samples before t (three_tier.py:309-310, 398-399);
+// optionally copies the conditioning frame of the current big frame.
+__global__ __launch_bounds__(256) void sr_prep_kernel(const int* __restrict__ samples, int len, const int* __restrict__ tbase,
+                                                      int toff, int n, float half_q, float* __restrict__ xf, int B,
+                                                      const float* __restrict__ feats, float* __restrict__ feat_cur,
+                                                      int feat_dim, int bfs) {
+    const int t = tbase[0] + toff;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < B * n) {
+        const int b = idx / n, i = idx % n;
+        xf[idx] = ((float)samples[(size_t)b * len + t - n + i] / half_q - 1.0f) * 2.0f;
+    }
+    if (feats && idx < B * feat_dim) {
+        const int b = idx / feat_dim, f = idx % feat_dim;
+        feat_cur[idx] = feats[((size_t)(t / bfs) * B + b) * feat_dim + f];
+    }
+}
+
+// o1[b][d] = sum_pos tbl[pos][samples[b][t-FS+pos]][d] + frame_out[b][d]   (frame_out row already offset)
+__global__ __launch_bounds__(256) void sr_embed_sum_kernel(const int* __restrict__ samples, int len,
+                                                           const int* __restrict__ tbase, int toff, int FS, int Q, int D,
+                                                           const float* __restrict__ tbl, const float* __restrict__ frame_out,
+                                                           int ldf, float* __restrict__ o1) {
+    const int t = tbase[0] + toff;
+    const int b = blockIdx.y;
+    const int d4 = blockIdx.x * 256 + threadIdx.x;  // float4 index
+    if (d4 * 4 >= D) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(frame_out + (size_t)b * ldf + d4 * 4);
+    for (int pos = 0; pos < FS; ++pos) {
+        const int q = samples[(size_t)b * len + t - FS + pos];
+        acc += *reinterpret_cast<const f32x4*>(tbl + ((size_t)pos * Q + q) * D + d4 * 4);
+    }
+    *reinterpret_cast<f32x4*>(o1 + (size_t)b * D + d4 * 4) = acc;
+}
+
+// samples[b][t] = argmax_q logits[b][q] (lowest index on ties, like numpy / Theano argmax), or a
+// temperature-scaled multinomial draw from a counter-based generator when temperature > 0.
+__global__ __launch_bounds__(256) void sr_pick_kernel(const float* __restrict__ logits, int Q, int* __restrict__ samples,
+                                                      int len, const int* __restrict__ tbase, int toff, float temperature,
+                                                      unsigned long long seed) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int t = tbase[0] + toff;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* lg = logits + (size_t)b * Q;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int q = tid; q < Q; q += 256) {
+        const float v = lg[q];
+        if (v > best || (v == best && q < bi)) { best = v; bi = q; }
+    }
+    sv[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float v = sv[tid + s];
+            const int i = si[tid + s];
+            if (v > sv[tid] || (v == sv[tid] && i < si[tid])) { sv[tid] = v; si[tid] = i; }
+        }
+        __syncthreads();
+    }
+    if (temperature <= 0.f) {
+        if (tid == 0) samples[(size_t)b * len + t] = si[0];
+        return;
+    }
+    // inverse-CDF sampling of softmax(logits / temperature) by one thread (Q = 256)
+    if (tid == 0) {
+        const float mx = sv[0];
+        float tot = 0.f;
+        for (int q = 0; q < Q; ++q) tot += expf((lg[q] - mx) / temperature);
+        unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * (unsigned long long)(t + 1)) ^
+                               (0xBF58476D1CE4E5B9ull * (unsigned long long)(b + 1));
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;  // splitmix64
+        const float u = (float)((x >> 40) + 0.5) * (1.0f / 16777216.0f) * tot;
+        float c = 0.f;
+        int pick = Q - 1;
+        for (int q = 0; q < Q; ++q) {
+            c += expf((lg[q] - mx) / temperature);
+            if (u < c) { pick = q; break; }
+        }
+        samples[(size_t)b * len + t] = pick;
+    }
+}
+
+__global__ void sr_tick_kernel(int* tbase, int inc, int set) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) tbase[0] = set ? inc : tbase[0] + inc;
+}
+
+#define SR_TRY(x)                 \
+    do {                          \
+        const int rc__ = (x);     \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+struct SrPlan {
+    SampleRnnGenDesc d;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = nullptr;
+    int last_error = 0;
+    ~SrPlan() {
+        if (exec) hipGraphExecDestroy(exec);
+        if (cap) hipStreamDestroy(cap);
+    }
+
+    int linear(const float* A, int lda, const float* W, int ldw, int K, int N, const float* bias, const float* add,
+               int ld_add, float* out, int ldo, int act, hipStream_t st, const float* A2 = nullptr, int lda2 = 0,
+               const float* W2 = nullptr, int K2 = 0) {
+        SkJob j;
+        sk_job_init(j);
+        j.nseg = 1;
+        j.seg[0] = sk_seg(A, lda, W, ldw, K, 0);
+        if (A2) { j.seg[1] = sk_seg(A2, lda2, W2, ldw, K2, 0); j.nseg = 2; }
+        j.M = d.B; j.N = N; j.H = N; j.epi = SK_EPI_LINEAR; j.act = act;
+        j.bias = bias; j.add = add; j.ld_add = ld_add;
+        j.out = out; j.ldo = ldo;
+        SkLaunch L;
+        SR_TRY(sk_make_launch(L, &j, 1));
+        return sk_launch(L, st);
+    }
+
+    // GRU step of a tier (ops.py:356-393): P = x.U + b; gates = sigm(h.Wg + P[:, :2D]); cand; in-place h.
+    int gru(const float* x, const float* U, const float* bU, const float* Wg, const float* Wc, float* h, hipStream_t st) {
+        const int D = d.D;
+        SR_TRY(linear(x, D, U, 3 * D, D, 3 * D, bU, nullptr, 0, d.P, 3 * D, 0, st));
+        SkJob j;
+        SkLaunch L;
+        sk_job_init(j);
+        j.nseg = 1;
+        j.seg[0] = sk_seg(h, D, Wg, 2 * D, D, 0);
+        j.M = d.B; j.N = 2 * D; j.H = D; j.epi = SK_EPI_GRU_GATES;
+        j.add = d.P; j.ld_add = 3 * D;
+        j.e0 = h; j.lde0 = D;
+        j.o1 = d.z; j.ldo1 = D; j.o2 = d.r; j.ldo2 = D; j.out = d.rh; j.ldo = D;
+        SR_TRY(sk_make_launch(L, &j, 1));
+        SR_TRY(sk_launch(L, st));
+        sk_job_init(j);
+        j.nseg = 1;
+        j.seg[0] = sk_seg(d.rh, D, Wc, D, D, 0);
+        j.M = d.B; j.N = D; j.H = D; j.epi = SK_EPI_GRU_CAND;
+        j.add = d.P + 2 * D; j.ld_add = 3 * D;
+        j.e0 = h; j.lde0 = D; j.e1 = d.z; j.lde1 = D;
+        j.o1 = nullptr; j.out = h; j.ldo = D;
+        SR_TRY(sk_make_launch(L, &j, 1));
+        return sk_launch(L, st);
+    }
+
+    int period(hipStream_t st) {
+        const int B = d.B, D = d.D, FS = d.FS, BFS = d.BFS, len = BFS * d.T;
+        const float half_q = (float)(d.Q / 2);
+        const int nfr = BFS / FS;
+        // ---- big-frame tier (three_tier.py:291-380), consumes samples[t-80:t] and features[t/80]
+        {
+            const int n = B * (BFS > d.feat_dim ? BFS : d.feat_dim);
+            hipLaunchKernelGGL(sr_prep_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, d.samples, len, d.tbase, 0, BFS,
+                               half_q, d.xf_big, B, d.features, d.feat_cur, d.feat_dim, BFS);
+            SR_TRY(linear(d.xf_big, BFS, d.big_Win_frames, D, BFS, D, d.big_bin, nullptr, 0, d.gru_in, D, 0, st,
+                          d.feat_cur, d.feat_dim, d.big_Win_feats, d.feat_dim));
+            SR_TRY(gru(d.gru_in, d.big_U, d.big_bU, d.big_Wg, d.big_Wc, d.big_h, st));
+            SR_TRY(linear(d.big_h, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st));
+        }
+        for (int f = 0; f < nfr; ++f) {
+            // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
+            const int toff = f * FS;
+            hipLaunchKernelGGL(sr_prep_kernel, dim3(ceil_div(B * FS, 256)), dim3(256), 0, st, d.samples, len, d.tbase, toff,
+                               FS, half_q, d.xf_frm, B, (const float*)nullptr, (float*)nullptr, 0, BFS);
+            SR_TRY(linear(d.xf_frm, FS, d.frm_Win, D, FS, D, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D, 0,
+                          st));
+            SR_TRY(gru(d.gru_in, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st));
+            SR_TRY(linear(d.frm_h, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st));
+            for (int i = 0; i < FS; ++i) {
+                // ---- sample-level MLP (three_tier.py:452-515) + pick (ops.py:268-297)
+                const int to = toff + i;
+                hipLaunchKernelGGL(sr_embed_sum_kernel, dim3(ceil_div(D / 4, 256), B), dim3(256), 0, st, d.samples, len,
+                                   d.tbase, to, FS, d.Q, D, d.emb_tbl, d.frame_out + (size_t)i * D, FS * D, d.o1);
+                SR_TRY(linear(d.o1, D, d.W2, D, D, D, d.b2, nullptr, 0, d.o2, D, SK_ACT_RELU, st));
+                SR_TRY(linear(d.o2, D, d.W3, D, D, D, d.b3, nullptr, 0, d.o3, D, SK_ACT_RELU, st));
+                SR_TRY(linear(d.o3, D, d.W4, d.Q, D, d.Q, d.b4, nullptr, 0, d.logits, d.Q, 0, st));
+                hipLaunchKernelGGL(sr_pick_kernel, dim3(B), dim3(256), 0, st, d.logits, d.Q, d.samples, len, d.tbase, to,
+                                   d.temperature, d.seed);
+            }
+        }
+        hipLaunchKernelGGL(sr_tick_kernel, dim3(1), dim3(64), 0, st, d.tbase, BFS, 0);
+        return (int)hipGetLastError();
+    }
+
+    int run(hipStream_t st) {
+        // tbase starts at BFS (first 80 samples are Q_ZERO, set by the caller); T-1 periods follow.
+        hipLaunchKernelGGL(sr_tick_kernel, dim3(1), dim3(64), 0, st, d.tbase, d.BFS, 1);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        const int periods = d.T - 1;
+        if (!d.use_graph) {
+            for (int p = 0; p < periods; ++p) SR_TRY(period(st));
+            return 0;
+        }
+        if (!exec) {
+            if (!cap) {
+                e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
+                if (e != hipSuccess) return (int)e;
+            }
+            e = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
+            if (e != hipSuccess) return (int)e;
+            const int rc = period(cap);
+            hipGraph_t graph = nullptr;
+            e = hipStreamEndCapture(cap, &graph);
+            if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) return (int)e;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) { exec = nullptr; return (int)e; }
+        }
+        for (int p = 0; p < periods; ++p) {
+            e = hipGraphLaunch(exec, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) {
+    if (!desc || !plan || desc->B < 1 || desc->T < 2 || desc->D < 4 || (desc->D & 3) || desc->FS < 1 ||
+        desc->BFS % desc->FS != 0 || desc->Q < 2)
+        return PARROT_ERR_BADARG;
+    SrPlan* p = new (std::nothrow) SrPlan();
+    if (!p) return PARROT_ERR_BADARG;
+    p->d = *desc;
+    *plan = p;
+    return 0;
+}
+
+int samplernn_generate_run(void* plan, void* stream) {
+    SrPlan* p = static_cast<SrPlan*>(plan);
+    const int rc = p->run((hipStream_t)stream);
+    if (rc != 0 && p->last_error == 0) p->last_error = rc;
+    return rc;
+}
+
+int samplernn_generate_destroy(void* plan) {
+    delete static_cast<SrPlan*>(plan);
+    return 0;
+}
+
+}  // extern "C"
