@@ -13,6 +13,7 @@ struct AttFwdArgs {
     float* w_out; int ldw;         // [B,E]
     int B, H, A, U, E, esplit, att_type;
     float eps, alignment, sharpening, timing;
+    int dbg;  // development only: bit0 skip projection, bit1 skip phi, bit2 skip weighted sum
 };
 
 struct AttBwdArgs {

@@ -18,6 +18,8 @@
 // inputs).  Reductions over A happen in-lane, reductions over U / H use wave shuffles + LDS.
 #include "attention.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int ATT_THREADS = 256;
@@ -65,18 +67,28 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     const float* h = g.h1 + (size_t)b * g.ldh;
 
     // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
-    for (int j = wave; j < 3 * A; j += 4) {
-        const float* wr = g.WattT + (size_t)j * H;
-        float acc = 0.f;
-        int k = lane;
-        for (; k + 192 < H; k += 256) {  // 8 independent loads in flight per lane
-            const float h0 = h[k], h1 = h[k + 64], h2 = h[k + 128], h3 = h[k + 192];
-            const float w0 = wr[k], w1 = wr[k + 64], w2 = wr[k + 128], w3 = wr[k + 192];
-            acc += h0 * w0 + h1 * w1 + h2 * w2 + h3 * w3;
+    // Wave w owns outputs j = w, w+4, ... (up to 8 per pass); the loads of all its outputs for one k-slab
+    // are issued together (8 rows + h in flight), instead of one output after the other.
+    if (g.dbg & 1) { if (t < 3 * A) s_p[t] = 0.01f * t; } else
+    for (int jb = wave; jb < 3 * A; jb += 32) {
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int k = lane; k < H; k += 64) {
+            const float hv = h[k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q;
+                const float wv = (j < 3 * A) ? g.WattT[(size_t)j * H + k] : 0.f;
+                acc[q] += hv * wv;
+            }
         }
-        for (; k < H; k += 64) acc += h[k] * wr[k];
-        acc = wave_sum(acc);
-        if (lane == 0) s_p[j] = acc + (g.batt ? g.batt[j] : 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float r = wave_sum(acc[q]);
+            const int j = jb + 4 * q;
+            if (lane == 0 && j < 3 * A) s_p[j] = r + (g.batt ? g.batt[j] : 0.f);
+        }
     }
     __syncthreads();
 
@@ -110,6 +122,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     __syncthreads();
 
     // 3) phi[u]
+    if (g.dbg & 2) { for (int u = t; u < U; u += ATT_THREADS) s_phi[u] = 0.001f * u; } else
     for (int u = t; u < U; u += ATT_THREADS) {
         float ph = 0.f;
         const float uf = (float)u;
@@ -138,6 +151,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     const int G = ATT_THREADS / CW;                // u-groups
     const int c = t % CW, ug = t / CW;
     const float* ctx = g.ctx + (size_t)b * U * E;
+    if (g.dbg & 4) return;
     for (int eb = e0; eb < e1; eb += CW) {
         const int e = eb + c;
         float acc = 0.f;
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     float* s_dp = s_k + ATT_MAXA;     // [3A]
     float* s_red = s_dp + 3 * ATT_MAXA;  // [24]
     float* s_dw = s_red + 24;          // [E]
-    float* s_dphi = s_dw + ((E + 3) & ~3);  // [U]
+    float* s_dphi = s_dw + (((E + 3) & ~3) > 16 * 3 * ATT_MAXA ? ((E + 3) & ~3) : 16 * 3 * ATT_MAXA);  // [U]
 
     const int b = blockIdx.x, t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -214,34 +228,47 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     }
     __syncthreads();
 
-    // da, db, dkappa: for each mixture j reduce over u.
-    for (int j = 0; j < A; ++j) {
-        const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
-        float da = 0.f, db = 0.f, dk = 0.f;
-        for (int u = t; u < U; u += ATTB_THREADS) {
-            const float d = kj - (float)u;
-            const float dph = s_dphi[u];
-            if (g.att_type == 1) {
-                const float sq = sqrtf(bj);
-                const float ex = 0.3989422917366028f * expf(-0.5f * bj * d * d);
-                da += dph * sq * ex;
-                // d/db [a sqrt(b) exp(-b d^2/2)] = a ex (1/(2 sqrt b) - sqrt(b) d^2 / 2)
-                db += dph * aj * ex * (0.5f / sq - 0.5f * sq * d * d);
-                dk += dph * aj * sq * ex * (-bj * d);
-            } else {
-                const float ex = expf(-bj * d * d);
-                da += dph * ex;
-                db += dph * aj * ex * (-d * d);
-                dk += dph * aj * ex * (-2.f * bj * d);
+    // da, db, dkappa: reduce over u for every mixture j.  Each wave first reduces its lanes with
+    // shuffles and parks 3A partial sums in LDS; one barrier later 3A threads add the per-wave rows.
+    // (s_part reuses the dw staging area, which is dead after the dphi pass.)
+    {
+        constexpr int NWB2 = ATTB_THREADS / 64;
+        float* s_part = s_dw;  // needs NWB2 * 3A floats <= E (checked on the host)
+        for (int j = 0; j < A; ++j) {
+            const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
+            float da = 0.f, db = 0.f, dk = 0.f;
+            for (int u = t; u < U; u += ATTB_THREADS) {
+                const float d = kj - (float)u;
+                const float dph = s_dphi[u];
+                if (g.att_type == 1) {
+                    const float sq = sqrtf(bj);
+                    const float ex = 0.3989422917366028f * expf(-0.5f * bj * d * d);
+                    da += dph * sq * ex;
+                    // d/db [a sqrt(b) exp(-b d^2/2)] = a ex (1/(2 sqrt b) - sqrt(b) d^2 / 2)
+                    db += dph * aj * ex * (0.5f / sq - 0.5f * sq * d * d);
+                    dk += dph * aj * sq * ex * (-bj * d);
+                } else {
+                    const float ex = expf(-bj * d * d);
+                    da += dph * ex;
+                    db += dph * aj * ex * (-d * d);
+                    dk += dph * aj * ex * (-2.f * bj * d);
+                }
+            }
+            da = wave_sum(da);
+            db = wave_sum(db);
+            dk = wave_sum(dk);
+            if (lane == 0) {
+                s_part[wave * 3 * A + j] = da;
+                s_part[wave * 3 * A + A + j] = db;
+                s_part[wave * 3 * A + 2 * A + j] = dk;
             }
         }
-        da = block_sum8(da, s_red);
-        db = block_sum8(db, s_red);
-        dk = block_sum8(dk, s_red);
-        if (t == 0) {
-            s_dp[j] = da;           // temporarily da
-            s_dp[A + j] = db;       // db
-            s_dp[2 * A + j] = dk;   // dkappa (without carry)
+        __syncthreads();
+        if (t < 3 * A) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWB2; ++w) acc += s_part[w * 3 * A + t];
+            s_dp[t] = acc;  // [da | db | dkappa (without carry)]
         }
     }
     __syncthreads();
@@ -291,10 +318,15 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
 
 static size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + ATT_THREADS); }
 static size_t att_bwd_lds(int U, int E) {
-    return sizeof(float) * (6 * ATT_MAXA + 24 + ((E + 3) & ~3) + ((U + 3) & ~3));
+    const int dwsz = ((E + 3) & ~3) > 16 * 3 * ATT_MAXA ? ((E + 3) & ~3) : 16 * 3 * ATT_MAXA;  // also holds s_part
+    return sizeof(float) * (6 * ATT_MAXA + 24 + dwsz + ((U + 3) & ~3));
 }
 
-int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream) {
+int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
+    AttFwdArgs g = gin;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("PARROT_ATT_DBG"); dbg = e ? atoi(e) : 0; }
+    g.dbg = dbg;
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.esplit < 1) return PH_ERR_BADARG;
     const size_t lds = att_fwd_lds(g.U);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
@@ -312,7 +344,15 @@ int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream) {
 
 int att_default_esplit(int B, int E) {
     // aim for >= 256 workgroups while keeping slices >= 32 columns
+    // every slice recomputes the projection (reads WattT, 3A*H floats), so more slices = more L2
+    // traffic; fewer = fewer busy CUs.  PARROT_ATT_ESPLIT overrides for experiments.
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PARROT_ATT_ESPLIT");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced > 0) return forced;
     int es = 1;
-    while (B * es < 512 && E / (es * 2) >= 32) es *= 2;
+    while (B * es < 128 && E / (es * 2) >= 32) es *= 2;
     return es;
 }

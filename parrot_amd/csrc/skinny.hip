@@ -25,6 +25,7 @@
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 template <bool AL>
@@ -93,84 +94,120 @@ __device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32
 
 // Branch-free operand fetch of the fast path: every segment has K % 16 == 0 and 16-byte aligned
 // rows, out-of-range rows / columns are clamped (their results are discarded by the epilogue).
-template <int MB>
-__device__ __forceinline__ void sk_fetch_fast(const SkSeg& sg, int kc, const int (&mrow)[MB], int ncol, int kk,
-                                              f32x4 (&a)[MB], f32x4& b) {
+// KC = weights stored [N][K] (K contiguous: one 16-byte load); otherwise [K][N] (4 dword loads).
+template <int MB, int NB, bool KC>
+__device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              int kc, const int (&mrow)[MB], const int (&ncol)[NB], int kk,
+                                              f32x4 (&a)[MB], f32x4 (&b)[NB]) {
     const int k = kc + 4 * kk;
 #pragma unroll
-    for (int rb = 0; rb < MB; ++rb)
-        a[rb] = *reinterpret_cast<const f32x4*>(sg.A + (size_t)mrow[rb] * sg.lda + k);
-    if (sg.b_kcontig) {
-        b = *reinterpret_cast<const f32x4*>(sg.B + (size_t)ncol * sg.ldb + k);
-    } else {
-        const float* bp = sg.B + (size_t)k * sg.ldb + ncol;
+    for (int rb = 0; rb < MB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + k);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) b[u] = bp[(size_t)u * sg.ldb];
+    for (int nb = 0; nb < NB; ++nb) {
+        if (KC) {
+            b[nb] = *reinterpret_cast<const f32x4*>(B + (size_t)ncol[nb] * ldb + k);
+        } else {
+            const float* bp = B + (size_t)k * ldb + ncol[nb];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[nb][u] = bp[(size_t)u * ldb];
+        }
     }
 }
 
-template <int MB, bool FAST>
-__device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) {
+template <int MB, int NB>
+__device__ __forceinline__ void sk_mma2(const f32x4 (&a)[MB], const f32x4 (&b)[NB], f32x4 (&acc)[MB][NB]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[nb][u], acc[rb][nb], 0, 0, 0);
+}
+
+// One workgroup: (16*MB rows) x (16*NB columns) output tile, K split over the SK_NW waves.
+template <int MB, int NB, bool FAST>
+__device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 4, i = lane & 15;
-    const int m0 = blockIdx.y * (16 * MB);  // the launch picks MB = row blocks per workgroup
+    const int m0 = blockIdx.y * (16 * MB);  // the launch picks MB / NB
     const int M = job.M, N = job.N;
     if (m0 >= M) return;
 
-    const int ncol = sk_col(job.epi, job.H, tile, i);
-    const bool ncol_ok = ncol < N;
-
-    f32x4 acc[MB];
+    f32x4 acc[MB][NB];
 #pragma unroll
-    for (int rb = 0; rb < MB; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (FAST) {
-        // One flat sequence of 16-deep chunks over all segments, dealt round-robin to the waves, with
-        // the next chunk's loads in flight while the current one feeds the matrix cores.
-        int cend[SK_MAXSEG];
+        // One flat sequence of 16-deep chunks over all segments, dealt round-robin to the waves.  The
+        // loop body is straight-line code: segment descriptors sit in scalar registers and are picked
+        // with selects, fetch indices are clamped to the wave's last chunk, and the weight layout is a
+        // per-job constant (two copies of the loop).  That lets the compiler keep the next chunk's
+        // loads in flight behind counted s_waitcnt vmcnt(N) while the current chunk feeds the MFMAs.
+        int cend[SK_MAXSEG], slda[SK_MAXSEG], sldb[SK_MAXSEG];
+        const float* sA[SK_MAXSEG];
+        const float* sB[SK_MAXSEG];
         int total = 0;
 #pragma unroll
         for (int s = 0; s < SK_MAXSEG; ++s) {
-            if (s < job.nseg) total += job.seg[s].K >> 4;
+            const bool on = s < job.nseg;
+            const int ss = on ? s : 0;
+            if (on) total += job.seg[ss].K >> 4;
             cend[s] = total;
+            sA[s] = job.seg[ss].A; sB[s] = job.seg[ss].B; slda[s] = job.seg[ss].lda; sldb[s] = job.seg[ss].ldb;
         }
-        int mrow[MB];
+        int mrow[MB], ncl[NB];
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + i, M - 1);
-        const int ncl = min(ncol, N - 1);
-        auto locate = [&](int g, int& sidx, int& kc) {
-            sidx = 0;
-            int beg = 0;
 #pragma unroll
-            for (int s = 0; s < SK_MAXSEG - 1; ++s)
-                if (g >= cend[s]) { sidx = s + 1; beg = cend[s]; }
-            kc = (g - beg) << 4;
-        };
-        f32x4 a_cur[MB], b_cur, a_nxt[MB], b_nxt;
-        int g = wave;
-        if (g < total) {
-            int sidx, kc;
-            locate(g, sidx, kc);
-            sk_fetch_fast<MB>(job.seg[sidx], kc, mrow, ncl, kk, a_cur, b_cur);
-        }
-        while (g < total) {
-            const int gn = g + SK_NW;
-            if (gn < total) {
-                int sidx, kc;
-                locate(gn, sidx, kc);
-                sk_fetch_fast<MB>(job.seg[sidx], kc, mrow, ncl, kk, a_nxt, b_nxt);
+        for (int nb = 0; nb < NB; ++nb) ncl[nb] = min(sk_col(job.epi, job.H, tile0 + nb, i), N - 1);
+        const int mine = (total - wave + SK_NW - 1) / SK_NW;  // chunks of this wave
+        const int last = wave + (mine - 1) * SK_NW;
+        auto run = [&](auto kc_tag) {
+            constexpr bool KC = decltype(kc_tag)::value;
+            auto fetch = [&](int g, f32x4 (&a)[MB], f32x4 (&b)[NB]) {
+                const float* A = sA[0];
+                const float* B = sB[0];
+                int lda = slda[0], ldb = sldb[0], beg = 0;
+#pragma unroll
+                for (int s = 0; s < SK_MAXSEG - 1; ++s) {
+                    const bool nx = g >= cend[s];
+                    A = nx ? sA[s + 1] : A; B = nx ? sB[s + 1] : B;
+                    lda = nx ? slda[s + 1] : lda; ldb = nx ? sldb[s + 1] : ldb; beg = nx ? cend[s] : beg;
+                }
+                sk_fetch_fast<MB, NB, KC>(A, lda, B, ldb, (g - beg) << 4, mrow, ncl, kk, a, b);
+            };
+            // Ping-pong register buffers, two chunks per iteration: no register copies, so nothing in the
+            // body has to wait for the loads it has just issued.
+            f32x4 a0[MB], b0[NB], a1[MB], b1[NB];
+            fetch(wave, a0, b0);
+            int g = wave;
+            const int npairs = mine >> 1;
+            for (int pr = 0; pr < npairs; ++pr) {
+                fetch(min(g + SK_NW, last), a1, b1);
+                sk_mma2<MB, NB>(a0, b0, acc);
+                fetch(min(g + 2 * SK_NW, last), a0, b0);
+                sk_mma2<MB, NB>(a1, b1, acc);
+                g += 2 * SK_NW;
             }
-            sk_mma<MB>(a_cur, b_cur, acc);
-#pragma unroll
-            for (int rb = 0; rb < MB; ++rb) a_cur[rb] = a_nxt[rb];
-            b_cur = b_nxt;
-            g = gn;
+            if (mine & 1) sk_mma2<MB, NB>(a0, b0, acc);
+        };
+        if (mine > 0) {
+            if (job.seg[0].b_kcontig) run(std::true_type{});
+            else run(std::false_type{});
         }
     } else {
-        // Generic path: per-element masks for K tails / unaligned operands (e.g. the 63-wide fed-back
-        // output frame).  Round-robin 16-deep K chunks over the waves, segment by segment.
+        // Generic path (NB == 1): per-element masks for K tails / unaligned operands (e.g. the 63-wide
+        // fed-back output frame).  Round-robin 16-deep K chunks over the waves, segment by segment.
+        const int ncol = sk_col(job.epi, job.H, tile0, i);
+        const bool ncol_ok = ncol < N;
+        f32x4 accg[MB];
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) accg[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int base = 0;
         for (int s = 0; s < job.nseg; ++s) {
             const SkSeg sg = job.seg[s];
@@ -182,7 +219,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) 
                 const int cn = c + SK_NW;
                 f32x4 a_nxt[MB], b_nxt;
                 if (cn < nch) sk_fetch<MB, false>(sg, cn * 16, m0, M, ncol, ncol_ok, kk, i, a_nxt, b_nxt);
-                sk_mma<MB>(a_cur, b_cur, acc);
+                sk_mma<MB>(a_cur, b_cur, accg);
                 if (cn < nch) {
 #pragma unroll
                     for (int rb = 0; rb < MB; ++rb) a_cur[rb] = a_nxt[rb];
@@ -192,17 +229,23 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) 
             }
             base += nch;
         }
+#pragma unroll
+        for (int rb = 0; rb < MB; ++rb) acc[rb][0] = accg[rb];
     }
 
     // Intra-workgroup split-K reduction through LDS.
 #pragma unroll
-    for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
-    __syncthreads();
-    if (tid >= MB * 64) return;
-    const int rb = tid >> 6;
-    f32x4 v = red[rb * 64 + lane];
+    for (int rb = 0; rb < MB; ++rb)
 #pragma unroll
-    for (int w = 1; w < SK_NW; ++w) v += red[(w * MB + rb) * 64 + lane];
+        for (int nb = 0; nb < NB; ++nb) red[((wave * MB + rb) * NB + nb) * 64 + lane] = acc[rb][nb];
+    __syncthreads();
+    if (tid >= MB * NB * 64) return;
+    const int blk = tid >> 6;
+    const int rb = blk / NB, nbi = blk % NB;
+    const int tile = tile0 + nbi;
+    f32x4 v = red[blk * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < SK_NW; ++w) v += red[(w * MB * NB + blk) * 64 + lane];
 
     // Fused epilogue.  MFMA C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int g = lane >> 4, jj = lane & 15;
@@ -297,7 +340,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile, f32x4* red) 
     }
 }
 
-template <int MB>
+template <int MB, int NB>
 __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     f32x4* red = reinterpret_cast<f32x4*>(sk_smem);
@@ -306,10 +349,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
 #pragma unroll
     for (int q = 0; q < SK_MAXJOB - 1; ++q)
         if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
-    const int tile = bx - (j > 0 ? L.tile_end[j - 1] : 0);
+    const int tile0 = (bx - (j > 0 ? L.tile_end[j - 1] : 0)) * NB;  // first 16-column tile of this workgroup
     const SkJob& job = L.job[j];
-    if (job.aligned) sk_body<MB, true>(job, tile, red);   // fast path: branch-free operand fetch
-    else sk_body<MB, false>(job, tile, red);
+    if (NB > 1 || job.aligned) sk_body<MB, NB, true>(job, tile0, red);  // fast path: branch-free operand fetch
+    else sk_body<MB, 1, false>(job, tile0, red);
 }
 
 void sk_job_init(SkJob& j) { memset(&j, 0, sizeof(j)); }
@@ -320,6 +363,7 @@ void sk_finalize_job(SkJob& j) {
         const SkSeg& g = j.seg[s];
         if (((uintptr_t)g.A & 15) || (g.lda & 3) || (g.K & 15)) al = 0;
         if (g.b_kcontig && (((uintptr_t)g.B & 15) || (g.ldb & 3))) al = 0;
+        if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
 }
@@ -340,8 +384,8 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
         } else {
             tiles = ceil_div(j.N, 16);
         }
-        t += tiles;
-        L.tile_end[q] = t;
+        (void)t;
+        L.tile_end[q] = tiles;  // 16-column tiles of the job; sk_launch turns this into a prefix of workgroups
     }
     L.njobs = njobs;
     return 0;
@@ -399,37 +443,73 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
     return n;
 }
 
-template <int MB>
+template <int MB, int NB>
 static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t stream) {
     if (g_prof.on) {
         SkProfRec r;
         hipEventCreate(&r.e0);
         hipEventCreate(&r.e1);
         sk_account(L, r.flops, r.bytes);
-        hipExtLaunchKernelGGL(sk_kernel<MB>, grid, dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, L);
+        hipExtLaunchKernelGGL((sk_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, L);
         g_prof.recs.push_back(r);
     } else {
-        hipLaunchKernelGGL(sk_kernel<MB>, grid, dim3(SK_THREADS), lds, stream, L);
+        hipLaunchKernelGGL((sk_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, L);
     }
 }
 
-int sk_launch(const SkLaunch& L, hipStream_t stream) {
-    int maxM = 0;
-    for (int q = 0; q < L.njobs; ++q) maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
-    const int tiles = L.tile_end[L.njobs - 1];
-    // Rows per workgroup (16*mb).  Each weight element should ideally be streamed by one workgroup
-    // (mb = 4 covers 64 batch rows), but a launch with few column tiles would leave most of the 256
-    // CUs idle, so split the batch rows over more workgroups until the grid reaches ~256 (the
-    // duplicated weight reads are served by L2; measured 22 -> 13.5 us for the cfg2 gate GEMM).
-    int mb = maxM >= 49 ? 4 : (maxM + 15) / 16;
-    while (mb > 1 && tiles * ceil_div(maxM, 16 * mb) < 224) mb = (mb + 1) / 2;
-    dim3 grid(tiles, ceil_div(maxM, 16 * mb));
-    const size_t lds = (size_t)SK_NW * mb * 64 * sizeof(f32x4);
-    switch (mb) {
-        case 1: sk_dispatch<1>(L, grid, lds, stream); break;
-        case 2: sk_dispatch<2>(L, grid, lds, stream); break;
-        case 3: sk_dispatch<3>(L, grid, lds, stream); break;
-        default: sk_dispatch<4>(L, grid, lds, stream); break;
+int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
+    SkLaunch L = Lin;
+    int maxM = 0, tiles = 0;
+    bool nb2_ok = true;
+    for (int q = 0; q < L.njobs; ++q) {
+        maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
+        tiles += L.tile_end[q];
+        if (!L.job[q].aligned || L.job[q].epi == SK_EPI_LSTM) nb2_ok = false;
+    }
+    // Tile shape per workgroup: (16*mb rows) x (16*nb columns).  Per-CU load bandwidth (~50 GB/s measured)
+    // is what limits this kernel, so prefer the shape with the fewest operand bytes per flop
+    // (1/(16 mb) + 1/(16 nb)) among those that still give the chip >= 224 workgroups; if none does,
+    // take the shape with the most workgroups.
+    const int mbmax = maxM >= 49 ? 4 : (maxM + 15) / 16;
+    int best_mb = 1, best_nb = 1, best_wg = -1;
+    double best_cost = 1e30;
+    const int mbs[4] = {4, 3, 2, 1};
+    for (int a = 0; a < 4; ++a) {
+        const int mb = mbs[a];
+        if (mb > mbmax) continue;
+        // do not pad the batch by more than one 16-row MFMA block (mb = 3 on 64 rows would compute 96)
+        if (ceil_div(maxM, 16 * mb) * 16 * mb - maxM >= 16) continue;
+        for (int nb = 2; nb >= 1; --nb) {
+            if (nb == 2 && !nb2_ok) continue;
+            int wgx = 0;
+            for (int q = 0; q < L.njobs; ++q) wgx += ceil_div(L.tile_end[q], nb);
+            const int wg = wgx * ceil_div(maxM, 16 * mb);
+            const double cost = 1.0 / mb + 1.0 / nb;
+            const bool full = wg >= 224, best_full = best_wg >= 224;
+            bool better;
+            if (full != best_full) better = full;
+            else if (full) better = cost < best_cost - 1e-9;
+            else better = wg > best_wg;
+            if (better) { best_mb = mb; best_nb = nb; best_wg = wg; best_cost = cost; }
+        }
+    }
+    const int mb = best_mb, nb = best_nb;
+    int t = 0;
+    for (int q = 0; q < L.njobs; ++q) {
+        t += ceil_div(L.tile_end[q], nb);
+        L.tile_end[q] = t;
+    }
+    dim3 grid(t, ceil_div(maxM, 16 * mb));
+    const size_t lds = (size_t)SK_NW * mb * nb * 64 * sizeof(f32x4);
+    switch (mb * 10 + nb) {
+        case 11: sk_dispatch<1, 1>(L, grid, lds, stream); break;
+        case 12: sk_dispatch<1, 2>(L, grid, lds, stream); break;
+        case 21: sk_dispatch<2, 1>(L, grid, lds, stream); break;
+        case 22: sk_dispatch<2, 2>(L, grid, lds, stream); break;
+        case 31: sk_dispatch<3, 1>(L, grid, lds, stream); break;
+        case 32: sk_dispatch<3, 2>(L, grid, lds, stream); break;
+        case 41: sk_dispatch<4, 1>(L, grid, lds, stream); break;
+        default: sk_dispatch<4, 2>(L, grid, lds, stream); break;
     }
     return (int)hipGetLastError();
 }

@@ -68,27 +68,33 @@ __global__ __launch_bounds__(NW * 64) void probe(const float* __restrict__ A, co
     const int rot = ROT ? (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)nch) : 0;
     auto kof = [&](int c) { int x = c + rot; if (x >= nch) x -= nch; return x * 16; };
     Frag<ALAY, BLAY, ROWS> ring[PF + 1];
-    // prologue
+    // Branch-free software pipeline: this wave owns chunks wave, wave+NW, ...; fetches beyond the
+    // last chunk are clamped to it (harmless re-read), so the loop body is straight-line code and the
+    // compiler can keep PF chunks in flight with counted s_waitcnt vmcnt(N).
+    const int mine = (nch - wave + NW - 1) / NW;       // chunks of this wave (>= 0)
+    const int lastc = wave + (mine - 1) * NW;
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
-        const int c = wave + p * NW;
-        if (c < nch) fetch<ALAY, BLAY, ROWS>(ring[p], A, W, K, N, kof(c), m0, tile, kk, i);
+        const int c = min(wave + p * NW, lastc);
+        fetch<ALAY, BLAY, ROWS>(ring[p], A, W, K, N, kof(c), m0, tile, kk, i);
     }
-    int c = wave;
-    while (c < nch) {
+    const int rounds = (mine + PF) / (PF + 1);
+    int cbase = wave;
+    for (int rd = 0; rd < rounds; ++rd) {
 #pragma unroll
-        for (int p = 0; p <= PF; ++p) {  // static ring indices: slot p consumed, slot (p+PF)%(PF+1) filled
-            if (c < nch) {
-                const int cn = c + PF * NW;
-                if (cn < nch) fetch<ALAY, BLAY, ROWS>(ring[(p + PF) % (PF + 1)], A, W, K, N, kof(cn), m0, tile, kk, i);
+        for (int p = 0; p <= PF; ++p) {
+            const int c = cbase + p * NW;
+            const int cn = min(c + PF * NW, lastc);
+            fetch<ALAY, BLAY, ROWS>(ring[(p + PF) % (PF + 1)], A, W, K, N, kof(cn), m0, tile, kk, i);
+            if (c <= lastc) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int rb = 0; rb < MB; ++rb)
                         acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[p].a[rb][u], ring[p].b[u], acc[rb], 0, 0, 0);
-                c += NW;
             }
         }
+        cbase += (PF + 1) * NW;
     }
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) red[(wave * MB + rb) * 64 + lane] = acc[rb];
@@ -254,15 +260,17 @@ int main() {
     CK(hipStreamCreate(&st));
 #define R(a, b, rows, nw, pf, rot) run<a, b, rows, nw, pf, rot>("gatesL2", K, N, A, W, out, st)
     R(0, 0, 32, 8, 1, 0);
-    R(0, 0, 32, 8, 1, 1);
-    R(1, 2, 32, 8, 1, 0);
-    R(1, 2, 32, 8, 1, 1);
+    R(0, 0, 32, 8, 2, 0);
+    R(0, 0, 32, 8, 3, 0);
     R(0, 0, 64, 8, 1, 0);
-    R(0, 0, 64, 8, 1, 1);
-    R(1, 2, 64, 8, 1, 1);
-    R(0, 2, 32, 8, 1, 1);
-    R(0, 2, 64, 8, 1, 1);
-    R(0, 2, 32, 8, 2, 1);
+    R(0, 0, 64, 8, 2, 0);
+    R(0, 0, 64, 8, 3, 0);
+    R(0, 2, 32, 8, 2, 0);
+    R(0, 2, 64, 8, 2, 0);
+    R(1, 2, 32, 8, 2, 0);
+    R(1, 2, 64, 8, 2, 0);
+    R(1, 2, 64, 8, 3, 0);
+    R(1, 2, 64, 16, 2, 0);
     float* slab = dalloc((size_t)16 * 64 * N);
     run2<2, 8>(K, N, 16, A, W, slab, st);
     run_stream((size_t)K * N, W, out, st, 256);
