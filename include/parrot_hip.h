@@ -160,6 +160,8 @@ typedef struct ParrotDecoderDesc {
     float* dh[PARROT_MAX_LAYERS];  /* [T+1,B,H] in: gradient from the readouts per slot; out: total */
     float* dw;                     /* [T+1,B,E] in: gradient from att_to_readout per slot; out: total */
     float* dw0;                    /* [T+1,B,E] scratch, zero-filled by the caller: layer-0 share of dw */
+    float* dhup[PARROT_MAX_LAYERS];/* [T+1,B,H] scratch, zero-filled by the caller: share of dh[l] that comes from
+                                      the layers above (needed for l < L-1) */
     float* dkappa;                 /* [B,A] in: gradient wrt final kappa (0); out: wrt initial kappa */
     float* dG[PARROT_MAX_LAYERS];  /* [T,B,2H] out: gradient wrt gate pre-activations */
     float* dC[PARROT_MAX_LAYERS];  /* [T,B,H]  out: gradient wrt candidate pre-activations */

@@ -52,7 +52,8 @@ class DecoderDesc(C.Structure):
         ("z", C.c_void_p * MAX_LAYERS), ("r", C.c_void_p * MAX_LAYERS),
         ("rh", C.c_void_p * MAX_LAYERS), ("c", C.c_void_p * MAX_LAYERS),
         ("a", C.c_void_p), ("b", C.c_void_p), ("phi", C.c_void_p),
-        ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dw0", C.c_void_p), ("dkappa", C.c_void_p),
+        ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dw0", C.c_void_p), ("dhup", C.c_void_p * MAX_LAYERS),
+        ("dkappa", C.c_void_p),
         ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
     ]
 

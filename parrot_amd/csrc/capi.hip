@@ -119,7 +119,7 @@ int parrot_gru_step_bwd(const float* dh_out, const float* h, const float* mask, 
     if (e != hipSuccess) return (int)e;
     GruStateBwdArgs ga;
     ga.nchain = 1; ga.B = B; ga.H = H;
-    ga.chain[0].dh = dh_out; ga.chain[0].hprev = h; ga.chain[0].z = z; ga.chain[0].c = c;
+    ga.chain[0].dh = dh_out; ga.chain[0].dh2 = nullptr; ga.chain[0].hprev = h; ga.chain[0].z = z; ga.chain[0].c = c;
     ga.chain[0].mask = mask; ga.chain[0].dC = d_inputs; ga.chain[0].dG = d_gate_inputs; ga.chain[0].dhprev = dh;
     int rc = gru_state_bwd_launch(ga, st);
     if (rc) return rc;

@@ -3,7 +3,8 @@
 #include "common.h"
 
 struct GruStateBwdChain {
-    const float* dh;     // [B,H] total gradient wrt h_t
+    const float* dh;     // [B,H] gradient wrt h_t
+    const float* dh2;    // [B,H] optional second share of it (from the layers above) or null
     const float* hprev;  // [B,H]
     const float* z;      // [B,H]
     const float* c;      // [B,H]

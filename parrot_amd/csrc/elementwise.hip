@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void gru_state_bwd_kernel(const GruStateBwdArg
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int m = (int)(i / g.H), k = (int)(i % g.H);
         float dh = c.dh[(size_t)m * g.H + k];
+        if (c.dh2) dh += c.dh2[(size_t)m * g.H + k];
         const float hp = c.hprev[(size_t)m * g.H + k];
         float dhp_direct = 0.f;
         if (c.mask) {

@@ -2,6 +2,8 @@
 // the reference (model.py:726-737, 1038-1057; ops.py:299-327) become fixed launch sequences of the
 // fused step kernels, captured once into a hipGraph and replayed per window (all pointers in a
 // plan are fixed, so a replay costs one hipGraphLaunch instead of thousands of host launches).
+#include <stdlib.h>
+
 #include <new>
 #include <vector>
 
@@ -121,6 +123,7 @@ struct GruSeqPlan : PlanBase {
                 const int t = d.reverse[ch] ? d.T - 1 - s : s;
                 GruStateBwdChain& c = ga.chain[ch];
                 c.dh = d.dh[ch] + (s + 1) * BH;
+                c.dh2 = nullptr;
                 c.hprev = d.h[ch] + s * BH;
                 c.z = d.z[ch] + t * BH;
                 c.c = d.c[ch] + t * BH;
@@ -159,7 +162,15 @@ struct DecoderPlan : PlanBase {
     ParrotDecoderDesc d;
     int esplit = 1;
 
-    int enqueue(int which, hipStream_t s) override { return which == 0 ? fwd(s) : bwd(s); }
+    int enqueue(int which, hipStream_t s) override {
+        static int streams = -1;
+        if (streams < 0) {
+            const char* e = getenv("PARROT_LAYER_STREAMS");
+            streams = e ? atoi(e) : 0;
+        }
+        if (streams) return which == 0 ? fwd_streams(s) : bwd_streams(s);
+        return which == 0 ? fwd(s) : bwd(s);
+    }
 
     // Adds the K-segments [h_l ; w ; h_0..h_{l-1}] against weight W (row-major [K_l, ldw]).
     void layer_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw) const {
@@ -242,8 +253,9 @@ struct DecoderPlan : PlanBase {
     // Backward wavefront: at tick q layer l (upper layers first) handles step t = T-1-(q-(L-1-l)).
     // Per tick: attention backward of layer 0's step, then one elementwise launch, one launch of the
     // d(r*h) GEMMs and one launch of the input-gradient GEMMs for all active layers.
-    // Layer 0 sends its w-gradient to dw0 (slot t) because in the same launch layer 1 writes
-    // dw slot t; the attention backward of step t-1 adds the two.
+    // Gradient contributions that cross layers land in separate buffers (dhup[l] for the state, dw0
+    // for layer 0's share of dw), so no two jobs of a launch update the same element: no atomics, and
+    // the result is deterministic.  The consumers add the parts when they read.
     int bwd(hipStream_t st) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
         const int H = d.H, E = d.E;
@@ -273,6 +285,7 @@ struct DecoderPlan : PlanBase {
                 if (t < 0 || t >= d.T) continue;
                 GruStateBwdChain& c = ga.chain[ga.nchain++];
                 c.dh = d.dh[l] + (t + 1) * BH;
+                c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
                 c.hprev = d.h[l] + t * BH;
                 c.z = d.z[l] + t * BH;
                 c.c = d.c[l] + t * BH;
@@ -300,8 +313,7 @@ struct DecoderPlan : PlanBase {
                     sk_job_init(j);
                     j.nseg = 1;
                     j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
-                    // layer l+1 (one step ahead in reverse time) adds into the same slot in this launch
-                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 2;
+                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dh[l] + t * BH; j.ldo = H;
                 }
                 {   // attention context
@@ -319,8 +331,8 @@ struct DecoderPlan : PlanBase {
                     j.nseg = 2;
                     j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + p * H) * 2 * H, 2 * H, 2 * H, 1);
                     j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + p * H) * H, H, H, 1);
-                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 2;
-                    j.out = d.dh[p] + (t + 1) * BH; j.ldo = H;
+                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                    j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;  // separate buffer: no two jobs share a tile
                 }
             }
             if (ga.nchain == 0) continue;
@@ -329,6 +341,178 @@ struct DecoderPlan : PlanBase {
             PL_TRY(launch_jobs(jy, ny, st));
         }
         return 0;
+    }
+
+    // ---- alternative schedule, kept for experiments (PARROT_LAYER_STREAMS=1) ----------------------------
+    // Measured on MI355X (cfg2, T=800): the merged wavefront launches above run the scan in 50 ms fwd /
+    // 81 ms bwd, the stream-per-layer pipeline below in 69 / 105 ms when replayed from a hipGraph (parallel
+    // graph branches are not overlapped by the runtime) and is host-bound when launched eagerly.
+    // ---- layer-parallel streams ------------------------------------------------------------------
+    // Layer 0 runs on the caller's stream, layer l >= 1 on its own side stream.  Layer l at step t only
+    // waits for layer l-1 at step t (event), so while layer 0 is busy with the attention of step t the
+    // upper layers fill the chip with their GEMMs of earlier steps: the per-step critical path is one
+    // layer's chain instead of the sum over layers.  Under stream capture the side streams join the
+    // capture through the event waits, which turns the events into graph edges.
+    hipStream_t side[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> events;
+    size_t ev_next = 0;
+
+    ~DecoderPlan() override {
+        for (auto e : events) hipEventDestroy(e);
+        for (int l = 0; l < PARROT_MAX_LAYERS; ++l)
+            if (side[l]) hipStreamDestroy(side[l]);
+    }
+
+    int ensure_streams() {
+        for (int l = 1; l < d.L; ++l)
+            if (!side[l]) {
+                hipError_t e = hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking);
+                if (e != hipSuccess) return (int)e;
+            }
+        return 0;
+    }
+    hipEvent_t next_event() {
+        if (ev_next == events.size()) {
+            hipEvent_t e = nullptr;
+            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            events.push_back(e);
+        }
+        return events[ev_next++];
+    }
+    hipStream_t stream_of(int l, hipStream_t main) const { return l == 0 ? main : side[l]; }
+
+    int fork(hipStream_t main) {
+        PL_TRY(ensure_streams());
+        ev_next = 0;
+        if (d.L > 1) {
+            hipEvent_t e = next_event();
+            PL_TRY((int)hipEventRecord(e, main));
+            for (int l = 1; l < d.L; ++l) PL_TRY((int)hipStreamWaitEvent(side[l], e, 0));
+        }
+        return 0;
+    }
+    int join(hipStream_t main) {
+        for (int l = 1; l < d.L; ++l) {
+            hipEvent_t e = next_event();
+            PL_TRY((int)hipEventRecord(e, side[l]));
+            PL_TRY((int)hipStreamWaitEvent(main, e, 0));
+        }
+        return 0;
+    }
+
+    int fwd_streams(hipStream_t main) {
+        PL_TRY(fork(main));
+        hipEvent_t done[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+        for (int t = 0; t < d.T; ++t) {
+            for (int l = 0; l < d.L; ++l) {
+                hipStream_t st = stream_of(l, main);
+                if (l > 0) PL_TRY((int)hipStreamWaitEvent(st, done[l - 1], 0));  // h_{l-1}(t) and w_t are ready
+                SkJob j;
+                gates_job(j, l, t);
+                PL_TRY(launch_jobs(&j, 1, st));
+                cand_job(j, l, t);
+                PL_TRY(launch_jobs(&j, 1, st));
+                if (l == 0) PL_TRY(att_fwd_step(t, st));
+                if (l + 1 < d.L) {
+                    done[l] = next_event();
+                    PL_TRY((int)hipEventRecord(done[l], st));
+                }
+            }
+        }
+        return join(main);
+    }
+
+    // Backward: same stream-per-layer pipeline in reverse time.  Layer l at step t waits for layer l+1
+    // at step t.  Cross-layer gradient contributions land in separate buffers (dhup[l] for the state,
+    // dw0 for layer 0's share of dw), so concurrent kernels never update the same element and no
+    // atomics are needed; the consumers add the two parts when they read.
+    int bwd_streams(hipStream_t main) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+        const int H = d.H, E = d.E;
+        PL_TRY(fork(main));
+        hipEvent_t done[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+        for (int t = d.T - 1; t >= 0; --t) {
+            for (int l = d.L - 1; l >= 0; --l) {
+                hipStream_t st = stream_of(l, main);
+                if (l + 1 < d.L) PL_TRY((int)hipStreamWaitEvent(st, done[l + 1], 0));
+                if (l == 0) {
+                    AttBwdArgs g;
+                    g.dw = d.dw + (t + 1) * BE; g.dw2 = d.dw0 + (t + 1) * BE; g.lddw = E;
+                    g.ctx = d.ctx;
+                    g.a = d.a + t * BA; g.b = d.b + t * BA;
+                    g.kappa = d.kappa + (t + 1) * BA; g.kappa_prev = d.kappa + t * BA;
+                    g.WattT = d.WattT;
+                    g.dkappa = d.dkappa;
+                    g.dp_out = d.dp + (size_t)t * d.B * 3 * d.A;
+                    g.dh1 = d.dh[0] + (t + 1) * BH; g.lddh = H;
+                    g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
+                    PL_TRY(att_bwd_launch(g, st));
+                }
+                GruStateBwdArgs ga;
+                ga.nchain = 1; ga.B = d.B; ga.H = H;
+                GruStateBwdChain& c = ga.chain[0];
+                c.dh = d.dh[l] + (t + 1) * BH;
+                c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
+                c.hprev = d.h[l] + t * BH;
+                c.z = d.z[l] + t * BH;
+                c.c = d.c[l] + t * BH;
+                c.mask = nullptr;
+                c.dC = d.dC[l] + t * BH;
+                c.dG = d.dG[l] + t * 2 * BH;
+                c.dhprev = d.dh[l] + t * BH;
+                PL_TRY(gru_state_bwd_launch(ga, st));
+
+                // X: d(r*h_prev) = dC . Wc[0:H,:]^T ; epilogue -> dG_r, dh_prev += d(rh) * r
+                SkJob x;
+                sk_job_init(x);
+                x.nseg = 1;
+                x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+                x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
+                x.e0 = d.h[l] + t * BH; x.lde0 = H;
+                x.e1 = d.r[l] + t * BH; x.lde1 = H;
+                x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
+                x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
+                PL_TRY(launch_jobs(&x, 1, st));
+
+                // Y: gradients flowing to the layer's inputs, one job per destination.
+                SkJob jy[2 + PARROT_MAX_LAYERS];
+                int ny = 0;
+                const float* dG = d.dG[l] + t * 2 * BH;
+                const float* dC = d.dC[l] + t * BH;
+                {   // previous state of this layer: only the gate GEMM (rh part handled by X)
+                    SkJob& j = jy[ny++];
+                    sk_job_init(j);
+                    j.nseg = 1;
+                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                    j.out = d.dh[l] + t * BH; j.ldo = H;
+                }
+                {   // attention context
+                    SkJob& j = jy[ny++];
+                    sk_job_init(j);
+                    j.nseg = 2;
+                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
+                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)H * H, H, H, 1);
+                    j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                    j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
+                }
+                for (int p = 0; p < l; ++p) {  // lower layers' states of the same step -> their dhup buffers
+                    SkJob& j = jy[ny++];
+                    sk_job_init(j);
+                    j.nseg = 2;
+                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + p * H) * 2 * H, 2 * H, 2 * H, 1);
+                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + p * H) * H, H, H, 1);
+                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                    j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
+                }
+                PL_TRY(launch_jobs(jy, ny, st));
+                if (l > 0) {
+                    done[l] = next_event();
+                    PL_TRY((int)hipEventRecord(done[l], st));
+                }
+            }
+        }
+        return join(main);
     }
 };
 

@@ -423,6 +423,7 @@ class Parrot(Brick):
             a=torch.empty(T, B, A, **f), b=torch.empty(T, B, A, **f), phi=torch.empty(T, B, U, **f),
             dh=[torch.zeros(T + 1, B, H, **f) for _ in range(L)], dw=torch.zeros(T + 1, B, E, **f),
             dw0=torch.zeros(T + 1, B, E, **f),
+            dhup=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
             dkappa=torch.zeros(B, A, **f),
             dG=[torch.empty(T, B, 2 * H, **f) for _ in range(L)], dC=[torch.empty(T, B, H, **f) for _ in range(L)],
             dp=torch.empty(T, B, 3 * A, **f),
@@ -449,6 +450,7 @@ class Parrot(Brick):
             d.seq_g[l] = ws['seq_g'][l].data_ptr() if ws['seq_g'][l] is not None else None
             for n in ('h', 'z', 'r', 'rh', 'c', 'dh', 'dG', 'dC'):
                 getattr(d, n)[l] = ws[n][l].data_ptr()
+            d.dhup[l] = ws['dhup'][l].data_ptr() if ws['dhup'][l] is not None else None
         d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
         for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dw0', 'dkappa', 'dp'):
             setattr(d, n, ws[n].data_ptr())
@@ -649,6 +651,9 @@ class Parrot(Brick):
         ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
         ws['dw0'].zero_()
+        for t_ in ws['dhup']:
+            if t_ is not None:
+                t_.zero_()
 
         _lib.call('parrot_decoder_seq_bwd', ws['plan'], ops._stream())
 
