@@ -27,6 +27,7 @@ struct AttBwdArgs {
     float* dh1; int lddh;          // [B,H] accumulated (+=)
     int B, H, A, U, E, att_type;
     float eps;
+    int dbg;  // development only: bit0 skip dphi, bit1 skip mixture reductions, bit2 skip dh1 update
 };
 
 int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream);

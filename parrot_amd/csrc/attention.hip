@@ -74,6 +74,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll 4
         for (int k = lane; k < H; k += 64) {
             const float hv = h[k];
 #pragma unroll
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
 
     // dphi[u] = sum_e dw[e] ctx[u][e]: one wave per u, lanes over e (coalesced row reads).
     constexpr int NWB = ATTB_THREADS / 64;
+    if (g.dbg & 1) { for (int u = t; u < U; u += ATTB_THREADS) s_dphi[u] = 0.01f; } else
     for (int u0 = wave * 4; u0 < U; u0 += NWB * 4) {  // 4 context rows in flight per wave
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int e = lane; e < E; e += 64) {
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     {
         constexpr int NWB2 = ATTB_THREADS / 64;
         float* s_part = s_dw;  // needs NWB2 * 3A floats <= E (checked on the host)
-        for (int j = 0; j < A; ++j) {
+        for (int j = 0; j < ((g.dbg & 2) ? 0 : A); ++j) {
             const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
             float da = 0.f, db = 0.f, dk = 0.f;
             for (int u = t; u < U; u += ATTB_THREADS) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
 
     // dh1[b][k] += sum_j dp[j] Watt[k][j]
     float* dh = g.dh1 + (size_t)b * g.lddh;
+    if (g.dbg & 4) return;
     for (int k = t; k < H; k += ATTB_THREADS) {
         float acc = 0.f;
 #pragma unroll 6
@@ -334,7 +337,11 @@ int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream) {
+int att_bwd_launch(const AttBwdArgs& gin, hipStream_t stream) {
+    AttBwdArgs g = gin;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("PARROT_ATTB_DBG"); dbg = e ? atoi(e) : 0; }
+    g.dbg = dbg;
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1) return PH_ERR_BADARG;
     const size_t lds = att_bwd_lds(g.U, g.E);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;

@@ -19,10 +19,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float ph_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Sum over the 64 lanes of a wave, result broadcast to every lane.  Uses DPP row shifts / row
+// broadcasts (a few cycles each) instead of ds_bpermute-based shuffles (an LDS round trip each): the
+// attention kernels are made of dozens of such reductions.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define PH_DPP_ADD(ctrl, rmask)                                                                      \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, true))
+    PH_DPP_ADD(0x111, 0xf);  // row_shr:1   (inclusive prefix sums inside each row of 16 lanes)
+    PH_DPP_ADD(0x112, 0xf);  // row_shr:2
+    PH_DPP_ADD(0x114, 0xf);  // row_shr:4
+    PH_DPP_ADD(0x118, 0xf);  // row_shr:8   -> lane 15 of every row holds the row total
+#undef PH_DPP_ADD
+    // row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

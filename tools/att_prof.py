@@ -10,3 +10,8 @@ batt = torch.zeros(3*A, device=dev); kp = torch.rand(B, A, generator=g).to(dev)*
 ctx = torch.randn(B, U, E, generator=g).to(dev)
 for _ in range(50): ops.gmm_attention_fwd(h1, WT, batt, kp, ctx)
 torch.cuda.synchronize()
+
+a,b,k,phi,w = ops.gmm_attention_fwd(h1, WT, batt, kp, ctx)
+dw = torch.randn(B, E, device=dev); dk = torch.zeros(B, A, device=dev); dh = torch.zeros(B, H, device=dev)
+for _ in range(50): ops.gmm_attention_bwd(dw, ctx, a, b, k, kp, WT, dk, dh)
+torch.cuda.synchronize()
