@@ -207,6 +207,17 @@ typedef struct ParrotSampleDesc {
     float* bwork;  /* [B,A] scratch */
     float* phi;    /* [S,B,U] */
     float* zwork; float* rwork; float* rhwork; float* readout; /* [B,H],[B,H],[B,H],[B,R] scratch */
+    /* GMM head (which_cost = 'GMM', model.py:1017-1033 + sample_gmm :94-118); gmm_K = 0 selects the MSE head.
+     * Randomness is supplied by the caller: unif [S,B] in [0,1) picks the component exactly like Theano's
+     * multinomial (first k with cumsum(pi) > u), noise [S,B,O] ~ N(0,1) scales sigma. */
+    int gmm_K, reserved2;
+    float sampling_bias, reserved3;
+    const float* Wmu; const float* bmu; const float* Wsig; const float* bsig; const float* Wco; const float* bco;
+                                 /* [R,O*K],[O*K] x2 (column o*K + k), [R,K],[K] */
+    const float* add_mu; const float* add_sig; const float* add_co; /* [B,O*K] x2, [B,K] speaker terms or NULL */
+    const float* unif; const float* noise;
+    float* gmm_mu; float* gmm_sig; float* gmm_co;   /* scratch [B,O*K] x2, [B,K] */
+    float* pi_out;                                   /* [S,B,K] mixture weights per step (the reference's `pi`) */
 } ParrotSampleDesc;
 
 int parrot_sample_create(const ParrotSampleDesc* desc, void** plan);

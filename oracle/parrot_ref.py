@@ -350,11 +350,28 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
     return cost, new_carry, attention_vars, extras
 
 
-def sample_model(p, cfg, labels, labels_mask, speaker, num_steps):
-    """Parrot.sample_model / sample_model_fun (model.py:826-1083) for the MSE head:
-    x_t = readout_to_output(readouts_t) is fed back deterministically (model.py:1010-1016).
-    Returns [sample_x [S,N,O], k, w, pi(=x for MSE), phi, pi_att] like the reference."""
-    assert cfg['which_cost'] == 'MSE', 'stochastic GMM sampling has no deterministic oracle'
+def sample_gmm(mu, sigma, weight, unif, noise):
+    """sample_gmm (model.py:94-118) with the randomness made explicit: Theano's
+    theano_rng.multinomial(pvals=weight) one-hot draw + argmax == first k with cumsum(weight) > u
+    (rng_mrg multinomial), epsilon = theano_rng.normal(...) == `noise`."""
+    k = weight.shape[-1]
+    dim = mu.shape[-1] // k  # model.py:97 (py2 integer division)
+    mu = mu.reshape(-1, dim, k)
+    sigma = sigma.reshape(-1, dim, k)
+    cum = torch.cumsum(weight.reshape(-1, k), -1)
+    idx = (cum > unif.reshape(-1, 1)).to(torch.int64).argmax(-1)
+    idx = torch.where((cum > unif.reshape(-1, 1)).any(-1), idx, torch.full_like(idx, k - 1))
+    ar = torch.arange(mu.shape[0])
+    return mu[ar, :, idx] + sigma[ar, :, idx] * noise.reshape(-1, dim)
+
+
+def sample_model(p, cfg, labels, labels_mask, speaker, num_steps, unif=None, noise=None):
+    """Parrot.sample_model / sample_model_fun (model.py:826-1083).  MSE head:
+    x_t = readout_to_output(readouts_t) is fed back deterministically (model.py:1010-1016).  GMM head
+    (model.py:1017-1033): needs the explicit randomness unif [S,N], noise [S,N,O] (see sample_gmm).
+    Returns [sample_x [S,N,O], k, w, pi, phi, pi_att] like the reference."""
+    gmm = cfg['which_cost'] == 'GMM'
+    assert not gmm or (unif is not None and noise is not None), 'GMM sampling needs explicit randomness'
     L, H, ln = cfg['num_layers'], cfg['rnn_h_dim'], cfg['layer_norm']
     N = labels.shape[0]
     dt = p['/parrot.initial_w'].dtype
@@ -363,7 +380,8 @@ def sample_model(p, cfg, labels, labels_mask, speaker, num_steps):
     if cfg['use_speaker']:  # model.py:846-874
         emb = p['/parrot/lookuptable.W'][speaker[:, 0]]
         spk_readout = linear(p, 'speaker_to_readout', emb)
-        spk_output = linear(p, 'speaker_to_output', emb)
+        spk_output = (fork(p, 'speaker_to_output', emb, ['gmm_mu', 'gmm_sigma', 'gmm_coeff']) if gmm
+                      else linear(p, 'speaker_to_output', emb))
         for l in range(1, L + 1):
             sc, sg = fork(p, f'speaker_to_h{l}', emb[None], [f'rnn{l}_inputs', f'rnn{l}_gates'])
             const[l - 1][0] = const[l - 1][0] + apply_norm(sc, ln)[0]
@@ -372,8 +390,8 @@ def sample_model(p, cfg, labels, labels_mask, speaker, num_steps):
     init = initial_carry(p, cfg, N)  # always the learned initial states (model.py:1049-1054)
     h, w, k = init['h'], init['w'], init['k']
     x = torch.zeros(N, cfg['output_dim'], dtype=dt)  # model.py:834-835
-    xs, ks, ws, phis, pis = [], [], [], [], []
-    for _ in range(num_steps):
+    xs, ks, ws, phis, pis, cos = [], [], [], [], [], []
+    for step in range(num_steps):
         seq_in = [[c[0].clone(), c[1].clone()] for c in const]
         if cfg['weak_feedback']:  # model.py:899-908
             oc, og = fork(p, 'out_to_h1', x, ['rnn1_inputs', 'rnn1_gates'])
@@ -391,12 +409,22 @@ def sample_model(p, cfg, labels, labels_mask, speaker, num_steps):
         readout = readout + linear(p, 'att_to_readout', w)
         if cfg['use_speaker']:
             readout = readout + spk_readout
-        x = linear(p, 'readout_to_output', readout)  # model.py:1008-1013
-        if cfg['use_speaker']:
-            x = x + spk_output
+        if not gmm:
+            x = linear(p, 'readout_to_output', readout)  # model.py:1008-1013
+            if cfg['use_speaker']:
+                x = x + spk_output
+            cos.append(x)
+        else:  # model.py:1017-1033
+            mu, sig, co = fork(p, 'readout_to_output', readout, ['gmm_mu', 'gmm_sigma', 'gmm_coeff'])
+            if cfg['use_speaker']:
+                mu, sig, co = mu + spk_output[0], sig + spk_output[1], co + spk_output[2]
+            sig = torch.exp(sig - cfg['sampling_bias']) + cfg['epsilon']
+            co = torch.softmax(co * (1. + cfg['sampling_bias']), -1) + cfg['epsilon']
+            x = sample_gmm(mu, sig, co, unif[step].to(dt), noise[step].to(dt))
+            cos.append(co)
         xs.append(x); ks.append(k); ws.append(w); phis.append(phi); pis.append(a)
-    sx, kk, ww, ph, pa = (torch.stack(v, 0) for v in (xs, ks, ws, phis, pis))
-    return [sx, kk, ww, sx, ph, pa]
+    sx, kk, ww, ph, pa, cc = (torch.stack(v, 0) for v in (xs, ks, ws, phis, pis, cos))
+    return [sx, kk, ww, cc, ph, pa]
 
 
 # ----------------------------------------------------------------------------- optimiser

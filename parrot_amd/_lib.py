@@ -75,6 +75,12 @@ class SampleDesc(C.Structure):
         ("x", C.c_void_p), ("h", C.c_void_p * MAX_LAYERS), ("w", C.c_void_p), ("kappa", C.c_void_p),
         ("a", C.c_void_p), ("bwork", C.c_void_p), ("phi", C.c_void_p),
         ("zwork", C.c_void_p), ("rwork", C.c_void_p), ("rhwork", C.c_void_p), ("readout", C.c_void_p),
+        ("gmm_K", C.c_int), ("reserved2", C.c_int), ("sampling_bias", C.c_float), ("reserved3", C.c_float),
+        ("Wmu", C.c_void_p), ("bmu", C.c_void_p), ("Wsig", C.c_void_p), ("bsig", C.c_void_p),
+        ("Wco", C.c_void_p), ("bco", C.c_void_p),
+        ("add_mu", C.c_void_p), ("add_sig", C.c_void_p), ("add_co", C.c_void_p),
+        ("unif", C.c_void_p), ("noise", C.c_void_p),
+        ("gmm_mu", C.c_void_p), ("gmm_sig", C.c_void_p), ("gmm_co", C.c_void_p), ("pi_out", C.c_void_p),
     ]
 
 

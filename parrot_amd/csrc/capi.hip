@@ -7,6 +7,16 @@
 #include "skinny.h"
 
 #include <math.h>
+#include <stdlib.h>
+
+static int gemm_target_wgs() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PARROT_GEMM_TARGET_WGS");
+        v = e ? atoi(e) : 2048;
+    }
+    return v;
+}
 
 extern "C" {
 
@@ -54,8 +64,8 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
         // -> spread K over enough workgroups to fill 256 CUs.
         const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
         split = 1;
-        if (act == 0 && tiles < 256 && K >= 512) {
-            split = (int)((512 + tiles - 1) / tiles);
+        if (act == 0 && tiles < 512 && K >= 512) {
+            split = (int)((gemm_target_wgs() + tiles - 1) / tiles);
             const int maxs = K / 256 > 0 ? K / 256 : 1;
             if (split > maxs) split = maxs;
             if (split > 64) split = 64;

@@ -24,3 +24,8 @@ int sumsq_launch(const float* x, size_t n, float* out, hipStream_t stream);
 int adam_clip_launch(float* p, const float* g, float* m, float* v, size_t n, const float* gnorm_sq,
                      float grad_scale, float threshold, float lr_t, float b1, float b2, float eps,
                      hipStream_t stream);
+
+// GMM output head of the sampling step (model.py:1024-1033, sample_gmm model.py:94-118).
+int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat, int B, int O, int K, float bias,
+                      float eps, const float* unif, const float* noise, float* x, int ldx, float* pi_out,
+                      hipStream_t stream);

@@ -96,7 +96,51 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
     }
 }
 
+// One workgroup per batch row: pi = softmax(co_hat (1 + bias)) + eps; component = first k with
+// cumsum(pi) > u (Theano multinomial); x[o] = mu[o,k] + (exp(sig_hat[o,k] - bias) + eps) * noise[o].
+__global__ __launch_bounds__(64) void gmm_sample_kernel(const float* __restrict__ mu, const float* __restrict__ sig_hat,
+                                                        const float* __restrict__ co_hat, int O, int K, float bias,
+                                                        float eps, const float* __restrict__ unif,
+                                                        const float* __restrict__ noise, float* __restrict__ x, int ldx,
+                                                        float* __restrict__ pi_out) {
+    __shared__ int s_pick;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t == 0) {
+        const float* c = co_hat + (size_t)b * K;
+        const float sc = 1.f + bias;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, c[k] * sc);
+        float tot = 0.f;
+        for (int k = 0; k < K; ++k) tot += expf(c[k] * sc - mx);
+        const float u = unif[b];
+        float cum = 0.f;
+        int pick = K - 1;
+        bool found = false;
+        for (int k = 0; k < K; ++k) {
+            const float pk = expf(c[k] * sc - mx) / tot + eps;
+            if (pi_out) pi_out[(size_t)b * K + k] = pk;
+            cum += pk;
+            if (!found && cum > u) { pick = k; found = true; }
+        }
+        s_pick = pick;
+    }
+    __syncthreads();
+    const int k = s_pick;
+    for (int o = t; o < O; o += 64) {
+        const size_t i = (size_t)b * O * K + (size_t)o * K + k;
+        x[(size_t)b * ldx + o] = mu[i] + (expf(sig_hat[i] - bias) + eps) * noise[(size_t)b * O + o];
+    }
+}
+
 }  // namespace
+
+int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat, int B, int O, int K, float bias,
+                      float eps, const float* unif, const float* noise, float* x, int ldx, float* pi_out,
+                      hipStream_t stream) {
+    hipLaunchKernelGGL(gmm_sample_kernel, dim3(B), dim3(64), 0, stream, mu, sig_hat, co_hat, O, K, bias, eps, unif, noise,
+                       x, ldx, pi_out);
+    return (int)hipGetLastError();
+}
 
 int gru_state_bwd_launch(const GruStateBwdArgs& g, hipStream_t stream) {
     if (g.nchain < 1 || g.nchain > 4) return PH_ERR_BADARG;

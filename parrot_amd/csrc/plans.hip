@@ -593,6 +593,30 @@ struct SamplePlan : PlanBase {
             j.out = d.readout; j.ldo = d.R;
             PL_TRY(launch_jobs(&j, 1, st));
 
+            if (d.gmm_K > 0) {
+                // GMM head: three projections of the readout in one launch, then the sampling kernel.
+                const int OK = d.O * d.gmm_K;
+                SkJob g3[3];
+                const float* Ws[3] = {d.Wmu, d.Wsig, d.Wco};
+                const float* bs[3] = {d.bmu, d.bsig, d.bco};
+                const float* as[3] = {d.add_mu, d.add_sig, d.add_co};
+                float* os[3] = {d.gmm_mu, d.gmm_sig, d.gmm_co};
+                const int ns[3] = {OK, OK, d.gmm_K};
+                for (int q = 0; q < 3; ++q) {
+                    sk_job_init(g3[q]);
+                    g3[q].nseg = 1;
+                    g3[q].seg[0] = sk_seg(d.readout, d.R, Ws[q], ns[q], d.R, 0);
+                    g3[q].M = d.B; g3[q].N = ns[q]; g3[q].H = H; g3[q].epi = SK_EPI_LINEAR;
+                    g3[q].bias = bs[q]; g3[q].add = as[q]; g3[q].ld_add = ns[q];
+                    g3[q].out = os[q]; g3[q].ldo = ns[q];
+                }
+                PL_TRY(launch_jobs(g3, 3, st));
+                PL_TRY(gmm_sample_launch(d.gmm_mu, d.gmm_sig, d.gmm_co, d.B, d.O, d.gmm_K, d.sampling_bias, d.eps,
+                                         d.unif + (size_t)t * d.B, d.noise + (size_t)t * d.B * d.O,
+                                         d.x + (size_t)(t + 1) * d.B * d.ldx, d.ldx,
+                                         d.pi_out ? d.pi_out + (size_t)t * d.B * d.gmm_K : nullptr, st));
+                continue;
+            }
             sk_job_init(j);
             j.nseg = 1;
             j.seg[0] = sk_seg(d.readout, d.R, d.Wo, d.O, d.R, 0);

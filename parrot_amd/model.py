@@ -15,8 +15,8 @@ drives the HIP library directly:
 
 Generalisations beyond the reference (flagged in SURVEY.md 8a): ``num_layers`` in {1,2,3} (the
 reference hard-wires 3) and ``encoder_literal`` (True reproduces the reference's encoder scan over
-the batch axis).  Not built yet on the HIP path and therefore rejected loudly: ``layer_norm=True``,
-GMM *sampling*, ``raw_output=True`` inside compute_cost (the SampleRNN head is driven separately).
+the batch axis).  Not built yet on the HIP path and therefore rejected loudly: ``layer_norm=True`` and
+``raw_output=True`` inside compute_cost (the SampleRNN head is driven separately).
 """
 from __future__ import annotations
 
@@ -739,8 +739,17 @@ class Parrot(Brick):
             seq_c=[torch.zeros(N, H, **f) if self.use_speaker else None for _ in range(L)],
             seq_g=[torch.zeros(N, 2 * H, **f) if self.use_speaker else None for _ in range(L)],
             radd=torch.zeros(N, R, **f) if self.use_speaker else None,
-            oadd=torch.zeros(N, O, **f) if self.use_speaker else None,
+            oadd=torch.zeros(N, O, **f) if (self.use_speaker and self.which_cost == 'MSE') else None,
         )
+        gmm = self.which_cost == 'GMM'
+        if gmm:
+            K = self.k_gmm
+            ws.update(unif=torch.zeros(S, N, **f), noise=torch.zeros(S, N, O, **f),
+                      gmm_mu=torch.empty(N, O * K, **f), gmm_sig=torch.empty(N, O * K, **f),
+                      gmm_co=torch.empty(N, K, **f), pi_out=torch.empty(S, N, K, **f),
+                      add_mu=torch.zeros(N, O * K, **f) if self.use_speaker else None,
+                      add_sig=torch.zeros(N, O * K, **f) if self.use_speaker else None,
+                      add_co=torch.zeros(N, K, **f) if self.use_speaker else None)
         d = _lib.SampleDesc()
         d.S, d.B, d.H, d.E, d.A, d.U, d.L, d.O, d.R, d.ldx = S, N, H, E, A, U, L, O, R, ldx
         d.att_type = 1 if self.attention_type == 'softmax' else 0
@@ -760,8 +769,18 @@ class Parrot(Brick):
         d.WattT, d.batt = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr()
         d.Wr, d.br = st['dec.Wr'].data_ptr(), ws['br'].data_ptr()
         d.radd = ws['radd'].data_ptr() if ws['radd'] is not None else None
-        d.Wo, d.bo = self._p('/readout_to_output.W').data_ptr(), self._p('/readout_to_output.b').data_ptr()
-        d.oadd = ws['oadd'].data_ptr() if ws['oadd'] is not None else None
+        if not gmm:
+            d.Wo, d.bo = self._p('/readout_to_output.W').data_ptr(), self._p('/readout_to_output.b').data_ptr()
+            d.oadd = ws['oadd'].data_ptr() if ws['oadd'] is not None else None
+        else:
+            d.gmm_K, d.sampling_bias = self.k_gmm, float(self.sampling_bias)
+            for nm, key in (('mu', 'gmm_mu'), ('sig', 'gmm_sigma'), ('co', 'gmm_coeff')):
+                setattr(d, 'W' + nm, self._p(f'/readout_to_output/fork_{key}.W').data_ptr())
+                setattr(d, 'b' + nm, self._p(f'/readout_to_output/fork_{key}.b').data_ptr())
+                if self.use_speaker:
+                    setattr(d, 'add_' + nm, ws['add_' + nm].data_ptr())
+            for n in ('unif', 'noise', 'gmm_mu', 'gmm_sig', 'gmm_co', 'pi_out'):
+                setattr(d, n, ws[n].data_ptr())
         d.ctx = ws['ctx'].data_ptr()
         for n in ('x', 'w', 'kappa', 'a', 'bwork', 'phi', 'zwork', 'rwork', 'rhwork', 'readout'):
             setattr(d, n, ws[n].data_ptr())
@@ -771,13 +790,13 @@ class Parrot(Brick):
         self._sample_ws[key] = ws
         return ws
 
-    def sample_model_device(self, labels, labels_mask, speaker, num_samples, num_steps):
+    def sample_model_device(self, labels, labels_mask, speaker, num_samples, num_steps, unif=None, noise=None,
+                            seed=None):
         """Device-resident version of sample_model: returns torch tensors
-        [sample_x [S,N,O], k [S,N,A], w [S,N,E], pi, phi [S,N,U], pi_att [S,N,A]]."""
+        [sample_x [S,N,O], k [S,N,A], w [S,N,E], pi, phi [S,N,U], pi_att [S,N,A]].
+        GMM head: the component choice / Gaussian noise come from `unif` [S,N] and `noise` [S,N,O] if given,
+        else from torch's generator (`seed`); Theano's MRG stream itself is not reproducible."""
         self.allocate()
-        if self.which_cost != 'MSE':
-            raise NotImplementedError("GMM sampling (model.py:1017-1033) needs the reference's Theano RNG "
-                                      "stream; only the deterministic MSE head is built")
         dev = self._dev()
         labels = torch.as_tensor(labels).to(dev)
         labels_mask = torch.as_tensor(labels_mask).to(dev, torch.float32)
@@ -807,13 +826,27 @@ class Parrot(Brick):
                 ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.W'),
                          bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.b'), out=ws['seq_g'][l - 1])
             ops.gemm(emb, self._p('/speaker_to_readout.W'), bias=self._p('/speaker_to_readout.b'), out=ws['radd'])
-            ops.gemm(emb, self._p('/speaker_to_output.W'), bias=self._p('/speaker_to_output.b'), out=ws['oadd'])
+            if self.which_cost == 'MSE':
+                ops.gemm(emb, self._p('/speaker_to_output.W'), bias=self._p('/speaker_to_output.b'), out=ws['oadd'])
+            else:
+                for nm, key in (('mu', 'gmm_mu'), ('sig', 'gmm_sigma'), ('co', 'gmm_coeff')):
+                    ops.gemm(emb, self._p(f'/speaker_to_output/fork_{key}.W'),
+                             bias=self._p(f'/speaker_to_output/fork_{key}.b'), out=ws['add_' + nm])
         ws['x'][0].zero_()  # initial_x, model.py:834-835
         ws['w'][0].copy_(self._p('.initial_w').unsqueeze(0).expand(N, -1))
         ws['kappa'][0].zero_()
+        if self.which_cost == 'GMM':
+            if unif is None or noise is None:
+                g = torch.Generator(device=dev)
+                g.manual_seed(int(self.seed if seed is None else seed))
+                unif = torch.rand(S, N, device=dev, generator=g)
+                noise = torch.randn(S, N, O, device=dev, generator=g)
+            ws['unif'].copy_(torch.as_tensor(unif).to(dev, torch.float32))
+            ws['noise'].copy_(torch.as_tensor(noise).to(dev, torch.float32))
         _lib.call('parrot_sample_run', ws['plan'], ops._stream())
         sx = ws['x'][1:, :, :O]
-        return [sx, ws['kappa'][1:], ws['w'][1:], sx, ws['phi'], ws['a']]
+        pi = ws['pi_out'] if self.which_cost == 'GMM' else sx
+        return [sx, ws['kappa'][1:], ws['w'][1:], pi, ws['phi'], ws['a']]
 
     def sample_model(self, labels_tr, labels_mask_tr, features_mask_tr, speaker_tr, num_samples, num_steps):
         """Parrot.sample_model (model.py:1061-1083): numpy in, list of numpy arrays out

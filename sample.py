@@ -7,6 +7,7 @@ import pickle
 import numpy
 import torch
 
+from parrot_amd.checkpoint import load_parameters
 from parrot_amd.datasets import parrot_stream
 from parrot_amd.generate import generate_wav
 from parrot_amd.model import Parrot
@@ -20,8 +21,7 @@ def main(argv=None):
     assert saved_args.dataset == args.dataset
     params_mode = 'last_' if args.use_last else 'best_'
     args.samples_name = params_mode + args.samples_name
-    with open(os.path.join(args.save_dir, 'pkl', params_mode + args.experiment_name + '.tar'), 'rb') as f:
-        parameters = pickle.load(f)['parameters']
+    parameters = load_parameters(os.path.join(args.save_dir, 'pkl', params_mode + args.experiment_name + '.tar'))
 
     labels_type = saved_args.labels_type if saved_args.labels_type in ('text', 'unaligned_phonemes') else 'text'
     test_stream = parrot_stream(args.dataset, saved_args.use_speaker, ('test',), args.num_samples,

@@ -97,3 +97,20 @@ def test_parrot_parameter_names_match_oracle():
         got = m.get_parameter_values()
         for k in vals:
             assert (torch.as_tensor(got[k]) == vals[k]).all(), k
+
+
+def test_blocks_checkpoint_roundtrip(tmp_path):
+    """tar + `_parameters` npz with '/' -> '|' (Blocks Checkpoint layout, train.py:157-173, sample.py:39-42)."""
+    import tarfile
+    import numpy as np
+    from oracle import parrot_ref as R
+    from parrot_amd.checkpoint import dump_parameters, load_parameters
+    cfg = R.default_config(rnn_h_dim=8, readouts_dim=6, encoder_type='bidirectional', encoder_dim=4, input_dim=5)
+    vals = {k: v.numpy() for k, v in R.init_params(cfg, seed=1, dtype=torch.float32).items()}
+    path = str(tmp_path / "best_x.tar")
+    dump_parameters(path, vals, carry={"B4|last_k": np.ones((4, 10), dtype='float32')})
+    with tarfile.open(path) as t:
+        assert t.getnames() == ['_parameters']
+    got, carry = load_parameters(path, with_carry=True)
+    assert set(got) == set(vals) and all(np.array_equal(got[k], vals[k]) for k in vals)
+    assert '/parrot/rnn1.state_to_state' in got and carry["B4|last_k"].shape == (4, 10)

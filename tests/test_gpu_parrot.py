@@ -150,3 +150,24 @@ def test_full_width_short_window(dev):
     g = m.flat_gradients
     assert torch.isfinite(g).all() and float(g.abs().max()) > 0
     m.close()
+
+
+def test_sample_model_gmm_head_parity(dev):
+    """GMM sampling head (model.py:1017-1033, sample_gmm :94-118) with explicit randomness."""
+    from oracle import parrot_ref as R
+    cfg, p, m = _build(dev, use_graph=True, encoder_type='bidirectional', num_layers=2, which_cost='GMM', k_gmm=4,
+                       weak_feedback=True, use_speaker=True, sampling_bias=0.5)
+    N, U, S = 3, 7, 9
+    _, _, lab, lm, spk = make_batch(cfg, 2, N, U, seed=4, speaker=True)
+    g = torch.Generator().manual_seed(11)
+    unif = torch.rand(S, N, generator=g, dtype=torch.float64)
+    noise = torch.randn(S, N, 63, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        ref = R.sample_model(p, cfg, lab, lm, spk, S, unif=unif, noise=noise)
+    outs = m.sample_model_device(lab, lm.float(), spk, N, S, unif=unif.float(), noise=noise.float())
+    for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+        assert tuple(o.shape) == tuple(r.shape), n
+        assert_close(o, r, 2e-4, n)
+    outs2 = m.sample_model(lab.numpy(), lm.float().numpy(), None, spk.numpy(), N, S)  # own seeded RNG
+    assert outs2[0].shape == (S, N, 63)
+    m.close()

@@ -12,6 +12,7 @@ import torch
 
 from parrot_amd import dist as pdist
 from parrot_amd.bricks import Constant, IsotropicGaussian
+from parrot_amd.checkpoint import dump_parameters, load_parameters
 from parrot_amd.datasets import PinnedAsyncLoader, parrot_stream
 from parrot_amd.model import Parrot
 from parrot_amd.trainer import Trainer
@@ -19,10 +20,15 @@ from parrot_amd.utils import train_parse
 
 
 def save_parameters(path, parrot, extra=None):
+    """Blocks-style checkpoint (tar with a `_parameters` npz, train.py:157-173) + the TBPTT carry."""
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    blob = dict(parameters=parrot.get_parameter_values(), extra=extra or {})
-    with open(path, 'wb') as f:
-        pickle.dump(blob, f, protocol=2)
+    carry = {}
+    for B, c in parrot._carry.items():
+        for l, h in enumerate(c['h']):
+            carry['B%d|last_h%d' % (B, l + 1)] = h.detach().cpu().numpy()
+        carry['B%d|last_k' % B] = c['k'].detach().cpu().numpy()
+        carry['B%d|last_w' % B] = c['w'].detach().cpu().numpy()
+    dump_parameters(path, parrot.get_parameter_values(), carry)
 
 
 def main(argv=None):
@@ -57,8 +63,8 @@ def main(argv=None):
         use_graph=bool(args.use_graph))
     parrot.initialize()
     if args.load_experiment:
-        with open(os.path.join(save_dir, 'pkl', 'best_' + args.load_experiment + '.tar'), 'rb') as f:
-            parrot.set_parameter_values(pickle.load(f)['parameters'])
+        parrot.set_parameter_values(load_parameters(
+            os.path.join(save_dir, 'pkl', 'best_' + args.load_experiment + '.tar')))
     trainer = Trainer(parrot, learning_rate=args.learning_rate, grad_clip=args.grad_clip)
     lo, hi = pdist.shard_batch(args.batch_size, rank, world)
 
