@@ -10,12 +10,23 @@
 
 namespace {
 
+// Pass 1: per-row min / max with many workgroups per row (grid.x chunks x grid.y rows).  Floats are
+// combined with integer atomics on an order-preserving key (monotone map float -> uint32), so the result is
+// exact and independent of the order of arrival.
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 __global__ __launch_bounds__(256) void row_minmax_kernel(const float* __restrict__ x, int n, int ld,
-                                                         double* __restrict__ mnmx) {
+                                                         unsigned* __restrict__ keys) {
     __shared__ float smn[4], smx[4];
-    const float* row = x + (size_t)blockIdx.x * ld;
+    const float* row = x + (size_t)blockIdx.y * ld;
     float mn = INFINITY, mx = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const float v = row[i];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -33,9 +44,16 @@ __global__ __launch_bounds__(256) void row_minmax_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
         mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-        const double dmn = (double)mn;
-        mnmx[2 * blockIdx.x] = dmn;
-        mnmx[2 * blockIdx.x + 1] = (double)mx - dmn;  // max of the shifted row (quantize.py:16-17)
+        atomicMin(&keys[2 * blockIdx.y], f2key(mn));
+        atomicMax(&keys[2 * blockIdx.y + 1], f2key(mx));
+    }
+}
+
+__global__ void minmax_init_kernel(unsigned* keys, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) {
+        keys[2 * i] = 0xffffffffu;
+        keys[2 * i + 1] = 0u;
     }
 }
 
@@ -44,7 +62,9 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
                                                        const double* __restrict__ mnmx, void* __restrict__ out,
                                                        int ldo, int q_levels) {
     const int r = blockIdx.y;
-    const double mn = mnmx[2 * r], rng = mnmx[2 * r + 1];
+    const unsigned* keys = reinterpret_cast<const unsigned*>(mnmx);
+    const double mn = (double)key2f(keys[2 * r]);
+    const double rng = (double)key2f(keys[2 * r + 1]) - mn;  // max of the shifted row (quantize.py:16-17)
     const float* row = x + (size_t)r * ld;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         double d = (double)row[i];
@@ -80,8 +100,14 @@ __global__ __launch_bounds__(256) void mu2linear_kernel(const int32_t* __restric
 int quantize_launch(const float* x, int rows, int n, int ld, double* mnmx_ws, void* out, int ldo, int mode,
                     int q_levels, hipStream_t stream) {
     if (rows < 1 || n < 1 || (mode != 0 && mode != 1)) return PH_ERR_BADARG;
-    hipLaunchKernelGGL(row_minmax_kernel, dim3(rows), dim3(256), 0, stream, x, n, ld, mnmx_ws);
-    int bx = ceil_div(n, 256);
+    unsigned* keys = reinterpret_cast<unsigned*>(mnmx_ws);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, stream, keys, rows);
+    int bx = ceil_div(n, 256 * 8);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(row_minmax_kernel, dim3(bx, rows), dim3(256), 0, stream, x, n, ld, keys);
+    bx = ceil_div(n, 256 * 4);
+    if (bx < 1) bx = 1;
     if (bx > 256) bx = 256;
     if (mode == 0)
         hipLaunchKernelGGL(quantize_kernel<0>, dim3(bx, rows), dim3(256), 0, stream, x, n, ld, mnmx_ws, out, ldo, q_levels);

@@ -314,6 +314,13 @@ class Parrot(Brick):
             self._carry[B] = c
         return c
 
+    def _samplernn_carry(self, B):
+        c = self._carry.get(('srn', B))
+        if c is None:
+            c = self.sampleRnn.initial_states(B)
+            self._carry[('srn', B)] = c
+        return c
+
     def apply_updates(self, updates):
         """Applies the (shared variable, new value) pairs compute_cost returns -- what Blocks'
         GradientDescent.add_updates(extra_updates) did implicitly (train.py:108, model.py:786-791)."""
@@ -479,8 +486,8 @@ class Parrot(Brick):
         self.allocate()
         if speaker is None:
             assert not self.use_speaker  # model.py:556-557
-        if self.raw_output or raw_audio is not None:
-            raise NotImplementedError("raw_output inside compute_cost: drive SampleRnn separately")
+        if self.raw_output and raw_audio is None:
+            raise ValueError("raw_output=True needs the raw_audio source (datasets.py:194-203)")
         dev = self._dev()
         features = features.to(dev, torch.float32)
         features_mask = features_mask.to(dev, torch.float32)
@@ -588,19 +595,38 @@ class Parrot(Brick):
                 cost_tb = cost_gmm(target, leafs[0], sigma, coeff_)
                 next_x, coeff = preds[0], coeff_.detach()  # sampled next_x is stochastic in the reference
             cost_val = (cost_tb * mask).sum() / (mask.sum() + 1e-5)
-        dpreds = torch.autograd.grad(cost_val, leafs)
-        save['dpreds'] = [d.reshape(T * B, -1).contiguous() for d in dpreds]
+        cost_raw = None
+        if self.raw_output:
+            # model.py:793-820: the SampleRNN head is trained on the predicted frames; the reference sets
+            # cost = 0 * cost + 1 * cost_raw, so only the raw-audio cost drives the gradient.
+            tt = self.sampleRnn.three_tier
+            raw = torch.as_tensor(raw_audio).to(dev)
+            raw_mask = features_mask.repeat_interleave(80, dim=0).t().contiguous()          # model.py:795-796
+            raw_seq = raw.permute(1, 0, 2).reshape(B, -1).long()                              # model.py:805-806
+            last_h0, last_big_h0 = self._samplernn_carry(B)
+            with torch.enable_grad():
+                cost_raw, ip_cost, _, _, _, new_h0, new_big_h0 = tt.compute_cost(
+                    raw_seq, leafs[0].transpose(0, 1), last_h0, last_big_h0, bool(start_flag), raw_mask)
+                total = 0.0 * cost_val + 1.0 * cost_raw                                       # model.py:818-820
+            save['torch_cost'] = total
+            save['leafs'] = leafs
+            cost_val = total.detach()
+        else:
+            dpreds = torch.autograd.grad(cost_val, leafs)
+            save['dpreds'] = [d.reshape(T * B, -1).contiguous() for d in dpreds]
 
         # --- carried state (model.py:786-791)
         updates = [(carry['h'][l], ws['h'][l][T].clone()) for l in range(L)]
         updates += [(carry['k'], ws['kappa'][T].clone()), (carry['w'], ws['w'][T].clone())]
 
+        if self.raw_output:
+            updates += [(last_h0, new_h0.detach()), (last_big_h0, new_big_h0.detach())]    # model.py:815-816
         attention_vars = [next_x, ws['kappa'][1:], ws['w'][1:], coeff, ws['phi'], ws['a']]
         self._token += 1
         self._saved = (self._token, save)
         anchor = torch.zeros((), device=dev, requires_grad=True)
         cost = _CostFn.apply(anchor, self, self._token, cost_val.detach())
-        return cost, updates, attention_vars, None
+        return cost, updates, attention_vars, (cost_raw.detach() if cost_raw is not None else None)
 
     # ------------------------------------------------------------------ backward
     def _backward(self, token, gscale):
@@ -615,6 +641,16 @@ class Parrot(Brick):
         emb_spk = save.get('emb_spk')
         demb_spk = torch.zeros_like(emb_spk) if emb_spk is not None else None
 
+        if 'torch_cost' in save:
+            # SampleRNN head: torch autograd through the HIP ops gives d(cost)/d(predicted frames) and
+            # accumulates the SampleRNN parameter gradients into their registry tensors.
+            leafs = save['leafs']
+            srn = [p_ for p_ in self.sampleRnn.parameters if p_.requires_grad]
+            torch.autograd.backward(save['torch_cost'], grad_tensors=gscale.to(save['torch_cost'].dtype),
+                                    inputs=list(leafs) + srn)
+            save['dpreds'] = [(l.grad if l.grad is not None else torch.zeros_like(l)).reshape(T * B, -1).contiguous()
+                              for l in leafs]
+            gscale = torch.ones((), device=gscale.device)
         # output layer
         dread = torch.zeros(T * B, R, device=readouts.device, dtype=torch.float32)
         for i, (wn, bn, dim) in enumerate(self._out_names):
@@ -881,9 +917,22 @@ class SampleRnn(Brick):
 
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
+        from .sampleRNN import lib as srn_lib
         from .sampleRNN.models.conditional import three_tier
         self.three_tier = three_tier
         self.N_RNN = three_tier.N_RNN
+        dev = self._dev()
+        if dev.type == 'cuda':
+            # model.py:124: the parameters are registered by building the cost graph once on dummy inputs
+            srn_lib.set_device(dev)
+            tt = three_tier
+            with torch.no_grad():
+                seq = torch.full((1, 2 * tt.BIG_FRAME_SIZE), int(tt.Q_ZERO), device=dev, dtype=torch.long)
+                tt.compute_cost(seq, torch.zeros(1, 1, tt.FEAT_DIM, device=dev),
+                                torch.zeros(1, tt.N_RNN, tt.H0_MULT * tt.DIM, device=dev),
+                                torch.zeros(1, tt.N_RNN, tt.H0_MULT * tt.BIG_DIM, device=dev), True,
+                                torch.ones(1, 2 * tt.BIG_FRAME_SIZE, device=dev))
+        self.parameters = srn_lib.get_params(lambda n, p_: getattr(p_, 'param', False))
 
     def initial_states(self, batch_size):
         tt = self.three_tier

@@ -85,3 +85,32 @@ def set_params(values):
                 _params[n].copy_(v.to(_params[n].device))
             else:
                 param(n, v)
+
+
+def flatten_params():
+    """Moves every registered parameter into one flat float32 buffer (and its gradient into a second one),
+    keeping the registry objects' identity semantics: `param(name)` now returns a leaf view of the flat
+    buffer whose `.grad` is a view of the flat gradient buffer.  Returns (flat, flat_grad).  This is what
+    the fused clip+Adam kernel and the data-parallel all-reduce operate on."""
+    names = list(_params.keys())
+    sizes = [(_params[n].numel() + 3) // 4 * 4 for n in names]
+    total = sum(sizes)
+    dev = device()
+    flat = torch.zeros(total, device=dev, dtype=torch.float32)
+    flat_grad = torch.zeros(total, device=dev, dtype=torch.float32)
+    off = 0
+    for n, sz in zip(names, sizes):
+        old = _params[n]
+        k = old.numel()
+        with torch.no_grad():
+            flat[off:off + k].copy_(old.detach().reshape(-1))
+        view = flat[off:off + k].view(old.shape).detach()
+        trainable = bool(getattr(old, 'param', True))
+        view.requires_grad_(trainable)
+        if trainable:
+            view.grad = flat_grad[off:off + k].view(old.shape)
+        view.param = trainable
+        view.name_ = n
+        _params[n] = view
+        off += sz
+    return flat, flat_grad

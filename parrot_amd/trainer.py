@@ -18,44 +18,59 @@ class Trainer:
         self.lr = float(learning_rate)
         self.clip = 10.0 * float(grad_clip)  # train.py:100-101: "for adam is 10x"
         self.beta1, self.beta2, self.eps = beta1, beta2, eps
-        self.m = torch.zeros_like(parrot.flat_parameters)
-        self.v = torch.zeros_like(parrot.flat_parameters)
+        self.groups = [(parrot.flat_parameters, parrot.flat_gradients)]
+        if getattr(parrot, 'raw_output', False):
+            from .sampleRNN import lib as srn_lib
+            flat, flat_grad = srn_lib.flatten_params()  # SampleRNN head: same clip + Adam, same global norm
+            parrot.sampleRnn.parameters = srn_lib.get_params(lambda n, p_: getattr(p_, 'param', False))
+            self.groups.append((flat, flat_grad))
+        self.ms = [torch.zeros_like(p_) for p_, _ in self.groups]
+        self.vs = [torch.zeros_like(p_) for p_, _ in self.groups]
+        self.m, self.v = self.ms[0], self.vs[0]
+        self._part = torch.zeros(1, device=parrot.flat_parameters.device, dtype=torch.float32)
         self.gnorm_sq = torch.zeros(1, device=parrot.flat_parameters.device, dtype=torch.float32)
         self.step_count = 0
         self.last_grad_norm = None
         pdist.broadcast_parameters_(parrot.flat_parameters)
 
     def step(self, features, features_mask, labels, labels_mask, speaker=None, start_flag=1,
-             feedback_noise=None):
+             feedback_noise=None, raw_audio=None):
         """One training step on this rank's shard.  Returns the (global) cost as a 0-dim tensor."""
         p = self.parrot
         p.zero_grad()
+        for _, g_ in self.groups[1:]:
+            g_.zero_()
         B = features_mask.shape[1]
         cost, updates, _, _ = p.compute_cost(features, features_mask, labels, labels_mask, speaker,
-                                             start_flag, B, feedback_noise=feedback_noise)
+                                             start_flag, B, raw_audio=raw_audio, feedback_noise=feedback_noise)
         den_local = features_mask[1:].to(cost.device, torch.float32).sum()
         if pdist.is_distributed():
             scale, den_global = pdist.global_cost_scale(den_local)
             cost.backward(gradient=scale.to(cost.dtype))
-            pdist.allreduce_flat_(p.flat_gradients)
+            for _, g_ in self.groups:
+                pdist.allreduce_flat_(g_)
             gcost = pdist.allreduce_cost(cost.detach() * (den_local + pdist.COST_EPS), den_global)
         else:
             cost.backward()
             gcost = cost.detach()
         p.apply_updates(updates)  # TBPTT carry (model.py:786-791)
         ops.sumsq(p.flat_gradients, out=self.gnorm_sq)
+        for _, g_ in self.groups[1:]:  # StepClipping norm is over ALL parameters (train.py:100-101)
+            ops.sumsq(g_, out=self._part)
+            self.gnorm_sq.add_(self._part)
         self.step_count += 1
-        ops.adam_clip_step(p.flat_parameters, p.flat_gradients, self.m, self.v, self.gnorm_sq,
-                           self.step_count, lr=self.lr, clip=self.clip, beta1=self.beta1, beta2=self.beta2,
-                           eps=self.eps)
+        for (p_, g_), m_, v_ in zip(self.groups, self.ms, self.vs):
+            ops.adam_clip_step(p_, g_, m_, v_, self.gnorm_sq, self.step_count, lr=self.lr, clip=self.clip,
+                               beta1=self.beta1, beta2=self.beta2, eps=self.eps)
         self.last_grad_norm = self.gnorm_sq
         return gcost
 
     # -- extensions.py:83-152 (LearningRateSchedule) arithmetic: halve LR, zero Adam buffers
     def cut_learning_rate(self, factor=0.5):
         self.lr *= factor
-        self.m.zero_()
-        self.v.zero_()
+        for m_, v_ in zip(self.ms, self.vs):
+            m_.zero_()
+            v_.zero_()
         self.step_count = 0
 
     def state_dict(self):

@@ -171,3 +171,52 @@ def test_sample_model_gmm_head_parity(dev):
     outs2 = m.sample_model(lab.numpy(), lm.float().numpy(), None, spk.numpy(), N, S)  # own seeded RNG
     assert outs2[0].shape == (S, N, 63)
     m.close()
+
+
+def test_raw_output_head_trains_samplernn_on_predicted_frames(dev):
+    """model.py:793-820: cost = 0*cost + 1*cost_raw, SampleRNN conditioned on the predicted frames."""
+    from oracle import parrot_ref as R
+    from oracle import samplernn_ref as S
+    from parrot_amd.model import Parrot
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=32, EMB_SIZE=8)
+    try:
+        base = dict(SMALL, num_layers=2, encoder_type='bidirectional')
+        cfg = R.default_config(**base)
+        p = R.init_params(cfg, seed=7, scale_by_fan_in=True)
+        c = S.config(DIM=32, EMB_SIZE=8)
+        ps = S.init_params(c, seed=5, perturb=0.2)
+        lib.set_params(ps)
+        m = Parrot(device=dev, use_graph=False, raw_output=True, **base).allocate()
+        m.set_parameter_values(p)
+        T, B, U = 3, 2, 5
+        feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=3)
+        g = torch.Generator().manual_seed(8)
+        raw = torch.randint(0, 256, (T + 1, B, 80), generator=g)
+        for v in list(p.values()) + list(ps.values()):
+            v.requires_grad_()
+        _, _, rav, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
+        raw_mask = fm.repeat_interleave(80, dim=0).t()
+        raw_seq = raw.permute(1, 0, 2).reshape(B, -1)
+        z = torch.zeros(B, 1, 32, dtype=torch.float64)
+        rc, rip, _, _ = S.compute_cost(ps, c, raw_seq, rav[0].transpose(0, 1), z, z, 1, raw_mask)
+        rc.backward()
+        m.zero_grad()
+        cost, upd, av, cost_raw = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev),
+                                                 lm.float().to(dev), None, 1, B, raw_audio=raw.to(dev))
+        cost.backward()
+        assert_close(cost, rc, 1e-4, "cost == cost_raw")
+        assert_close(cost_raw, rc, 1e-4, "cost_raw")
+        grads = m.get_gradient_dict()
+        for name in ('/parrot/readout_to_output.W', '/parrot/rnn1.state_to_gates', '/parrot/h1_to_readout.W'):
+            assert rel_err(grads[name], p[name].grad) < 2e-3, name
+        for name in ('SampleLevel.L2.W0', 'BigFrameLevel.rnn_inp_fusion.W1', 'FrameLevel.GRU1.Step.Recurrent_Gates.W0'):
+            assert rel_err(lib.param(name).grad, ps[name].grad) < 2e-3, name
+        assert len(upd) == 2 + 2 + 2  # h1, h2, k, w + SampleRNN h0 / big_h0
+        m.close()
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256)

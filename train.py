@@ -24,6 +24,8 @@ def save_parameters(path, parrot, extra=None):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     carry = {}
     for B, c in parrot._carry.items():
+        if not isinstance(B, int):
+            continue
         for l, h in enumerate(c['h']):
             carry['B%d|last_h%d' % (B, l + 1)] = h.detach().cpu().numpy()
         carry['B%d|last_k' % B] = c['k'].detach().cpu().numpy()
