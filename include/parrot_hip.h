@@ -107,6 +107,31 @@ int parrot_gru_seq_bwd(void* plan, void* stream);
 int parrot_gru_seq_destroy(void* plan);
 
 /* ------------------------------------------------------------------------------------------
+ * LSTM scans (lib.ops.__LSTMStep / LowMemLSTM / stackedLSTM, sampleRNN/lib/ops.py:461-610, 823-989):
+ *   pre = s_{t-1} . W + pre_in[t]   (pre_in = x_t . U + b, gate order i | f | o | g, each H wide)
+ *   i,f,o = sigmoid, g = tanh;  c_t = c_{t-1}*f + g*i;  s_t = tanh(c_t)*o
+ * W = Recurrent_Gates [H,4H].  s / c histories have T+1 slots (slot 0 = initial state).
+ * Backward: in dS [T+1,B,H] (gradient wrt s slots from the consumers), in/out dc [B,H] (carry: gradient
+ * wrt the final cell on entry, wrt the initial cell on return); out dP [T,B,4H] (gradient wrt pre_in) and
+ * dS slot 0 (gradient wrt the initial state).  dW = s[0:T]^T dP is left to the caller (parrot_gemm).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct ParrotLstmSeqDesc {
+    int T, B, H, use_graph;
+    const float* W;        /* [H,4H] */
+    const float* pre_in;   /* [T,B,4H] */
+    float* s; float* c;    /* [T+1,B,H] */
+    float* gates;          /* [T,B,4H] saved activations (i|f|o|g after the nonlinearity) */
+    float* dS;             /* [T+1,B,H] */
+    float* dc;             /* [B,H] */
+    float* dP;             /* [T,B,4H] */
+} ParrotLstmSeqDesc;
+
+int parrot_lstm_seq_create(const ParrotLstmSeqDesc* desc, void** plan);
+int parrot_lstm_seq_fwd(void* plan, void* stream);
+int parrot_lstm_seq_bwd(void* plan, void* stream);
+int parrot_lstm_seq_destroy(void* plan);
+
+/* ------------------------------------------------------------------------------------------
  * GMM-window attention step (model.py:664-690; sampling variant :931-958).
  * att_type 0 = graves, 1 = softmax.  WattT = h1_to_att [alpha;beta;kappa] weights stored
  * TRANSPOSED, [3A,H] (row j = output j), so the per-row dot products read contiguous memory.

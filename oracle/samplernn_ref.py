@@ -18,13 +18,14 @@ import torch
 
 # three_tier.py:145-202 (hard-coded run configuration)
 DEFAULTS = dict(BIG_FRAME_SIZE=80, FRAME_SIZE=10, EMB_SIZE=256, DIM=1024, N_RNN=1, Q_LEVELS=256,
-                WEIGHT_NORM=True, LEARN_H0=True, SKIP_CONN=False, FEAT_DIM=63)
+                WEIGHT_NORM=True, LEARN_H0=True, SKIP_CONN=False, FEAT_DIM=63, RNN_TYPE='GRU')
 
 
 def config(**kw):
     c = dict(DEFAULTS)
     c.update(kw)
     c['BIG_DIM'] = c['DIM']
+    c['H0_MULT'] = 2 if c['RNN_TYPE'] == 'LSTM' else 1  # three_tier.py:163
     return c
 
 
@@ -66,16 +67,27 @@ def init_params(c, seed=1234, dtype=torch.float64, perturb=0.0):
     D, BD, wn = c['DIM'], c['BIG_DIM'], c['WEIGHT_NORM']
     BFS, FS, Q, EMB = c['BIG_FRAME_SIZE'], c['FRAME_SIZE'], c['Q_LEVELS'], c['EMB_SIZE']
     _linear_params(p, g, 'BigFrameLevel.rnn_inp_fusion', [BFS, c['FEAT_DIM']], BD, init='he', weightnorm=wn)
-    p['BigFrameLevel.h0'] = torch.zeros(c['N_RNN'], BD, dtype=torch.float64)
+    HM = c['H0_MULT']
+    p['BigFrameLevel.h0'] = torch.zeros(c['N_RNN'], HM * BD, dtype=torch.float64)
     for tier, dim in (('BigFrameLevel', BD), ('FrameLevel', D)):
-        pre = f'{tier}.GRU1.Step'
-        _linear_params(p, g, f'{pre}.Input', dim, 3 * dim, weightnorm=wn)
-        _linear_params(p, g, f'{pre}.Recurrent_Gates', dim, 2 * dim, biases=False, weightnorm=wn)
-        _linear_params(p, g, f'{pre}.Recurrent_Candidate', dim, dim, biases=False, init='orthogonal', weightnorm=wn)
+        for layer in range(1, c['N_RNN'] + 1):
+            if c['RNN_TYPE'] == 'GRU':
+                pre = f'{tier}.GRU{layer}.Step'
+                _linear_params(p, g, f'{pre}.Input', dim, 3 * dim, weightnorm=wn)
+                _linear_params(p, g, f'{pre}.Recurrent_Gates', dim, 2 * dim, biases=False, weightnorm=wn)
+                _linear_params(p, g, f'{pre}.Recurrent_Candidate', dim, dim, biases=False, init='orthogonal',
+                               weightnorm=wn)
+            else:  # ops.py:505-530
+                pre = f'{tier}.LSTM{layer}.Step'
+                _linear_params(p, g, f'{pre}.Input', dim, 4 * dim, biases=False, weightnorm=wn)
+                _linear_params(p, g, f'{pre}.Recurrent_Gates', dim, 4 * dim, biases=False, weightnorm=wn)
+                b = torch.zeros(4 * dim, dtype=torch.float64)
+                b[dim:2 * dim] = 3.0
+                p[f'{pre}.b'] = b
     _linear_params(p, g, 'BigFrameLevel.Output', BD, D * BFS // FS, init='he', weightnorm=wn)
     _linear_params(p, g, 'BigFrameLevel.IndependentPreds', BD, Q * BFS, init='he', weightnorm=wn)
     _linear_params(p, g, 'FrameLevel.InputExpand', FS, D, init='he', weightnorm=wn)
-    p['FrameLevel.h0'] = torch.zeros(c['N_RNN'], D, dtype=torch.float64)
+    p['FrameLevel.h0'] = torch.zeros(c['N_RNN'], HM * D, dtype=torch.float64)
     _linear_params(p, g, 'FrameLevel.Output', D, FS * D, init='he', weightnorm=wn)
     p['SampleLevel.Embedding'] = torch.randn(Q, EMB, generator=g, dtype=torch.float64)
     _linear_params(p, g, 'SampleLevel.L1_PrevSamples', FS * EMB, D, biases=False, init='he', weightnorm=wn)
@@ -114,16 +126,36 @@ def gru_step(p, c, name, dim, x, h):
     return update * cand + (1 - update) * h
 
 
+def lstm_step(p, c, name, dim, x, hc):
+    """__LSTMStep (ops.py:461-553): hc = [s | c]; gate order i | f | o | g."""
+    s_tm1, c_tm1 = hc[:, :dim], hc[:, dim:]
+    pre = linear(p, c, f'{name}.Input', x, biases=False) + linear(p, c, f'{name}.Recurrent_Gates', s_tm1, biases=False) \
+        + p[f'{name}.b']
+    gates = torch.sigmoid(pre[:, :3 * dim])
+    i, f, o = gates[:, :dim], gates[:, dim:2 * dim], gates[:, 2 * dim:]
+    g = torch.tanh(pre[:, 3 * dim:])
+    c_t = c_tm1 * f + g * i
+    return torch.cat([torch.tanh(c_t) * o, c_t], -1)
+
+
 def stacked_gru(p, c, name, dim, inputs, h0):
-    """stackedGRU with n_rnn = 1, no skip connections (ops.py:612-777): inputs [B,n,dim], h0 [B,1,dim]."""
-    assert c['N_RNN'] == 1 and not c['SKIP_CONN']
-    h = h0[:, 0]
-    outs = []
-    for t in range(inputs.shape[1]):
-        h = gru_step(p, c, f'{name}1.Step', dim, inputs[:, t], h)
-        outs.append(h)
-    out = torch.stack(outs, 1)
-    return out, out[:, -1][:, None]
+    """stackedGRU / stackedLSTM without skip connections (ops.py:612-777, 823-989): inputs [B,n,dim],
+    h0 [B,n_rnn,H0_MULT*dim].  `name` ends in '.GRU'; the LSTM parameters use '.LSTM' instead."""
+    assert not c['SKIP_CONN']
+    lstm = c['RNN_TYPE'] == 'LSTM'
+    base = name[:-4] + ('.LSTM' if lstm else '.GRU')
+    x = inputs
+    lasts = []
+    for layer in range(c['N_RNN']):
+        h = h0[:, layer]
+        outs = []
+        for t in range(x.shape[1]):
+            h = (lstm_step if lstm else gru_step)(p, c, f'{base}{layer + 1}.Step', dim, x[:, t], h)
+            outs.append(h)
+        full = torch.stack(outs, 1)
+        lasts.append(full[:, -1])
+        x = full[:, :, :dim]
+    return x, torch.stack(lasts, 1)
 
 
 def _frames_to_float(frames, c):
@@ -205,8 +237,8 @@ def generate(p, c, features, return_logits=False):
     samples = torch.zeros(B, LENGTH, dtype=torch.int64)
     samples[:, :BFS] = c['Q_LEVELS'] // 2
     dt = p['FrameLevel.h0'].dtype
-    big_h0 = torch.zeros(B, 1, c['BIG_DIM'], dtype=dt)
-    h0 = torch.zeros(B, 1, D, dtype=dt)
+    big_h0 = torch.zeros(B, c['N_RNN'], c['H0_MULT'] * c['BIG_DIM'], dtype=dt)
+    h0 = torch.zeros(B, c['N_RNN'], c['H0_MULT'] * D, dtype=dt)
     big_out = frame_out = None
     all_logits = []
     for t in range(BFS, LENGTH):

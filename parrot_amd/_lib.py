@@ -38,6 +38,11 @@ class GruSeqDesc(C.Structure):
     ]
 
 
+class LstmSeqDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("T", "B", "H", "use_graph")] + \
+               [(n, C.c_void_p) for n in ("W", "pre_in", "s", "c", "gates", "dS", "dc", "dP")]
+
+
 class DecoderDesc(C.Structure):
     _fields_ = [
         ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("E", C.c_int), ("A", C.c_int),
@@ -110,6 +115,10 @@ SIGNATURES = {
     "parrot_gru_seq_fwd": (_i, [_vp, _vp]),
     "parrot_gru_seq_bwd": (_i, [_vp, _vp]),
     "parrot_gru_seq_destroy": (_i, [_vp]),
+    "parrot_lstm_seq_create": (_i, [C.POINTER(LstmSeqDesc), C.POINTER(C.c_void_p)]),
+    "parrot_lstm_seq_fwd": (_i, [_vp, _vp]),
+    "parrot_lstm_seq_bwd": (_i, [_vp, _vp]),
+    "parrot_lstm_seq_destroy": (_i, [_vp]),
     "parrot_gmm_attention_fwd": (_i, [_vp] * 10 + [_i] * 6 + [_f] * 4 + [_vp]),
     "parrot_gmm_attention_bwd": (_i, [_vp] * 10 + [_i] * 6 + [_f, _vp]),
     "parrot_decoder_create": (_i, [C.POINTER(DecoderDesc), C.POINTER(C.c_void_p)]),

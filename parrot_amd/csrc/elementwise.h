@@ -29,3 +29,8 @@ int adam_clip_launch(float* p, const float* g, float* m, float* v, size_t n, con
 int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat, int B, int O, int K, float bias,
                       float eps, const float* unif, const float* noise, float* x, int ldx, float* pi_out,
                       hipStream_t stream);
+
+// Elementwise half of the LSTM backward step (ops.py:505-553 reversed).  dh: gradient wrt s_t; dc: carry
+// (in: gradient wrt c_t from step t+1, out: gradient wrt c_{t-1}); gates [B,4H] = i|f|o|g; dP [B,4H] out.
+int lstm_state_bwd_launch(const float* dh, float* dc, const float* gates, const float* c_prev, const float* c_new,
+                          float* dP, int B, int H, hipStream_t stream);

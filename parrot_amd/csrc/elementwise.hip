@@ -132,7 +132,38 @@ __global__ __launch_bounds__(64) void gmm_sample_kernel(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void lstm_state_bwd_kernel(const float* __restrict__ dh, float* __restrict__ dc,
+                                                             const float* __restrict__ gates,
+                                                             const float* __restrict__ c_prev,
+                                                             const float* __restrict__ c_new, float* __restrict__ dP,
+                                                             int B, int H) {
+    const size_t n = (size_t)B * H;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / H), k = (int)(idx % H);
+        const float* g = gates + (size_t)m * 4 * H;
+        const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
+        const float tc = tanhf(c_new[idx]);
+        const float dhv = dh[idx];
+        const float dcv = dhv * go * (1.f - tc * tc) + dc[idx];
+        float* o = dP + (size_t)m * 4 * H;
+        o[k] = dcv * gg * gi * (1.f - gi);
+        o[H + k] = dcv * c_prev[idx] * gf * (1.f - gf);
+        o[2 * H + k] = dhv * tc * go * (1.f - go);
+        o[3 * H + k] = dcv * gi * (1.f - gg * gg);
+        dc[idx] = dcv * gf;
+    }
+}
+
 }  // namespace
+
+int lstm_state_bwd_launch(const float* dh, float* dc, const float* gates, const float* c_prev, const float* c_new,
+                          float* dP, int B, int H, hipStream_t stream) {
+    const size_t n = (size_t)B * H;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(lstm_state_bwd_kernel, dim3(bx), dim3(256), 0, stream, dh, dc, gates, c_prev, c_new, dP, B, H);
+    return (int)hipGetLastError();
+}
 
 int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat, int B, int O, int K, float bias,
                       float eps, const float* unif, const float* noise, float* x, int ldx, float* pi_out,

@@ -157,6 +157,46 @@ struct GruSeqPlan : PlanBase {
     }
 };
 
+// ----------------------------------------------------------------------------- LSTM scan
+struct LstmSeqPlan : PlanBase {
+    ParrotLstmSeqDesc d;
+    int enqueue(int which, hipStream_t s) override { return which == 0 ? fwd(s) : bwd(s); }
+
+    int fwd(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H;
+        for (int t = 0; t < d.T; ++t) {
+            SkJob j;
+            sk_job_init(j);
+            j.nseg = 1;
+            j.seg[0] = sk_seg(d.s + t * BH, d.H, d.W, 4 * d.H, d.H, 0);
+            j.M = d.B; j.N = 4 * d.H; j.H = d.H; j.epi = SK_EPI_LSTM;
+            j.add = d.pre_in + (size_t)t * 4 * BH; j.ld_add = 4 * d.H;
+            j.e1 = d.c + t * BH; j.lde1 = d.H;
+            j.o1 = d.c + (t + 1) * BH; j.ldo1 = d.H;
+            j.o2 = d.gates + (size_t)t * 4 * BH; j.ldo2 = 4 * d.H;
+            j.out = d.s + (t + 1) * BH; j.ldo = d.H;
+            PL_TRY(launch_jobs(&j, 1, st));
+        }
+        return 0;
+    }
+
+    int bwd(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H;
+        for (int t = d.T - 1; t >= 0; --t) {
+            PL_TRY(lstm_state_bwd_launch(d.dS + (t + 1) * BH, d.dc, d.gates + (size_t)t * 4 * BH, d.c + t * BH,
+                                         d.c + (t + 1) * BH, d.dP + (size_t)t * 4 * BH, d.B, d.H, st));
+            SkJob y;
+            sk_job_init(y);
+            y.nseg = 1;
+            y.seg[0] = sk_seg(d.dP + (size_t)t * 4 * BH, 4 * d.H, d.W, 4 * d.H, 4 * d.H, 1);
+            y.M = d.B; y.N = d.H; y.H = d.H; y.epi = SK_EPI_LINEAR; y.accumulate = 1;
+            y.out = d.dS + t * BH; y.ldo = d.H;
+            PL_TRY(launch_jobs(&y, 1, st));
+        }
+        return 0;
+    }
+};
+
 // ----------------------------------------------------------------------------- decoder (training)
 struct DecoderPlan : PlanBase {
     ParrotDecoderDesc d;
@@ -648,6 +688,22 @@ int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan) {
 int parrot_gru_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_gru_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
 int parrot_gru_seq_destroy(void* plan) {
+    delete static_cast<PlanBase*>(plan);
+    return 0;
+}
+
+int parrot_lstm_seq_create(const ParrotLstmSeqDesc* desc, void** plan) {
+    if (!desc || !plan || desc->T < 1 || desc->B < 1 || desc->H < 4 || (desc->H & 3)) return PARROT_ERR_BADARG;
+    LstmSeqPlan* p = new (std::nothrow) LstmSeqPlan();
+    if (!p) return PARROT_ERR_BADARG;
+    p->d = *desc;
+    p->use_graph = desc->use_graph;
+    *plan = p;
+    return 0;
+}
+int parrot_lstm_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_lstm_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_lstm_seq_destroy(void* plan) {
     delete static_cast<PlanBase*>(plan);
     return 0;
 }

@@ -299,6 +299,54 @@ def gru_seq(inputs, gate_inputs, h0, Wc, Wg, mask=None, reverse=False):
     return _GruSeqFn.apply(inputs.contiguous(), gate_inputs.contiguous(), h0.contiguous(), Wc, Wg, mask, reverse)
 
 
+class _LstmSeqFn(torch.autograd.Function):
+    """LSTM scan (ops.py:461-610): pre_in [T,B,4H] (= x.U + b), s0, c0 [B,H], W [H,4H] -> (s [T,B,H], c [T,B,H])."""
+
+    @staticmethod
+    def forward(ctx, pre_in, s0, c0, W):
+        import ctypes as C
+        T, B, H4 = pre_in.shape
+        H = H4 // 4
+        f = dict(device=pre_in.device, dtype=torch.float32)
+        ws = dict(s=torch.empty(T + 1, B, H, **f), c=torch.empty(T + 1, B, H, **f), gates=torch.empty(T, B, 4 * H, **f),
+                  dS=torch.zeros(T + 1, B, H, **f), dc=torch.zeros(B, H, **f), dP=torch.empty(T, B, 4 * H, **f),
+                  pre_in=pre_in.contiguous(), W=W.contiguous())
+        ws['s'][0].copy_(s0)
+        ws['c'][0].copy_(c0)
+        d = _lib.LstmSeqDesc()
+        d.T, d.B, d.H, d.use_graph = T, B, H, 0
+        for k in ('W', 'pre_in', 's', 'c', 'gates', 'dS', 'dc', 'dP'):
+            setattr(d, k, ws[k].data_ptr())
+        plan = C.c_void_p()
+        _lib.call('parrot_lstm_seq_create', C.byref(d), C.byref(plan))
+        _lib.call('parrot_lstm_seq_fwd', plan, _stream())
+        ctx.ws, ctx.plan, ctx.desc = ws, plan, d
+        return ws['s'][1:].clone(), ws['c'][1:].clone()
+
+    @staticmethod
+    def backward(ctx, ds, dc_seq):
+        ws, T = ctx.ws, ctx.desc.T
+        B, H = ctx.desc.B, ctx.desc.H
+        ws['dS'].zero_()
+        ws['dS'][1:].copy_(ds)
+        ws['dc'].zero_()
+        if dc_seq is not None and bool((dc_seq[:-1] != 0).any()):
+            raise NotImplementedError("gradients into intermediate cell states are not supported")
+        if dc_seq is not None:
+            ws['dc'].copy_(dc_seq[-1])  # only the final cell state may carry a gradient (TBPTT carry)
+        _lib.call('parrot_lstm_seq_bwd', ctx.plan, _stream())
+        dP = ws['dP']
+        dW = gemm(ws['s'][:T].reshape(T * B, H).t(), dP.reshape(T * B, 4 * H)) if ctx.needs_input_grad[3] else None
+        out = (dP, ws['dS'][0].clone(), ws['dc'].clone(), dW)
+        _lib.load().parrot_lstm_seq_destroy(ctx.plan)
+        return out
+
+
+def lstm_seq(pre_in, s0, c0, W):
+    """Differentiable LSTM scan; returns (s [T,B,H], c [T,B,H])."""
+    return _LstmSeqFn.apply(pre_in.contiguous(), s0.contiguous(), c0.contiguous(), W)
+
+
 # ----------------------------------------------------------------------------- attention step
 def gmm_attention_fwd(h1, WattT, batt, kappa_prev, ctx, att_type=0, eps=1e-5, alignment=1.0,
                       sharpening=1.0, timing=1.0):

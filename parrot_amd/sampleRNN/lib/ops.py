@@ -6,7 +6,8 @@ reference sampleRNN/lib/ops.py: ``Linear`` (:32-128, weight norm :101-110), ``Em
 Dense products run in libparrot_hip.so (parrot_amd.ops.linear / gru_seq, differentiable); the weight
 norm scaling, the embedding gather and the softmax are small torch tensor ops around them.
 Off-path functions of the reference file (Batchnorm, MLP, GMM, conv1d, T_one_hot, LSTM variants) are
-not provided: nothing on the Char2Wav path calls them; LSTM raises.
+not provided: nothing on the Char2Wav path calls them.  ``LowMemLSTM`` /
+``stackedLSTM`` (:461-610, :823-989) run on the HIP LSTM scan.
 """
 from __future__ import annotations
 
@@ -152,6 +153,39 @@ def stackedGRU(name, n_rnn, input_dim, hidden_dim, inputs, h0, weightnorm, skip_
     return out, torch.stack(last, dim=1)
 
 
-def stackedLSTM(*args, **kwargs):
-    raise NotImplementedError("RNN_TYPE='LSTM' (ops.py:461-610, 823-989) is not wired into a scan plan yet; "
-                              "the reference run configuration uses GRU (three_tier.py:145)")
+def LowMemLSTM(name, input_dim, hidden_dim, inputs, h0=None, mask=None, weightnorm=True):
+    """ops.py:555-610 with the step of :461-553: inputs [B,n,input_dim], h0 [B, 2*hidden] = [s | c] ->
+    states [B,n,2*hidden] (s and c concatenated, like the reference).  Gate order i | f | o | g, forget
+    bias initialised to 3 (ops.py:469, 524-530)."""
+    step = name + '.Step'
+    processed = Linear(step + '.Input', input_dim, 4 * hidden_dim, inputs, biases=False, weightnorm=weightnorm)
+    Linear(step + '.Recurrent_Gates', hidden_dim, 4 * hidden_dim, None, biases=False, weightnorm=weightnorm,
+           just_params=True)
+    bias_init = numpy.zeros((4 * hidden_dim,), dtype='float32')
+    bias_init[hidden_dim:2 * hidden_dim] = 3.
+    b = lib.param(step + '.b', bias_init)
+    W = effective_weight(step + '.Recurrent_Gates', 0, weightnorm).contiguous()
+    pre_in = (processed + b).transpose(0, 1).contiguous()  # time-major [n,B,4H]
+    if h0 is None:
+        h0v = lib.param(name + '.Recurrent.h0_0', numpy.zeros((2 * hidden_dim,), dtype='float32'))
+        h0 = h0v.unsqueeze(0).expand(inputs.shape[0], -1)
+    s0, c0 = h0[:, :hidden_dim], h0[:, hidden_dim:]
+    s, c = hip.lstm_seq(pre_in, s0, c0, W)
+    return torch.cat([s, c], dim=-1).transpose(0, 1)
+
+
+def stackedLSTM(name, n_rnn, input_dim, hidden_dim, inputs, h0, weightnorm, skip_conn):
+    """ops.py:823-989; h0 [B, n_rnn, 2*hidden_dim].  Returns (out [B,n,hidden], last_hiddens [B,n_rnn,2*hidden])."""
+    assert n_rnn in range(1, 6), "n_rnn should be in [1,2,3,4,5]"
+    assert not (n_rnn == 1 and skip_conn), "Single layer RNN cannot have skip connections"
+    if skip_conn:
+        raise NotImplementedError("skip connections (ops.py:861-880) are off in the reference run configuration")
+    out = inputs
+    last = []
+    dim = input_dim
+    for layer in range(n_rnn):
+        full = LowMemLSTM(name + str(layer + 1), dim, hidden_dim, out, h0=h0[:, layer], weightnorm=weightnorm)
+        last.append(full[:, -1])
+        out = full[:, :, :hidden_dim]
+        dim = hidden_dim
+    return out, torch.stack(last, dim=1)

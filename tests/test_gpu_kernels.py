@@ -138,6 +138,34 @@ def test_gru_seq_fwd_bwd(dev, reverse, use_mask):
         assert_close(t.grad, r.grad, 1e-4, n)
 
 
+@pytest.mark.parametrize("T,B,H", [(5, 3, 16), (7, 37, 64)])
+def test_lstm_seq_fwd_bwd(dev, T, B, H):
+    """LSTM scan (ops.py:461-553 arithmetic) vs an fp64 torch loop, values and all gradients."""
+    from parrot_amd import ops
+    pre = _rand((T, B, 4 * H), dev, 1)
+    s0, c0 = _rand((B, H), dev, 2), _rand((B, H), dev, 3)
+    W = _rand((H, 4 * H), dev, 4, 1 / math.sqrt(H))
+    ts = [t.clone().requires_grad_() for t in (pre, s0, c0, W)]
+    s, c = ops.lstm_seq(*ts)
+    gs, gc = _rand((T, B, H), dev, 5), _rand((B, H), dev, 6)
+    ((s * gs).sum() + (c[-1] * gc).sum()).backward()
+    rp, rs, rc, rW = (t.detach().double().cpu().requires_grad_() for t in (pre, s0, c0, W))
+    hs, cs, hh, cc = [], [], rs, rc
+    for t in range(T):
+        z = hh @ rW + rp[t]
+        i, f, o = torch.sigmoid(z[:, :H]), torch.sigmoid(z[:, H:2 * H]), torch.sigmoid(z[:, 2 * H:3 * H])
+        g = torch.tanh(z[:, 3 * H:])
+        cc = cc * f + g * i
+        hh = torch.tanh(cc) * o
+        hs.append(hh); cs.append(cc)
+    rs_all, rc_all = torch.stack(hs), torch.stack(cs)
+    ((rs_all * gs.double().cpu()).sum() + (rc_all[-1] * gc.double().cpu()).sum()).backward()
+    assert_close(s, rs_all, 2e-5, "s")
+    assert_close(c, rc_all, 2e-5, "c")
+    for t, r, n in zip(ts, (rp, rs, rc, rW), ("d_pre", "ds0", "dc0", "dW")):
+        assert_close(t.grad, r.grad, 1e-4, n)
+
+
 @pytest.mark.parametrize("att_type", ["graves", "softmax"])
 @pytest.mark.parametrize("B,H,A,U,E", [(4, 64, 10, 23, 32), (64, 256, 10, 200, 256), (3, 40, 5, 17, 420)])
 def test_attention_fwd_bwd(dev, att_type, B, H, A, U, E):

@@ -103,3 +103,43 @@ def test_param_registry_roundtrip(dev, small_model, tmp_path):
     lib.load_params(path)
     assert torch.equal(lib.param('SampleLevel.L2.W0'), before)
     assert lib.param('SampleLevel.L2.W0') is w  # shared object between graphs (lib/__init__.py:28-47)
+
+
+@pytest.mark.parametrize("rnn_type,n_rnn", [("LSTM", 1), ("LSTM", 2), ("GRU", 2)])
+def test_compute_cost_lstm_and_stacked(dev, rnn_type, n_rnn):
+    """RNN_TYPE = 'LSTM' (ops.py:461-610, 823-989) and stacked (n_rnn > 1) variants of the tiers."""
+    from oracle import samplernn_ref as S
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=32, EMB_SIZE=8, RNN_TYPE=rnn_type, N_RNN=n_rnn)
+    try:
+        c = S.config(DIM=32, EMB_SIZE=8, RNN_TYPE=rnn_type, N_RNN=n_rnn)
+        p = S.init_params(c, seed=9, perturb=0.2)
+        lib.set_params(p)
+        g = torch.Generator().manual_seed(3)
+        B, S_len, hm = 2, 160, c['H0_MULT']
+        seq = torch.randint(0, 256, (B, S_len + 80), generator=g)
+        feats = torch.randn(B, S_len // 80, 63, generator=g, dtype=torch.float64)
+        mask = torch.ones(B, S_len + 80, dtype=torch.float64)
+        h0 = torch.randn(B, n_rnn, hm * 32, generator=g, dtype=torch.float64) * 0.3
+        bh0 = torch.randn(B, n_rnn, hm * 32, generator=g, dtype=torch.float64) * 0.3
+        ref_p = {k: v.clone().requires_grad_() for k, v in p.items()}
+        rc, rip, rh0, rbh0 = S.compute_cost(ref_p, c, seq, feats, h0, bh0, 0, mask)
+        (rc + rip).backward()
+        cost, ip_cost, _, _, _, nh0, nbh0 = tt.compute_cost(seq.to(dev), feats.float().to(dev), h0.float().to(dev),
+                                                            bh0.float().to(dev), 0, mask.float().to(dev))
+        (cost + ip_cost).backward()
+        assert_close(cost, rc, 1e-4, "cost")
+        assert_close(nh0, rh0, 1e-4, "new_h0")
+        assert_close(nbh0, rbh0, 1e-4, "new_big_h0")
+        assert set(lib.named_params()) == set(p), set(lib.named_params()) ^ set(p)
+        for name, t in lib.named_params().items():
+            rg = ref_p[name].grad
+            if rg is None or float(rg.abs().max()) < 1e-12:
+                continue
+            assert t.grad is not None and rel_err(t.grad, rg) < 2e-3, (name, rel_err(t.grad, rg))
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
