@@ -191,6 +191,14 @@ typedef struct ParrotDecoderDesc {
     float* dG[PARROT_MAX_LAYERS];  /* [T,B,2H] out: gradient wrt gate pre-activations */
     float* dC[PARROT_MAX_LAYERS];  /* [T,B,H]  out: gradient wrt candidate pre-activations */
     float* dp;                     /* [T,B,3A] out: gradient wrt attention projection */
+    /* LSTM variant of the layers (cell = 1; generalisation for BASELINE configs[3], cell algebra of
+     * sampleRNN/lib/ops.py:505-553, gate order i|f|o|g): one packed matrix per layer, passed in Wg
+     * ([K_l,4H], rows as above), bias in bg ([4H]), per-step inputs in seq_g ([T,B,4H]), gradient wrt the
+     * pre-activations out in dG ([T,B,4H]); Wc / bc / seq_c / z / r / rh / c / dC are unused. */
+    int cell, reserved4;
+    float* cst[PARROT_MAX_LAYERS];    /* [T+1,B,H] cell-state history (slot 0 = entering the window) */
+    float* gate4[PARROT_MAX_LAYERS];  /* [T,B,4H] saved gate activations */
+    float* dcell[PARROT_MAX_LAYERS];  /* [B,H] in: gradient wrt the final cell (0), out: wrt the initial cell */
 } ParrotDecoderDesc;
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
@@ -243,6 +251,11 @@ typedef struct ParrotSampleDesc {
     const float* unif; const float* noise;
     float* gmm_mu; float* gmm_sig; float* gmm_co;   /* scratch [B,O*K] x2, [B,K] */
     float* pi_out;                                   /* [S,B,K] mixture weights per step (the reference's `pi`) */
+    /* LSTM variant (cell = 1): Wg/bg/Wfg/seq_g are 4H wide, Wc/bc/Wfc/seq_c unused; cwork [2,B,H] ping-pong
+     * cell state (slot 0 = initial cell), gwork [B,4H] scratch. */
+    int cell, reserved5;
+    float* cwork[PARROT_MAX_LAYERS];
+    float* gwork;
 } ParrotSampleDesc;
 
 int parrot_sample_create(const ParrotSampleDesc* desc, void** plan);

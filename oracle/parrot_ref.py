@@ -7,7 +7,11 @@ run here.  Every function cites the reference lines it restates.  Row-vector con
 
 Parameters live in a flat dict keyed by Blocks-style brick paths (sample.py:83 shows the style:
 ``/parrot/lookuptable.W``), see ``init_params``.  Generalisation beyond the reference: the number
-of decoder layers L may be 1, 2 or 3 (the reference hard-wires 3, model.py:312-314).
+of decoder layers L may be 1, 2 or 3 (the reference hard-wires 3, model.py:312-314), and
+``cell_type='lstm'`` swaps the GatedRecurrent layers for LSTM layers (BASELINE configs[3]; the reference's
+own model.py has no LSTM decoder, so the cell algebra is the one the reference does contain,
+sampleRNN/lib/ops.py:505-553: gates i|f|o|g, state = [s | c]; each Fork then has the single output
+``rnn{l}_inputs`` of width 4H and the layer owns ``W_state`` [H,4H], ``initial_state``, ``initial_cells``).
 """
 from __future__ import annotations
 
@@ -29,13 +33,25 @@ def default_config(**kw):
         sampling_bias=0., epsilon=1e-5, num_characters=43, attention_type='graves',
         attention_size=10, attention_alignment=1., sharpening_coeff=1., timing_coeff=1.,
         encoder_type=None, encoder_dim=128, raw_output=False,
-        num_layers=3, encoder_literal=True)
+        num_layers=3, encoder_literal=True, cell_type='gru', lstm_forget_bias=3.0)
     cfg.update(kw)
     if cfg['full_feedback']:
         cfg['weak_feedback'] = True  # model.py:485
     cfg['encoded_input_dim'] = (2 * cfg['encoder_dim'] if cfg['encoder_type'] == 'bidirectional'
                                 else cfg['input_dim'])  # model.py:302-307
     return cfg
+
+
+def layer_outs(cfg, l):
+    """Fork output names / widths feeding layer l (model.py:331-349 for the GRU: inputs H, gates 2H)."""
+    H = cfg['rnn_h_dim']
+    if cfg.get('cell_type', 'gru') == 'lstm':
+        return [(f'rnn{l}_inputs', 4 * H)]
+    return [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)]
+
+
+def _names(cfg, l):
+    return [n for n, _ in layer_outs(cfg, l)]
 
 
 def param_shapes(cfg):
@@ -65,14 +81,19 @@ def param_shapes(cfg):
             s[f'{p}/gatedrecurrent.state_to_state'] = (ED, ED)
             s[f'{p}/gatedrecurrent.state_to_gates'] = (ED, 2 * ED)
             s[f'{p}/gatedrecurrent.initial_state'] = (ED,)
+    lstm = cfg.get('cell_type', 'gru') == 'lstm'
     for l in range(1, L + 1):
-        s[f'/parrot/rnn{l}.state_to_state'] = (H, H)
-        s[f'/parrot/rnn{l}.state_to_gates'] = (H, 2 * H)
+        if lstm:
+            s[f'/parrot/rnn{l}.W_state'] = (H, 4 * H)
+            s[f'/parrot/rnn{l}.initial_cells'] = (H,)
+        else:
+            s[f'/parrot/rnn{l}.state_to_state'] = (H, H)
+            s[f'/parrot/rnn{l}.state_to_gates'] = (H, 2 * H)
         s[f'/parrot/rnn{l}.initial_state'] = (H,)
         linear(f'h{l}_to_readout', H, R)
-        fork(f'inp_to_h{l}', E, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+        fork(f'inp_to_h{l}', E, layer_outs(cfg, l))
         for j in range(1, l):
-            fork(f'h{j}_to_h{l}', H, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+            fork(f'h{j}_to_h{l}', H, layer_outs(cfg, l))
     fork('h1_to_att', H, [('alpha', A), ('beta', A), ('kappa', A)])
     linear('att_to_readout', E, R)
     if cfg['which_cost'] == 'MSE':
@@ -84,7 +105,7 @@ def param_shapes(cfg):
         SD = cfg['speaker_dim']
         s['/parrot/lookuptable.W'] = (cfg['num_speakers'], SD)
         for l in range(1, L + 1):
-            fork(f'speaker_to_h{l}', SD, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+            fork(f'speaker_to_h{l}', SD, layer_outs(cfg, l))
         linear('speaker_to_readout', SD, R)
         if cfg['which_cost'] == 'MSE':
             linear('speaker_to_output', SD, O)
@@ -92,10 +113,10 @@ def param_shapes(cfg):
             K = cfg['k_gmm']
             fork('speaker_to_output', SD, [('gmm_mu', O * K), ('gmm_sigma', O * K), ('gmm_coeff', K)])
     if cfg['weak_feedback']:
-        fork('out_to_h1', O, [('rnn1_inputs', H), ('rnn1_gates', 2 * H)])
+        fork('out_to_h1', O, layer_outs(cfg, 1))
     if cfg['full_feedback']:
         for l in range(2, L + 1):
-            fork(f'out_to_h{l}', O, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+            fork(f'out_to_h{l}', O, layer_outs(cfg, l))
     s['/parrot.initial_w'] = (E,)
     return s
 
@@ -107,7 +128,8 @@ def init_params(cfg, seed=1234, std=0.01, dtype=torch.float64, scale_by_fan_in=F
     g = torch.Generator().manual_seed(seed)
     p = {}
     for name, shape in param_shapes(cfg).items():
-        is_w = (name.endswith('.W') or name.endswith('state_to_state') or name.endswith('state_to_gates'))
+        is_w = (name.endswith('.W') or name.endswith('state_to_state') or name.endswith('state_to_gates')
+                or name.endswith('W_state'))
         if is_w:
             sd = (1.0 / math.sqrt(shape[0])) if scale_by_fan_in else std
             p[name] = (torch.randn(shape, generator=g, dtype=torch.float64) * sd).to(dtype)
@@ -116,6 +138,10 @@ def init_params(cfg, seed=1234, std=0.01, dtype=torch.float64, scale_by_fan_in=F
                 p[name] = (torch.randn(shape, generator=g, dtype=torch.float64) * 0.1).to(dtype)
             else:
                 p[name] = torch.zeros(shape, dtype=dtype)
+    if cfg.get('cell_type', 'gru') == 'lstm':  # forget-gate bias, sampleRNN/lib/ops.py:526 (FORGET_BIAS = 3)
+        H = cfg['rnn_h_dim']
+        for l in range(1, cfg['num_layers'] + 1):
+            p[f'/parrot/inp_to_h{l}/fork_rnn{l}_inputs.b'][H:2 * H] += cfg.get('lstm_forget_bias', 3.0)
     return p
 
 
@@ -153,6 +179,27 @@ def gru_step(inputs, gate_inputs, h, W_ss, W_sg, mask=None):
     if mask is not None:
         hn = mask[..., None] * hn + (1 - mask[..., None]) * h
     return hn
+
+
+def lstm_cell(pre_in, s, c, W_state):
+    """sampleRNN/lib/ops.py:505-553 (LSTM step, gate order i|f|o|g) with the forget bias kept in the
+    learnable bias of `pre_in` (see init_params)."""
+    H = s.shape[-1]
+    g = s @ W_state + pre_in
+    i, f, o = torch.sigmoid(g[..., :H]), torch.sigmoid(g[..., H:2 * H]), torch.sigmoid(g[..., 2 * H:3 * H])
+    gg = torch.tanh(g[..., 3 * H:])
+    cn = f * c + i * gg
+    return torch.tanh(cn) * o, cn
+
+
+def cell_step(p, cfg, l, ins, state):
+    """One recurrent layer step; `ins` follows layer_outs(cfg, l), `state` is h (GRU) or (s, c) (LSTM).
+    Returns (new state, output fed to the layers above / attention / readout)."""
+    if cfg.get('cell_type', 'gru') == 'lstm':
+        s, c = lstm_cell(ins[0], state[0], state[1], p[f'/parrot/rnn{l}.W_state'])
+        return (s, c), s
+    h = gru_step(ins[0], ins[1], state, p[f'/parrot/rnn{l}.state_to_state'], p[f'/parrot/rnn{l}.state_to_gates'])
+    return h, h
 
 
 def gru_scan(inputs, gate_inputs, h0, W_ss, W_sg, mask=None):
@@ -212,28 +259,25 @@ def attention_step(cfg, a_hat, b_hat, k_hat, k_tm1, ctx, sampling=False):
 
 def decoder_step(p, cfg, seq_in, h_tm1, k_tm1, w_tm1, ctx, sampling=False):
     """One `step` of the training scan (model.py:651-724) for L layers.
-    seq_in: list of (cell_l, gate_l) additive inputs for this timestep."""
+    seq_in: per layer, the list of additive inputs for this timestep in layer_outs order
+    ((cell, gates) for the GRU).  h_tm1: per-layer states (h, or (s, c) for LSTM layers)."""
     L, ln = cfg['num_layers'], cfg['layer_norm']
-    hs = []
+    states, hs = [], []
     # layer 1: context of the previous step
-    ci, gi = fork(p, 'inp_to_h1', w_tm1, ['rnn1_inputs', 'rnn1_gates'])
-    h1 = gru_step(seq_in[0][0] + ci, seq_in[0][1] + gi, h_tm1[0],
-                  p['/parrot/rnn1.state_to_state'], p['/parrot/rnn1.state_to_gates'])
-    hs.append(h1)
+    ins = fork(p, 'inp_to_h1', w_tm1, _names(cfg, 1))
+    st, h1 = cell_step(p, cfg, 1, [a + b for a, b in zip(seq_in[0], ins)], h_tm1[0])
+    states.append(st); hs.append(h1)
     a_hat, b_hat, k_hat = fork(p, 'h1_to_att', h1, ['alpha', 'beta', 'kappa'])
     a, k, phi, w = attention_step(cfg, a_hat, b_hat, k_hat, k_tm1, ctx, sampling)
     for l in range(2, L + 1):
-        ci, gi = fork(p, f'inp_to_h{l}', w, [f'rnn{l}_inputs', f'rnn{l}_gates'])
-        c_in = seq_in[l - 1][0] + ci
-        g_in = seq_in[l - 1][1] + gi
+        ins = fork(p, f'inp_to_h{l}', w, _names(cfg, l))
+        tot = [a_ + b_ for a_, b_ in zip(seq_in[l - 1], ins)]
         for j in range(1, l):
-            cj, gj = fork(p, f'h{j}_to_h{l}', hs[j - 1], [f'rnn{l}_inputs', f'rnn{l}_gates'])
-            c_in = c_in + apply_norm(cj, ln)
-            g_in = g_in + apply_norm(gj, ln)
-        hl = gru_step(c_in, g_in, h_tm1[l - 1],
-                      p[f'/parrot/rnn{l}.state_to_state'], p[f'/parrot/rnn{l}.state_to_gates'])
-        hs.append(hl)
-    return hs, k, w, phi, a
+            outs = fork(p, f'h{j}_to_h{l}', hs[j - 1], _names(cfg, l))
+            tot = [t_ + apply_norm(o_, ln) for t_, o_ in zip(tot, outs)]
+        st, hl = cell_step(p, cfg, l, tot, h_tm1[l - 1])
+        states.append(st); hs.append(hl)
+    return states, hs, k, w, phi, a
 
 
 def logsumexp(x, axis):
@@ -261,6 +305,8 @@ def initial_carry(p, cfg, batch):
     """Parrot.initial_states (model.py:529-549): learned initial h, learned initial_w, zero k."""
     dt = p['/parrot.initial_w'].dtype
     hs = [p[f'/parrot/rnn{l}.initial_state'].expand(batch, -1) for l in range(1, cfg['num_layers'] + 1)]
+    if cfg.get('cell_type', 'gru') == 'lstm':
+        hs = [(h, p[f'/parrot/rnn{l + 1}.initial_cells'].expand(batch, -1)) for l, h in enumerate(hs)]
     w = p['/parrot.initial_w'].expand(batch, -1)
     k = torch.zeros(batch, cfg['attention_size'], dtype=dt)
     return dict(h=hs, w=w, k=k)
@@ -278,27 +324,24 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
     target = features[1:]
     mask = features_mask[1:]
     T, B = mask.shape
-    seq = [[torch.zeros(T, B, H, dtype=dt), torch.zeros(T, B, 2 * H, dtype=dt)] for _ in range(L)]
+    seq = [[torch.zeros(T, B, wd, dtype=dt) for _, wd in layer_outs(cfg, l)] for l in range(1, L + 1)]
+
+    def add_to(l, outs, first=False):
+        seq[l - 1] = [s_ + apply_norm(o_, ln) for s_, o_ in zip(seq[l - 1], outs)]
 
     if cfg['weak_feedback']:  # model.py:571-588
         inp = features[:-1]
         if feedback_noise is not None:
             inp = inp + feedback_noise
-        oc, og = fork(p, 'out_to_h1', inp, ['rnn1_inputs', 'rnn1_gates'])
-        seq[0][0] = seq[0][0] + apply_norm(oc, ln)
-        seq[0][1] = seq[0][1] + apply_norm(og, ln)
+        add_to(1, fork(p, 'out_to_h1', inp, _names(cfg, 1)))
     if cfg['full_feedback']:  # model.py:590-603
         for l in range(2, L + 1):
-            oc, og = fork(p, f'out_to_h{l}', inp, [f'rnn{l}_inputs', f'rnn{l}_gates'])
-            seq[l - 1][0] = seq[l - 1][0] + apply_norm(oc, ln)
-            seq[l - 1][1] = seq[l - 1][1] + apply_norm(og, ln)
+            add_to(l, fork(p, f'out_to_h{l}', inp, _names(cfg, l)))
     emb_speaker = None
     if cfg['use_speaker']:  # model.py:605-627
         emb_speaker = p['/parrot/lookuptable.W'][speaker[:, 0]][None]
         for l in range(1, L + 1):
-            sc, sg = fork(p, f'speaker_to_h{l}', emb_speaker, [f'rnn{l}_inputs', f'rnn{l}_gates'])
-            seq[l - 1][0] = apply_norm(sc, ln) + seq[l - 1][0]
-            seq[l - 1][1] = apply_norm(sg, ln) + seq[l - 1][1]
+            add_to(l, fork(p, f'speaker_to_h{l}', emb_speaker, _names(cfg, l)))
 
     init = initial_carry(p, cfg, B)
     if start_flag or carry is None:  # model.py:633-643
@@ -311,9 +354,9 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
     hs_all = [[] for _ in range(L)]
     ks, ws, phis, pis = [], [], [], []
     for t in range(T):  # theano.scan, model.py:726-737
-        h, k, w, phi, a = decoder_step(p, cfg, [(s[0][t], s[1][t]) for s in seq], h, k, w, ctx)
+        h, outs, k, w, phi, a = decoder_step(p, cfg, [[x[t] for x in s] for s in seq], h, k, w, ctx)
         for l in range(L):
-            hs_all[l].append(h[l])
+            hs_all[l].append(outs[l])
         ks.append(k); ws.append(w); phis.append(phi); pis.append(a)
     hs_all = [torch.stack(x, 0) for x in hs_all]
     k_all, w_all, phi_all, pi_all = (torch.stack(x, 0) for x in (ks, ws, phis, pis))
@@ -344,7 +387,7 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
         extras.update(mu=mu, sigma=sigma)
     cost = (cost * mask).sum() / (mask.sum() + 1e-5)  # model.py:784
 
-    new_carry = dict(h=[x[-1] for x in hs_all], k=k_all[-1], w=w_all[-1])  # model.py:786-791
+    new_carry = dict(h=list(h), k=k_all[-1], w=w_all[-1])  # model.py:786-791
     attention_vars = [next_x, k_all, w_all, coeff, phi_all, pi_all]
     extras.update(h=hs_all, ctx=ctx, readouts=readouts)
     return cost, new_carry, attention_vars, extras
@@ -375,7 +418,7 @@ def sample_model(p, cfg, labels, labels_mask, speaker, num_steps, unif=None, noi
     L, H, ln = cfg['num_layers'], cfg['rnn_h_dim'], cfg['layer_norm']
     N = labels.shape[0]
     dt = p['/parrot.initial_w'].dtype
-    const = [[torch.zeros(N, H, dtype=dt), torch.zeros(N, 2 * H, dtype=dt)] for _ in range(L)]
+    const = [[torch.zeros(N, wd, dtype=dt) for _, wd in layer_outs(cfg, l)] for l in range(1, L + 1)]
     spk_readout = spk_output = None
     if cfg['use_speaker']:  # model.py:846-874
         emb = p['/parrot/lookuptable.W'][speaker[:, 0]]
@@ -383,29 +426,26 @@ def sample_model(p, cfg, labels, labels_mask, speaker, num_steps, unif=None, noi
         spk_output = (fork(p, 'speaker_to_output', emb, ['gmm_mu', 'gmm_sigma', 'gmm_coeff']) if gmm
                       else linear(p, 'speaker_to_output', emb))
         for l in range(1, L + 1):
-            sc, sg = fork(p, f'speaker_to_h{l}', emb[None], [f'rnn{l}_inputs', f'rnn{l}_gates'])
-            const[l - 1][0] = const[l - 1][0] + apply_norm(sc, ln)[0]
-            const[l - 1][1] = const[l - 1][1] + apply_norm(sg, ln)[0]
+            outs = fork(p, f'speaker_to_h{l}', emb[None], _names(cfg, l))
+            const[l - 1] = [c_ + apply_norm(o_, ln)[0] for c_, o_ in zip(const[l - 1], outs)]
     ctx = encoder_apply(p, cfg, labels) * labels_mask[..., None]  # model.py:876-877
     init = initial_carry(p, cfg, N)  # always the learned initial states (model.py:1049-1054)
     h, w, k = init['h'], init['w'], init['k']
     x = torch.zeros(N, cfg['output_dim'], dtype=dt)  # model.py:834-835
     xs, ks, ws, phis, pis, cos = [], [], [], [], [], []
     for step in range(num_steps):
-        seq_in = [[c[0].clone(), c[1].clone()] for c in const]
+        seq_in = [[c_.clone() for c_ in c] for c in const]
         if cfg['weak_feedback']:  # model.py:899-908
-            oc, og = fork(p, 'out_to_h1', x, ['rnn1_inputs', 'rnn1_gates'])
-            seq_in[0][0] = seq_in[0][0] + apply_norm(oc, ln)
-            seq_in[0][1] = seq_in[0][1] + apply_norm(og, ln)
+            outs = fork(p, 'out_to_h1', x, _names(cfg, 1))
+            seq_in[0] = [s_ + apply_norm(o_, ln) for s_, o_ in zip(seq_in[0], outs)]
         if cfg['full_feedback']:  # model.py:910-924
             for l in range(2, L + 1):
-                oc, og = fork(p, f'out_to_h{l}', x, [f'rnn{l}_inputs', f'rnn{l}_gates'])
-                seq_in[l - 1][0] = seq_in[l - 1][0] + apply_norm(oc, ln)
-                seq_in[l - 1][1] = seq_in[l - 1][1] + apply_norm(og, ln)
-        h, k, w, phi, a = decoder_step(p, cfg, seq_in, h, k, w, ctx, sampling=True)
+                outs = fork(p, f'out_to_h{l}', x, _names(cfg, l))
+                seq_in[l - 1] = [s_ + apply_norm(o_, ln) for s_, o_ in zip(seq_in[l - 1], outs)]
+        h, hout, k, w, phi, a = decoder_step(p, cfg, seq_in, h, k, w, ctx, sampling=True)
         readout = 0  # model.py:992-1006
         for l in range(1, L + 1):
-            readout = readout + apply_norm(linear(p, f'h{l}_to_readout', h[l - 1]), ln)
+            readout = readout + apply_norm(linear(p, f'h{l}_to_readout', hout[l - 1]), ln)
         readout = readout + linear(p, 'att_to_readout', w)
         if cfg['use_speaker']:
             readout = readout + spk_readout

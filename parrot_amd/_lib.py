@@ -60,6 +60,8 @@ class DecoderDesc(C.Structure):
         ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dw0", C.c_void_p), ("dhup", C.c_void_p * MAX_LAYERS),
         ("dkappa", C.c_void_p),
         ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
+        ("cell", C.c_int), ("reserved4", C.c_int),
+        ("cst", C.c_void_p * MAX_LAYERS), ("gate4", C.c_void_p * MAX_LAYERS), ("dcell", C.c_void_p * MAX_LAYERS),
     ]
 
 
@@ -86,6 +88,8 @@ class SampleDesc(C.Structure):
         ("add_mu", C.c_void_p), ("add_sig", C.c_void_p), ("add_co", C.c_void_p),
         ("unif", C.c_void_p), ("noise", C.c_void_p),
         ("gmm_mu", C.c_void_p), ("gmm_sig", C.c_void_p), ("gmm_co", C.c_void_p), ("pi_out", C.c_void_p),
+        ("cell", C.c_int), ("reserved5", C.c_int),
+        ("cwork", C.c_void_p * MAX_LAYERS), ("gwork", C.c_void_p),
     ]
 
 

@@ -32,5 +32,5 @@ int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat
 
 // Elementwise half of the LSTM backward step (ops.py:505-553 reversed).  dh: gradient wrt s_t; dc: carry
 // (in: gradient wrt c_t from step t+1, out: gradient wrt c_{t-1}); gates [B,4H] = i|f|o|g; dP [B,4H] out.
-int lstm_state_bwd_launch(const float* dh, float* dc, const float* gates, const float* c_prev, const float* c_new,
+int lstm_state_bwd_launch(const float* dh, const float* dh2, float* dc, const float* gates, const float* c_prev, const float* c_new,
                           float* dP, int B, int H, hipStream_t stream);

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(64) void gmm_sample_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void lstm_state_bwd_kernel(const float* __restrict__ dh, float* __restrict__ dc,
+__global__ __launch_bounds__(256) void lstm_state_bwd_kernel(const float* __restrict__ dh,
+                                                             const float* __restrict__ dh2, float* __restrict__ dc,
                                                              const float* __restrict__ gates,
                                                              const float* __restrict__ c_prev,
                                                              const float* __restrict__ c_new, float* __restrict__ dP,
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void lstm_state_bwd_kernel(const float* __rest
         const float* g = gates + (size_t)m * 4 * H;
         const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
         const float tc = tanhf(c_new[idx]);
-        const float dhv = dh[idx];
+        const float dhv = dh[idx] + (dh2 ? dh2[idx] : 0.f);
         const float dcv = dhv * go * (1.f - tc * tc) + dc[idx];
         float* o = dP + (size_t)m * 4 * H;
         o[k] = dcv * gg * gi * (1.f - gi);
@@ -156,12 +157,13 @@ __global__ __launch_bounds__(256) void lstm_state_bwd_kernel(const float* __rest
 
 }  // namespace
 
-int lstm_state_bwd_launch(const float* dh, float* dc, const float* gates, const float* c_prev, const float* c_new,
-                          float* dP, int B, int H, hipStream_t stream) {
+int lstm_state_bwd_launch(const float* dh, const float* dh2, float* dc, const float* gates, const float* c_prev,
+                          const float* c_new, float* dP, int B, int H, hipStream_t stream) {
     const size_t n = (size_t)B * H;
     int bx = (int)((n + 255) / 256);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(lstm_state_bwd_kernel, dim3(bx), dim3(256), 0, stream, dh, dc, gates, c_prev, c_new, dP, B, H);
+    hipLaunchKernelGGL(lstm_state_bwd_kernel, dim3(bx), dim3(256), 0, stream, dh, dh2, dc, gates, c_prev, c_new, dP, B,
+                       H);
     return (int)hipGetLastError();
 }
 

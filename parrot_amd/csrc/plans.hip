@@ -183,7 +183,7 @@ struct LstmSeqPlan : PlanBase {
     int bwd(hipStream_t st) {
         const size_t BH = (size_t)d.B * d.H;
         for (int t = d.T - 1; t >= 0; --t) {
-            PL_TRY(lstm_state_bwd_launch(d.dS + (t + 1) * BH, d.dc, d.gates + (size_t)t * 4 * BH, d.c + t * BH,
+            PL_TRY(lstm_state_bwd_launch(d.dS + (t + 1) * BH, nullptr, d.dc, d.gates + (size_t)t * 4 * BH, d.c + t * BH,
                                          d.c + (t + 1) * BH, d.dP + (size_t)t * 4 * BH, d.B, d.H, st));
             SkJob y;
             sk_job_init(y);
@@ -251,6 +251,19 @@ struct DecoderPlan : PlanBase {
         j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
     }
 
+    void lstm_job(SkJob& j, int l, int t) const {
+        const size_t BH = (size_t)d.B * d.H;
+        sk_job_init(j);
+        layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 4 * d.H);
+        j.M = d.B; j.N = 4 * d.H; j.H = d.H; j.epi = SK_EPI_LSTM;
+        j.bias = d.bg[l];
+        j.add = d.seq_g[l] ? d.seq_g[l] + t * 4 * BH : nullptr; j.ld_add = 4 * d.H;
+        j.e1 = d.cst[l] + t * BH; j.lde1 = d.H;
+        j.o1 = d.cst[l] + (t + 1) * BH; j.ldo1 = d.H;
+        j.o2 = d.gate4[l] + t * 4 * BH; j.ldo2 = 4 * d.H;
+        j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
+    }
+
     int att_fwd_step(int t, hipStream_t st) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
         AttFwdArgs g;
@@ -274,6 +287,15 @@ struct DecoderPlan : PlanBase {
         for (int q = 0; q < d.T + d.L - 1; ++q) {
             SkJob jobs[PARROT_MAX_LAYERS];
             int n = 0;
+            if (d.cell == 1) {  // LSTM layers: a single fused GEMM + cell update per layer-step
+                for (int l = 0; l < d.L; ++l) {
+                    const int t = q - l;
+                    if (t >= 0 && t < d.T) lstm_job(jobs[n++], l, t);
+                }
+                PL_TRY(launch_jobs(jobs, n, st));
+                if (q < d.T) PL_TRY(att_fwd_step(q, st));
+                continue;
+            }
             for (int l = 0; l < d.L; ++l) {
                 const int t = q - l;
                 if (t >= 0 && t < d.T) gates_job(jobs[n++], l, t);
@@ -315,6 +337,44 @@ struct DecoderPlan : PlanBase {
                 g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
                 g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
                 PL_TRY(att_bwd_launch(g, st));
+            }
+            if (d.cell == 1) {
+                SkJob jl[SK_MAXJOB];
+                int nl = 0;
+                for (int l = d.L - 1; l >= 0; --l) {
+                    const int t = tl[l];
+                    if (t < 0 || t >= d.T) continue;
+                    float* dP = d.dG[l] + (size_t)t * 4 * BH;
+                    PL_TRY(lstm_state_bwd_launch(d.dh[l] + (t + 1) * BH, (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr,
+                                                 d.dcell[l], d.gate4[l] + (size_t)t * 4 * BH, d.cst[l] + t * BH,
+                                                 d.cst[l] + (t + 1) * BH, dP, d.B, H, st));
+                    {   // previous state of this layer
+                        SkJob& j = jl[nl++];
+                        sk_job_init(j);
+                        j.nseg = 1;
+                        j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l], 4 * H, 4 * H, 1);
+                        j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                        j.out = d.dh[l] + t * BH; j.ldo = H;
+                    }
+                    {   // attention context
+                        SkJob& j = jl[nl++];
+                        sk_job_init(j);
+                        j.nseg = 1;
+                        j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l] + (size_t)H * 4 * H, 4 * H, 4 * H, 1);
+                        j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                        j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
+                    }
+                    for (int p = 0; p < l; ++p) {
+                        SkJob& j = jl[nl++];
+                        sk_job_init(j);
+                        j.nseg = 1;
+                        j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l] + (size_t)(H + E + p * H) * 4 * H, 4 * H, 4 * H, 1);
+                        j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                        j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
+                    }
+                }
+                if (nl > 0) PL_TRY(launch_jobs(jl, nl, st));
+                continue;
             }
             GruStateBwdArgs ga;
             ga.nchain = 0; ga.B = d.B; ga.H = H;
@@ -583,6 +643,18 @@ struct SamplePlan : PlanBase {
             const int cur = t & 1, nxt = (t + 1) & 1;
             for (int l = 0; l < d.L; ++l) {
                 SkJob j;
+                if (d.cell == 1) {
+                    sk_job_init(j);
+                    layer_segs(j, l, t, d.h[l] + cur * BH, d.Wg[l], 4 * H, d.Wfg[l]);
+                    j.M = d.B; j.N = 4 * H; j.H = H; j.epi = SK_EPI_LSTM;
+                    j.bias = d.bg[l];
+                    j.add = d.seq_g[l]; j.ld_add = 4 * H;
+                    j.e1 = d.cwork[l] + cur * BH; j.lde1 = H;
+                    j.o1 = d.cwork[l] + nxt * BH; j.ldo1 = H;
+                    j.o2 = d.gwork; j.ldo2 = 4 * H;
+                    j.out = d.h[l] + nxt * BH; j.ldo = H;
+                    PL_TRY(launch_jobs(&j, 1, st));
+                } else {
                 sk_job_init(j);
                 layer_segs(j, l, t, d.h[l] + cur * BH, d.Wg[l], 2 * H, d.Wfg[l]);
                 j.M = d.B; j.N = 2 * H; j.H = H; j.epi = SK_EPI_GRU_GATES;
@@ -604,6 +676,7 @@ struct SamplePlan : PlanBase {
                 j.o1 = nullptr;
                 j.out = d.h[l] + nxt * BH; j.ldo = H;
                 PL_TRY(launch_jobs(&j, 1, st));
+                }
 
                 if (l == 0) {
                     AttFwdArgs g;

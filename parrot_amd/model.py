@@ -84,6 +84,7 @@ class Parrot(Brick):
             raw_output=False,
             # --- extensions (not in the reference) ---
             num_layers=3, encoder_literal=True, use_graph=True, seed=1234,
+            cell_type='gru', lstm_forget_bias=3.0,
             **kwargs):
         kwargs.setdefault('name', 'parrot')
         kwargs.setdefault('weights_init', IsotropicGaussian(0.01))  # train.py:30
@@ -93,6 +94,7 @@ class Parrot(Brick):
         assert attention_type in ('graves', 'softmax')
         assert encoder_type in (None, 'bidirectional')  # model.py:209
         assert 1 <= num_layers <= _lib.MAX_LAYERS
+        assert cell_type in ('gru', 'lstm')
         if layer_norm:
             raise NotImplementedError(
                 "layer_norm=True (model.py:24-34) is not built on the HIP path yet")
@@ -112,6 +114,16 @@ class Parrot(Brick):
         self.num_speakers, self.speaker_dim = num_speakers, speaker_dim
         self.k_gmm, self.sampling_bias = k_gmm, sampling_bias
         self.num_layers, self.encoder_literal, self.use_graph = num_layers, encoder_literal, use_graph
+        # Pre-activation groups of a decoder layer: (key, width, Fork output suffix, packed matrix, name of the
+        # recurrent block).  GRU (Blocks GatedRecurrent): gates 2H + candidate H.  LSTM (cell_type='lstm', the
+        # BASELINE configs[3] generalisation; cell algebra of sampleRNN/lib/ops.py:505-553): one 4H group.
+        self.cell_type, self.lstm_forget_bias = cell_type, float(lstm_forget_bias)
+        H_ = rnn_h_dim
+        if cell_type == 'lstm':
+            self._groups = [('g', 4 * H_, 'inputs', 'dec.Wg', 'W_state')]
+        else:
+            self._groups = [('g', 2 * H_, 'gates', 'dec.Wg', 'state_to_gates'),
+                            ('c', H_, 'inputs', 'dec.Wc', 'state_to_state')]
 
         self.store = ParamStore()
         self._declare_parameters()
@@ -152,21 +164,21 @@ class Parrot(Brick):
         # decoder layers: packed [h_l ; w ; h_1..h_{l-1}] weight matrices (include/parrot_hip.h)
         for l in range(1, L + 1):
             K = H + E + (l - 1) * H
-            s.add(f'dec.Wg{l}', (K, 2 * H), 'weight', alias=False)
-            s.add(f'dec.Wc{l}', (K, H), 'weight', alias=False)
-            s.alias(f'{P}/rnn{l}.state_to_state', f'dec.Wc{l}', rows=(0, H))
-            s.alias(f'{P}/rnn{l}.state_to_gates', f'dec.Wg{l}', rows=(0, H))
+            for key, wd, suf, mat, rec in self._groups:
+                s.add(f'{mat}{l}', (K, wd), 'weight', alias=False)
+            for key, wd, suf, mat, rec in reversed(self._groups):
+                s.alias(f'{P}/rnn{l}.{rec}', f'{mat}{l}', rows=(0, H))
             s.add(f'{P}/rnn{l}.initial_state', (H,), 'initial_state')
-            s.alias(f'{P}/inp_to_h{l}/fork_rnn{l}_inputs.W', f'dec.Wc{l}', rows=(H, H + E))
-            s.add(f'{P}/inp_to_h{l}/fork_rnn{l}_inputs.b', (H,), 'bias')
-            s.alias(f'{P}/inp_to_h{l}/fork_rnn{l}_gates.W', f'dec.Wg{l}', rows=(H, H + E))
-            s.add(f'{P}/inp_to_h{l}/fork_rnn{l}_gates.b', (2 * H,), 'bias')
+            if self.cell_type == 'lstm':
+                s.add(f'{P}/rnn{l}.initial_cells', (H,), 'initial_state')
+            for key, wd, suf, mat, rec in reversed(self._groups):
+                s.alias(f'{P}/inp_to_h{l}/fork_rnn{l}_{suf}.W', f'{mat}{l}', rows=(H, H + E))
+                s.add(f'{P}/inp_to_h{l}/fork_rnn{l}_{suf}.b', (wd,), 'bias')
             for j in range(1, l):
                 r0 = H + E + (j - 1) * H
-                s.alias(f'{P}/h{j}_to_h{l}/fork_rnn{l}_inputs.W', f'dec.Wc{l}', rows=(r0, r0 + H))
-                s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_inputs.b', (H,), 'bias')
-                s.alias(f'{P}/h{j}_to_h{l}/fork_rnn{l}_gates.W', f'dec.Wg{l}', rows=(r0, r0 + H))
-                s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_gates.b', (2 * H,), 'bias')
+                for key, wd, suf, mat, rec in reversed(self._groups):
+                    s.alias(f'{P}/h{j}_to_h{l}/fork_rnn{l}_{suf}.W', f'{mat}{l}', rows=(r0, r0 + H))
+                    s.add(f'{P}/h{j}_to_h{l}/fork_rnn{l}_{suf}.b', (wd,), 'bias')
         s.add('dec.WattT', (3 * A, H), 'weight', alias=False)  # h1_to_att weights, stored transposed
         s.add('dec.batt', (3 * A,), 'bias', alias=False)
         for i, n in enumerate(('alpha', 'beta', 'kappa')):
@@ -191,7 +203,7 @@ class Parrot(Brick):
             SD = self.speaker_dim
             s.add(f'{P}/lookuptable.W', (self.num_speakers, SD), 'weight')  # sample.py:83
             for l in range(1, L + 1):
-                fork_separate(f'speaker_to_h{l}', SD, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+                fork_separate(f'speaker_to_h{l}', SD, self._fork_outs(l))
             s.add(f'{P}/speaker_to_readout.W', (SD, R), 'weight')
             s.add(f'{P}/speaker_to_readout.b', (R,), 'bias')
             if self.which_cost == 'MSE':
@@ -211,8 +223,13 @@ class Parrot(Brick):
         if self.full_feedback:
             self._fb_layers = list(range(1, L + 1))
         for l in self._fb_layers:
-            fork_separate(f'out_to_h{l}', O, [(f'rnn{l}_inputs', H), (f'rnn{l}_gates', 2 * H)])
+            fork_separate(f'out_to_h{l}', O, self._fork_outs(l))
         s.add(f'{P}.initial_w', (E,), 'initial_state')
+
+    def _fork_outs(self, l):
+        """Fork output (name, width) list feeding layer l, reference order (inputs before gates,
+        model.py:331-349)."""
+        return [(f'rnn{l}_{suf}', wd) for key, wd, suf, mat, rec in reversed(self._groups)]
 
     def allocate(self):
         if not self._allocated:
@@ -236,6 +253,10 @@ class Parrot(Brick):
                     t.copy_(self.biases_init.generate(gen, tuple(t.shape)).to(t.device))
                 else:
                     t.zero_()
+            if self.cell_type == 'lstm':  # forget-gate bias (sampleRNN/lib/ops.py:526) lives in the learnable bias
+                H = self.rnn_h_dim
+                for l in range(1, self.num_layers + 1):
+                    self._p(f'/inp_to_h{l}/fork_rnn{l}_inputs.b')[H:2 * H].add_(self.lstm_forget_bias)
         self.initialized = True
         return self
 
@@ -309,6 +330,7 @@ class Parrot(Brick):
         if c is None:
             f = dict(device=self._dev(), dtype=torch.float32)
             c = dict(h=[torch.zeros(B, self.rnn_h_dim, **f) for _ in range(self.num_layers)],
+                     c=[torch.zeros(B, self.rnn_h_dim, **f) for _ in range(self.num_layers)],
                      w=torch.zeros(B, self.encoded_input_dim, **f),
                      k=torch.zeros(B, self.attention_size, **f))
             self._carry[B] = c
@@ -425,37 +447,43 @@ class Parrot(Brick):
         ws = dict(
             h=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
             w=torch.zeros(T + 1, B, E, **f), kappa=torch.zeros(T + 1, B, A, **f),
-            z=[torch.empty(T, B, H, **f) for _ in range(L)], r=[torch.empty(T, B, H, **f) for _ in range(L)],
-            rh=[torch.empty(T, B, H, **f) for _ in range(L)], c=[torch.empty(T, B, H, **f) for _ in range(L)],
             a=torch.empty(T, B, A, **f), b=torch.empty(T, B, A, **f), phi=torch.empty(T, B, U, **f),
             dh=[torch.zeros(T + 1, B, H, **f) for _ in range(L)], dw=torch.zeros(T + 1, B, E, **f),
             dw0=torch.zeros(T + 1, B, E, **f),
             dhup=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
             dkappa=torch.zeros(B, A, **f),
-            dG=[torch.empty(T, B, 2 * H, **f) for _ in range(L)], dC=[torch.empty(T, B, H, **f) for _ in range(L)],
             dp=torch.empty(T, B, 3 * A, **f),
             ctx=torch.zeros(B, U, E, **f),
-            bg=[torch.zeros(2 * H, **f) for _ in range(L)], bc=[torch.zeros(H, **f) for _ in range(L)],
             readouts=torch.empty(T * B, R, **f),
         )
-        ws['seq_c'] = [None] * L
-        ws['seq_g'] = [None] * L
-        for l in range(1, L + 1):
-            if l in self._fb_layers or self.use_speaker:
-                ws['seq_c'][l - 1] = torch.zeros(T, B, H, **f)
-                ws['seq_g'][l - 1] = torch.zeros(T, B, 2 * H, **f)
+        lstm = self.cell_type == 'lstm'
+        if lstm:
+            ws.update(cst=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
+                      gate4=[torch.empty(T, B, 4 * H, **f) for _ in range(L)],
+                      dcell=[torch.zeros(B, H, **f) for _ in range(L)])
+        else:
+            for n in ('z', 'r', 'rh', 'c'):
+                ws[n] = [torch.empty(T, B, H, **f) for _ in range(L)]
+        for key, wd, suf, mat, rec in self._groups:
+            ws['d' + key.upper()] = [torch.empty(T, B, wd, **f) for _ in range(L)]
+            ws['b' + key] = [torch.zeros(wd, **f) for _ in range(L)]
+            ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker) else None
+                                for l in range(1, L + 1)]
         d = _lib.DecoderDesc()
+        d.cell = 1 if lstm else 0
         d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, L
         d.att_type = 1 if self.attention_type == 'softmax' else 0
         d.use_graph = int(self.use_graph)
         d.eps, d.alignment, d.sharpening, d.timing = self.epsilon, self.attention_alignment, 1.0, 1.0
         st = self.store.storage
         for l in range(L):
-            d.Wg[l], d.Wc[l] = st[f'dec.Wg{l + 1}'].data_ptr(), st[f'dec.Wc{l + 1}'].data_ptr()
-            d.bg[l], d.bc[l] = ws['bg'][l].data_ptr(), ws['bc'][l].data_ptr()
-            d.seq_c[l] = ws['seq_c'][l].data_ptr() if ws['seq_c'][l] is not None else None
-            d.seq_g[l] = ws['seq_g'][l].data_ptr() if ws['seq_g'][l] is not None else None
-            for n in ('h', 'z', 'r', 'rh', 'c', 'dh', 'dG', 'dC'):
+            for key, wd, suf, mat, rec in self._groups:
+                getattr(d, 'W' + key)[l] = st[f'{mat}{l + 1}'].data_ptr()
+                getattr(d, 'b' + key)[l] = ws['b' + key][l].data_ptr()
+                sq = ws['seq_' + key][l]
+                getattr(d, 'seq_' + key)[l] = sq.data_ptr() if sq is not None else None
+                getattr(d, 'd' + key.upper())[l] = ws['d' + key.upper()][l].data_ptr()
+            for n in (('h', 'dh', 'cst', 'gate4', 'dcell') if lstm else ('h', 'dh', 'z', 'r', 'rh', 'c')):
                 getattr(d, n)[l] = ws[n][l].data_ptr()
             d.dhup[l] = ws['dhup'][l].data_ptr() if ws['dhup'][l] is not None else None
         d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
@@ -467,12 +495,20 @@ class Parrot(Brick):
         self._train_ws[key] = ws
         return ws
 
-    def _layer_bias_names(self, l):
-        """Names of the bias parameters that add into layer l's pre-activations (cell, gates)."""
-        names = [(f'/inp_to_h{l}/fork_rnn{l}_inputs.b', f'/inp_to_h{l}/fork_rnn{l}_gates.b')]
-        for j in range(1, l):
-            names.append((f'/h{j}_to_h{l}/fork_rnn{l}_inputs.b', f'/h{j}_to_h{l}/fork_rnn{l}_gates.b'))
-        return names
+    def _layer_bias_names(self, l, suf):
+        """Names of the bias parameters that add into layer l's pre-activation group `suf`
+        ('inputs' / 'gates'): the Forks from the attention context and from the layers below."""
+        return [f'/inp_to_h{l}/fork_rnn{l}_{suf}.b'] + [f'/h{j}_to_h{l}/fork_rnn{l}_{suf}.b' for j in range(1, l)]
+
+    def _sum_layer_biases(self, ws, extra_fb=False):
+        for l in range(1, self.num_layers + 1):
+            for key, wd, suf, mat, rec in self._groups:
+                b = ws['b' + key][l - 1]
+                b.zero_()
+                for n in self._layer_bias_names(l, suf):
+                    b.add_(self._p(n))
+                if extra_fb and l in self._fb_layers:
+                    b.add_(self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.b'))
 
     # ------------------------------------------------------------------ compute_cost
     def compute_cost(self, features, features_mask, labels, labels_mask, speaker, start_flag,
@@ -517,25 +553,22 @@ class Parrot(Brick):
             emb_spk = self._p('/lookuptable.W')[speaker[:, 0].long()].contiguous()  # [B,SD]
             save['spk_idx'], save['emb_spk'] = speaker[:, 0].long(), emb_spk
         for l in range(1, L + 1):
-            sc, sg = ws['seq_c'][l - 1], ws['seq_g'][l - 1]
-            if sc is None:
-                continue
-            have = False
-            if l in self._fb_layers:
-                ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_inputs.W'),
-                         bias=self._p(f'/out_to_h{l}/fork_rnn{l}_inputs.b'), out=sc.view(T * B, H))
-                ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_gates.W'),
-                         bias=self._p(f'/out_to_h{l}/fork_rnn{l}_gates.b'), out=sg.view(T * B, 2 * H))
-                have = True
-            if self.use_speaker:
-                spc = ops.gemm(emb_spk, self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.W'),
-                               bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.b'))
-                spg = ops.gemm(emb_spk, self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.W'),
-                               bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.b'))
-                if have:
-                    sc.add_(spc.unsqueeze(0)); sg.add_(spg.unsqueeze(0))
-                else:
-                    sc.copy_(spc.unsqueeze(0).expand(T, -1, -1)); sg.copy_(spg.unsqueeze(0).expand(T, -1, -1))
+            for key, wd, suf, mat, rec in self._groups:
+                sq = ws['seq_' + key][l - 1]
+                if sq is None:
+                    continue
+                have = False
+                if l in self._fb_layers:
+                    ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.W'),
+                             bias=self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.b'), out=sq.view(T * B, wd))
+                    have = True
+                if self.use_speaker:
+                    sp = ops.gemm(emb_spk, self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.W'),
+                                  bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.b'))
+                    if have:
+                        sq.add_(sp.unsqueeze(0))
+                    else:
+                        sq.copy_(sp.unsqueeze(0).expand(T, -1, -1))
 
         # --- initial state of the window (model.py:629-643)
         carry = self._get_carry(B)
@@ -544,6 +577,11 @@ class Parrot(Brick):
                 ws['h'][l][0].copy_(self._p(f'/rnn{l + 1}.initial_state').unsqueeze(0).expand(B, -1))
             else:
                 ws['h'][l][0].copy_(carry['h'][l])
+            if self.cell_type == 'lstm':
+                if start_flag:
+                    ws['cst'][l][0].copy_(self._p(f'/rnn{l + 1}.initial_cells').unsqueeze(0).expand(B, -1))
+                else:
+                    ws['cst'][l][0].copy_(carry['c'][l])
         if start_flag:
             ws['w'][0].copy_(self._p('.initial_w').unsqueeze(0).expand(B, -1))
             ws['kappa'][0].zero_()
@@ -553,11 +591,7 @@ class Parrot(Brick):
 
         # --- encoder (model.py:645-646) and summed layer biases
         ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, save))
-        for l in range(1, L + 1):
-            bc, bg = ws['bc'][l - 1], ws['bg'][l - 1]
-            bc.zero_(); bg.zero_()
-            for nc, ng in self._layer_bias_names(l):
-                bc.add_(self._p(nc)); bg.add_(self._p(ng))
+        self._sum_layer_biases(ws)
 
         # --- the scan (model.py:651-737)
         _lib.call('parrot_decoder_seq_fwd', ws['plan'], ops._stream())
@@ -618,6 +652,8 @@ class Parrot(Brick):
         # --- carried state (model.py:786-791)
         updates = [(carry['h'][l], ws['h'][l][T].clone()) for l in range(L)]
         updates += [(carry['k'], ws['kappa'][T].clone()), (carry['w'], ws['w'][T].clone())]
+        if self.cell_type == 'lstm':
+            updates += [(carry['c'][l], ws['cst'][l][T].clone()) for l in range(L)]
 
         if self.raw_output:
             updates += [(last_h0, new_h0.detach()), (last_big_h0, new_big_h0.detach())]    # model.py:815-816
@@ -687,7 +723,7 @@ class Parrot(Brick):
         ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
         ws['dw0'].zero_()
-        for t_ in ws['dhup']:
+        for t_ in ws['dhup'] + ws.get('dcell', []):
             if t_ is not None:
                 t_.zero_()
 
@@ -696,41 +732,38 @@ class Parrot(Brick):
         # deferred weight gradients of the scan: dW = X^T dPre over all (t, b) rows
         sg_, sc_ = self.store.storage_grad, self.store.storage
         for l in range(L):
-            dG = ws['dG'][l].view(T * B, 2 * H)
-            dC = ws['dC'][l].view(T * B, H)
-            gWg, gWc = sg_[f'dec.Wg{l + 1}'], sg_[f'dec.Wc{l + 1}']
+            ll = l + 1
             hprev = ws['h'][l][:T].view(T * B, H)
             wsrc = (ws['w'][:T] if l == 0 else ws['w'][1:]).view(T * B, E)
-            ops.gemm(hprev.t(), dG, out=gWg[0:H], accumulate=True)
-            ops.gemm(ws['rh'][l].view(T * B, H).t(), dC, out=gWc[0:H], accumulate=True)
-            ops.gemm(wsrc.t(), dG, out=gWg[H:H + E], accumulate=True)
-            ops.gemm(wsrc.t(), dC, out=gWc[H:H + E], accumulate=True)
-            for j in range(l):
-                r0 = H + E + j * H
-                hj = ws['h'][j][1:].view(T * B, H)
-                ops.gemm(hj.t(), dG, out=gWg[r0:r0 + H], accumulate=True)
-                ops.gemm(hj.t(), dC, out=gWc[r0:r0 + H], accumulate=True)
-            dbg, dbc = ops.colsum(dG), ops.colsum(dC)
-            for nc, ng in self._layer_bias_names(l + 1):
-                self._g(nc).add_(dbc); self._g(ng).add_(dbg)
-            # per-step additive inputs
-            ll = l + 1
-            if ll in self._fb_layers:
-                inp = save['fb_inp']
-                ops.gemm(inp.t(), dC, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.W'), accumulate=True)
-                ops.gemm(inp.t(), dG, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.W'), accumulate=True)
-                self._g(f'/out_to_h{ll}/fork_rnn{ll}_inputs.b').add_(dbc)
-                self._g(f'/out_to_h{ll}/fork_rnn{ll}_gates.b').add_(dbg)
-            if self.use_speaker:
-                dCs, dGs = dC.view(T, B, H).sum(0), dG.view(T, B, 2 * H).sum(0)
-                ops.gemm(emb_spk.t(), dCs, out=self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_inputs.W'), accumulate=True)
-                ops.gemm(emb_spk.t(), dGs, out=self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_gates.W'), accumulate=True)
-                self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_inputs.b').add_(dbc)
-                self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_gates.b').add_(dbg)
-                ops.gemm(dCs, self._p(f'/speaker_to_h{ll}/fork_rnn{ll}_inputs.W').t(), out=demb_spk, accumulate=True)
-                ops.gemm(dGs, self._p(f'/speaker_to_h{ll}/fork_rnn{ll}_gates.W').t(), out=demb_spk, accumulate=True)
+            for key, wd, suf, mat, rec in self._groups:
+                dP = ws['d' + key.upper()][l].view(T * B, wd)
+                gW = sg_[f'{mat}{ll}']
+                # the candidate block of the GRU multiplies r*h_prev, every other block h_prev
+                rec_in = ws['rh'][l].view(T * B, H) if key == 'c' else hprev
+                ops.gemm(rec_in.t(), dP, out=gW[0:H], accumulate=True)
+                ops.gemm(wsrc.t(), dP, out=gW[H:H + E], accumulate=True)
+                for j in range(l):
+                    r0 = H + E + j * H
+                    ops.gemm(ws['h'][j][1:].view(T * B, H).t(), dP, out=gW[r0:r0 + H], accumulate=True)
+                db = ops.colsum(dP)
+                for n in self._layer_bias_names(ll, suf):
+                    self._g(n).add_(db)
+                # per-step additive inputs
+                if ll in self._fb_layers:
+                    ops.gemm(save['fb_inp'].t(), dP, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_{suf}.W'),
+                             accumulate=True)
+                    self._g(f'/out_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(db)
+                if self.use_speaker:
+                    dPs = dP.view(T, B, wd).sum(0)
+                    ops.gemm(emb_spk.t(), dPs, out=self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_{suf}.W'),
+                             accumulate=True)
+                    self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(db)
+                    ops.gemm(dPs, self._p(f'/speaker_to_h{ll}/fork_rnn{ll}_{suf}.W').t(), out=demb_spk,
+                             accumulate=True)
             if save['start_flag']:
                 ops.colsum(ws['dh'][l][0], out=self._g(f'/rnn{ll}.initial_state'), accumulate=True)
+                if self.cell_type == 'lstm':
+                    ops.colsum(ws['dcell'][l], out=self._g(f'/rnn{ll}.initial_cells'), accumulate=True)
         if save['start_flag']:
             ops.colsum(ws['dw'][0], out=self._g('.initial_w'), accumulate=True)
             ops.colsum(ws['dw0'][0], out=self._g('.initial_w'), accumulate=True)
@@ -770,13 +803,16 @@ class Parrot(Brick):
             a=torch.empty(S, N, A, **f), bwork=torch.empty(N, A, **f), phi=torch.empty(S, N, U, **f),
             zwork=torch.empty(N, H, **f), rwork=torch.empty(N, H, **f), rhwork=torch.empty(N, H, **f),
             readout=torch.empty(N, R, **f), ctx=torch.zeros(N, U, E, **f),
-            bg=[torch.zeros(2 * H, **f) for _ in range(L)], bc=[torch.zeros(H, **f) for _ in range(L)],
             br=torch.zeros(R, **f), ldx=ldx,
-            seq_c=[torch.zeros(N, H, **f) if self.use_speaker else None for _ in range(L)],
-            seq_g=[torch.zeros(N, 2 * H, **f) if self.use_speaker else None for _ in range(L)],
             radd=torch.zeros(N, R, **f) if self.use_speaker else None,
             oadd=torch.zeros(N, O, **f) if (self.use_speaker and self.which_cost == 'MSE') else None,
         )
+        lstm = self.cell_type == 'lstm'
+        for key, wd, suf, mat, rec in self._groups:
+            ws['b' + key] = [torch.zeros(wd, **f) for _ in range(L)]
+            ws['seq_' + key] = [torch.zeros(N, wd, **f) if self.use_speaker else None for _ in range(L)]
+        if lstm:
+            ws.update(cwork=[torch.zeros(2, N, H, **f) for _ in range(L)], gwork=torch.empty(N, 4 * H, **f))
         gmm = self.which_cost == 'GMM'
         if gmm:
             K = self.k_gmm
@@ -793,15 +829,20 @@ class Parrot(Brick):
         d.eps, d.alignment = self.epsilon, self.attention_alignment
         d.sharpening, d.timing = self.sharpening_coeff, self.timing_coeff
         st = self.store.storage
+        d.cell = 1 if lstm else 0
         for l in range(L):
-            d.Wg[l], d.Wc[l] = st[f'dec.Wg{l + 1}'].data_ptr(), st[f'dec.Wc{l + 1}'].data_ptr()
-            d.bg[l], d.bc[l] = ws['bg'][l].data_ptr(), ws['bc'][l].data_ptr()
-            if (l + 1) in self._fb_layers:
-                d.Wfg[l] = self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_gates.W').data_ptr()
-                d.Wfc[l] = self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_inputs.W').data_ptr()
-            if self.use_speaker:
-                d.seq_c[l], d.seq_g[l] = ws['seq_c'][l].data_ptr(), ws['seq_g'][l].data_ptr()
+            for key, wd, suf, mat, rec in self._groups:
+                getattr(d, 'W' + key)[l] = st[f'{mat}{l + 1}'].data_ptr()
+                getattr(d, 'b' + key)[l] = ws['b' + key][l].data_ptr()
+                if (l + 1) in self._fb_layers:
+                    getattr(d, 'Wf' + key)[l] = self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_{suf}.W').data_ptr()
+                if self.use_speaker:
+                    getattr(d, 'seq_' + key)[l] = ws['seq_' + key][l].data_ptr()
             d.h[l] = ws['h'][l].data_ptr()
+            if lstm:
+                d.cwork[l] = ws['cwork'][l].data_ptr()
+        if lstm:
+            d.gwork = ws['gwork'].data_ptr()
         d.WattT, d.batt = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr()
         d.Wr, d.br = st['dec.Wr'].data_ptr(), ws['br'].data_ptr()
         d.radd = ws['radd'].data_ptr() if ws['radd'] is not None else None
@@ -841,15 +882,11 @@ class Parrot(Brick):
         S, L, H, O = num_steps, self.num_layers, self.rnn_h_dim, self.output_dim
         ws = self._sample_workspace(S, N, U)
         ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, None))
+        self._sum_layer_biases(ws, extra_fb=True)
         for l in range(1, L + 1):
-            bc, bg = ws['bc'][l - 1], ws['bg'][l - 1]
-            bc.zero_(); bg.zero_()
-            for nc, ng in self._layer_bias_names(l):
-                bc.add_(self._p(nc)); bg.add_(self._p(ng))
-            if l in self._fb_layers:
-                bc.add_(self._p(f'/out_to_h{l}/fork_rnn{l}_inputs.b'))
-                bg.add_(self._p(f'/out_to_h{l}/fork_rnn{l}_gates.b'))
             ws['h'][l - 1][0].copy_(self._p(f'/rnn{l}.initial_state').unsqueeze(0).expand(N, -1))
+            if self.cell_type == 'lstm':
+                ws['cwork'][l - 1][0].copy_(self._p(f'/rnn{l}.initial_cells').unsqueeze(0).expand(N, -1))
         ws['br'].copy_(self._p('/att_to_readout.b'))
         for l in range(1, L + 1):
             ws['br'].add_(self._p(f'/h{l}_to_readout.b'))
@@ -857,10 +894,9 @@ class Parrot(Brick):
             speaker = torch.as_tensor(speaker).to(dev)
             emb = self._p('/lookuptable.W')[speaker[:, 0].long()].contiguous()
             for l in range(1, L + 1):
-                ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.W'),
-                         bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_inputs.b'), out=ws['seq_c'][l - 1])
-                ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.W'),
-                         bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_gates.b'), out=ws['seq_g'][l - 1])
+                for key, wd, suf, mat, rec in self._groups:
+                    ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.W'),
+                             bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.b'), out=ws['seq_' + key][l - 1])
             ops.gemm(emb, self._p('/speaker_to_readout.W'), bias=self._p('/speaker_to_readout.b'), out=ws['radd'])
             if self.which_cost == 'MSE':
                 ops.gemm(emb, self._p('/speaker_to_output.W'), bias=self._p('/speaker_to_output.b'), out=ws['oadd'])

@@ -63,7 +63,7 @@ def test_struct_sizes_match_header(lib):
     src = r'''
 #include <stdio.h>
 #include "parrot_hip.h"
-int main(void){printf("%zu %zu %zu %zu\n", sizeof(ParrotGruSeqDesc), sizeof(ParrotDecoderDesc), sizeof(ParrotSampleDesc), sizeof(SampleRnnGenDesc));return 0;}
+int main(void){printf("%zu %zu %zu %zu %zu\n", sizeof(ParrotGruSeqDesc), sizeof(ParrotDecoderDesc), sizeof(ParrotSampleDesc), sizeof(SampleRnnGenDesc), sizeof(ParrotLstmSeqDesc));return 0;}
 '''
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
@@ -72,7 +72,7 @@ int main(void){printf("%zu %zu %zu %zu\n", sizeof(ParrotGruSeqDesc), sizeof(Parr
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [C.sizeof(_lib.GruSeqDesc), C.sizeof(_lib.DecoderDesc), C.sizeof(_lib.SampleDesc),
-                     C.sizeof(_lib.SampleRnnGenDesc)]
+                     C.sizeof(_lib.SampleRnnGenDesc), C.sizeof(_lib.LstmSeqDesc)]
 
 
 def test_parrot_parameter_names_match_oracle():

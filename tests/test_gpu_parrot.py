@@ -220,3 +220,62 @@ def test_raw_output_head_trains_samplernn_on_predicted_frames(dev):
     finally:
         lib.delete_all_params()
         tt.configure(DIM=1024, EMB_SIZE=256)
+
+
+# ----------------------------------------------------------------------------- LSTM decoder layers
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_lstm_decoder_cost_and_grads(dev, L):
+    """cell_type='lstm' (BASELINE configs[3] generalisation): same scan with LSTM layers."""
+    _check_cost_and_grads(dev, T=6, B=4, U=9, num_layers=L, encoder_type='bidirectional', cell_type='lstm')
+
+
+def test_lstm_decoder_feedback_speaker_ragged(dev):
+    _check_cost_and_grads(dev, T=7, B=5, U=11, ragged=True, num_layers=3, encoder_type='bidirectional',
+                          full_feedback=True, use_speaker=True, cell_type='lstm')
+
+
+def test_lstm_decoder_gmm_batch70(dev):
+    _check_cost_and_grads(dev, T=4, B=70, U=8, num_layers=2, encoder_type='bidirectional', which_cost='GMM',
+                          k_gmm=3, tol_grad=2e-3, cell_type='lstm', weak_feedback=True)
+
+
+def test_lstm_decoder_graph_and_tbptt_carry(dev):
+    from oracle import parrot_ref as R
+    T, B, U = 8, 4, 6
+    cfg, p, m = _build(dev, use_graph=True, num_layers=2, encoder_type='bidirectional', weak_feedback=True,
+                       cell_type='lstm')
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=5)
+    args = [t.to(dev) for t in (feat.float(), fm.float(), lab, lm.float())]
+    for rep in range(2):
+        m.zero_grad()
+        c, upd, av, _ = m.compute_cost(args[0], args[1], args[2], args[3], None, 1, B)
+        c.backward()
+    full = av[0].clone()
+    with torch.no_grad():
+        rc1, carry, rav1, _ = R.compute_cost(p, cfg, feat[:5], fm[:5], lab, lm, None, 1)
+        rc2, _, rav2, _ = R.compute_cost(p, cfg, feat[4:], fm[4:], lab, lm, None, 0, carry=carry)
+    c1, u1, av1, _ = m.compute_cost(args[0][:5], args[1][:5], args[2], args[3], None, 1, B)
+    m.apply_updates(u1)
+    c2, u2, av2, _ = m.compute_cost(args[0][4:], args[1][4:], args[2], args[3], None, 0, B)
+    assert_close(torch.cat([av1[0], av2[0]], 0), full, 1e-5, "TBPTT carry (cells included)")
+    assert_close(c2, rc2, 1e-4, "second-window cost vs oracle")
+    assert_close(av2[0], rav2[0], 1e-4, "second-window frames vs oracle")
+    m.close()
+
+
+@pytest.mark.parametrize("kw", [dict(num_layers=3, full_feedback=True, use_speaker=True),
+                                dict(num_layers=2, weak_feedback=True, which_cost='GMM', k_gmm=3)])
+def test_lstm_decoder_sample_model_parity(dev, kw):
+    from oracle import parrot_ref as R
+    cfg, p, m = _build(dev, use_graph=True, encoder_type='bidirectional', cell_type='lstm', **kw)
+    N, U, S = 4, 9, 12
+    _, _, lab, lm, spk = make_batch(cfg, 2, N, U, seed=9, speaker=cfg['use_speaker'])
+    g = torch.Generator().manual_seed(11)
+    unif = torch.rand(S, N, generator=g, dtype=torch.float64)
+    noise = torch.randn(S, N, cfg['output_dim'], generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        ref = R.sample_model(p, cfg, lab, lm, spk, S, unif=unif, noise=noise)
+    outs = m.sample_model_device(lab, lm.float(), spk, N, S, unif=unif.float(), noise=noise.float())
+    for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+        assert_close(o, r, 2e-4 if cfg['which_cost'] == 'GMM' else 1e-4, n)
+    m.close()
