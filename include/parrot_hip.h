@@ -171,8 +171,13 @@ typedef struct ParrotDecoderDesc {
     const float* WattT; /* [3A,H] */
     const float* batt;  /* [3A]   */
     const float* ctx;   /* [B,U,E] encoder output * labels_mask (model.py:645-646) */
-    const float* seq_c[PARROT_MAX_LAYERS]; /* [T,B,H]  per-step additive cell inputs or NULL (model.py:562-627) */
-    const float* seq_g[PARROT_MAX_LAYERS]; /* [T,B,2H] per-step additive gate inputs or NULL */
+    /* Per-step additive inputs (teacher-forcing feedback + speaker, model.py:562-627), or NULL.
+     * For layers l >= 1 the buffers double as the destination of the chunk-batched projections of the lower
+     * layers' outputs (see plans.hip, "chunked layer pipeline"): when every layer l >= 1 has them the scan
+     * runs layer-pipelined and ADDS those projections in place (bit l of seq_init tells whether the buffer
+     * holds caller data or is scratch to be overwritten).  The caller must refill them before each seq_fwd. */
+    float* seq_c[PARROT_MAX_LAYERS]; /* [T,B,H]  */
+    float* seq_g[PARROT_MAX_LAYERS]; /* [T,B,2H] */
     /* forward state / saved activations */
     float* h[PARROT_MAX_LAYERS];   /* [T+1,B,H] */
     float* w;                      /* [T+1,B,E] */
@@ -195,7 +200,8 @@ typedef struct ParrotDecoderDesc {
      * sampleRNN/lib/ops.py:505-553, gate order i|f|o|g): one packed matrix per layer, passed in Wg
      * ([K_l,4H], rows as above), bias in bg ([4H]), per-step inputs in seq_g ([T,B,4H]), gradient wrt the
      * pre-activations out in dG ([T,B,4H]); Wc / bc / seq_c / z / r / rh / c / dC are unused. */
-    int cell, reserved4;
+    int cell;
+    int seq_init;                     /* bit l set: seq_g[l]/seq_c[l] hold caller data (else scratch), see below */
     float* cst[PARROT_MAX_LAYERS];    /* [T+1,B,H] cell-state history (slot 0 = entering the window) */
     float* gate4[PARROT_MAX_LAYERS];  /* [T,B,4H] saved gate activations */
     float* dcell[PARROT_MAX_LAYERS];  /* [B,H] in: gradient wrt the final cell (0), out: wrt the initial cell */
@@ -270,6 +276,16 @@ int parrot_plan_last_error(void* plan);
  * all-reduce in data-parallel runs); grad_scale rescales the raw gradient first (1/world_size).
  * ------------------------------------------------------------------------------------------ */
 int parrot_sumsq(const float* x, size_t n, float* out, void* stream);
+
+/* _simple_norm / _apply_norm of the reference (model.py:24-34; used when layer_norm=True on the Fork outputs
+ * and readout projections, model.py:585-620, 703-722, 746): y = (x - mean) / (eps + std) over the last axis
+ * (population std, no affine).  x [R,N] (leading dimension ldx); y [R,N] may alias x; sigma [R] receives the
+ * row std (saved for the backward); add_dst (or NULL) [R,N] gets += y. */
+int parrot_simple_norm_fwd(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
+                           float* add_dst, int ld_add, void* stream);
+/* Backward of the above: dx [R,N] (may alias dy or y) = J^T dy, from the saved y and sigma. */
+int parrot_simple_norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* sigma, float* dx,
+                           int lddx, long long R, int N, float eps, int accumulate, void* stream);
 int parrot_adam_clip_step(float* param, const float* grad, float* m, float* v, size_t n,
                           const float* gnorm_sq, float grad_scale, float clip_threshold, float lr,
                           float beta1, float beta2, float eps, int step, void* stream);

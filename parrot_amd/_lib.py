@@ -60,7 +60,7 @@ class DecoderDesc(C.Structure):
         ("dh", C.c_void_p * MAX_LAYERS), ("dw", C.c_void_p), ("dw0", C.c_void_p), ("dhup", C.c_void_p * MAX_LAYERS),
         ("dkappa", C.c_void_p),
         ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
-        ("cell", C.c_int), ("reserved4", C.c_int),
+        ("cell", C.c_int), ("seq_init", C.c_int),
         ("cst", C.c_void_p * MAX_LAYERS), ("gate4", C.c_void_p * MAX_LAYERS), ("dcell", C.c_void_p * MAX_LAYERS),
     ]
 
@@ -134,6 +134,8 @@ SIGNATURES = {
     "parrot_sample_destroy": (_i, [_vp]),
     "parrot_plan_last_error": (_i, [_vp]),
     "parrot_sumsq": (_i, [_vp, _sz, _vp, _vp]),
+    "parrot_simple_norm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _ll, _i, _f, _vp, _i, _vp]),
+    "parrot_simple_norm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     "parrot_adam_clip_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
     "parrot_batch_quantize": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp]),
     "parrot_mu2linear": (_i, [_vp, _sz, _vp, _vp]),

@@ -85,6 +85,18 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     return bg_launch(a, st);
 }
 
+int parrot_simple_norm_fwd(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
+                           float* add_dst, int ld_add, void* stream) {
+    if (!x || !y || !sigma) return PARROT_ERR_BADARG;
+    return simple_norm_fwd_launch(x, ldx, y, ldy, sigma, R, N, eps, add_dst, ld_add, (hipStream_t)stream);
+}
+
+int parrot_simple_norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* sigma, float* dx,
+                           int lddx, long long R, int N, float eps, int accumulate, void* stream) {
+    if (!dy || !y || !sigma || !dx) return PARROT_ERR_BADARG;
+    return simple_norm_bwd_launch(dy, lddy, y, ldy, sigma, dx, lddx, R, N, eps, accumulate, (hipStream_t)stream);
+}
+
 int parrot_colsum(const float* x, long long M, int N, int ld, float* out, int accumulate, void* stream) {
     return colsum_launch(x, M, N, ld, out, accumulate, (hipStream_t)stream);
 }

@@ -34,3 +34,12 @@ int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat
 // (in: gradient wrt c_t from step t+1, out: gradient wrt c_{t-1}); gates [B,4H] = i|f|o|g; dP [B,4H] out.
 int lstm_state_bwd_launch(const float* dh, const float* dh2, float* dc, const float* gates, const float* c_prev, const float* c_new,
                           float* dP, int B, int H, hipStream_t stream);
+
+// _simple_norm of the reference (model.py:24-27): y = (x - mean) / (eps + std) over the last axis, population
+// std, no affine.  fwd: y (may alias x) and sigma [R] are saved for the backward; if add_dst is given the
+// normalised rows are also added into it (the Fork outputs are summed after normalisation, model.py:703-722).
+int simple_norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
+                           float* add_dst, int ld_add, hipStream_t stream);
+// dx (may alias y or dy) = d/dx of the above given dy, y, sigma; accumulate: dx += instead of =.
+int simple_norm_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const float* sigma, float* dx, int lddx,
+                           long long R, int N, float eps, int accumulate, hipStream_t stream);

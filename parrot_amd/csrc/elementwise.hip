@@ -155,7 +155,83 @@ __global__ __launch_bounds__(256) void lstm_state_bwd_kernel(const float* __rest
     }
 }
 
+// Sum over the 256 threads of a workgroup, result in every thread (red: 4 floats of LDS).
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();  // protects red against the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// One workgroup per row.  Two passes over the row (mean, then centred second moment), like the oracle.
+__global__ __launch_bounds__(256) void simple_norm_fwd_kernel(const float* x, int ldx, float* y, int ldy,
+                                                              float* __restrict__ sigma, int N, float eps,
+                                                              float* add_dst, int ld_add) {
+    __shared__ float red[4];
+    const size_t r = blockIdx.x;
+    const float* xr = x + r * ldx;
+    float s = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) s += xr[n];
+    const float mean = block_sum256(s, red) / (float)N;
+    float q = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float d = xr[n] - mean;
+        q += d * d;
+    }
+    const float sd = sqrtf(block_sum256(q, red) / (float)N);
+    const float inv = 1.f / (eps + sd);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float v = (xr[n] - mean) * inv;
+        y[r * ldy + n] = v;
+        if (add_dst) add_dst[r * ld_add + n] += v;
+    }
+    if (threadIdx.x == 0) sigma[r] = sd;
+}
+
+// y = (x - mu) / s, s = eps + sigma  =>  dx = (dy - mean(dy)) / s - y * sum(dy * y) / (N * sigma)
+__global__ __launch_bounds__(256) void simple_norm_bwd_kernel(const float* dy, int lddy, const float* y, int ldy,
+                                                              const float* __restrict__ sigma, float* dx, int lddx,
+                                                              int N, float eps, int accumulate) {
+    __shared__ float red[4];
+    const size_t r = blockIdx.x;
+    const float* dyr = dy + r * lddy;
+    const float* yr = y + r * ldy;
+    float a = 0.f, b = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        a += dyr[n];
+        b += dyr[n] * yr[n];
+    }
+    const float mdy = block_sum256(a, red) / (float)N;
+    const float dot = block_sum256(b, red);
+    const float sd = sigma[r];
+    const float inv = 1.f / (eps + sd);
+    const float k = sd > 0.f ? dot / ((float)N * sd) : 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float v = (dyr[n] - mdy) * inv - yr[n] * k;
+        if (accumulate) dx[r * lddx + n] += v;
+        else dx[r * lddx + n] = v;
+    }
+}
+
 }  // namespace
+
+int simple_norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
+                           float* add_dst, int ld_add, hipStream_t stream) {
+    if (R < 1 || N < 1) return PH_ERR_BADARG;
+    hipLaunchKernelGGL(simple_norm_fwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, x, ldx, y, ldy, sigma, N, eps,
+                       add_dst, ld_add);
+    return (int)hipGetLastError();
+}
+
+int simple_norm_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const float* sigma, float* dx, int lddx,
+                           long long R, int N, float eps, int accumulate, hipStream_t stream) {
+    if (R < 1 || N < 1) return PH_ERR_BADARG;
+    hipLaunchKernelGGL(simple_norm_bwd_kernel, dim3((unsigned)R), dim3(256), 0, stream, dy, lddy, y, ldy, sigma, dx,
+                       lddx, N, eps, accumulate);
+    return (int)hipGetLastError();
+}
+
 
 int lstm_state_bwd_launch(const float* dh, const float* dh2, float* dc, const float* gates, const float* c_prev,
                           const float* c_new, float* dP, int B, int H, hipStream_t stream) {

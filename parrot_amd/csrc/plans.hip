@@ -26,7 +26,7 @@ struct PlanBase {
     }
     virtual int enqueue(int which, hipStream_t s) = 0;
 
-    int run(int which, hipStream_t s) {
+    virtual int run(int which, hipStream_t s) {
         if (!use_graph) return note(enqueue(which, s));
         if (!exec[which]) {
             if (!cap_stream) {
@@ -202,14 +202,33 @@ struct DecoderPlan : PlanBase {
     ParrotDecoderDesc d;
     int esplit = 1;
 
+    // Schedules: 0 = merged wavefront launches on one stream (default: fastest measured), 1 = stream per
+    // layer with per-step events (experiment), 2 = chunked layer pipeline (PARROT_SCHEDULE=2; needs seq
+    // buffers for the upper layers).  Measured on MI355X, cfg2 (T=800, B=64, H=1024, L=2), fwd/bwd ms:
+    //   0: 56/78   1: 69/105   2 (one graph per piece, chunk 50): 57/94   2 eager launches: 51/79.
+    // The per-step kernels are latency-bound (~12 us for a single layer's K=1024 GEMM, ~24 us for two merged
+    // layers), so splitting the layers apart doubles the number of ~10 us kernels and the second stream
+    // does not buy that back.
+    int schedule = 0, chunk = 50;
+
     int enqueue(int which, hipStream_t s) override {
-        static int streams = -1;
-        if (streams < 0) {
-            const char* e = getenv("PARROT_LAYER_STREAMS");
-            streams = e ? atoi(e) : 0;
-        }
-        if (streams) return which == 0 ? fwd_streams(s) : bwd_streams(s);
+        if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
         return which == 0 ? fwd(s) : bwd(s);
+    }
+
+    void choose_schedule() {
+        const char* e = getenv("PARROT_SCHEDULE");
+        int want = e ? atoi(e) : -1;
+        if (getenv("PARROT_LAYER_STREAMS") && atoi(getenv("PARROT_LAYER_STREAMS"))) want = 1;
+        bool pipe_ok = d.L >= 2;
+        for (int l = 1; l < d.L; ++l)
+            if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
+        if (want < 0) want = 0;
+        if (want == 2 && !pipe_ok) want = 0;
+        if (want == 1 && d.cell == 1) want = 0;
+        schedule = want;
+        const char* c = getenv("PARROT_CHUNK");
+        if (c && atoi(c) > 0) chunk = atoi(c);
     }
 
     // Adds the K-segments [h_l ; w ; h_0..h_{l-1}] against weight W (row-major [K_l, ldw]).
@@ -225,13 +244,17 @@ struct DecoderPlan : PlanBase {
         j.nseg = n;
     }
 
+    // The additive-input buffer of layer l is live when the caller filled it (seq_init bit) or when the
+    // pipeline schedule batches the lower layers' projections into it.
+    bool has_seq(int l, const float* p) const { return p && (((d.seq_init >> l) & 1) || (schedule == 2 && l > 0)); }
+
     void gates_job(SkJob& j, int l, int t) const {
         const size_t BH = (size_t)d.B * d.H;
         sk_job_init(j);
         layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
         j.M = d.B; j.N = 2 * d.H; j.H = d.H; j.epi = SK_EPI_GRU_GATES;
         j.bias = d.bg[l];
-        j.add = d.seq_g[l] ? d.seq_g[l] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
+        j.add = has_seq(l, d.seq_g[l]) ? d.seq_g[l] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
         j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
         j.o1 = d.z[l] + t * BH; j.ldo1 = d.H;
         j.o2 = d.r[l] + t * BH; j.ldo2 = d.H;
@@ -244,7 +267,7 @@ struct DecoderPlan : PlanBase {
         layer_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
         j.M = d.B; j.N = d.H; j.H = d.H; j.epi = SK_EPI_GRU_CAND;
         j.bias = d.bc[l];
-        j.add = d.seq_c[l] ? d.seq_c[l] + t * BH : nullptr; j.ld_add = d.H;
+        j.add = has_seq(l, d.seq_c[l]) ? d.seq_c[l] + t * BH : nullptr; j.ld_add = d.H;
         j.e0 = d.h[l] + t * BH; j.lde0 = d.H;
         j.e1 = d.z[l] + t * BH; j.lde1 = d.H;
         j.o1 = d.c[l] + t * BH; j.ldo1 = d.H;
@@ -257,7 +280,7 @@ struct DecoderPlan : PlanBase {
         layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 4 * d.H);
         j.M = d.B; j.N = 4 * d.H; j.H = d.H; j.epi = SK_EPI_LSTM;
         j.bias = d.bg[l];
-        j.add = d.seq_g[l] ? d.seq_g[l] + t * 4 * BH : nullptr; j.ld_add = 4 * d.H;
+        j.add = has_seq(l, d.seq_g[l]) ? d.seq_g[l] + t * 4 * BH : nullptr; j.ld_add = 4 * d.H;
         j.e1 = d.cst[l] + t * BH; j.lde1 = d.H;
         j.o1 = d.cst[l] + (t + 1) * BH; j.ldo1 = d.H;
         j.o2 = d.gate4[l] + t * 4 * BH; j.ldo2 = 4 * d.H;
@@ -443,6 +466,242 @@ struct DecoderPlan : PlanBase {
         return 0;
     }
 
+    // ---- chunked layer pipeline (default for L >= 2) ----------------------------------------------
+    // Layer l >= 1 only consumes finished outputs of the layers below (h_j(t), w_t), never the other way
+    // round.  So the scan is run layer by layer over chunks of `chunk` steps: once layer l-1 has finished
+    // a chunk, the projections of its outputs into layer l (the Fork bricks h{j}_to_h{l} / inp_to_h{l},
+    // model.py:692-722) are taken for the whole chunk by the LDS-tiled GEMM (M = chunk*B rows instead of
+    // B) into the layer's additive-input buffer seq_g/seq_c, and the sequential part of layer l shrinks to
+    // its own recurrent block h_l . W[0:H].  Each layer runs on its own stream; the only cross-stream
+    // edges are one event per (layer, chunk), so layer 0's latency-bound chain (GEMM -> attention per
+    // step) overlaps with the upper layers' work instead of adding to it.
+    int hoist_fwd(int l, int t0, int t1, hipStream_t st) const {
+        const int H = d.H, E = d.E, R = (t1 - t0) * d.B;
+        const size_t BH = (size_t)d.B * H, BE = (size_t)d.B * E;
+        const int ng = d.cell == 1 ? 1 : 2;
+        for (int g = 0; g < ng; ++g) {
+            const int wd = d.cell == 1 ? 4 * H : (g == 0 ? 2 * H : H);
+            const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
+            float* out = (g == 0 ? d.seq_g[l] : d.seq_c[l]) + (size_t)t0 * d.B * wd;
+            int acc = (d.seq_init >> l) & 1;
+            PL_TRY(parrot_gemm(d.w + (size_t)(t0 + 1) * BE, E, 0, W + (size_t)H * wd, wd, 0, out, wd, R, wd, E,
+                               nullptr, 1.f, acc, 0, 1, 0, 0, 0, 1, st));
+            for (int j = 0; j < l; ++j)
+                PL_TRY(parrot_gemm(d.h[j] + (size_t)(t0 + 1) * BH, H, 0, W + (size_t)(H + E + j * H) * wd, wd, 0, out,
+                                   wd, R, wd, H, nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1, st));
+        }
+        return 0;
+    }
+
+    // Gradients of the hoisted projections for one chunk: dw[t+1] and dhup[p][t+1] += dPre . W^T.
+    int hoist_bwd(int l, int t0, int t1, hipStream_t st) const {
+        const int H = d.H, E = d.E, R = (t1 - t0) * d.B;
+        const size_t BH = (size_t)d.B * H, BE = (size_t)d.B * E;
+        const int ng = d.cell == 1 ? 1 : 2;
+        for (int g = 0; g < ng; ++g) {
+            const int wd = d.cell == 1 ? 4 * H : (g == 0 ? 2 * H : H);
+            const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
+            const float* dP = (g == 0 ? d.dG[l] : d.dC[l]) + (size_t)t0 * d.B * wd;
+            PL_TRY(parrot_gemm(dP, wd, 0, W + (size_t)H * wd, wd, 1, d.dw + (size_t)(t0 + 1) * BE, E, R, E, wd,
+                               nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1, st));
+            for (int p = 0; p < l; ++p)
+                PL_TRY(parrot_gemm(dP, wd, 0, W + (size_t)(H + E + p * H) * wd, wd, 1,
+                                   d.dhup[p] + (size_t)(t0 + 1) * BH, H, R, H, wd, nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1,
+                                   st));
+        }
+        return 0;
+    }
+
+    void own_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw) const {
+        const size_t BE = (size_t)d.B * d.E;
+        j.seg[0] = sk_seg(first, d.H, W, ldw, d.H, 0);
+        j.nseg = 1;
+        if (l == 0) j.seg[j.nseg++] = sk_seg(d.w + (size_t)t * BE, d.E, W + (size_t)d.H * ldw, ldw, d.E, 0);
+    }
+
+    // Kernels of layer l for the steps of chunk c (forward): batched projections from below, then the
+    // layer's own sequential chain.
+    int fwd_piece(int l, int c, hipStream_t st) const {
+        const size_t BH = (size_t)d.B * d.H;
+        const int t0 = c * chunk, t1 = (t0 + chunk < d.T) ? t0 + chunk : d.T;
+        if (l > 0) PL_TRY(hoist_fwd(l, t0, t1, st));
+        for (int t = t0; t < t1; ++t) {
+            SkJob j;
+            if (d.cell == 1) {
+                lstm_job(j, l, t);
+                own_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 4 * d.H);
+                PL_TRY(launch_jobs(&j, 1, st));
+            } else {
+                gates_job(j, l, t);
+                own_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
+                PL_TRY(launch_jobs(&j, 1, st));
+                cand_job(j, l, t);
+                own_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
+                PL_TRY(launch_jobs(&j, 1, st));
+            }
+            if (l == 0) PL_TRY(att_fwd_step(t, st));
+        }
+        return 0;
+    }
+
+    int att_bwd_step(int t0, hipStream_t st) const {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+        AttBwdArgs g;
+        g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = d.E;
+        g.ctx = d.ctx;
+        g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
+        g.kappa = d.kappa + (t0 + 1) * BA; g.kappa_prev = d.kappa + t0 * BA;
+        g.WattT = d.WattT;
+        g.dkappa = d.dkappa;
+        g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
+        g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = d.H;
+        g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
+        return att_bwd_launch(g, st);
+    }
+
+    int bwd_piece(int l, int c, hipStream_t st) const {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        const int H = d.H, E = d.E;
+        const int t0 = c * chunk, t1 = (t0 + chunk < d.T) ? t0 + chunk : d.T;
+        for (int t = t1 - 1; t >= t0; --t) {
+            if (l == 0) PL_TRY(att_bwd_step(t, st));
+            const float* dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
+            SkJob jy[2];
+            int ny = 0;
+            if (d.cell == 1) {
+                float* dP = d.dG[l] + (size_t)t * 4 * BH;
+                PL_TRY(lstm_state_bwd_launch(d.dh[l] + (t + 1) * BH, dh2, d.dcell[l],
+                                             d.gate4[l] + (size_t)t * 4 * BH, d.cst[l] + t * BH,
+                                             d.cst[l] + (t + 1) * BH, dP, d.B, H, st));
+                SkJob& j = jy[ny++];
+                sk_job_init(j);
+                j.nseg = 1;
+                j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l], 4 * H, 4 * H, 1);
+                j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                j.out = d.dh[l] + t * BH; j.ldo = H;
+                if (l == 0) {
+                    SkJob& k = jy[ny++];
+                    sk_job_init(k);
+                    k.nseg = 1;
+                    k.seg[0] = sk_seg(dP, 4 * H, d.Wg[0] + (size_t)H * 4 * H, 4 * H, 4 * H, 1);
+                    k.M = d.B; k.N = E; k.H = H; k.epi = SK_EPI_LINEAR; k.accumulate = 1;
+                    k.out = d.dw0 + (size_t)t * BE; k.ldo = E;
+                }
+                PL_TRY(launch_jobs(jy, ny, st));
+                continue;
+            }
+            GruStateBwdArgs ga;
+            ga.nchain = 1; ga.B = d.B; ga.H = H;
+            GruStateBwdChain& ch = ga.chain[0];
+            ch.dh = d.dh[l] + (t + 1) * BH;
+            ch.dh2 = dh2;
+            ch.hprev = d.h[l] + t * BH;
+            ch.z = d.z[l] + t * BH;
+            ch.c = d.c[l] + t * BH;
+            ch.mask = nullptr;
+            ch.dC = d.dC[l] + t * BH;
+            ch.dG = d.dG[l] + t * 2 * BH;
+            ch.dhprev = d.dh[l] + t * BH;
+            PL_TRY(gru_state_bwd_launch(ga, st));
+            SkJob x;
+            sk_job_init(x);
+            x.nseg = 1;
+            x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+            x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
+            x.e0 = d.h[l] + t * BH; x.lde0 = H;
+            x.e1 = d.r[l] + t * BH; x.lde1 = H;
+            x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
+            x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
+            PL_TRY(launch_jobs(&x, 1, st));
+            const float* dG = d.dG[l] + t * 2 * BH;
+            const float* dC = d.dC[l] + t * BH;
+            {
+                SkJob& j = jy[ny++];
+                sk_job_init(j);
+                j.nseg = 1;
+                j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+                j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                j.out = d.dh[l] + t * BH; j.ldo = H;
+            }
+            if (l == 0) {
+                SkJob& j = jy[ny++];
+                sk_job_init(j);
+                j.nseg = 2;
+                j.seg[0] = sk_seg(dG, 2 * H, d.Wg[0] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
+                j.seg[1] = sk_seg(dC, H, d.Wc[0] + (size_t)H * H, H, H, 1);
+                j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                j.out = d.dw0 + (size_t)t * BE; j.ldo = E;
+            }
+            PL_TRY(launch_jobs(jy, ny, st));
+        }
+        if (l > 0) PL_TRY(hoist_bwd(l, t0, t1, st));
+        return 0;
+    }
+
+    // One linear hipGraph per (layer, chunk) piece; the pieces of a layer are launched back to back on the
+    // layer's stream and an event per piece carries the dependency to the neighbouring layer.  (A single
+    // graph with parallel branches replays its branches one after the other on this runtime -- measured --
+    // while launches on different streams do overlap.)
+    std::vector<hipGraphExec_t> pieces[2];
+
+    int capture_pieces(int which) {
+        const int C = ceil_div(d.T, chunk);
+        if (!cap_stream) PL_TRY((int)hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        pieces[which].assign((size_t)C * d.L, nullptr);
+        for (int c = 0; c < C; ++c)
+            for (int l = 0; l < d.L; ++l) {
+                PL_TRY((int)hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
+                const int rc = which == 0 ? fwd_piece(l, c, cap_stream) : bwd_piece(l, c, cap_stream);
+                hipGraph_t graph = nullptr;
+                hipError_t e = hipStreamEndCapture(cap_stream, &graph);
+                if (rc != 0 || e != hipSuccess) {
+                    if (graph) hipGraphDestroy(graph);
+                    return rc != 0 ? rc : (int)e;
+                }
+                e = hipGraphInstantiate(&pieces[which][(size_t)c * d.L + l], graph, nullptr, nullptr, 0);
+                hipGraphDestroy(graph);
+                if (e != hipSuccess) return (int)e;
+            }
+        return 0;
+    }
+
+    int run_pipe(int which, hipStream_t main) {
+        const int C = ceil_div(d.T, chunk);
+        if (use_graph && pieces[which].empty()) {
+            const int rc = capture_pieces(which);
+            if (rc != 0) {
+                for (auto g : pieces[which])
+                    if (g) hipGraphExecDestroy(g);
+                pieces[which].clear();
+                return rc;
+            }
+        }
+        PL_TRY(fork(main));
+        hipEvent_t done[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+        for (int ci = 0; ci < C; ++ci) {
+            const int c = which == 0 ? ci : C - 1 - ci;
+            for (int li = 0; li < d.L; ++li) {
+                const int l = which == 0 ? li : d.L - 1 - li;
+                const int dep = which == 0 ? l - 1 : l + 1;   // the layer whose chunk-c results this piece consumes
+                const int user = which == 0 ? l + 1 : l - 1;  // the layer that consumes this piece's results
+                hipStream_t st = stream_of(l, main);
+                if (dep >= 0 && dep < d.L) PL_TRY((int)hipStreamWaitEvent(st, done[dep], 0));
+                if (use_graph) PL_TRY((int)hipGraphLaunch(pieces[which][(size_t)c * d.L + l], st));
+                else PL_TRY(which == 0 ? fwd_piece(l, c, st) : bwd_piece(l, c, st));
+                if (user >= 0 && user < d.L) {
+                    done[l] = next_event();
+                    PL_TRY((int)hipEventRecord(done[l], st));
+                }
+            }
+        }
+        return join(main);
+    }
+
+    int run(int which, hipStream_t s) override {
+        if (schedule != 2) return PlanBase::run(which, s);
+        return note(run_pipe(which, s));
+    }
+
     // ---- alternative schedule, kept for experiments (PARROT_LAYER_STREAMS=1) ----------------------------
     // Measured on MI355X (cfg2, T=800): the merged wavefront launches above run the scan in 50 ms fwd /
     // 81 ms bwd, the stream-per-layer pipeline below in 69 / 105 ms when replayed from a hipGraph (parallel
@@ -458,6 +717,9 @@ struct DecoderPlan : PlanBase {
     size_t ev_next = 0;
 
     ~DecoderPlan() override {
+        for (int w = 0; w < 2; ++w)
+            for (auto g : pieces[w])
+                if (g) hipGraphExecDestroy(g);
         for (auto e : events) hipEventDestroy(e);
         for (int l = 0; l < PARROT_MAX_LAYERS; ++l)
             if (side[l]) hipStreamDestroy(side[l]);
@@ -788,6 +1050,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
     p->d = *desc;
     p->use_graph = desc->use_graph;
     p->esplit = att_default_esplit(desc->B, desc->E);
+    p->choose_schedule();
     *plan = p;
     return 0;
 }

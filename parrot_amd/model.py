@@ -467,10 +467,12 @@ class Parrot(Brick):
         for key, wd, suf, mat, rec in self._groups:
             ws['d' + key.upper()] = [torch.empty(T, B, wd, **f) for _ in range(L)]
             ws['b' + key] = [torch.zeros(wd, **f) for _ in range(L)]
-            ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker) else None
-                                for l in range(1, L + 1)]
+            # layers >= 2 always get the buffer: the plan batches the lower layers' projections into it
+            ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker or l >= 2)
+                                else None for l in range(1, L + 1)]
         d = _lib.DecoderDesc()
         d.cell = 1 if lstm else 0
+        d.seq_init = sum(1 << (l - 1) for l in range(1, L + 1) if (l in self._fb_layers or self.use_speaker))
         d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, L
         d.att_type = 1 if self.attention_type == 'softmax' else 0
         d.use_graph = int(self.use_graph)
@@ -555,7 +557,7 @@ class Parrot(Brick):
         for l in range(1, L + 1):
             for key, wd, suf, mat, rec in self._groups:
                 sq = ws['seq_' + key][l - 1]
-                if sq is None:
+                if sq is None or not (l in self._fb_layers or self.use_speaker):
                     continue
                 have = False
                 if l in self._fb_layers:

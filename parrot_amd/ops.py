@@ -419,3 +419,45 @@ def mu2linear(q):
     out = torch.empty(q32.shape, device=q.device, dtype=torch.float32)
     _lib.call("parrot_mu2linear", q32.data_ptr(), q32.numel(), out.data_ptr(), _stream())
     return out
+
+
+# ----------------------------------------------------------------------------- _simple_norm (model.py:24-34)
+def simple_norm_fwd(x, eps=1e-5, out=None, add_into=None):
+    """Rows of x [R,N] -> (y, sigma); y may be x itself (in place).  add_into [R,N] gets += y."""
+    assert x.dim() == 2
+    R, N = x.shape
+    y = x if out is None else out
+    sigma = torch.empty((R,), device=x.device, dtype=torch.float32)
+    _lib.call("parrot_simple_norm_fwd", ptr(x, "x"), N, ptr(y, "y"), N, ptr(sigma), R, N, float(eps),
+              ptr(add_into) if add_into is not None else None, N, _stream())
+    return y, sigma
+
+
+def simple_norm_bwd(dy, y, sigma, eps=1e-5, out=None, accumulate=False):
+    """dx = J^T dy for y = simple_norm(x); `out` may alias dy or y."""
+    R, N = y.shape
+    dx = torch.empty_like(y) if out is None else out
+    _lib.call("parrot_simple_norm_bwd", ptr(dy, "dy"), N, ptr(y, "y"), N, ptr(sigma), ptr(dx, "dx"), N, R, N,
+              float(eps), int(bool(accumulate)), _stream())
+    return dx
+
+
+class _SimpleNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y, sigma = simple_norm_fwd(x2, eps, out=torch.empty_like(x2))
+        ctx.save_for_backward(y, sigma)
+        ctx.eps, ctx.shape = eps, x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, sigma = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        return simple_norm_bwd(g2, y, sigma, ctx.eps).view(ctx.shape), None
+
+
+def simple_norm(x, eps=1e-5):
+    """Differentiable `_simple_norm` over the last axis (model.py:24-27)."""
+    return _SimpleNormFn.apply(x, eps)

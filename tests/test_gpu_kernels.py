@@ -261,3 +261,26 @@ def test_cpu_tensor_fails_loudly():
     from parrot_amd import _lib, ops
     with pytest.raises(_lib.HipCallError):
         ops.gemm(torch.zeros(2, 2), torch.zeros(2, 2))
+
+
+@pytest.mark.parametrize("R,N", [(1, 7), (5, 64), (33, 1000), (70, 3072)])
+def test_simple_norm_fwd_bwd(dev, R, N):
+    """_simple_norm (model.py:24-27) forward and backward vs the fp64 oracle + autograd."""
+    from oracle import parrot_ref as Rf
+    from parrot_amd import ops
+    g = torch.Generator().manual_seed(R * 1000 + N)
+    x = (torch.randn(R, N, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_()
+    dy = torch.randn(R, N, generator=g, dtype=torch.float64)
+    y = Rf.simple_norm(x)
+    y.backward(dy)
+    acc = torch.randn(R, N, generator=g).to(dev)
+    acc0 = acc.clone()
+    xd = x.detach().float().to(dev)
+    yd, sig = ops.simple_norm_fwd(xd.clone(), add_into=acc)  # in place + accumulate
+    assert_close(yd, y, 2e-5, "norm fwd")
+    assert_close(acc - acc0, y, 2e-5, "norm add_into")
+    dx = ops.simple_norm_bwd(dy.float().to(dev), yd, sig)
+    assert_close(dx, x.grad, 1e-4, "norm bwd")
+    xa = xd.clone().requires_grad_()
+    ops.simple_norm(xa).backward(dy.float().to(dev))
+    assert_close(xa.grad, x.grad, 1e-4, "norm autograd")

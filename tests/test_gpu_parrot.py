@@ -279,3 +279,18 @@ def test_lstm_decoder_sample_model_parity(dev, kw):
     for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
         assert_close(o, r, 2e-4 if cfg['which_cost'] == 'GMM' else 1e-4, n)
     m.close()
+
+
+# ----------------------------------------------------------------------------- scan schedules
+@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("2", "3"), ("2", "50")])
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
+    """The merged-wavefront schedule (0) and the chunked layer pipeline (2; chunk 3 forces several chunks and a
+    ragged last one) are two orders of the same arithmetic: both must match the oracle, eager and graph."""
+    monkeypatch.setenv("PARROT_SCHEDULE", sched)
+    monkeypatch.setenv("PARROT_CHUNK", chunk)
+    for use_graph in (False, True):
+        _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
+                              use_speaker=True, cell_type=cell, use_graph=use_graph)
+    _check_cost_and_grads(dev, T=7, B=4, U=6, num_layers=2, encoder_type='bidirectional', cell_type=cell,
+                          use_graph=True)
