@@ -30,6 +30,7 @@ extern "C" {
 #define PARROT_ERR_BADARG 10001
 #define PARROT_ERR_UNSUPPORTED 10002
 
+#define PARROT_NORM_EPS 1e-5f /* _simple_norm's eps default, model.py:24 */
 #define PARROT_MAX_LAYERS 3
 
 /* Library / build identification ("parrot_hip <ver> gfx950"). */
@@ -205,6 +206,20 @@ typedef struct ParrotDecoderDesc {
     float* cst[PARROT_MAX_LAYERS];    /* [T+1,B,H] cell-state history (slot 0 = entering the window) */
     float* gate4[PARROT_MAX_LAYERS];  /* [T,B,4H] saved gate activations */
     float* dcell[PARROT_MAX_LAYERS];  /* [B,H] in: gradient wrt the final cell (0), out: wrt the initial cell */
+    /* layer_norm = 1 (model.py:24-34, 703-722): the projections of the lower layers' outputs into layer l
+     * (Fork h{j}_to_h{l}, index [l*PARROT_MAX_LAYERS + j], j < l) are normalised row-wise before they are
+     * summed, so they cannot ride in the packed GEMM; the scan then runs on the chunked layer pipeline and
+     * needs, per (l, j) pair and group: the Fork bias (ln_b*, taken out of bg/bc by the caller), a buffer for
+     * the normalised projection (ln_y*, [T,B,width]; seq_bwd overwrites it with the gradient wrt the
+     * PRE-norm projection, which the caller turns into the weight/bias gradients) and the row std (ln_s*,
+     * [T,B]).  Rows of Wg/Wc keep the packed layout. */
+    int layer_norm, reserved6;
+    const float* ln_bg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    const float* ln_bc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    float* ln_yg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    float* ln_yc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    float* ln_sg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    float* ln_sc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
 } ParrotDecoderDesc;
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);

@@ -62,6 +62,10 @@ class DecoderDesc(C.Structure):
         ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
         ("cell", C.c_int), ("seq_init", C.c_int),
         ("cst", C.c_void_p * MAX_LAYERS), ("gate4", C.c_void_p * MAX_LAYERS), ("dcell", C.c_void_p * MAX_LAYERS),
+        ("layer_norm", C.c_int), ("reserved6", C.c_int),
+        ("ln_bg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_bc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
+        ("ln_yg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_yc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
+        ("ln_sg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_sc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
     ]
 
 

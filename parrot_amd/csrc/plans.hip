@@ -224,6 +224,7 @@ struct DecoderPlan : PlanBase {
         for (int l = 1; l < d.L; ++l)
             if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
         if (want < 0) want = 0;
+        if (d.layer_norm && d.L >= 2) want = 2;  // the in-scan normalisations only exist on the pipeline
         if (want == 2 && !pipe_ok) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
         schedule = want;
@@ -486,9 +487,21 @@ struct DecoderPlan : PlanBase {
             int acc = (d.seq_init >> l) & 1;
             PL_TRY(parrot_gemm(d.w + (size_t)(t0 + 1) * BE, E, 0, W + (size_t)H * wd, wd, 0, out, wd, R, wd, E,
                                nullptr, 1.f, acc, 0, 1, 0, 0, 0, 1, st));
-            for (int j = 0; j < l; ++j)
-                PL_TRY(parrot_gemm(d.h[j] + (size_t)(t0 + 1) * BH, H, 0, W + (size_t)(H + E + j * H) * wd, wd, 0, out,
-                                   wd, R, wd, H, nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1, st));
+            for (int j = 0; j < l; ++j) {
+                const float* A = d.h[j] + (size_t)(t0 + 1) * BH;
+                const float* Wj = W + (size_t)(H + E + j * H) * wd;
+                if (!d.layer_norm) {
+                    PL_TRY(parrot_gemm(A, H, 0, Wj, wd, 0, out, wd, R, wd, H, nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1, st));
+                    continue;
+                }
+                // layer_norm: project (with the Fork's own bias), normalise each row, then add (model.py:703-722)
+                const int pj = l * PARROT_MAX_LAYERS + j;
+                float* y = (g == 0 ? d.ln_yg[pj] : d.ln_yc[pj]) + (size_t)t0 * d.B * wd;
+                float* sg = (g == 0 ? d.ln_sg[pj] : d.ln_sc[pj]) + (size_t)t0 * d.B;
+                PL_TRY(parrot_gemm(A, H, 0, Wj, wd, 0, y, wd, R, wd, H, g == 0 ? d.ln_bg[pj] : d.ln_bc[pj], 1.f, 0, 0,
+                                   1, 0, 0, 0, 1, st));
+                PL_TRY(simple_norm_fwd_launch(y, wd, y, wd, sg, R, wd, PARROT_NORM_EPS, out, wd, st));
+            }
         }
         return 0;
     }
@@ -504,10 +517,19 @@ struct DecoderPlan : PlanBase {
             const float* dP = (g == 0 ? d.dG[l] : d.dC[l]) + (size_t)t0 * d.B * wd;
             PL_TRY(parrot_gemm(dP, wd, 0, W + (size_t)H * wd, wd, 1, d.dw + (size_t)(t0 + 1) * BE, E, R, E, wd,
                                nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1, st));
-            for (int p = 0; p < l; ++p)
-                PL_TRY(parrot_gemm(dP, wd, 0, W + (size_t)(H + E + p * H) * wd, wd, 1,
+            for (int p = 0; p < l; ++p) {
+                const float* dsrc = dP;
+                if (d.layer_norm) {  // back through the row normalisation; the pre-norm gradient replaces y
+                    const int pj = l * PARROT_MAX_LAYERS + p;
+                    float* y = (g == 0 ? d.ln_yg[pj] : d.ln_yc[pj]) + (size_t)t0 * d.B * wd;
+                    const float* sg = (g == 0 ? d.ln_sg[pj] : d.ln_sc[pj]) + (size_t)t0 * d.B;
+                    PL_TRY(simple_norm_bwd_launch(dP, wd, y, wd, sg, y, wd, R, wd, PARROT_NORM_EPS, 0, st));
+                    dsrc = y;
+                }
+                PL_TRY(parrot_gemm(dsrc, wd, 0, W + (size_t)(H + E + p * H) * wd, wd, 1,
                                    d.dhup[p] + (size_t)(t0 + 1) * BH, H, R, H, wd, nullptr, 1.f, 1, 0, 1, 0, 0, 0, 1,
                                    st));
+            }
         }
         return 0;
     }
@@ -1051,6 +1073,19 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
     p->use_graph = desc->use_graph;
     p->esplit = att_default_esplit(desc->B, desc->E);
     p->choose_schedule();
+    if (desc->layer_norm && desc->L >= 2) {
+        bool ok = p->schedule == 2;
+        for (int l = 1; l < desc->L && ok; ++l)
+            for (int j = 0; j < l; ++j) {
+                const int pj = l * PARROT_MAX_LAYERS + j;
+                if (!desc->ln_yg[pj] || !desc->ln_sg[pj] || !desc->ln_bg[pj]) ok = false;
+                if (desc->cell == 0 && (!desc->ln_yc[pj] || !desc->ln_sc[pj] || !desc->ln_bc[pj])) ok = false;
+            }
+        if (!ok) {
+            delete p;
+            return PARROT_ERR_BADARG;
+        }
+    }
     *plan = p;
     return 0;
 }

@@ -95,9 +95,6 @@ class Parrot(Brick):
         assert encoder_type in (None, 'bidirectional')  # model.py:209
         assert 1 <= num_layers <= _lib.MAX_LAYERS
         assert cell_type in ('gru', 'lstm')
-        if layer_norm:
-            raise NotImplementedError(
-                "layer_norm=True (model.py:24-34) is not built on the HIP path yet")
         self.input_dim, self.output_dim = input_dim, output_dim
         self.rnn_h_dim, self.readouts_dim = rnn_h_dim, readouts_dim
         self.layer_norm, self.which_cost, self.use_speaker = layer_norm, which_cost, use_speaker
@@ -470,8 +467,22 @@ class Parrot(Brick):
             # layers >= 2 always get the buffer: the plan batches the lower layers' projections into it
             ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker or l >= 2)
                                 else None for l in range(1, L + 1)]
+        ln = self.layer_norm and L >= 2
+        if ln:
+            # (l, j) pairs, 0-based, j < l: normalised projections of h_j into layer l and their row std
+            for key, wd, suf, mat, rec in self._groups:
+                ws['ln_y' + key] = {(l, j): torch.empty(T, B, wd, **f) for l in range(1, L) for j in range(l)}
+                ws['ln_s' + key] = {(l, j): torch.empty(T, B, **f) for l in range(1, L) for j in range(l)}
         d = _lib.DecoderDesc()
         d.cell = 1 if lstm else 0
+        d.layer_norm = 1 if ln else 0
+        if ln:
+            for key, wd, suf, mat, rec in self._groups:
+                for (l, j), t_ in ws['ln_y' + key].items():
+                    pj = l * _lib.MAX_LAYERS + j
+                    getattr(d, 'ln_y' + key)[pj] = t_.data_ptr()
+                    getattr(d, 'ln_s' + key)[pj] = ws['ln_s' + key][(l, j)].data_ptr()
+                    getattr(d, 'ln_b' + key)[pj] = self._p(f'/h{j + 1}_to_h{l + 1}/fork_rnn{l + 1}_{suf}.b').data_ptr()
         d.seq_init = sum(1 << (l - 1) for l in range(1, L + 1) if (l in self._fb_layers or self.use_speaker))
         d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, L
         d.att_type = 1 if self.attention_type == 'softmax' else 0
@@ -500,7 +511,10 @@ class Parrot(Brick):
     def _layer_bias_names(self, l, suf):
         """Names of the bias parameters that add into layer l's pre-activation group `suf`
         ('inputs' / 'gates'): the Forks from the attention context and from the layers below."""
-        return [f'/inp_to_h{l}/fork_rnn{l}_{suf}.b'] + [f'/h{j}_to_h{l}/fork_rnn{l}_{suf}.b' for j in range(1, l)]
+        names = [f'/inp_to_h{l}/fork_rnn{l}_{suf}.b']
+        if not self.layer_norm:  # with layer_norm those biases sit inside the normalised projection
+            names += [f'/h{j}_to_h{l}/fork_rnn{l}_{suf}.b' for j in range(1, l)]
+        return names
 
     def _sum_layer_biases(self, ws, extra_fb=False):
         for l in range(1, self.num_layers + 1):
@@ -561,12 +575,22 @@ class Parrot(Brick):
                     continue
                 have = False
                 if l in self._fb_layers:
-                    ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.W'),
-                             bias=self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.b'), out=sq.view(T * B, wd))
+                    if self.layer_norm:  # model.py:580-603: the Fork output is normalised row-wise
+                        y, sig = ops.simple_norm_fwd(
+                            ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.W'),
+                                     bias=self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.b')))
+                        save[('ln_fb', l, key)] = (y, sig)
+                        sq.view(T * B, wd).copy_(y)
+                    else:
+                        ops.gemm(inp, self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.W'),
+                                 bias=self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.b'), out=sq.view(T * B, wd))
                     have = True
                 if self.use_speaker:
                     sp = ops.gemm(emb_spk, self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.W'),
                                   bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.b'))
+                    if self.layer_norm:  # model.py:612-627
+                        sp, sig = ops.simple_norm_fwd(sp)
+                        save[('ln_spk', l, key)] = (sp, sig)
                     if have:
                         sq.add_(sp.unsqueeze(0))
                     else:
@@ -604,10 +628,19 @@ class Parrot(Brick):
         rb = self._p('/att_to_readout.b').clone()
         for l in range(1, L + 1):
             rb.add_(self._p(f'/h{l}_to_readout.b'))
-        ops.gemm(ws['h'][0][1:].view(T * B, H), Wr[0:H], bias=rb, out=readouts)
-        for l in range(1, L):
-            ops.gemm(ws['h'][l][1:].view(T * B, H), Wr[l * H:(l + 1) * H], out=readouts, accumulate=True)
-        ops.gemm(ws['w'][1:].view(T * B, E), Wr[L * H:], out=readouts, accumulate=True)
+        if self.layer_norm:
+            # model.py:739-753: each h{l}_to_readout output is normalised on its own, then summed
+            ops.gemm(ws['w'][1:].view(T * B, E), Wr[L * H:], bias=self._p('/att_to_readout.b'), out=readouts)
+            for l in range(L):
+                y, sig = ops.simple_norm_fwd(
+                    ops.gemm(ws['h'][l][1:].view(T * B, H), Wr[l * H:(l + 1) * H],
+                             bias=self._p(f'/h{l + 1}_to_readout.b')), add_into=readouts)
+                save[('ln_ro', l)] = (y, sig)
+        else:
+            ops.gemm(ws['h'][0][1:].view(T * B, H), Wr[0:H], bias=rb, out=readouts)
+            for l in range(1, L):
+                ops.gemm(ws['h'][l][1:].view(T * B, H), Wr[l * H:(l + 1) * H], out=readouts, accumulate=True)
+            ops.gemm(ws['w'][1:].view(T * B, E), Wr[L * H:], out=readouts, accumulate=True)
         if self.use_speaker:
             spr = ops.gemm(emb_spk, self._p('/speaker_to_readout.W'), bias=self._p('/speaker_to_readout.b'))
             readouts.view(T, B, R).add_(spr.unsqueeze(0))
@@ -705,12 +738,14 @@ class Parrot(Brick):
         # readouts
         gWr = self.store.storage_grad['dec.Wr']
         Wr = self.store.storage['dec.Wr']
-        for l in range(L):
-            ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dread, out=gWr[l * H:(l + 1) * H], accumulate=True)
-        ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True)
         db = ops.colsum(dread)
-        for l in range(1, L + 1):
-            self._g(f'/h{l}_to_readout.b').add_(db)
+        dro = [dread] * L  # gradient wrt each h{l}_to_readout output
+        if self.layer_norm:
+            dro = [ops.simple_norm_bwd(dread, *save[('ln_ro', l)]) for l in range(L)]
+        for l in range(L):
+            ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dro[l], out=gWr[l * H:(l + 1) * H], accumulate=True)
+            self._g(f'/h{l + 1}_to_readout.b').add_(ops.colsum(dro[l]) if self.layer_norm else db)
+        ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True)
         self._g('/att_to_readout.b').add_(db)
         if self.use_speaker:
             dsum = dread.view(T, B, R).sum(0)
@@ -720,7 +755,7 @@ class Parrot(Brick):
         # gradients entering the scan through the readouts
         for l in range(L):
             ws['dh'][l][0].zero_()
-            ops.gemm(dread, Wr[l * H:(l + 1) * H].t(), out=ws['dh'][l][1:].view(T * B, H))
+            ops.gemm(dro[l], Wr[l * H:(l + 1) * H].t(), out=ws['dh'][l][1:].view(T * B, H))
         ws['dw'][0].zero_()
         ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
@@ -746,17 +781,28 @@ class Parrot(Brick):
                 ops.gemm(wsrc.t(), dP, out=gW[H:H + E], accumulate=True)
                 for j in range(l):
                     r0 = H + E + j * H
-                    ops.gemm(ws['h'][j][1:].view(T * B, H).t(), dP, out=gW[r0:r0 + H], accumulate=True)
+                    dPj = dP
+                    if self.layer_norm:  # seq_bwd left the gradient wrt the pre-norm projection in ln_y
+                        dPj = ws['ln_y' + key][(l, j)].view(T * B, wd)
+                        self._g(f'/h{j + 1}_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(ops.colsum(dPj))
+                    ops.gemm(ws['h'][j][1:].view(T * B, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
                 db = ops.colsum(dP)
                 for n in self._layer_bias_names(ll, suf):
                     self._g(n).add_(db)
                 # per-step additive inputs
                 if ll in self._fb_layers:
-                    ops.gemm(save['fb_inp'].t(), dP, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_{suf}.W'),
+                    dPf, dbf = dP, db
+                    if self.layer_norm:
+                        dPf = ops.simple_norm_bwd(dP, *save[('ln_fb', ll, key)])
+                        dbf = ops.colsum(dPf)
+                    ops.gemm(save['fb_inp'].t(), dPf, out=self._g(f'/out_to_h{ll}/fork_rnn{ll}_{suf}.W'),
                              accumulate=True)
-                    self._g(f'/out_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(db)
+                    self._g(f'/out_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(dbf)
                 if self.use_speaker:
                     dPs = dP.view(T, B, wd).sum(0)
+                    if self.layer_norm:
+                        dPs = ops.simple_norm_bwd(dPs, *save[('ln_spk', ll, key)])
+                        db = ops.colsum(dPs)
                     ops.gemm(emb_spk.t(), dPs, out=self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_{suf}.W'),
                              accumulate=True)
                     self._g(f'/speaker_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(db)

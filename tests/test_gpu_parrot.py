@@ -294,3 +294,19 @@ def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
                               use_speaker=True, cell_type=cell, use_graph=use_graph)
     _check_cost_and_grads(dev, T=7, B=4, U=6, num_layers=2, encoder_type='bidirectional', cell_type=cell,
                           use_graph=True)
+
+
+# ----------------------------------------------------------------------------- layer_norm=True (model.py:24-34)
+@pytest.mark.parametrize("kw", [
+    dict(num_layers=3, full_feedback=True, use_speaker=True),
+    dict(num_layers=2, weak_feedback=True, which_cost='GMM', k_gmm=3),
+    dict(num_layers=1, weak_feedback=True),
+    dict(num_layers=3, cell_type='lstm', weak_feedback=True, use_speaker=True),
+])
+def test_layer_norm_cost_and_grads(dev, monkeypatch, kw):
+    """`_apply_norm` on every Fork output that the reference normalises (out_to_h*, speaker_to_h*, h{j}_to_h{l},
+    h{l}_to_readout); chunk 3 makes the in-scan normalisations span several pipeline chunks."""
+    monkeypatch.setenv("PARROT_CHUNK", "3")
+    for use_graph in (False, True):
+        _check_cost_and_grads(dev, T=8, B=5, U=9, ragged=True, encoder_type='bidirectional', layer_norm=True,
+                              use_graph=use_graph, tol_grad=2e-3, **kw)
