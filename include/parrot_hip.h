@@ -277,6 +277,19 @@ typedef struct ParrotSampleDesc {
     int cell, reserved5;
     float* cwork[PARROT_MAX_LAYERS];
     float* gwork;
+    /* layer_norm = 1 (model.py:899-1006 with _apply_norm active): the feedback Fork out_to_h{l}, the Forks
+     * h{j}_to_h{l} and the h{l}_to_readout projections are taken as separate small GEMMs, normalised row-wise
+     * and summed; their biases therefore come separately (bfg/bfc, ln_bg/ln_bc [l*PARROT_MAX_LAYERS + j],
+     * br_l) and must NOT be folded into bg/bc/br.  seq_g/seq_c hold the already normalised speaker terms.
+     * ln_scratch: at least B * (5*Ng + 5*Nc + (L+1)*R) floats (Ng/Nc = widths of the two groups). */
+    int layer_norm, reserved7;
+    const float* bfg[PARROT_MAX_LAYERS];
+    const float* bfc[PARROT_MAX_LAYERS];
+    const float* ln_bg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    const float* ln_bc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    const float* br_l[PARROT_MAX_LAYERS];
+    float* ln_scratch;
+    long long ln_scratch_floats;
 } ParrotSampleDesc;
 
 int parrot_sample_create(const ParrotSampleDesc* desc, void** plan);

@@ -94,6 +94,11 @@ class SampleDesc(C.Structure):
         ("gmm_mu", C.c_void_p), ("gmm_sig", C.c_void_p), ("gmm_co", C.c_void_p), ("pi_out", C.c_void_p),
         ("cell", C.c_int), ("reserved5", C.c_int),
         ("cwork", C.c_void_p * MAX_LAYERS), ("gwork", C.c_void_p),
+        ("layer_norm", C.c_int), ("reserved7", C.c_int),
+        ("bfg", C.c_void_p * MAX_LAYERS), ("bfc", C.c_void_p * MAX_LAYERS),
+        ("ln_bg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_bc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
+        ("br_l", C.c_void_p * MAX_LAYERS),
+        ("ln_scratch", C.c_void_p), ("ln_scratch_floats", C.c_longlong),
     ]
 
 

@@ -43,3 +43,13 @@ int simple_norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* si
 // dx (may alias y or dy) = d/dx of the above given dy, y, sigma; accumulate: dx += instead of =.
 int simple_norm_bwd_launch(const float* dy, int lddy, const float* y, int ldy, const float* sigma, float* dx, int lddx,
                            long long R, int N, float eps, int accumulate, hipStream_t stream);
+
+// dst[r,:] = (base ? base[r,:] : 0) + sum_s simple_norm(src[s][r,:]); all matrices [R,N] with leading dimension N
+// (the per-step form of the normalised Fork sums in the sampling scan, model.py:899-1006).
+struct NormSumGroup {
+    const float* src[4];
+    int nsrc, N;
+    const float* base;
+    float* dst;
+};
+int norm_sum_launch(const NormSumGroup* groups, int ngroups, int R, float eps, hipStream_t stream);

@@ -214,7 +214,41 @@ __global__ __launch_bounds__(256) void simple_norm_bwd_kernel(const float* dy, i
     }
 }
 
+struct NormSumArgs {
+    NormSumGroup g[2];
+};
+
+__global__ __launch_bounds__(256) void norm_sum_kernel(const NormSumArgs a, float eps) {
+    __shared__ float red[4];
+    const NormSumGroup& g = a.g[blockIdx.y];
+    const size_t r = blockIdx.x;
+    const int N = g.N;
+    float* dst = g.dst + r * N;
+    for (int n = threadIdx.x; n < N; n += 256) dst[n] = g.base ? g.base[r * N + n] : 0.f;
+    for (int s = 0; s < g.nsrc; ++s) {
+        const float* xr = g.src[s] + r * N;
+        float sum = 0.f;
+        for (int n = threadIdx.x; n < N; n += 256) sum += xr[n];
+        const float mean = block_sum256(sum, red) / (float)N;
+        float q = 0.f;
+        for (int n = threadIdx.x; n < N; n += 256) {
+            const float dlt = xr[n] - mean;
+            q += dlt * dlt;
+        }
+        const float inv = 1.f / (eps + sqrtf(block_sum256(q, red) / (float)N));
+        for (int n = threadIdx.x; n < N; n += 256) dst[n] += (xr[n] - mean) * inv;  // same thread owns column n
+    }
+}
+
 }  // namespace
+
+int norm_sum_launch(const NormSumGroup* groups, int ngroups, int R, float eps, hipStream_t stream) {
+    if (ngroups < 1 || ngroups > 2 || R < 1) return PH_ERR_BADARG;
+    NormSumArgs a;
+    for (int i = 0; i < ngroups; ++i) a.g[i] = groups[i];
+    hipLaunchKernelGGL(norm_sum_kernel, dim3((unsigned)R, (unsigned)ngroups), dim3(256), 0, stream, a, eps);
+    return (int)hipGetLastError();
+}
 
 int simple_norm_fwd_launch(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
                            float* add_dst, int ld_add, hipStream_t stream) {

@@ -914,10 +914,102 @@ struct SamplePlan : PlanBase {
         j.seg[n++] = sk_seg(first, d.H, W, ldw, d.H, 0);
         const float* wsrc = d.w + (size_t)(l == 0 ? t : t + 1) * BE;
         j.seg[n++] = sk_seg(wsrc, d.E, W + (size_t)d.H * ldw, ldw, d.E, 0);
-        for (int q = 0; q < l; ++q)
-            j.seg[n++] = sk_seg(d.h[q] + nxt * BH, d.H, W + (size_t)(d.H + d.E + q * d.H) * ldw, ldw, d.H, 0);
-        if (Wf) j.seg[n++] = sk_seg(d.x + (size_t)t * d.B * d.ldx, d.ldx, Wf, ldw, d.O, 0);
+        if (!d.layer_norm) {  // with layer_norm these arrive normalised through the additive input instead
+            for (int q = 0; q < l; ++q)
+                j.seg[n++] = sk_seg(d.h[q] + nxt * BH, d.H, W + (size_t)(d.H + d.E + q * d.H) * ldw, ldw, d.H, 0);
+            if (Wf) j.seg[n++] = sk_seg(d.x + (size_t)t * d.B * d.ldx, d.ldx, Wf, ldw, d.O, 0);
+        }
         j.nseg = n;
+    }
+
+    // ---- layer_norm: scratch layout and the per-step normalised sums --------------------------------
+    int ngrp() const { return d.cell == 1 ? 1 : 2; }
+    int gw(int g) const { return d.cell == 1 ? 4 * d.H : (g == 0 ? 2 * d.H : d.H); }
+    float* tmp(int g, int k) const {  // k = 0..3 projections, k = 4: the summed additive input
+        float* p = d.ln_scratch;
+        if (g == 1) p += (size_t)5 * d.B * gw(0);
+        return p + (size_t)k * d.B * gw(g);
+    }
+    float* rtmp(int k) const {  // k = 0..L-1 readout projections, k = L: un-normalised base
+        size_t off = (size_t)5 * d.B * gw(0) + (ngrp() == 2 ? (size_t)5 * d.B * gw(1) : 0);
+        return d.ln_scratch + off + (size_t)k * d.B * d.R;
+    }
+    long long scratch_need() const {
+        return (long long)5 * d.B * gw(0) + (ngrp() == 2 ? (long long)5 * d.B * gw(1) : 0) +
+               (long long)(d.L + 1) * d.B * d.R;
+    }
+
+    // Additive inputs of layer l at step t = speaker term + norm(feedback Fork) + sum_j norm(h_j Fork).
+    int ln_layer_inputs(int l, int t, hipStream_t st, const float*& addg, const float*& addc) const {
+        const size_t BH = (size_t)d.B * d.H;
+        const int nxt = (t + 1) & 1;
+        SkJob jobs[SK_MAXJOB];
+        NormSumGroup grp[2];
+        int nj = 0;
+        for (int g = 0; g < ngrp(); ++g) {
+            const int wd = gw(g);
+            const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
+            const float* Wf = g == 0 ? d.Wfg[l] : d.Wfc[l];
+            NormSumGroup& G = grp[g];
+            G.nsrc = 0; G.N = wd;
+            G.base = g == 0 ? d.seq_g[l] : d.seq_c[l];
+            G.dst = tmp(g, 4);
+            if (Wf) {
+                SkJob& j = jobs[nj++];
+                sk_job_init(j);
+                j.nseg = 1;
+                j.seg[0] = sk_seg(d.x + (size_t)t * d.B * d.ldx, d.ldx, Wf, wd, d.O, 0);
+                j.M = d.B; j.N = wd; j.H = d.H; j.epi = SK_EPI_LINEAR;
+                j.bias = g == 0 ? d.bfg[l] : d.bfc[l];
+                j.out = tmp(g, G.nsrc); j.ldo = wd;
+                G.src[G.nsrc++] = j.out;
+            }
+            for (int q = 0; q < l; ++q) {
+                SkJob& j = jobs[nj++];
+                sk_job_init(j);
+                j.nseg = 1;
+                j.seg[0] = sk_seg(d.h[q] + nxt * BH, d.H, W + (size_t)(d.H + d.E + q * d.H) * wd, wd, d.H, 0);
+                j.M = d.B; j.N = wd; j.H = d.H; j.epi = SK_EPI_LINEAR;
+                const int pj = l * PARROT_MAX_LAYERS + q;
+                j.bias = g == 0 ? d.ln_bg[pj] : d.ln_bc[pj];
+                j.out = tmp(g, G.nsrc); j.ldo = wd;
+                G.src[G.nsrc++] = j.out;
+            }
+        }
+        if (nj == 0) return 0;
+        PL_TRY(launch_jobs(jobs, nj, st));
+        PL_TRY(norm_sum_launch(grp, ngrp(), d.B, PARROT_NORM_EPS, st));
+        addg = tmp(0, 4);
+        if (ngrp() == 2) addc = tmp(1, 4);
+        return 0;
+    }
+
+    // readout = att_to_readout(w) + speaker term + sum_l norm(h{l}_to_readout(h_l))   (model.py:992-1006)
+    int ln_readout(int t, hipStream_t st) const {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        const int nxt = (t + 1) & 1;
+        SkJob jobs[PARROT_MAX_LAYERS + 1];
+        NormSumGroup G;
+        G.nsrc = 0; G.N = d.R; G.base = rtmp(d.L); G.dst = d.readout;
+        for (int l = 0; l < d.L; ++l) {
+            SkJob& j = jobs[l];
+            sk_job_init(j);
+            j.nseg = 1;
+            j.seg[0] = sk_seg(d.h[l] + nxt * BH, d.H, d.Wr + (size_t)l * d.H * d.R, d.R, d.H, 0);
+            j.M = d.B; j.N = d.R; j.H = d.H; j.epi = SK_EPI_LINEAR;
+            j.bias = d.br_l[l];
+            j.out = rtmp(l); j.ldo = d.R;
+            G.src[G.nsrc++] = j.out;
+        }
+        SkJob& b = jobs[d.L];
+        sk_job_init(b);
+        b.nseg = 1;
+        b.seg[0] = sk_seg(d.w + (t + 1) * BE, d.E, d.Wr + (size_t)d.L * d.H * d.R, d.R, d.E, 0);
+        b.M = d.B; b.N = d.R; b.H = d.H; b.epi = SK_EPI_LINEAR;
+        b.bias = d.br; b.add = d.radd; b.ld_add = d.R;
+        b.out = rtmp(d.L); b.ldo = d.R;
+        PL_TRY(launch_jobs(jobs, d.L + 1, st));
+        return norm_sum_launch(&G, 1, d.B, PARROT_NORM_EPS, st);
     }
 
     int run_all(hipStream_t st) {
@@ -927,12 +1019,15 @@ struct SamplePlan : PlanBase {
             const int cur = t & 1, nxt = (t + 1) & 1;
             for (int l = 0; l < d.L; ++l) {
                 SkJob j;
+                const float* addg = d.seq_g[l];
+                const float* addc = d.seq_c[l];
+                if (d.layer_norm) PL_TRY(ln_layer_inputs(l, t, st, addg, addc));
                 if (d.cell == 1) {
                     sk_job_init(j);
                     layer_segs(j, l, t, d.h[l] + cur * BH, d.Wg[l], 4 * H, d.Wfg[l]);
                     j.M = d.B; j.N = 4 * H; j.H = H; j.epi = SK_EPI_LSTM;
                     j.bias = d.bg[l];
-                    j.add = d.seq_g[l]; j.ld_add = 4 * H;
+                    j.add = addg; j.ld_add = 4 * H;
                     j.e1 = d.cwork[l] + cur * BH; j.lde1 = H;
                     j.o1 = d.cwork[l] + nxt * BH; j.ldo1 = H;
                     j.o2 = d.gwork; j.ldo2 = 4 * H;
@@ -943,7 +1038,7 @@ struct SamplePlan : PlanBase {
                 layer_segs(j, l, t, d.h[l] + cur * BH, d.Wg[l], 2 * H, d.Wfg[l]);
                 j.M = d.B; j.N = 2 * H; j.H = H; j.epi = SK_EPI_GRU_GATES;
                 j.bias = d.bg[l];
-                j.add = d.seq_g[l]; j.ld_add = 2 * H;
+                j.add = addg; j.ld_add = 2 * H;
                 j.e0 = d.h[l] + cur * BH; j.lde0 = H;
                 j.o1 = d.zwork; j.ldo1 = H;
                 j.o2 = d.rwork; j.ldo2 = H;
@@ -954,7 +1049,7 @@ struct SamplePlan : PlanBase {
                 layer_segs(j, l, t, d.rhwork, d.Wc[l], H, d.Wfc[l]);
                 j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_GRU_CAND;
                 j.bias = d.bc[l];
-                j.add = d.seq_c[l]; j.ld_add = H;
+                j.add = addc; j.ld_add = H;
                 j.e0 = d.h[l] + cur * BH; j.lde0 = H;
                 j.e1 = d.zwork; j.lde1 = H;
                 j.o1 = nullptr;
@@ -979,16 +1074,20 @@ struct SamplePlan : PlanBase {
             }
             // readouts (model.py:992-1006) and output (model.py:1008-1013)
             SkJob j;
-            sk_job_init(j);
-            int n = 0;
-            for (int l = 0; l < d.L; ++l)
-                j.seg[n++] = sk_seg(d.h[l] + nxt * BH, H, d.Wr + (size_t)l * H * d.R, d.R, H, 0);
-            j.seg[n++] = sk_seg(d.w + (t + 1) * BE, d.E, d.Wr + (size_t)d.L * H * d.R, d.R, d.E, 0);
-            j.nseg = n;
-            j.M = d.B; j.N = d.R; j.H = H; j.epi = SK_EPI_LINEAR;
-            j.bias = d.br; j.add = d.radd; j.ld_add = d.R;
-            j.out = d.readout; j.ldo = d.R;
-            PL_TRY(launch_jobs(&j, 1, st));
+            if (d.layer_norm) {
+                PL_TRY(ln_readout(t, st));
+            } else {
+                sk_job_init(j);
+                int n = 0;
+                for (int l = 0; l < d.L; ++l)
+                    j.seg[n++] = sk_seg(d.h[l] + nxt * BH, H, d.Wr + (size_t)l * H * d.R, d.R, H, 0);
+                j.seg[n++] = sk_seg(d.w + (t + 1) * BE, d.E, d.Wr + (size_t)d.L * H * d.R, d.R, d.E, 0);
+                j.nseg = n;
+                j.M = d.B; j.N = d.R; j.H = H; j.epi = SK_EPI_LINEAR;
+                j.bias = d.br; j.add = d.radd; j.ld_add = d.R;
+                j.out = d.readout; j.ldo = d.R;
+                PL_TRY(launch_jobs(&j, 1, st));
+            }
 
             if (d.gmm_K > 0) {
                 // GMM head: three projections of the readout in one launch, then the sampling kernel.
@@ -1104,6 +1203,14 @@ int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) {
     p->d = *desc;
     p->use_graph = desc->use_graph;
     p->esplit = att_default_esplit(desc->B, desc->E);
+    if (desc->layer_norm) {
+        bool ok = desc->ln_scratch && desc->ln_scratch_floats >= p->scratch_need();
+        for (int l = 0; l < desc->L; ++l) ok = ok && desc->br_l[l];
+        if (!ok) {
+            delete p;
+            return PARROT_ERR_BADARG;
+        }
+    }
     *plan = p;
     return 0;
 }

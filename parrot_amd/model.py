@@ -891,6 +891,21 @@ class Parrot(Brick):
                 d.cwork[l] = ws['cwork'][l].data_ptr()
         if lstm:
             d.gwork = ws['gwork'].data_ptr()
+        if self.layer_norm:
+            # model.py:899-1006 with _apply_norm active: the plan normalises the feedback / lower-layer / readout
+            # projections per step, so their biases are passed separately instead of being summed into bg/bc/br
+            widths = sum(wd for key, wd, suf, mat, rec in self._groups)
+            ws['ln_scratch'] = torch.empty(N * (5 * widths + (L + 1) * R), **f)
+            d.layer_norm = 1
+            d.ln_scratch, d.ln_scratch_floats = ws['ln_scratch'].data_ptr(), ws['ln_scratch'].numel()
+            for l in range(L):
+                d.br_l[l] = self._p(f'/h{l + 1}_to_readout.b').data_ptr()
+                for key, wd, suf, mat, rec in self._groups:
+                    if (l + 1) in self._fb_layers:
+                        getattr(d, 'bf' + key)[l] = self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_{suf}.b').data_ptr()
+                    for j in range(l):
+                        getattr(d, 'ln_b' + key)[l * _lib.MAX_LAYERS + j] = \
+                            self._p(f'/h{j + 1}_to_h{l + 1}/fork_rnn{l + 1}_{suf}.b').data_ptr()
         d.WattT, d.batt = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr()
         d.Wr, d.br = st['dec.Wr'].data_ptr(), ws['br'].data_ptr()
         d.radd = ws['radd'].data_ptr() if ws['radd'] is not None else None
@@ -930,14 +945,15 @@ class Parrot(Brick):
         S, L, H, O = num_steps, self.num_layers, self.rnn_h_dim, self.output_dim
         ws = self._sample_workspace(S, N, U)
         ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, None))
-        self._sum_layer_biases(ws, extra_fb=True)
+        self._sum_layer_biases(ws, extra_fb=not self.layer_norm)
         for l in range(1, L + 1):
             ws['h'][l - 1][0].copy_(self._p(f'/rnn{l}.initial_state').unsqueeze(0).expand(N, -1))
             if self.cell_type == 'lstm':
                 ws['cwork'][l - 1][0].copy_(self._p(f'/rnn{l}.initial_cells').unsqueeze(0).expand(N, -1))
         ws['br'].copy_(self._p('/att_to_readout.b'))
         for l in range(1, L + 1):
-            ws['br'].add_(self._p(f'/h{l}_to_readout.b'))
+            if not self.layer_norm:
+                ws['br'].add_(self._p(f'/h{l}_to_readout.b'))
         if self.use_speaker:
             speaker = torch.as_tensor(speaker).to(dev)
             emb = self._p('/lookuptable.W')[speaker[:, 0].long()].contiguous()
@@ -945,6 +961,8 @@ class Parrot(Brick):
                 for key, wd, suf, mat, rec in self._groups:
                     ops.gemm(emb, self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.W'),
                              bias=self._p(f'/speaker_to_h{l}/fork_rnn{l}_{suf}.b'), out=ws['seq_' + key][l - 1])
+                    if self.layer_norm:  # model.py:867
+                        ops.simple_norm_fwd(ws['seq_' + key][l - 1])
             ops.gemm(emb, self._p('/speaker_to_readout.W'), bias=self._p('/speaker_to_readout.b'), out=ws['radd'])
             if self.which_cost == 'MSE':
                 ops.gemm(emb, self._p('/speaker_to_output.W'), bias=self._p('/speaker_to_output.b'), out=ws['oadd'])

@@ -310,3 +310,22 @@ def test_layer_norm_cost_and_grads(dev, monkeypatch, kw):
     for use_graph in (False, True):
         _check_cost_and_grads(dev, T=8, B=5, U=9, ragged=True, encoder_type='bidirectional', layer_norm=True,
                               use_graph=use_graph, tol_grad=2e-3, **kw)
+
+
+@pytest.mark.parametrize("kw", [dict(num_layers=3, full_feedback=True, use_speaker=True),
+                                dict(num_layers=2, weak_feedback=True, cell_type='lstm'),
+                                dict(num_layers=1, weak_feedback=True, use_speaker=True, which_cost='GMM', k_gmm=3)])
+def test_layer_norm_sample_model_parity(dev, kw):
+    from oracle import parrot_ref as R
+    cfg, p, m = _build(dev, use_graph=True, encoder_type='bidirectional', layer_norm=True, **kw)
+    N, U, S = 4, 9, 10
+    _, _, lab, lm, spk = make_batch(cfg, 2, N, U, seed=9, speaker=cfg['use_speaker'])
+    g = torch.Generator().manual_seed(11)
+    unif = torch.rand(S, N, generator=g, dtype=torch.float64)
+    noise = torch.randn(S, N, cfg['output_dim'], generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        ref = R.sample_model(p, cfg, lab, lm, spk, S, unif=unif, noise=noise)
+    outs = m.sample_model_device(lab, lm.float(), spk, N, S, unif=unif.float(), noise=noise.float())
+    for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+        assert_close(o, r, 3e-4, n)
+    m.close()
