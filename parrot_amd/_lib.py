@@ -161,11 +161,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('PARROT_HIP_LIB', LIB_PATH)  # development knob: alternative builds of the same ABI
+    if not os.path.exists(path):
         raise HipLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m parrot_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res

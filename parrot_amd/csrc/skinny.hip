@@ -79,6 +79,13 @@ __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M,
     }
 }
 
+// Register-buffer ring depth of the fast path (chunks in flight per wave).  Measured on MI355X, cfg2 training
+// step fwd/bwd ms: depth 2: 55.9/79.9, 4: 57.4/80.0, 6: 61.9/82.5, 8: 60.7/87.9 -- more loads in flight do
+// not help (the clamped tail refills add traffic), so the ping-pong pair stays.
+#ifndef SK_DEPTH
+#define SK_DEPTH 2
+#endif
+
 template <int MB>
 __device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32x4 (&acc)[MB]) {
 #pragma unroll
@@ -181,20 +188,26 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 }
                 sk_fetch_fast<MB, NB, KC>(A, lda, B, ldb, (g - beg) << 4, mrow, ncl, kk, a, b);
             };
-            // Ping-pong register buffers, two chunks per iteration: no register copies, so nothing in the
-            // body has to wait for the loads it has just issued.
-            f32x4 a0[MB], b0[NB], a1[MB], b1[NB];
-            fetch(wave, a0, b0);
+            // Ring of SK_DEPTH register buffers, SK_DEPTH chunks per iteration, each slot refilled right after
+            // it has fed the MFMAs: no register copies, so nothing in the body waits for loads it has just
+            // issued, and SK_DEPTH chunks stay in flight per wave.
+            f32x4 ra[SK_DEPTH][MB], rb_[SK_DEPTH][NB];
+#pragma unroll
+            for (int dd = 0; dd < SK_DEPTH; ++dd) fetch(min(wave + dd * SK_NW, last), ra[dd], rb_[dd]);
             int g = wave;
-            const int npairs = mine >> 1;
-            for (int pr = 0; pr < npairs; ++pr) {
-                fetch(min(g + SK_NW, last), a1, b1);
-                sk_mma2<MB, NB>(a0, b0, acc);
-                fetch(min(g + 2 * SK_NW, last), a0, b0);
-                sk_mma2<MB, NB>(a1, b1, acc);
-                g += 2 * SK_NW;
+            const int ngroups = mine / SK_DEPTH;
+            for (int gr = 0; gr < ngroups; ++gr) {
+#pragma unroll
+                for (int dd = 0; dd < SK_DEPTH; ++dd) {
+                    sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
+                    fetch(min(g + (SK_DEPTH + dd) * SK_NW, last), ra[dd], rb_[dd]);
+                }
+                g += SK_DEPTH * SK_NW;
             }
-            if (mine & 1) sk_mma2<MB, NB>(a0, b0, acc);
+            const int rem = mine - ngroups * SK_DEPTH;
+#pragma unroll
+            for (int dd = 0; dd < SK_DEPTH - 1; ++dd)
+                if (dd < rem) sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
         };
         if (mine > 0) {
             if (job.seg[0].b_kcontig) run(std::true_type{});
