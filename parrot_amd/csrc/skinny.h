@@ -8,7 +8,10 @@
 #pragma once
 #include "common.h"
 
-enum { SK_MAXSEG = 5, SK_MAXJOB = 9, SK_NW = 8, SK_THREADS = SK_NW * 64 };
+#ifndef SK_NWAVES
+#define SK_NWAVES 8
+#endif
+enum { SK_MAXSEG = 5, SK_MAXJOB = 9, SK_NW = SK_NWAVES, SK_THREADS = SK_NW * 64 };
 
 enum SkEpi {
     SK_EPI_LINEAR = 0,     // out = act(acc + bias + add) (optionally accumulated into out)

@@ -108,9 +108,19 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
                                               f32x4 (&a)[MB], f32x4 (&b)[NB]) {
     const int k = kc + 4 * kk;
 #pragma unroll
-    for (int rb = 0; rb < MB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + k);
+    for (int rb = 0; rb < MB; ++rb) {
+#ifdef SK_DBG_NO_A
+        a[rb] = (f32x4){(float)k, 1.f, 2.f, (float)mrow[rb]};
+#else
+        a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + k);
+#endif
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
+#ifdef SK_DBG_NO_B
+        b[nb] = (f32x4){(float)k, 1.f, 2.f, (float)ncol[nb]};
+        continue;
+#endif
         if (KC) {
             b[nb] = *reinterpret_cast<const f32x4*>(B + (size_t)ncol[nb] * ldb + k);
         } else {
@@ -129,7 +139,11 @@ __device__ __forceinline__ void sk_mma2(const f32x4 (&a)[MB], const f32x4 (&b)[N
         for (int rb = 0; rb < MB; ++rb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
+#ifndef SK_DBG_NO_MMA
                 acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[nb][u], acc[rb][nb], 0, 0, 0);
+#else
+                acc[rb][nb][u] += a[rb][u] * b[nb][u];
+#endif
 }
 
 // One workgroup: (16*MB rows) x (16*NB columns) output tile, K split over the SK_NW waves.
@@ -172,8 +186,19 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + i, M - 1);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) ncl[nb] = min(sk_col(job.epi, job.H, tile0 + nb, i), N - 1);
-        const int mine = (total - wave + SK_NW - 1) / SK_NW;  // chunks of this wave
+#ifdef SK_BLOCKED
+        // contiguous range of chunks per wave: consecutive loads of a wave walk along the rows (whole 128-B lines)
+        const int base_n = total / SK_NW, extra = total % SK_NW;
+        const int mine = base_n + (wave < extra ? 1 : 0);
+        const int first = wave * base_n + min(wave, extra);
+        const int last = first + mine - 1;
+        constexpr int STR = 1;
+#else
+        const int mine = (total - wave + SK_NW - 1) / SK_NW;  // chunks of this wave (dealt round-robin)
+        const int first = wave;
         const int last = wave + (mine - 1) * SK_NW;
+        constexpr int STR = SK_NW;
+#endif
         auto run = [&](auto kc_tag) {
             constexpr bool KC = decltype(kc_tag)::value;
             auto fetch = [&](int g, f32x4 (&a)[MB], f32x4 (&b)[NB]) {
@@ -193,16 +218,16 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             // issued, and SK_DEPTH chunks stay in flight per wave.
             f32x4 ra[SK_DEPTH][MB], rb_[SK_DEPTH][NB];
 #pragma unroll
-            for (int dd = 0; dd < SK_DEPTH; ++dd) fetch(min(wave + dd * SK_NW, last), ra[dd], rb_[dd]);
-            int g = wave;
+            for (int dd = 0; dd < SK_DEPTH; ++dd) fetch(min(first + dd * STR, last), ra[dd], rb_[dd]);
+            int g = first;
             const int ngroups = mine / SK_DEPTH;
             for (int gr = 0; gr < ngroups; ++gr) {
 #pragma unroll
                 for (int dd = 0; dd < SK_DEPTH; ++dd) {
                     sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
-                    fetch(min(g + (SK_DEPTH + dd) * SK_NW, last), ra[dd], rb_[dd]);
+                    fetch(min(g + (SK_DEPTH + dd) * STR, last), ra[dd], rb_[dd]);
                 }
-                g += SK_DEPTH * SK_NW;
+                g += SK_DEPTH * STR;
             }
             const int rem = mine - ngroups * SK_DEPTH;
 #pragma unroll
