@@ -22,6 +22,9 @@
 //     sampleRNN/lib/ops.py:364-393), its backward counterpart, or the LSTM cell (ops.py:505-553).
 #include "skinny.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <string.h>
@@ -530,6 +533,17 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
             else better = wg > best_wg;
             if (better) { best_mb = mb; best_nb = nb; best_wg = wg; best_cost = cost; }
         }
+    }
+    // development knob: PARROT_SK_TILE="mb,nb" forces the tile shape where it is legal for the launch
+    static int force_mb = -1, force_nb = -1;
+    if (force_mb < 0) {
+        force_mb = 0;
+        const char* e = getenv("PARROT_SK_TILE");
+        if (e && sscanf(e, "%d,%d", &force_mb, &force_nb) != 2) force_mb = 0;
+    }
+    if (force_mb >= 1 && force_mb <= 4 && (force_nb == 1 || (force_nb == 2 && nb2_ok)) &&
+        16 * (force_mb - 1) < maxM) {
+        best_mb = force_mb; best_nb = force_nb;
     }
     const int mb = best_mb, nb = best_nb;
     int t = 0;
