@@ -220,6 +220,14 @@ typedef struct ParrotDecoderDesc {
     float* ln_yc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
     float* ln_sg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
     float* ln_sc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
+    /* Optional fragment-major copies of the packed layer matrices (parrot_tile_weights), same element count as
+     * Wg[l] / Wc[l]: *_f for the forward products (mode 0; LSTM: lstm_H = H), *_r for the backward products
+     * with the transpose (mode 1).  When all are given the scan reads the weights through them (contiguous
+     * 1 KB wave loads); the caller refreshes them whenever the weights change.  NULL: plain matrices. */
+    const float* Wg_f[PARROT_MAX_LAYERS];
+    const float* Wc_f[PARROT_MAX_LAYERS];
+    const float* Wg_r[PARROT_MAX_LAYERS];
+    const float* Wc_r[PARROT_MAX_LAYERS];
 } ParrotDecoderDesc;
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
@@ -304,6 +312,13 @@ int parrot_plan_last_error(void* plan);
  * all-reduce in data-parallel runs); grad_scale rescales the raw gradient first (1/world_size).
  * ------------------------------------------------------------------------------------------ */
 int parrot_sumsq(const float* x, size_t n, float* out, void* stream);
+
+/* Fragment-major copy of a row-major weight matrix W [rows, cols] (leading dimension ld; rows, cols multiples
+ * of 16) for the recurrent-step kernel: 256-float blocks ordered [column tile][16-deep chunk], each holding the
+ * 64 lanes' MFMA operand quads.  mode 0: for products x . W (tiles over columns, chunks over rows; lstm_H > 0
+ * applies the gate-interleaved column order of the fused LSTM step, cols = 4*lstm_H); mode 1: for products
+ * x . W^T (tiles over rows, chunks over columns).  out: rows*cols floats. */
+int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream);
 
 /* _simple_norm / _apply_norm of the reference (model.py:24-34; used when layer_norm=True on the Fork outputs
  * and readout projections, model.py:585-620, 703-722, 746): y = (x - mean) / (eps + std) over the last axis

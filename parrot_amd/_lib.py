@@ -66,6 +66,8 @@ class DecoderDesc(C.Structure):
         ("ln_bg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_bc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
         ("ln_yg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_yc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
         ("ln_sg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_sc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
+        ("Wg_f", C.c_void_p * MAX_LAYERS), ("Wc_f", C.c_void_p * MAX_LAYERS),
+        ("Wg_r", C.c_void_p * MAX_LAYERS), ("Wc_r", C.c_void_p * MAX_LAYERS),
     ]
 
 
@@ -143,6 +145,7 @@ SIGNATURES = {
     "parrot_sample_destroy": (_i, [_vp]),
     "parrot_plan_last_error": (_i, [_vp]),
     "parrot_sumsq": (_i, [_vp, _sz, _vp, _vp]),
+    "parrot_tile_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "parrot_simple_norm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _ll, _i, _f, _vp, _i, _vp]),
     "parrot_simple_norm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     "parrot_adam_clip_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),

@@ -85,6 +85,11 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     return bg_launch(a, st);
 }
 
+int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream) {
+    if (mode != 0 && mode != 1) return PARROT_ERR_BADARG;
+    return sk_tile_weights_launch(W, rows, cols, ld, out, mode, lstm_H, (hipStream_t)stream);
+}
+
 int parrot_simple_norm_fwd(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
                            float* add_dst, int ld_add, void* stream) {
     if (!x || !y || !sigma) return PARROT_ERR_BADARG;

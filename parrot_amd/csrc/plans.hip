@@ -232,16 +232,37 @@ struct DecoderPlan : PlanBase {
         if (c && atoi(c) > 0) chunk = atoi(c);
     }
 
-    // Adds the K-segments [h_l ; w ; h_0..h_{l-1}] against weight W (row-major [K_l, ldw]).
-    void layer_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw) const {
+    // ---- weight operands: plain packed matrices, or their fragment-major copies when the caller gave them
+    bool tiled = false;
+    int krows(int l) const { return d.H + d.E + l * d.H; }
+    // forward product x . W[r0 : r0+K, :] of layer l's matrix g (0: Wg, 1: Wc), width ldw
+    SkSeg fseg(const float* A, int lda, int l, int g, int r0, int K, int ldw) const {
+        if (tiled) {
+            const float* Wt = g == 0 ? d.Wg_f[l] : d.Wc_f[l];
+            return sk_seg(A, lda, Wt + (size_t)(r0 >> 4) * 256, (krows(l) >> 4) * 256, K, 2);
+        }
+        const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
+        return sk_seg(A, lda, W + (size_t)r0 * ldw, ldw, K, 0);
+    }
+    // backward product dP . W[r0 : r0+N, :]^T (K = ldw = width of the matrix)
+    SkSeg rseg(const float* A, int l, int g, int r0, int ldw) const {
+        if (tiled) {
+            const float* Wt = g == 0 ? d.Wg_r[l] : d.Wc_r[l];
+            return sk_seg(A, ldw, Wt + (size_t)(r0 >> 4) * (ldw >> 4) * 256, (ldw >> 4) * 256, ldw, 2);
+        }
+        const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
+        return sk_seg(A, ldw, W + (size_t)r0 * ldw, ldw, ldw, 1);
+    }
+
+    // Adds the K-segments [h_l ; w ; h_0..h_{l-1}] against layer l's matrix g (row-major [K_l, ldw]).
+    void layer_segs(SkJob& j, int l, int t, const float* first, int g, int ldw) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
         int n = 0;
-        j.seg[n++] = sk_seg(first, d.H, W, ldw, d.H, 0);
+        j.seg[n++] = fseg(first, d.H, l, g, 0, d.H, ldw);
         const float* wsrc = d.w + (size_t)(l == 0 ? t : t + 1) * BE;
-        j.seg[n++] = sk_seg(wsrc, d.E, W + (size_t)d.H * ldw, ldw, d.E, 0);
+        j.seg[n++] = fseg(wsrc, d.E, l, g, d.H, d.E, ldw);
         for (int q = 0; q < l; ++q)
-            j.seg[n++] = sk_seg(d.h[q] + (size_t)(t + 1) * BH, d.H, W + (size_t)(d.H + d.E + q * d.H) * ldw, ldw,
-                                d.H, 0);
+            j.seg[n++] = fseg(d.h[q] + (size_t)(t + 1) * BH, d.H, l, g, d.H + d.E + q * d.H, d.H, ldw);
         j.nseg = n;
     }
 
@@ -252,7 +273,7 @@ struct DecoderPlan : PlanBase {
     void gates_job(SkJob& j, int l, int t) const {
         const size_t BH = (size_t)d.B * d.H;
         sk_job_init(j);
-        layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
+        layer_segs(j, l, t, d.h[l] + t * BH, 0, 2 * d.H);
         j.M = d.B; j.N = 2 * d.H; j.H = d.H; j.epi = SK_EPI_GRU_GATES;
         j.bias = d.bg[l];
         j.add = has_seq(l, d.seq_g[l]) ? d.seq_g[l] + t * 2 * BH : nullptr; j.ld_add = 2 * d.H;
@@ -265,7 +286,7 @@ struct DecoderPlan : PlanBase {
     void cand_job(SkJob& j, int l, int t) const {
         const size_t BH = (size_t)d.B * d.H;
         sk_job_init(j);
-        layer_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
+        layer_segs(j, l, t, d.rh[l] + t * BH, 1, d.H);
         j.M = d.B; j.N = d.H; j.H = d.H; j.epi = SK_EPI_GRU_CAND;
         j.bias = d.bc[l];
         j.add = has_seq(l, d.seq_c[l]) ? d.seq_c[l] + t * BH : nullptr; j.ld_add = d.H;
@@ -278,7 +299,7 @@ struct DecoderPlan : PlanBase {
     void lstm_job(SkJob& j, int l, int t) const {
         const size_t BH = (size_t)d.B * d.H;
         sk_job_init(j);
-        layer_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 4 * d.H);
+        layer_segs(j, l, t, d.h[l] + t * BH, 0, 4 * d.H);
         j.M = d.B; j.N = 4 * d.H; j.H = d.H; j.epi = SK_EPI_LSTM;
         j.bias = d.bg[l];
         j.add = has_seq(l, d.seq_g[l]) ? d.seq_g[l] + t * 4 * BH : nullptr; j.ld_add = 4 * d.H;
@@ -376,7 +397,7 @@ struct DecoderPlan : PlanBase {
                         SkJob& j = jl[nl++];
                         sk_job_init(j);
                         j.nseg = 1;
-                        j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l], 4 * H, 4 * H, 1);
+                        j.seg[0] = rseg(dP, l, 0, 0, 4 * H);
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dh[l] + t * BH; j.ldo = H;
                     }
@@ -384,7 +405,7 @@ struct DecoderPlan : PlanBase {
                         SkJob& j = jl[nl++];
                         sk_job_init(j);
                         j.nseg = 1;
-                        j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l] + (size_t)H * 4 * H, 4 * H, 4 * H, 1);
+                        j.seg[0] = rseg(dP, l, 0, H, 4 * H);
                         j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
                     }
@@ -392,7 +413,7 @@ struct DecoderPlan : PlanBase {
                         SkJob& j = jl[nl++];
                         sk_job_init(j);
                         j.nseg = 1;
-                        j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l] + (size_t)(H + E + p * H) * 4 * H, 4 * H, 4 * H, 1);
+                        j.seg[0] = rseg(dP, l, 0, H + E + p * H, 4 * H);
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
                     }
@@ -422,7 +443,7 @@ struct DecoderPlan : PlanBase {
                 SkJob& x = jx[nx++];
                 sk_job_init(x);
                 x.nseg = 1;
-                x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+                x.seg[0] = rseg(d.dC[l] + t * BH, l, 1, 0, H);
                 x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
                 x.e0 = d.h[l] + t * BH; x.lde0 = H;
                 x.e1 = d.r[l] + t * BH; x.lde1 = H;
@@ -436,7 +457,7 @@ struct DecoderPlan : PlanBase {
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
                     j.nseg = 1;
-                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+                    j.seg[0] = rseg(dG, l, 0, 0, 2 * H);
                     j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dh[l] + t * BH; j.ldo = H;
                 }
@@ -444,8 +465,8 @@ struct DecoderPlan : PlanBase {
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
                     j.nseg = 2;
-                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
-                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)H * H, H, H, 1);
+                    j.seg[0] = rseg(dG, l, 0, H, 2 * H);
+                    j.seg[1] = rseg(dC, l, 1, H, H);
                     j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
                 }
@@ -453,8 +474,8 @@ struct DecoderPlan : PlanBase {
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
                     j.nseg = 2;
-                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + p * H) * 2 * H, 2 * H, 2 * H, 1);
-                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + p * H) * H, H, H, 1);
+                    j.seg[0] = rseg(dG, l, 0, H + E + p * H, 2 * H);
+                    j.seg[1] = rseg(dC, l, 1, H + E + p * H, H);
                     j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;  // separate buffer: no two jobs share a tile
                 }
@@ -534,11 +555,11 @@ struct DecoderPlan : PlanBase {
         return 0;
     }
 
-    void own_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw) const {
+    void own_segs(SkJob& j, int l, int t, const float* first, int g, int ldw) const {
         const size_t BE = (size_t)d.B * d.E;
-        j.seg[0] = sk_seg(first, d.H, W, ldw, d.H, 0);
+        j.seg[0] = fseg(first, d.H, l, g, 0, d.H, ldw);
         j.nseg = 1;
-        if (l == 0) j.seg[j.nseg++] = sk_seg(d.w + (size_t)t * BE, d.E, W + (size_t)d.H * ldw, ldw, d.E, 0);
+        if (l == 0) j.seg[j.nseg++] = fseg(d.w + (size_t)t * BE, d.E, l, g, d.H, d.E, ldw);
     }
 
     // Kernels of layer l for the steps of chunk c (forward): batched projections from below, then the
@@ -551,14 +572,14 @@ struct DecoderPlan : PlanBase {
             SkJob j;
             if (d.cell == 1) {
                 lstm_job(j, l, t);
-                own_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 4 * d.H);
+                own_segs(j, l, t, d.h[l] + t * BH, 0, 4 * d.H);
                 PL_TRY(launch_jobs(&j, 1, st));
             } else {
                 gates_job(j, l, t);
-                own_segs(j, l, t, d.h[l] + t * BH, d.Wg[l], 2 * d.H);
+                own_segs(j, l, t, d.h[l] + t * BH, 0, 2 * d.H);
                 PL_TRY(launch_jobs(&j, 1, st));
                 cand_job(j, l, t);
-                own_segs(j, l, t, d.rh[l] + t * BH, d.Wc[l], d.H);
+                own_segs(j, l, t, d.rh[l] + t * BH, 1, d.H);
                 PL_TRY(launch_jobs(&j, 1, st));
             }
             if (l == 0) PL_TRY(att_fwd_step(t, st));
@@ -598,14 +619,14 @@ struct DecoderPlan : PlanBase {
                 SkJob& j = jy[ny++];
                 sk_job_init(j);
                 j.nseg = 1;
-                j.seg[0] = sk_seg(dP, 4 * H, d.Wg[l], 4 * H, 4 * H, 1);
+                j.seg[0] = rseg(dP, l, 0, 0, 4 * H);
                 j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                 j.out = d.dh[l] + t * BH; j.ldo = H;
                 if (l == 0) {
                     SkJob& k = jy[ny++];
                     sk_job_init(k);
                     k.nseg = 1;
-                    k.seg[0] = sk_seg(dP, 4 * H, d.Wg[0] + (size_t)H * 4 * H, 4 * H, 4 * H, 1);
+                    k.seg[0] = rseg(dP, 0, 0, H, 4 * H);
                     k.M = d.B; k.N = E; k.H = H; k.epi = SK_EPI_LINEAR; k.accumulate = 1;
                     k.out = d.dw0 + (size_t)t * BE; k.ldo = E;
                 }
@@ -628,7 +649,7 @@ struct DecoderPlan : PlanBase {
             SkJob x;
             sk_job_init(x);
             x.nseg = 1;
-            x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+            x.seg[0] = rseg(d.dC[l] + t * BH, l, 1, 0, H);
             x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
             x.e0 = d.h[l] + t * BH; x.lde0 = H;
             x.e1 = d.r[l] + t * BH; x.lde1 = H;
@@ -641,7 +662,7 @@ struct DecoderPlan : PlanBase {
                 SkJob& j = jy[ny++];
                 sk_job_init(j);
                 j.nseg = 1;
-                j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+                j.seg[0] = rseg(dG, l, 0, 0, 2 * H);
                 j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                 j.out = d.dh[l] + t * BH; j.ldo = H;
             }
@@ -649,8 +670,8 @@ struct DecoderPlan : PlanBase {
                 SkJob& j = jy[ny++];
                 sk_job_init(j);
                 j.nseg = 2;
-                j.seg[0] = sk_seg(dG, 2 * H, d.Wg[0] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
-                j.seg[1] = sk_seg(dC, H, d.Wc[0] + (size_t)H * H, H, H, 1);
+                j.seg[0] = rseg(dG, 0, 0, H, 2 * H);
+                j.seg[1] = rseg(dC, 0, 1, H, H);
                 j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                 j.out = d.dw0 + (size_t)t * BE; j.ldo = E;
             }
@@ -850,7 +871,7 @@ struct DecoderPlan : PlanBase {
                 SkJob x;
                 sk_job_init(x);
                 x.nseg = 1;
-                x.seg[0] = sk_seg(d.dC[l] + t * BH, H, d.Wc[l], H, H, 1);
+                x.seg[0] = rseg(d.dC[l] + t * BH, l, 1, 0, H);
                 x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
                 x.e0 = d.h[l] + t * BH; x.lde0 = H;
                 x.e1 = d.r[l] + t * BH; x.lde1 = H;
@@ -867,7 +888,7 @@ struct DecoderPlan : PlanBase {
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
                     j.nseg = 1;
-                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l], 2 * H, 2 * H, 1);
+                    j.seg[0] = rseg(dG, l, 0, 0, 2 * H);
                     j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dh[l] + t * BH; j.ldo = H;
                 }
@@ -875,8 +896,8 @@ struct DecoderPlan : PlanBase {
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
                     j.nseg = 2;
-                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)H * 2 * H, 2 * H, 2 * H, 1);
-                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)H * H, H, H, 1);
+                    j.seg[0] = rseg(dG, l, 0, H, 2 * H);
+                    j.seg[1] = rseg(dC, l, 1, H, H);
                     j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
                 }
@@ -884,8 +905,8 @@ struct DecoderPlan : PlanBase {
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
                     j.nseg = 2;
-                    j.seg[0] = sk_seg(dG, 2 * H, d.Wg[l] + (size_t)(H + E + p * H) * 2 * H, 2 * H, 2 * H, 1);
-                    j.seg[1] = sk_seg(dC, H, d.Wc[l] + (size_t)(H + E + p * H) * H, H, H, 1);
+                    j.seg[0] = rseg(dG, l, 0, H + E + p * H, 2 * H);
+                    j.seg[1] = rseg(dC, l, 1, H + E + p * H, H);
                     j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
                 }
@@ -1172,6 +1193,15 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
     p->use_graph = desc->use_graph;
     p->esplit = att_default_esplit(desc->B, desc->E);
     p->choose_schedule();
+    {
+        bool all = (desc->H % 16 == 0) && (desc->E % 16 == 0);
+        for (int l = 0; l < desc->L; ++l) {
+            if (!desc->Wg_f[l] || !desc->Wg_r[l]) all = false;
+            if (desc->cell == 0 && (!desc->Wc_f[l] || !desc->Wc_r[l])) all = false;
+        }
+        const char* e = getenv("PARROT_TILED_WEIGHTS");
+        p->tiled = all && !(e && atoi(e) == 0);
+    }
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule == 2;
         for (int l = 1; l < desc->L && ok; ++l)

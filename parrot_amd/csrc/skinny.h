@@ -25,7 +25,9 @@ enum SkAct { SK_ACT_NONE = 0, SK_ACT_RELU = 1, SK_ACT_TANH = 2, SK_ACT_SIGMOID =
 
 struct SkSeg {
     const float* A;  // [M, K] row-major, leading dimension lda (K contiguous)
-    const float* B;  // b_kcontig ? B[n * ldb + k] : B[k * ldb + n]
+    const float* B;  // b_kcontig: 0: B[k * ldb + n]   1: B[n * ldb + k]
+                     //            2: fragment-major copy (sk_tile_weights): B = block of column tile 0 / this
+                     //               segment's first chunk, ldb = floats between consecutive column tiles
     int lda, ldb, K, b_kcontig;
 };
 
@@ -62,6 +64,8 @@ static inline SkSeg sk_seg(const float* A, int lda, const float* B, int ldb, int
     s.A = A; s.B = B; s.lda = lda; s.ldb = ldb; s.K = K; s.b_kcontig = b_kcontig;
     return s;
 }
+int sk_tile_weights_launch(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H,
+                           hipStream_t stream);
 void sk_job_init(SkJob& j);
 void sk_finalize_job(SkJob& j);  // computes `aligned`
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs);

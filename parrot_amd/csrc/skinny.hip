@@ -105,15 +105,19 @@ __device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32
 // Branch-free operand fetch of the fast path: every segment has K % 16 == 0 and 16-byte aligned
 // rows, out-of-range rows / columns are clamped (their results are discarded by the epilogue).
 // KC = weights stored [N][K] (K contiguous: one 16-byte load); otherwise [K][N] (4 dword loads).
-template <int MB, int NB, bool KC>
+template <int MB, int NB, int BM>
 __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                              int kc, const int (&mrow)[MB], const int (&ncol)[NB], int kk,
-                                              f32x4 (&a)[MB], f32x4 (&b)[NB]) {
+                                              int kc, const int (&mrow)[MB], const int (&ncol)[NB],
+                                              const int (&btile)[NB], int kk, f32x4 (&a)[MB], f32x4 (&b)[NB]) {
     const int k = kc + 4 * kk;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) {
 #ifdef SK_DBG_NO_A
         a[rb] = (f32x4){(float)k, 1.f, 2.f, (float)mrow[rb]};
+#elif defined(SK_DBG_TILED)
+        // probe only (wrong values): same bytes, but the 64 lanes read one contiguous 1 KB block
+        a[rb] = *reinterpret_cast<const f32x4*>(A + ((size_t)(mrow[rb] >> 4) * (lda >> 4) + (kc >> 4)) * 256 +
+                                                (threadIdx.x & 63) * 4);
 #else
         a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + k);
 #endif
@@ -123,8 +127,17 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
 #ifdef SK_DBG_NO_B
         b[nb] = (f32x4){(float)k, 1.f, 2.f, (float)ncol[nb]};
         continue;
+#elif defined(SK_DBG_TILED)
+        b[nb] = *reinterpret_cast<const f32x4*>(B + (BM == 1 ? ((size_t)(ncol[nb] >> 4) * (ldb >> 4) + (kc >> 4)) * 256
+                                                        : (size_t)(kc >> 4) * ldb * 16 + (size_t)(ncol[nb] >> 4) * 256) +
+                                                (threadIdx.x & 63) * 4);
+        continue;
 #endif
-        if (KC) {
+        if (BM == 2) {
+            // fragment-major weights (sk_tile_weights): the 64 lanes read one contiguous 1 KB block
+            b[nb] = *reinterpret_cast<const f32x4*>(B + (size_t)btile[nb] * ldb + ((size_t)(kc >> 4) << 8) +
+                                                    ((threadIdx.x & 63) << 2));
+        } else if (BM == 1) {
             b[nb] = *reinterpret_cast<const f32x4*>(B + (size_t)ncol[nb] * ldb + k);
         } else {
             const float* bp = B + (size_t)k * ldb + ncol[nb];
@@ -184,11 +197,14 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             cend[s] = total;
             sA[s] = job.seg[ss].A; sB[s] = job.seg[ss].B; slda[s] = job.seg[ss].lda; sldb[s] = job.seg[ss].ldb;
         }
-        int mrow[MB], ncl[NB];
+        int mrow[MB], ncl[NB], btile[NB];
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + i, M - 1);
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) ncl[nb] = min(sk_col(job.epi, job.H, tile0 + nb, i), N - 1);
+        for (int nb = 0; nb < NB; ++nb) {
+            ncl[nb] = min(sk_col(job.epi, job.H, tile0 + nb, i), N - 1);
+            btile[nb] = min(tile0 + nb, ((N + 15) >> 4) - 1);
+        }
 #ifdef SK_BLOCKED
         // contiguous range of chunks per wave: consecutive loads of a wave walk along the rows (whole 128-B lines)
         const int base_n = total / SK_NW, extra = total % SK_NW;
@@ -203,7 +219,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         constexpr int STR = SK_NW;
 #endif
         auto run = [&](auto kc_tag) {
-            constexpr bool KC = decltype(kc_tag)::value;
+            constexpr int BM = decltype(kc_tag)::value;
             auto fetch = [&](int g, f32x4 (&a)[MB], f32x4 (&b)[NB]) {
                 const float* A = sA[0];
                 const float* B = sB[0];
@@ -214,7 +230,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                     A = nx ? sA[s + 1] : A; B = nx ? sB[s + 1] : B;
                     lda = nx ? slda[s + 1] : lda; ldb = nx ? sldb[s + 1] : ldb; beg = nx ? cend[s] : beg;
                 }
-                sk_fetch_fast<MB, NB, KC>(A, lda, B, ldb, (g - beg) << 4, mrow, ncl, kk, a, b);
+                sk_fetch_fast<MB, NB, BM>(A, lda, B, ldb, (g - beg) << 4, mrow, ncl, btile, kk, a, b);
             };
             // Ring of SK_DEPTH register buffers, SK_DEPTH chunks per iteration, each slot refilled right after
             // it has fed the MFMAs: no register copies, so nothing in the body waits for loads it has just
@@ -238,8 +254,9 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 if (dd < rem) sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
         };
         if (mine > 0) {
-            if (job.seg[0].b_kcontig) run(std::true_type{});
-            else run(std::false_type{});
+            if (job.seg[0].b_kcontig == 2) run(std::integral_constant<int, 2>{});
+            else if (job.seg[0].b_kcontig == 1) run(std::integral_constant<int, 1>{});
+            else run(std::integral_constant<int, 0>{});
         }
     } else {
         // Generic path (NB == 1): per-element masks for K tails / unaligned operands (e.g. the 63-wide
@@ -404,6 +421,7 @@ void sk_finalize_job(SkJob& j) {
         const SkSeg& g = j.seg[s];
         if (((uintptr_t)g.A & 15) || (g.lda & 3) || (g.K & 15)) al = 0;
         if (g.b_kcontig && (((uintptr_t)g.B & 15) || (g.ldb & 3))) al = 0;
+        if (g.b_kcontig == 2 && (j.N & 15)) al = 0;
         if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
@@ -418,6 +436,7 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
         sk_finalize_job(L.job[q]);
         const SkJob& j = L.job[q];
         if (j.nseg < 1 || j.nseg > SK_MAXSEG || j.M < 1 || j.N < 1) return PH_ERR_BADARG;
+        if (j.seg[0].b_kcontig == 2 && !j.aligned) return PH_ERR_BADARG;  // tiled weights: fast path only
         int tiles;
         if (j.epi == SK_EPI_LSTM) {
             if (j.N != 4 * j.H || (j.H & 3)) return PH_ERR_BADARG;
@@ -430,6 +449,52 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
     }
     L.njobs = njobs;
     return 0;
+}
+
+// ---- fragment-major weight copies ------------------------------------------------------------
+// The step kernels are bound by how fast a CU's texture path turns wave loads into cache-line requests:
+// a wave load whose 64 lanes hit 16+ different lines (activation rows 4 KB apart, or 4-byte-per-lane
+// weight loads) moves 16 B per clock, one contiguous 1 KB block moves 64 B per clock (measured: -20..27 %
+// per launch with both operands contiguous).  So the scan reads its weights from copies laid out in the
+// exact order the MFMA operand registers want them: block (column tile ct, 16-deep chunk c) holds
+// [kk][i][u] = W[16c + 4kk + u][col(ct, i)]  (mode 0, forward: out = A . W), or
+// [kk][i][u] = W[16ct + i][16c + 4kk + u]    (mode 1, backward: out = A . W^T),
+// 256 floats each, blocks ordered [ct][c].  lstm_H > 0 applies the gate-interleaved column order of
+// SK_EPI_LSTM (sk_col) in mode 0.  The copies are refreshed once per training step (44 MB, ~30 us).
+namespace {
+__global__ __launch_bounds__(256) void sk_tile_weights_kernel(const float* __restrict__ W, int rows, int cols, int ld,
+                                                              float* __restrict__ out, int mode, int lstm_H) {
+    const int nct = mode == 0 ? cols >> 4 : rows >> 4;
+    const int nch = mode == 0 ? rows >> 4 : cols >> 4;
+    const size_t total = (size_t)nct * nch * 64;  // one f32x4 per thread-item
+    for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+        const int lane = (int)(it & 63);
+        const size_t blk = it >> 6;
+        const int c = (int)(blk % nch), ct = (int)(blk / nch);
+        const int i = lane & 15, kk = lane >> 4;
+        f32x4 v;
+        if (mode == 0) {
+            const int col = lstm_H > 0 ? (i >> 2) * lstm_H + ct * 4 + (i & 3) : ct * 16 + i;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = W[(size_t)(c * 16 + kk * 4 + u) * ld + col];
+        } else {
+            v = *reinterpret_cast<const f32x4*>(W + (size_t)(ct * 16 + i) * ld + c * 16 + kk * 4);
+        }
+        *reinterpret_cast<f32x4*>(out + it * 4) = v;
+    }
+}
+}  // namespace
+
+int sk_tile_weights_launch(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H,
+                           hipStream_t stream) {
+    if (!W || !out || rows < 16 || cols < 16 || (rows & 15) || (cols & 15) || (ld & 3) || ((uintptr_t)W & 15) ||
+        ((uintptr_t)out & 15) || (lstm_H > 0 && (mode != 0 || cols != 4 * lstm_H)))
+        return PH_ERR_BADARG;
+    const size_t items = (size_t)rows * cols / 4;
+    int blocks = (int)((items + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sk_tile_weights_kernel, dim3(blocks), dim3(256), 0, stream, W, rows, cols, ld, out, mode, lstm_H);
+    return (int)hipGetLastError();
 }
 
 // ---- optional per-dispatch timing (bench.py roofline leg) ------------------------------------

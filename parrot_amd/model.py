@@ -499,6 +499,12 @@ class Parrot(Brick):
             for n in (('h', 'dh', 'cst', 'gate4', 'dcell') if lstm else ('h', 'dh', 'z', 'r', 'rh', 'c')):
                 getattr(d, n)[l] = ws[n][l].data_ptr()
             d.dhup[l] = ws['dhup'][l].data_ptr() if ws['dhup'][l] is not None else None
+        tl = self._tiled_weights()
+        if tl is not None:
+            for l in range(L):
+                for key, wd, suf, mat, rec in self._groups:
+                    getattr(d, f'W{key}_f')[l] = tl[(l, key, 'f')].data_ptr()
+                    getattr(d, f'W{key}_r')[l] = tl[(l, key, 'r')].data_ptr()
         d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
         for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dw0', 'dkappa', 'dp'):
             setattr(d, n, ws[n].data_ptr())
@@ -507,6 +513,32 @@ class Parrot(Brick):
         ws['plan'], ws['desc'] = plan, d
         self._train_ws[key] = ws
         return ws
+
+    def _tiled_weights(self, refresh=False):
+        """Fragment-major copies of the packed layer matrices for the scan kernels (parrot_tile_weights);
+        None when the widths are not multiples of 16.  refresh=True re-derives them from the current weights."""
+        H, E = self.rnn_h_dim, self.encoded_input_dim
+        if H % 16 or E % 16:
+            return None
+        if getattr(self, '_tiled', None) is None:
+            st = self.store.storage
+            self._tiled = {}
+            for l in range(self.num_layers):
+                for key, wd, suf, mat, rec in self._groups:
+                    for which in ('f', 'r'):
+                        self._tiled[(l, key, which)] = torch.empty_like(st[f'{mat}{l + 1}'])
+            refresh = True
+        if refresh:
+            st = self.store.storage
+            for l in range(self.num_layers):
+                for key, wd, suf, mat, rec in self._groups:
+                    W = st[f'{mat}{l + 1}']
+                    lstm_h = H if self.cell_type == 'lstm' else 0
+                    _lib.call('parrot_tile_weights', W.data_ptr(), W.shape[0], W.shape[1], W.shape[1],
+                              self._tiled[(l, key, 'f')].data_ptr(), 0, lstm_h, ops._stream())
+                    _lib.call('parrot_tile_weights', W.data_ptr(), W.shape[0], W.shape[1], W.shape[1],
+                              self._tiled[(l, key, 'r')].data_ptr(), 1, 0, ops._stream())
+        return self._tiled
 
     def _layer_bias_names(self, l, suf):
         """Names of the bias parameters that add into layer l's pre-activation group `suf`
@@ -618,6 +650,7 @@ class Parrot(Brick):
         # --- encoder (model.py:645-646) and summed layer biases
         ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, save))
         self._sum_layer_biases(ws)
+        self._tiled_weights(refresh=True)
 
         # --- the scan (model.py:651-737)
         _lib.call('parrot_decoder_seq_fwd', ws['plan'], ops._stream())

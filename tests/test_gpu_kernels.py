@@ -284,3 +284,29 @@ def test_simple_norm_fwd_bwd(dev, R, N):
     xa = xd.clone().requires_grad_()
     ops.simple_norm(xa).backward(dy.float().to(dev))
     assert_close(xa.grad, x.grad, 1e-4, "norm autograd")
+
+
+@pytest.mark.parametrize("rows,cols,mode,lstm_h", [(32, 48, 0, 0), (48, 32, 1, 0), (32, 64, 0, 16), (2304, 2048, 0, 0)])
+def test_tile_weights_layout(dev, rows, cols, mode, lstm_h):
+    """parrot_tile_weights: 256-float blocks [column tile][chunk] holding [kk][i][u] (bit-exact copy)."""
+    import ctypes as C
+    from parrot_amd import _lib, ops
+    g = torch.Generator().manual_seed(rows + cols + mode)
+    W = torch.randn(rows, cols, generator=g)
+    Wd = W.to(dev)
+    out = torch.empty_like(Wd)
+    _lib.call('parrot_tile_weights', Wd.data_ptr(), rows, cols, cols, out.data_ptr(), mode, lstm_h, ops._stream())
+    got = out.cpu().reshape(-1)
+    Wn = W.numpy()
+    nct, nch = (cols // 16, rows // 16) if mode == 0 else (rows // 16, cols // 16)
+    ref = np.empty((nct, nch, 4, 16, 4), dtype=np.float32)
+    for ct in range(nct):
+        for i in range(16):
+            col = ((i >> 2) * lstm_h + ct * 4 + (i & 3)) if lstm_h else ct * 16 + i
+            for kk in range(4):
+                for u in range(4):
+                    if mode == 0:
+                        ref[ct, :, kk, i, u] = Wn[np.arange(nch) * 16 + kk * 4 + u, col]
+                    else:
+                        ref[ct, :, kk, i, u] = Wn[ct * 16 + i, np.arange(nch) * 16 + kk * 4 + u]
+    assert np.array_equal(got.numpy(), ref.reshape(-1))
