@@ -82,6 +82,12 @@ __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M,
     }
 }
 
+// Activation operand of the fast path: 1 = quad-contiguous loads + ds_bpermute into the MFMA lanes (see
+// sk_fetch_fast / sk_a_unpermute), 0 = each lane loads its own row directly.
+#ifndef SK_A_PERMUTE
+#define SK_A_PERMUTE 1
+#endif
+
 // Register-buffer ring depth of the fast path (chunks in flight per wave).  Measured on MI355X, cfg2 training
 // step fwd/bwd ms: depth 2: 55.9/79.9, 4: 57.4/80.0, 6: 61.9/82.5, 8: 60.7/87.9 -- more loads in flight do
 // not help (the clamped tail refills add traffic), so the ping-pong pair stays.
@@ -114,10 +120,14 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
     for (int rb = 0; rb < MB; ++rb) {
 #ifdef SK_DBG_NO_A
         a[rb] = (f32x4){(float)k, 1.f, 2.f, (float)mrow[rb]};
-#elif defined(SK_DBG_TILED)
+#elif defined(SK_DBG_TILED) && !defined(SK_DBG_TILED_B_ONLY)
         // probe only (wrong values): same bytes, but the 64 lanes read one contiguous 1 KB block
         a[rb] = *reinterpret_cast<const f32x4*>(A + ((size_t)(mrow[rb] >> 4) * (lda >> 4) + (kc >> 4)) * 256 +
                                                 (threadIdx.x & 63) * 4);
+#elif SK_A_PERMUTE
+        // quad-contiguous mapping: lane l reads 16 B of row (l >> 2) at k-offset 4 * (l & 3), so every quad of
+        // lanes covers one contiguous 64-B segment; sk_a_unpermute moves the quads to the MFMA lanes later.
+        a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + kc + 4 * (threadIdx.x & 3));
 #else
         a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + k);
 #endif
@@ -145,6 +155,20 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
             for (int u = 0; u < 4; ++u) b[nb][u] = bp[(size_t)u * ldb];
         }
     }
+}
+
+// MFMA lane (kk, i) = kk * 16 + i takes the quad that lane 4 * i + kk loaded (see sk_fetch_fast).
+template <int MB>
+__device__ __forceinline__ void sk_a_unpermute(f32x4 (&a)[MB]) {
+#if SK_A_PERMUTE
+    const int lane = threadIdx.x & 63;
+    const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;  // byte address of the source lane
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            a[rb][u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a[rb][u])));
+#endif
 }
 
 template <int MB, int NB>
@@ -199,7 +223,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         }
         int mrow[MB], ncl[NB], btile[NB];
 #pragma unroll
-        for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + i, M - 1);
+        for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + (SK_A_PERMUTE ? ((lane >> 2) & 15) : i), M - 1);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             ncl[nb] = min(sk_col(job.epi, job.H, tile0 + nb, i), N - 1);
@@ -243,6 +267,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             for (int gr = 0; gr < ngroups; ++gr) {
 #pragma unroll
                 for (int dd = 0; dd < SK_DEPTH; ++dd) {
+                    sk_a_unpermute<MB>(ra[dd]);
                     sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
                     fetch(min(g + (SK_DEPTH + dd) * STR, last), ra[dd], rb_[dd]);
                 }
@@ -251,7 +276,10 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             const int rem = mine - ngroups * SK_DEPTH;
 #pragma unroll
             for (int dd = 0; dd < SK_DEPTH - 1; ++dd)
-                if (dd < rem) sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
+                if (dd < rem) {
+                    sk_a_unpermute<MB>(ra[dd]);
+                    sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
+                }
         };
         if (mine > 0) {
             if (job.seg[0].b_kcontig == 2) run(std::integral_constant<int, 2>{});
@@ -526,7 +554,7 @@ void sk_account(const SkLaunch& L, double& flops, double& bytes) {
 }  // namespace
 
 void sk_profile_begin() {
-    for (auto& r : g_prof.recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.recs.clear();
     g_prof.on = true;
 }
@@ -539,7 +567,7 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) us += 1000.0 * ms;
         fl += r.flops; by += r.bytes;
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     const long long n = (long long)g_prof.recs.size();
     g_prof.recs.clear();
@@ -553,8 +581,8 @@ template <int MB, int NB>
 static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t stream) {
     if (g_prof.on) {
         SkProfRec r;
-        hipEventCreate(&r.e0);
-        hipEventCreate(&r.e1);
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
         sk_account(L, r.flops, r.bytes);
         hipExtLaunchKernelGGL((sk_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, L);
         g_prof.recs.push_back(r);
