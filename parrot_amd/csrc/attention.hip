@@ -20,6 +20,13 @@
 
 #include <stdlib.h>
 
+#ifndef ATT_PROJ_UNROLL
+#define ATT_PROJ_UNROLL 8
+#endif
+#ifndef ATT_FWD_PRELOAD
+#define ATT_FWD_PRELOAD 0  // measured: no gain in the forward kernel (the backward preloads pay)
+#endif
+
 namespace {
 
 constexpr int ATT_THREADS = 256;
@@ -66,6 +73,28 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     const int lane = t & 63, wave = t >> 6;
     const float* h = g.h1 + (size_t)b * g.ldh;
 
+    // Geometry of step 4 (w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E), fixed up front so
+    // that the context values can be requested before anything else: they do not depend on phi, and their
+    // latency then hides behind the projection / window phases instead of following them.
+    const int EW = (E + g.esplit - 1) / g.esplit;
+    const int e0 = es * EW, e1 = min(E, e0 + EW);
+    int CW = 1;
+    while (CW < EW && CW < ATT_THREADS) CW <<= 1;  // columns handled per pass (power of two)
+    const int G = ATT_THREADS / CW;                // u-groups
+    const int c = t % CW, ug = t / CW;
+    const float* ctx = g.ctx + (size_t)b * U * E;
+    constexpr int NPRE = 32;
+    const bool use_pre = ATT_FWD_PRELOAD && (EW <= CW) && ((U + G - 1) / G <= NPRE) && !(g.dbg & 4);
+    float pre[NPRE];
+    if (use_pre) {
+        const int e = e0 + c;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int u = ug + q * G;
+            pre[q] = (u < U && e < e1) ? ctx[(size_t)u * E + e] : 0.f;
+        }
+    }
+
     // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
     // Wave w owns outputs j = w, w+4, ... (up to 8 per pass); the loads of all its outputs for one k-slab
     // are issued together (8 rows + h in flight), instead of one output after the other.
@@ -74,7 +103,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-#pragma unroll 4
+#pragma unroll ATT_PROJ_UNROLL
         for (int k = lane; k < H; k += 64) {
             const float hv = h[k];
 #pragma unroll
@@ -145,18 +174,17 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     __syncthreads();
 
     // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
-    const int EW = (E + g.esplit - 1) / g.esplit;
-    const int e0 = es * EW, e1 = min(E, e0 + EW);
-    int CW = 1;
-    while (CW < EW && CW < ATT_THREADS) CW <<= 1;  // columns handled per pass (power of two)
-    const int G = ATT_THREADS / CW;                // u-groups
-    const int c = t % CW, ug = t / CW;
-    const float* ctx = g.ctx + (size_t)b * U * E;
     if (g.dbg & 4) return;
     for (int eb = e0; eb < e1; eb += CW) {
         const int e = eb + c;
         float acc = 0.f;
-        if (e < e1) {
+        if (use_pre) {
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                const int u = ug + q * G;
+                if (u < U) acc += s_phi[u] * pre[q];
+            }
+        } else if (e < e1) {
             int u = ug;
             for (; u + 7 * G < U; u += 8 * G) {  // 8 independent row reads in flight
                 float v[8];
@@ -194,6 +222,28 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     const int lane = t & 63, wave = t >> 6;
     const float* ctx = g.ctx + (size_t)b * U * E;
 
+    // Everything that does not depend on the incoming gradient is requested first: this wave's context rows
+    // (for dphi) and this thread's column of the projection matrix (for dh1).  One round trip instead of a
+    // chain of four dependent ones.
+    constexpr int NWB = ATTB_THREADS / 64;
+    constexpr int RPW = 16, SEG = 4;  // rows per wave / 64-float segments per row covered by the preload
+    const bool use_pre = (U <= NWB * RPW) && (E <= 64 * SEG) && !(g.dbg & 1);
+    float cpre[RPW][SEG];
+    if (use_pre) {
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int u = wave + q * NWB;
+#pragma unroll
+            for (int sg = 0; sg < SEG; ++sg) {
+                const int e = lane + 64 * sg;
+                cpre[q][sg] = (u < U && e < E) ? ctx[(size_t)u * E + e] : 0.f;
+            }
+        }
+    }
+    constexpr int WPRE = 32;
+    const bool use_wpre = (H <= ATTB_THREADS) && (3 * A <= WPRE) && !(g.dbg & 4);
+    float wpre[WPRE];
+
     for (int e = t; e < E; e += ATTB_THREADS) {
         float v = g.dw[(size_t)b * g.lddw + e];
         if (g.dw2) {
@@ -210,8 +260,23 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     __syncthreads();
 
     // dphi[u] = sum_e dw[e] ctx[u][e]: one wave per u, lanes over e (coalesced row reads).
-    constexpr int NWB = ATTB_THREADS / 64;
     if (g.dbg & 1) { for (int u = t; u < U; u += ATTB_THREADS) s_dphi[u] = 0.01f; } else
+    if (use_pre) {
+        float dseg[SEG];
+#pragma unroll
+        for (int sg = 0; sg < SEG; ++sg) dseg[sg] = (lane + 64 * sg < E) ? s_dw[lane + 64 * sg] : 0.f;
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int u = wave + q * NWB;
+            float acc = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < SEG; ++sg) acc += dseg[sg] * cpre[q][sg];
+            if (u < U) {  // wave-uniform
+                const float r = wave_sum(acc);
+                if (lane == 0) s_dphi[u] = r;
+            }
+        }
+    } else
     for (int u0 = wave * 4; u0 < U; u0 += NWB * 4) {  // 4 context rows in flight per wave
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int e = lane; e < E; e += 64) {
@@ -229,6 +294,13 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
         }
     }
     __syncthreads();
+
+    // The context registers are dead now: request this thread's column of the projection matrix (used by the
+    // last phase) so that its latency hides behind the reductions below.
+    if (use_wpre && t < H) {
+#pragma unroll
+        for (int j = 0; j < WPRE; ++j) wpre[j] = (j < 3 * A) ? g.WattT[(size_t)j * H + t] : 0.f;
+    }
 
     // da, db, dkappa: reduce over u for every mixture j.  Each wave first reduces its lanes with
     // shuffles and parks 3A partial sums in LDS; one barrier later 3A threads add the per-wave rows.
@@ -309,6 +381,16 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     // dh1[b][k] += sum_j dp[j] Watt[k][j]
     float* dh = g.dh1 + (size_t)b * g.lddh;
     if (g.dbg & 4) return;
+    if (use_wpre) {
+        if (t < H) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < WPRE; ++j)
+                if (j < 3 * A) acc += s_dp[j] * wpre[j];
+            dh[t] += acc;
+        }
+        return;
+    }
     for (int k = t; k < H; k += ATTB_THREADS) {
         float acc = 0.f;
 #pragma unroll 6
