@@ -13,6 +13,7 @@
 #include "biggemm.h"
 
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -179,6 +180,138 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
         }
 }
 
+
+// ---- 8-wave variant (512 threads, same 128x128x16 tile): waves as 2 x 4, each 64 x 32 (2 MFMA blocks, 32
+// accumulator VGPRs), twice the waves per CU for the same LDS: the default (PARROT_GEMM_W8=0 selects the 4-wave
+// kernel above).  PMC on the 4-wave kernel: MFMA pipe 56 % busy, waves parked at s_waitcnt/barriers 45 % of
+// their cycles, no LDS bank conflicts -- more resident waves hide those waits.
+template <bool XC>
+__device__ __forceinline__ void bg_load8(const float* __restrict__ p, int x0, int X, int k0, int kend,
+                                         long long sx, long long sk, bool vec, int t, f32x4& v) {
+    v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (XC) {
+        const int xq = t & 31, kr = t >> 5;
+        const int k = k0 + kr, x = x0 + 4 * xq;
+        if (k < kend) {
+            const float* q = p + (long long)k * sk + x;
+            if (vec && x + 3 < X) v = *reinterpret_cast<const f32x4*>(q);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (x + u < X) v[u] = q[u];
+            }
+        }
+    } else {
+        const int x = x0 + (t >> 2), k = k0 + 4 * (t & 3);
+        if (x < X) {
+            const float* q = p + (long long)x * sx + k;
+            if (vec && k + 3 < kend) v = *reinterpret_cast<const f32x4*>(q);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u < kend) v[u] = q[u];
+            }
+        }
+    }
+}
+
+template <bool XC>
+__device__ __forceinline__ void bg_store8(float* __restrict__ s, int t, const f32x4& v) {
+    if (XC) {
+        *reinterpret_cast<f32x4*>(s + (t >> 5) * PITCH + 4 * (t & 31)) = v;
+    } else {
+        const int x = t >> 2, kq = t & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[(4 * kq + u) * PITCH + x] = v[u];
+    }
+}
+
+template <bool AXC, bool BXC>
+__global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * PITCH];
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8;
+        const int xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int batch = z / a.splitk, ks = z % a.splitk;
+    int kchunk = (a.K + a.splitk - 1) / a.splitk;
+    kchunk = (kchunk + BK - 1) / BK * BK;
+    const int kbeg = ks * kchunk;
+    const int kend = min(a.K, kbeg + kchunk);
+    if (kbeg >= kend && ks > 0) return;
+    const float* A = a.A + (long long)batch * a.batchA;
+    const float* B = a.B + (long long)batch * a.batchB;
+    float* C = a.C + (long long)batch * a.batchC;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kk = lane >> 5, li = lane & 31;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    f32x4 ra, rb;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        bg_load8<AXC>(A, m0, a.M, kbeg, kend, a.sam, a.sak, vecA, t, ra);
+        bg_load8<BXC>(B, n0, a.N, kbeg, kend, a.sbn, a.sbk, vecB, t, rb);
+        bg_store8<AXC>(As[0], t, ra);
+        bg_store8<BXC>(Bs[0], t, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            bg_load8<AXC>(A, m0, a.M, kbeg + (kt + 1) * BK, kend, a.sam, a.sak, vecA, t, ra);
+            bg_load8<BXC>(B, n0, a.N, kbeg + (kt + 1) * BK, kend, a.sbn, a.sbk, vecB, t, rb);
+        }
+        const float* as = As[cur] + wm * 64 + li;
+        const float* bs = Bs[cur] + wn * 32 + li;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const int row = (2 * kp + kk) * PITCH;
+            const float a0 = as[row], a1 = as[row + 32];
+            const float b0 = bs[row];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            bg_store8<AXC>(As[cur ^ 1], t, ra);
+            bg_store8<BXC>(Bs[cur ^ 1], t, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + wn * 32 + li;
+        if (n >= a.N) continue;
+        const float bias = (a.bias && ks == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+            if (m >= a.M) continue;
+            float v = a.alpha * acc[i][q] + bias;
+            float* c = C + (long long)m * a.ldc + n;
+            if (a.splitk > 1) {
+                unsafeAtomicAdd(c, v);
+            } else {
+                if (a.accumulate) v += *c;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = tanhf(v);
+                else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+                *c = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int bg_launch(const BgArgs& a, hipStream_t stream) {
@@ -195,6 +328,19 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
     dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
     dim3 block(256);
+    static int w8 = -1;
+    if (w8 < 0) {
+        const char* e = getenv("PARROT_GEMM_W8");
+        w8 = e ? atoi(e) : 1;  // measured on MI355X: 113-124 TFLOP/s vs 87-102 for the 4-wave kernel
+    }
+    if (w8) {
+        dim3 b8(512);
+        if (axc && bxc) hipLaunchKernelGGL((bg_kernel8<true, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel8<true, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel8<false, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((bg_kernel8<false, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        return (int)hipGetLastError();
+    }
     if (axc && bxc) hipLaunchKernelGGL((bg_kernel<true, true>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
     else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel<true, false>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
     else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel<false, true>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
