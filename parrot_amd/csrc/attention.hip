@@ -17,8 +17,10 @@
 // row-segment reads; the tiny projection and the window are recomputed per slice (L2-resident
 // inputs).  Reductions over A happen in-lane, reductions over U / H use wave shuffles + LDS.
 #include "attention.h"
+#include "elementwise.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef ATT_PROJ_UNROLL
 #define ATT_PROJ_UNROLL 8
@@ -207,8 +209,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
 }
 
 // Backward of one step for batch row b (one workgroup per row).
-__global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+__device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* sm) {
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_a = sm;                  // [A]
     float* s_b = s_a + ATT_MAXA;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     float* s_dw = s_red + 24;          // [E]
     float* s_dphi = s_dw + (((E + 3) & ~3) > 16 * 3 * ATT_MAXA ? ((E + 3) & ~3) : 16 * 3 * ATT_MAXA);  // [U]
 
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const float* ctx = g.ctx + (size_t)b * U * E;
 
@@ -399,6 +400,31 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
     }
 }
 
+__global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    att_bwd_row(g, blockIdx.x, sm);
+}
+
+// One launch for the attention backward of layer 0's step AND the elementwise GRU state backward of every layer
+// active in this tick of the backward wavefront (plans.hip): blocks [0, att_rows) take one attention row each
+// and then, with the same threads (thread k updated dh1[b][k] itself), layer 0's state backward for that row;
+// the remaining blocks take one (chain, row) pair of the other layers.  Saves a kernel boundary per step.
+__global__ __launch_bounds__(ATTB_THREADS) void att_state_bwd_kernel(const AttBwdArgs g, const GruStateBwdArgs sa,
+                                                                      int att_rows, int l0_chain) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bx = blockIdx.x;
+    if (bx < att_rows) {
+        att_bwd_row(g, bx, sm);
+        if (l0_chain >= 0) gru_state_bwd_row(sa.chain[l0_chain], bx, sa.H, threadIdx.x, ATTB_THREADS);
+        return;
+    }
+    const int idx = bx - att_rows;
+    int ch = idx / sa.B;
+    const int m = idx % sa.B;
+    if (att_rows > 0 && l0_chain >= 0 && ch >= l0_chain) ++ch;  // skip the chain fused above
+    if (ch < sa.nchain) gru_state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
+}
+
 }  // namespace
 
 static size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + ATT_THREADS); }
@@ -428,6 +454,29 @@ int att_bwd_launch(const AttBwdArgs& gin, hipStream_t stream) {
     const size_t lds = att_bwd_lds(g.U, g.E);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(att_bwd_kernel, dim3(g.B), dim3(ATTB_THREADS), lds, stream, g);
+    return (int)hipGetLastError();
+}
+
+int att_state_bwd_launch(const AttBwdArgs* gin, const GruStateBwdArgs& sa, int l0_chain, hipStream_t stream) {
+    AttBwdArgs g;
+    int att_rows = 0;
+    size_t lds = 0;
+    if (gin) {
+        g = *gin;
+        g.dbg = 0;
+        if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.B != sa.B) return PH_ERR_BADARG;
+        lds = att_bwd_lds(g.U, g.E);
+        if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
+        att_rows = g.B;
+    } else {
+        memset(&g, 0, sizeof(g));
+        l0_chain = -1;
+    }
+    if (sa.nchain < 0 || sa.nchain > 4 || l0_chain >= sa.nchain) return PH_ERR_BADARG;
+    const int others = sa.nchain - ((att_rows > 0 && l0_chain >= 0) ? 1 : 0);
+    const int blocks = att_rows + others * sa.B;
+    if (blocks < 1) return 0;
+    hipLaunchKernelGGL(att_state_bwd_kernel, dim3(blocks), dim3(ATTB_THREADS), lds, stream, g, sa, att_rows, l0_chain);
     return (int)hipGetLastError();
 }
 

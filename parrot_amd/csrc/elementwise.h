@@ -18,6 +18,28 @@ struct GruStateBwdArgs {
     int nchain, B, H;
 };
 
+// Elementwise half of the GRU backward step for row m of one chain (h_t = z*c + (1-z)*h_prev):
+// dC = dh*z*(1-c^2), dG_z = dh*(c-h_prev)*z*(1-z), dh_prev += dh*(1-z).  Threads tid, tid+nthr, ... of the caller.
+__device__ __forceinline__ void gru_state_bwd_row(const GruStateBwdChain& c, int m, int H, int tid, int nthr) {
+    for (int k = tid; k < H; k += nthr) {
+        const size_t i = (size_t)m * H + k;
+        float dh = c.dh[i];
+        if (c.dh2) dh += c.dh2[i];
+        const float hp = c.hprev[i];
+        float dhp_direct = 0.f;
+        if (c.mask) {
+            const float mk = c.mask[m];
+            dhp_direct = dh * (1.f - mk);
+            dh *= mk;
+        }
+        const float z = c.z[i];
+        const float cc = c.c[i];
+        c.dC[i] = dh * z * (1.f - cc * cc);
+        c.dG[(size_t)m * 2 * H + k] = dh * (cc - hp) * z * (1.f - z);
+        c.dhprev[i] += dh * (1.f - z) + dhp_direct;
+    }
+}
+
 int gru_state_bwd_launch(const GruStateBwdArgs& g, hipStream_t stream);
 int colsum_launch(const float* x, long long M, int N, int ld, float* out, int accumulate, hipStream_t stream);
 int sumsq_launch(const float* x, size_t n, float* out, hipStream_t stream);

@@ -10,26 +10,8 @@ namespace {
 // dh: total gradient wrt h_t. Emits dC = dh*z*(1-c^2), dGz = dh*(c-hp)*z*(1-z),
 // and accumulates dh_prev += dh*(1-z).   (h_t = z*c + (1-z)*hp)
 __global__ __launch_bounds__(256) void gru_state_bwd_kernel(const GruStateBwdArgs g) {
-    const int ch = blockIdx.y;
-    const GruStateBwdChain& c = g.chain[ch];
-    const size_t n = (size_t)g.B * g.H;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int m = (int)(i / g.H), k = (int)(i % g.H);
-        float dh = c.dh[(size_t)m * g.H + k];
-        if (c.dh2) dh += c.dh2[(size_t)m * g.H + k];
-        const float hp = c.hprev[(size_t)m * g.H + k];
-        float dhp_direct = 0.f;
-        if (c.mask) {
-            const float mk = c.mask[m];
-            dhp_direct = dh * (1.f - mk);
-            dh *= mk;
-        }
-        const float z = c.z[(size_t)m * g.H + k];
-        const float cc = c.c[(size_t)m * g.H + k];
-        c.dC[(size_t)m * g.H + k] = dh * z * (1.f - cc * cc);
-        c.dG[(size_t)m * 2 * g.H + k] = dh * (cc - hp) * z * (1.f - z);
-        c.dhprev[(size_t)m * g.H + k] += dh * (1.f - z) + dhp_direct;
-    }
+    const GruStateBwdChain& c = g.chain[blockIdx.y];
+    for (int m = blockIdx.x; m < g.B; m += gridDim.x) gru_state_bwd_row(c, m, g.H, threadIdx.x, 256);
 }
 
 // out[n] (+)= sum_m x[m*ld + n]
@@ -287,9 +269,7 @@ int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat
 
 int gru_state_bwd_launch(const GruStateBwdArgs& g, hipStream_t stream) {
     if (g.nchain < 1 || g.nchain > 4) return PH_ERR_BADARG;
-    const size_t n = (size_t)g.B * g.H;
-    int bx = (int)((n + 255) / 256);
-    if (bx > 1024) bx = 1024;
+    const int bx = g.B < 1024 ? g.B : 1024;  // one row per block
     hipLaunchKernelGGL(gru_state_bwd_kernel, dim3(bx, g.nchain), dim3(256), 0, stream, g);
     return (int)hipGetLastError();
 }

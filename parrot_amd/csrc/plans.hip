@@ -370,8 +370,9 @@ struct DecoderPlan : PlanBase {
             int tl[PARROT_MAX_LAYERS];
             for (int l = 0; l < d.L; ++l) tl[l] = d.T - 1 - (q - (d.L - 1 - l));
             const int t0 = tl[0];
-            if (t0 >= 0 && t0 < d.T) {
-                AttBwdArgs g;
+            const bool att_on = t0 >= 0 && t0 < d.T;
+            AttBwdArgs g;
+            if (att_on) {
                 g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
                 g.ctx = d.ctx;
                 g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
@@ -381,7 +382,8 @@ struct DecoderPlan : PlanBase {
                 g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
                 g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
                 g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
-                PL_TRY(att_bwd_launch(g, st));
+                g.dbg = 0;
+                if (d.cell == 1) PL_TRY(att_bwd_launch(g, st));  // GRU: fused with the state backward below
             }
             if (d.cell == 1) {
                 SkJob jl[SK_MAXJOB];
@@ -481,7 +483,8 @@ struct DecoderPlan : PlanBase {
                 }
             }
             if (ga.nchain == 0) continue;
-            PL_TRY(gru_state_bwd_launch(ga, st));
+            // layer 0's chain (if active) is the last one added; attention + all state updates in one launch
+            PL_TRY(att_state_bwd_launch(att_on ? &g : nullptr, ga, att_on ? ga.nchain - 1 : -1, st));
             PL_TRY(launch_jobs(jx, nx, st));
             PL_TRY(launch_jobs(jy, ny, st));
         }
