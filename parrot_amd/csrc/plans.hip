@@ -213,6 +213,7 @@ struct DecoderPlan : PlanBase {
 
     int enqueue(int which, hipStream_t s) override {
         if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
+        if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
         return which == 0 ? fwd(s) : bwd(s);
     }
 
@@ -225,7 +226,7 @@ struct DecoderPlan : PlanBase {
             if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
         if (want < 0) want = 0;
         if (d.layer_norm && d.L >= 2) want = 2;  // the in-scan normalisations only exist on the pipeline
-        if (want == 2 && !pipe_ok) want = 0;
+        if (want >= 2 && !pipe_ok) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
         schedule = want;
         const char* c = getenv("PARROT_CHUNK");
@@ -268,7 +269,7 @@ struct DecoderPlan : PlanBase {
 
     // The additive-input buffer of layer l is live when the caller filled it (seq_init bit) or when the
     // pipeline schedule batches the lower layers' projections into it.
-    bool has_seq(int l, const float* p) const { return p && (((d.seq_init >> l) & 1) || (schedule == 2 && l > 0)); }
+    bool has_seq(int l, const float* p) const { return p && (((d.seq_init >> l) & 1) || (schedule >= 2 && l > 0)); }
 
     void gates_job(SkJob& j, int l, int t) const {
         const size_t BH = (size_t)d.B * d.H;
@@ -681,6 +682,167 @@ struct DecoderPlan : PlanBase {
             PL_TRY(launch_jobs(jy, ny, st));
         }
         if (l > 0) PL_TRY(hoist_bwd(l, t0, t1, st));
+        return 0;
+    }
+
+    // ---- schedule 3: skewed wavefront with hoisting -------------------------------------------------
+    // Merged launches as in schedule 0, but layer l lags layer l-1 by one CHUNK of steps instead of one step.
+    // When layer l-1 has finished a chunk, the Fork projections of its outputs (and of w) into layer l are taken
+    // for the whole chunk by the LDS-tiled GEMM (hoist_fwd), so every per-step job keeps only the layer's own
+    // recurrent block (+ w_{t-1} for layer 0): the slowest workgroups of a merged launch shrink from
+    // K = H+E+lH to K <= H+E, and ~36 % of the step-kernel flops move to a kernel that runs at 115+ TFLOP/s.
+    // One stream, one graph; costs (L-1) extra chunks of (light) ticks at the ends.
+    int fwd_skew(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H;
+        const int C = ceil_div(d.T, chunk);
+        for (int sc = 0; sc < C + d.L - 1; ++sc) {
+            for (int l = 1; l < d.L; ++l) {
+                const int c = sc - l;
+                if (c >= 0 && c < C) PL_TRY(hoist_fwd(l, c * chunk, (c + 1) * chunk < d.T ? (c + 1) * chunk : d.T, st));
+            }
+            for (int s = 0; s < chunk; ++s) {
+                SkJob jobs[PARROT_MAX_LAYERS];
+                int n = 0, t0 = -1;
+                for (int l = 0; l < d.L; ++l) {
+                    const int c = sc - l, t = c * chunk + s;
+                    if (c < 0 || c >= C || t >= d.T) continue;
+                    if (l == 0) t0 = t;
+                    if (d.cell == 1) {
+                        lstm_job(jobs[n], l, t);
+                        own_segs(jobs[n], l, t, d.h[l] + t * BH, 0, 4 * d.H);
+                    } else {
+                        gates_job(jobs[n], l, t);
+                        own_segs(jobs[n], l, t, d.h[l] + t * BH, 0, 2 * d.H);
+                    }
+                    ++n;
+                }
+                if (n == 0) continue;
+                PL_TRY(launch_jobs(jobs, n, st));
+                if (d.cell == 0) {
+                    n = 0;
+                    for (int l = 0; l < d.L; ++l) {
+                        const int c = sc - l, t = c * chunk + s;
+                        if (c < 0 || c >= C || t >= d.T) continue;
+                        cand_job(jobs[n], l, t);
+                        own_segs(jobs[n], l, t, d.rh[l] + t * BH, 1, d.H);
+                        ++n;
+                    }
+                    PL_TRY(launch_jobs(jobs, n, st));
+                }
+                if (t0 >= 0) PL_TRY(att_fwd_step(t0, st));
+            }
+        }
+        return 0;
+    }
+
+    int bwd_skew(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+        const int H = d.H, E = d.E;
+        const int C = ceil_div(d.T, chunk);
+        for (int sc = 0; sc < C + d.L - 1; ++sc) {
+            int cl[PARROT_MAX_LAYERS];
+            for (int l = 0; l < d.L; ++l) cl[l] = C - 1 - (sc - (d.L - 1 - l));  // upper layers lead
+            for (int s = chunk - 1; s >= 0; --s) {
+                int tl[PARROT_MAX_LAYERS];
+                for (int l = 0; l < d.L; ++l) {
+                    const int t = cl[l] * chunk + s;
+                    tl[l] = (cl[l] >= 0 && cl[l] < C && t < d.T) ? t : -1;
+                }
+                const int t0 = tl[0];
+                AttBwdArgs g;
+                if (t0 >= 0) {
+                    g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
+                    g.ctx = d.ctx;
+                    g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
+                    g.kappa = d.kappa + (t0 + 1) * BA; g.kappa_prev = d.kappa + t0 * BA;
+                    g.WattT = d.WattT;
+                    g.dkappa = d.dkappa;
+                    g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
+                    g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
+                    g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
+                    g.dbg = 0;
+                    if (d.cell == 1) PL_TRY(att_bwd_launch(g, st));
+                }
+                GruStateBwdArgs ga;
+                ga.nchain = 0; ga.B = d.B; ga.H = H;
+                SkJob jx[PARROT_MAX_LAYERS], jy[2 * PARROT_MAX_LAYERS];
+                int nx = 0, ny = 0;
+                for (int l = d.L - 1; l >= 0; --l) {
+                    const int t = tl[l];
+                    if (t < 0) continue;
+                    const float* dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
+                    if (d.cell == 1) {
+                        float* dP = d.dG[l] + (size_t)t * 4 * BH;
+                        PL_TRY(lstm_state_bwd_launch(d.dh[l] + (t + 1) * BH, dh2, d.dcell[l],
+                                                     d.gate4[l] + (size_t)t * 4 * BH, d.cst[l] + t * BH,
+                                                     d.cst[l] + (t + 1) * BH, dP, d.B, H, st));
+                        SkJob& j = jy[ny++];
+                        sk_job_init(j);
+                        j.nseg = 1;
+                        j.seg[0] = rseg(dP, l, 0, 0, 4 * H);
+                        j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                        j.out = d.dh[l] + t * BH; j.ldo = H;
+                        if (l == 0) {
+                            SkJob& k = jy[ny++];
+                            sk_job_init(k);
+                            k.nseg = 1;
+                            k.seg[0] = rseg(dP, 0, 0, H, 4 * H);
+                            k.M = d.B; k.N = E; k.H = H; k.epi = SK_EPI_LINEAR; k.accumulate = 1;
+                            k.out = d.dw0 + (size_t)t * BE; k.ldo = E;
+                        }
+                        continue;
+                    }
+                    GruStateBwdChain& ch = ga.chain[ga.nchain++];
+                    ch.dh = d.dh[l] + (t + 1) * BH;
+                    ch.dh2 = dh2;
+                    ch.hprev = d.h[l] + t * BH;
+                    ch.z = d.z[l] + t * BH;
+                    ch.c = d.c[l] + t * BH;
+                    ch.mask = nullptr;
+                    ch.dC = d.dC[l] + t * BH;
+                    ch.dG = d.dG[l] + t * 2 * BH;
+                    ch.dhprev = d.dh[l] + t * BH;
+                    SkJob& x = jx[nx++];
+                    sk_job_init(x);
+                    x.nseg = 1;
+                    x.seg[0] = rseg(d.dC[l] + t * BH, l, 1, 0, H);
+                    x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
+                    x.e0 = d.h[l] + t * BH; x.lde0 = H;
+                    x.e1 = d.r[l] + t * BH; x.lde1 = H;
+                    x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
+                    x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
+                    const float* dG = d.dG[l] + t * 2 * BH;
+                    const float* dC = d.dC[l] + t * BH;
+                    {
+                        SkJob& j = jy[ny++];
+                        sk_job_init(j);
+                        j.nseg = 1;
+                        j.seg[0] = rseg(dG, l, 0, 0, 2 * H);
+                        j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                        j.out = d.dh[l] + t * BH; j.ldo = H;
+                    }
+                    if (l == 0) {
+                        SkJob& j = jy[ny++];
+                        sk_job_init(j);
+                        j.nseg = 2;
+                        j.seg[0] = rseg(dG, 0, 0, H, 2 * H);
+                        j.seg[1] = rseg(dC, 0, 1, H, H);
+                        j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
+                        j.out = d.dw0 + (size_t)t * BE; j.ldo = E;
+                    }
+                }
+                if (d.cell == 0) {
+                    if (ga.nchain == 0) continue;
+                    PL_TRY(att_state_bwd_launch(t0 >= 0 ? &g : nullptr, ga, t0 >= 0 ? ga.nchain - 1 : -1, st));
+                    PL_TRY(launch_jobs(jx, nx, st));
+                }
+                if (ny > 0) PL_TRY(launch_jobs(jy, ny, st));
+            }
+            for (int l = 1; l < d.L; ++l) {
+                const int c = cl[l];
+                if (c >= 0 && c < C) PL_TRY(hoist_bwd(l, c * chunk, (c + 1) * chunk < d.T ? (c + 1) * chunk : d.T, st));
+            }
+        }
         return 0;
     }
 

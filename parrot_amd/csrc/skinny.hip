@@ -203,6 +203,47 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue operands (bias, additive input, previous state / gates, accumulate targets) are requested now by
+    // the waves that will run the epilogue: nothing in this launch writes them, and their latency then hides
+    // behind the K loop instead of adding a dependent memory round trip after the reduction.
+    float p_bias = 0.f, p_add[4] = {0.f, 0.f, 0.f, 0.f}, p_e0[4] = {0.f, 0.f, 0.f, 0.f}, p_e1[4] = {0.f, 0.f, 0.f, 0.f},
+          p_oc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tid < MB * NB * 64) {
+        const int blk_ = tid >> 6;
+        const int rb_ = blk_ / NB, tile_ = tile0 + blk_ % NB;
+        const int g_ = lane >> 4, jj_ = lane & 15;
+        const int n_ = sk_col(job.epi, job.H, tile_, jj_);
+        const bool n_ok_ = n_ < N;
+        if (job.bias && n_ok_) p_bias = job.bias[n_];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + rb_ * 16 + 4 * g_ + r;
+            if (m >= M || !n_ok_) continue;
+            if (job.add) p_add[r] = job.add[(size_t)m * job.ld_add + n_];
+            switch (job.epi) {
+                case SK_EPI_LINEAR:
+                    if (job.accumulate == 1) p_oc[r] = job.out[(size_t)m * job.ldo + n_];
+                    break;
+                case SK_EPI_GRU_GATES:
+                    if (n_ >= job.H) p_e0[r] = job.e0[(size_t)m * job.lde0 + n_ - job.H];
+                    break;
+                case SK_EPI_GRU_CAND:
+                    p_e0[r] = job.e0[(size_t)m * job.lde0 + n_];
+                    p_e1[r] = job.e1[(size_t)m * job.lde1 + n_];
+                    break;
+                case SK_EPI_BWD_RH:
+                    p_e0[r] = job.e0[(size_t)m * job.lde0 + n_];
+                    p_e1[r] = job.e1[(size_t)m * job.lde1 + n_];
+                    p_oc[r] = job.o1[(size_t)m * job.ldo1 + n_];
+                    break;
+                case SK_EPI_LSTM:
+                    if ((jj_ >> 2) == 0) p_e1[r] = job.e1[(size_t)m * job.lde1 + n_];
+                    break;
+                default: break;
+            }
+        }
+    }
+
     if (FAST) {
         // One flat sequence of 16-deep chunks over all segments, dealt round-robin to the waves.  The
         // loop body is straight-line code: segment descriptors sit in scalar registers and are picked
@@ -337,7 +378,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
     const int g = lane >> 4, jj = lane & 15;
     const int n = sk_col(job.epi, job.H, tile, jj);
     const bool n_ok = n < N;
-    const float bias = (job.bias && n_ok) ? job.bias[n] : 0.f;
+    const float bias = p_bias;
     const int H = job.H;
 
     if (job.epi == SK_EPI_LSTM) {
@@ -347,8 +388,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + rb * 16 + 4 * g + r;
             const bool ok = (m < M) && n_ok;
-            float pre = v[r] + bias;
-            if (job.add && ok) pre += job.add[(size_t)m * job.ld_add + n];
+            const float pre = v[r] + bias + p_add[r];
             const int q = jj >> 2;
             const float gate = (q == 3) ? tanhf(pre) : ph_sigmoid(pre);
             if (job.o2 && ok) job.o2[(size_t)m * job.ldo2 + n] = gate;  // saved activations [M,4H]
@@ -359,7 +399,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             const float gg = __shfl(gate, src | 12, 64);
             if (q == 0 && ok) {
                 const int j = n;  // q == 0 -> n = hidden index
-                const float cp = job.e1[(size_t)m * job.lde1 + j];
+                const float cp = p_e1[r];
                 const float cn = cp * gf + gg * gi;
                 job.o1[(size_t)m * job.ldo1 + j] = cn;
                 job.out[(size_t)m * job.ldo + j] = tanhf(cn) * go;
@@ -375,8 +415,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         float x = v[r];
         switch (job.epi) {
             case SK_EPI_LINEAR: {
-                x += bias;
-                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                x += bias + p_add[r];
                 if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
@@ -384,28 +423,26 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 if (job.accumulate == 2) {
                     unsafeAtomicAdd(o, x);  // another job of the same launch adds into this tile too
                 } else {
-                    if (job.accumulate) x += *o;
+                    if (job.accumulate) x += p_oc[r];
                     *o = x;
                 }
             } break;
             case SK_EPI_GRU_GATES: {
-                x += bias;
-                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                x += bias + p_add[r];
                 const float gt = ph_sigmoid(x);
                 if (n < H) {
                     job.o1[(size_t)m * job.ldo1 + n] = gt;  // update gate z
                 } else {
                     const int j = n - H;
                     job.o2[(size_t)m * job.ldo2 + j] = gt;  // reset gate r
-                    job.out[(size_t)m * job.ldo + j] = gt * job.e0[(size_t)m * job.lde0 + j];
+                    job.out[(size_t)m * job.ldo + j] = gt * p_e0[r];
                 }
             } break;
             case SK_EPI_GRU_CAND: {
-                x += bias;
-                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                x += bias + p_add[r];
                 const float c = tanhf(x);
-                const float z = job.e1[(size_t)m * job.lde1 + n];
-                const float hp = job.e0[(size_t)m * job.lde0 + n];
+                const float z = p_e1[r];
+                const float hp = p_e0[r];
                 float hn = z * c + (1.f - z) * hp;
                 if (job.mask) {
                     const float mk = job.mask[m];
@@ -416,10 +453,10 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             } break;
             case SK_EPI_BWD_RH: {
                 // x = d(r*h_prev)[m][n]
-                const float r_ = job.e1[(size_t)m * job.lde1 + n];
-                const float hp = job.e0[(size_t)m * job.lde0 + n];
+                const float r_ = p_e1[r];
+                const float hp = p_e0[r];
                 job.out[(size_t)m * job.ldo + n] = x * hp * r_ * (1.f - r_);  // dG_r
-                job.o1[(size_t)m * job.ldo1 + n] += x * r_;                   // dh_prev +=
+                job.o1[(size_t)m * job.ldo1 + n] = p_oc[r] + x * r_;          // dh_prev +=
             } break;
             default: break;
         }

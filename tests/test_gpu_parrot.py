@@ -282,11 +282,12 @@ def test_lstm_decoder_sample_model_parity(dev, kw):
 
 
 # ----------------------------------------------------------------------------- scan schedules
-@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("2", "3"), ("2", "50")])
+@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("2", "3"), ("2", "50"), ("3", "3"), ("3", "50")])
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
 def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
-    """The merged-wavefront schedule (0) and the chunked layer pipeline (2; chunk 3 forces several chunks and a
-    ragged last one) are two orders of the same arithmetic: both must match the oracle, eager and graph."""
+    """The merged-wavefront schedule (0), the chunked layer pipeline (2) and the chunk-skewed wavefront with hoisted
+    projections (3) -- chunk 3 forces several chunks and a ragged last one -- are orders of the same arithmetic:
+    all must match the oracle, eager and graph."""
     monkeypatch.setenv("PARROT_SCHEDULE", sched)
     monkeypatch.setenv("PARROT_CHUNK", chunk)
     for use_graph in (False, True):
