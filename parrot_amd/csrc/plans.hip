@@ -202,13 +202,16 @@ struct DecoderPlan : PlanBase {
     ParrotDecoderDesc d;
     int esplit = 1;
 
-    // Schedules: 0 = merged wavefront launches on one stream (default: fastest measured), 1 = stream per
-    // layer with per-step events (experiment), 2 = chunked layer pipeline (PARROT_SCHEDULE=2; needs seq
-    // buffers for the upper layers).  Measured on MI355X, cfg2 (T=800, B=64, H=1024, L=2), fwd/bwd ms:
-    //   0: 56/78   1: 69/105   2 (one graph per piece, chunk 50): 57/94   2 eager launches: 51/79.
-    // The per-step kernels are latency-bound (~12 us for a single layer's K=1024 GEMM, ~24 us for two merged
-    // layers), so splitting the layers apart doubles the number of ~10 us kernels and the second stream
-    // does not buy that back.
+    // Schedules (PARROT_SCHEDULE; 2 and 3 need seq buffers for the upper layers).  cfg2 (T=800, B=64, H=1024, L=2)
+    // on MI355X, fwd/bwd ms at the time each was measured against schedule 0:
+    //   0 merged wavefront launches, one stream (default)                         46 / 60
+    //   1 stream per layer with per-step events in one graph (experiment)         69 / 105  (0: 56 / 78)
+    //   2 chunked layer pipeline, one graph per (layer, chunk) piece, 2 streams   57 / 94   (0: 56 / 78)
+    //   3 chunk-skewed merged wavefront with hoisted projections, one stream      49 / 70   (0: 46 / 60)
+    // The per-step kernels are latency-bound: a merged launch costs ~9 us + ~7.7 us per 1024 of its longest K, so
+    // moving K from the step kernels to batched GEMMs (2, 3) or splitting layers over streams (1, 2) buys less than
+    // the extra kernels / GEMMs cost.  2 and 3 are what layer_norm needs (the projections that must be normalised
+    // are the hoisted ones); layer_norm with L >= 2 therefore runs on 3.
     int schedule = 0, chunk = 50;
 
     int enqueue(int which, hipStream_t s) override {
@@ -225,7 +228,7 @@ struct DecoderPlan : PlanBase {
         for (int l = 1; l < d.L; ++l)
             if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
         if (want < 0) want = 0;
-        if (d.layer_norm && d.L >= 2) want = 2;  // the in-scan normalisations only exist on the pipeline
+        if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
         if (want >= 2 && !pipe_ok) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
         schedule = want;
@@ -1368,7 +1371,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
         p->tiled = all && !(e && atoi(e) == 0);
     }
     if (desc->layer_norm && desc->L >= 2) {
-        bool ok = p->schedule == 2;
+        bool ok = p->schedule >= 2;
         for (int l = 1; l < desc->L && ok; ++l)
             for (int j = 0; j < l; ++j) {
                 const int pj = l * PARROT_MAX_LAYERS + j;
