@@ -49,8 +49,8 @@ struct SkJob {
 
 struct SkLaunch {
     SkJob job[SK_MAXJOB];
-    int njobs;
-    int tile_end[SK_MAXJOB];  // exclusive prefix of 16-column tiles per job
+    int njobs, zmode;  // zmode: grid.z = job index (all jobs have the same number of workgroups)
+    int tile_end[SK_MAXJOB];  // 16-column tiles per job; sk_launch turns it into the prefix of workgroups
 };
 
 // Enqueue one launch on `stream`. Returns hipError_t / PH_ERR_*.

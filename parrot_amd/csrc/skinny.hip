@@ -467,13 +467,20 @@ template <int MB, int NB>
 __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     f32x4* red = reinterpret_cast<f32x4*>(sk_smem);
-    const int bx = blockIdx.x;
-    int j = 0;
+    // Launches whose jobs all have the same number of workgroups use grid.z = job: the descriptor address then
+    // follows from the block id alone and the wave's first scalar loads fetch the job itself.  Otherwise the
+    // workgroups of the jobs are laid out back to back along x and the job is found in the prefix table
+    // (a z-grid sized for the largest job was measured slower there: 59 -> 65 ms backward at cfg2).
+    int j = blockIdx.z, bx = blockIdx.x;
+    if (!L.zmode) {
+        j = 0;
 #pragma unroll
-    for (int q = 0; q < SK_MAXJOB - 1; ++q)
-        if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
-    const int tile0 = (bx - (j > 0 ? L.tile_end[j - 1] : 0)) * NB;  // first 16-column tile of this workgroup
+        for (int q = 0; q < SK_MAXJOB - 1; ++q)
+            if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
+        bx -= (j > 0 ? L.tile_end[j - 1] : 0);
+    }
     const SkJob& job = L.job[j];
+    const int tile0 = bx * NB;  // first 16-column tile of this workgroup
     if (NB > 1 || job.aligned) sk_body<MB, NB, true>(job, tile0, red);  // fast path: branch-free operand fetch
     else sk_body<MB, 1, false>(job, tile0, red);
 }
@@ -676,12 +683,17 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
         best_mb = force_mb; best_nb = force_nb;
     }
     const int mb = best_mb, nb = best_nb;
-    int t = 0;
+    int t = 0, wmax = 0;
+    bool equal = true;
     for (int q = 0; q < L.njobs; ++q) {
-        t += ceil_div(L.tile_end[q], nb);
-        L.tile_end[q] = t;
+        const int w = ceil_div(L.tile_end[q], nb);
+        if (q > 0 && w != wmax) equal = false;
+        wmax = w > wmax ? w : wmax;
+        t += w;
+        L.tile_end[q] = t;  // prefix of workgroups (used when !zmode)
     }
-    dim3 grid(t, ceil_div(maxM, 16 * mb));
+    L.zmode = equal ? 1 : 0;
+    dim3 grid(equal ? wmax : t, ceil_div(maxM, 16 * mb), equal ? L.njobs : 1);
     const size_t lds = (size_t)SK_NW * mb * nb * 64 * sizeof(f32x4);
     switch (mb * 10 + nb) {
         case 11: sk_dispatch<1, 1>(L, grid, lds, stream); break;
