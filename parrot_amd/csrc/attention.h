@@ -14,6 +14,7 @@ struct AttFwdArgs {
     int B, H, A, U, E, esplit, att_type;
     float eps, alignment, sharpening, timing;
     int dbg;  // development only: bit0 skip projection, bit1 skip phi, bit2 skip weighted sum
+    int dense;  // set by att_fwd_launch (PARROT_ATT_DENSE=1): read all U context rows, also those with phi == 0
 };
 
 struct AttBwdArgs {

@@ -145,6 +145,10 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
         s_a[t] = av;
         s_b[t] = bv;
         s_k[t] = kv;
+        if (t == 0) {  // support of the window: [lo, hi] = positions whose phi is not exactly zero
+            reinterpret_cast<int*>(s_red)[6] = U;
+            reinterpret_cast<int*>(s_red)[7] = -1;
+        }
         if (es == 0) {
             g.a_out[(size_t)b * A + t] = av;
             g.b_out[(size_t)b * A + t] = bv;
@@ -171,9 +175,21 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
             }
         }
         s_phi[u] = ph;
+        if (ph != 0.f) {
+            atomicMin(&reinterpret_cast<int*>(s_red)[6], u);
+            atomicMax(&reinterpret_cast<int*>(s_red)[7], u);
+        }
         if (es == 0) g.phi_out[(size_t)b * U + u] = ph;
     }
     __syncthreads();
+    // The Gaussian window underflows to exactly 0.0f a few positions away from kappa (exp(-b d^2), fp32), and a
+    // zero weight adds exactly nothing to w: rows outside [lo, hi] are not read.  Same sums, same order, minus
+    // the +0 terms -- bit-identical to reading all U rows (PARROT_ATT_DENSE=1 reads them all).
+    int u_lo = 0, u_hi = U - 1;
+    if (!g.dense && !(g.dbg & 2)) {
+        u_lo = reinterpret_cast<int*>(s_red)[6];
+        u_hi = reinterpret_cast<int*>(s_red)[7];
+    }
 
     // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
     if (g.dbg & 4) return;
@@ -186,16 +202,22 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
                 const int u = ug + q * G;
                 if (u < U) acc += s_phi[u] * pre[q];
             }
-        } else if (e < e1) {
-            int u = ug;
-            for (; u + 7 * G < U; u += 8 * G) {  // 8 independent row reads in flight
+        } else if (e < e1 && u_lo <= u_hi) {
+            // rows of this thread: u = ug (mod G), as in the dense walk, starting at the first one >= u_lo
+            int u = u_lo + ((ug - u_lo % G + G) % G);
+            for (; u + 7 * G <= u_hi; u += 8 * G) {  // 8 independent row reads in flight
                 float v[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc += s_phi[u + q * G] * v[q];
             }
-            for (; u < U; u += G) acc += s_phi[u] * ctx[(size_t)u * E + e];
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (u + q * G <= u_hi) ? ctx[(size_t)(u + q * G) * E + e] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (u + q * G <= u_hi) acc += s_phi[u + q * G] * v[q];
         }
         __syncthreads();
         s_acc[t] = acc;
@@ -438,6 +460,9 @@ int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("PARROT_ATT_DBG"); dbg = e ? atoi(e) : 0; }
     g.dbg = dbg;
+    static int dense = -1;
+    if (dense < 0) { const char* e = getenv("PARROT_ATT_DENSE"); dense = e ? atoi(e) : 0; }
+    g.dense = dense;
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.esplit < 1) return PH_ERR_BADARG;
     const size_t lds = att_fwd_lds(g.U);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;

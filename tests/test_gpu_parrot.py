@@ -330,3 +330,48 @@ def test_layer_norm_sample_model_parity(dev, kw):
     for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
         assert_close(o, r, 3e-4, n)
     m.close()
+
+
+# ----------------------------------------------------------------------------- frozen vectors
+def test_hip_path_matches_frozen_oracle_vectors(dev):
+    """HIP path vs tests/golden/parrot_golden.npz (oracle-generated, see make_parrot_golden.py): cost, frames, window
+    state, a handful of gradients and the decode loop for GRU / GMM / LSTM / layer_norm configurations."""
+    import importlib.util
+    import os
+    import numpy as np
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(here, "golden", "make_parrot_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = np.load(os.path.join(here, "golden", "parrot_golden.npz"))
+    for name, kw in mk.CASES.items():
+        full = dict(mk.SMALL, **kw)
+        cfg = R.default_config(**full)
+        p = R.init_params(cfg, seed=11, scale_by_fan_in=True)
+        m = Parrot(device=dev, use_graph=True, **full).allocate()
+        m.set_parameter_values(p)
+        feat, fm, lab, lm, spk = make_batch(cfg, 6, 4, 9, seed=21, ragged=True, speaker=cfg['use_speaker'])
+        m.zero_grad()
+        cost, upd, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev),
+                                          None if spk is None else spk.to(dev), 1, 4)
+        cost.backward()
+        g = lambda k: torch.from_numpy(gold[f"{name}|{k}"])
+        assert_close(cost, g('cost'), 1e-4, f"{name} cost")
+        if cfg['which_cost'] == 'MSE':
+            assert_close(av[0], g('next_x'), 1e-4, f"{name} frames")
+        assert_close(av[1], g('kappa'), 1e-4, f"{name} kappa")
+        assert_close(av[2], g('w'), 1e-4, f"{name} w")
+        assert_close(av[4], g('phi'), 1e-4, f"{name} phi")
+        grads = m.get_gradient_dict()
+        for k in mk.GRAD_KEYS:
+            assert_close(grads[k], g('grad:' + k), 2e-3, f"{name} grad {k}")
+        S = 5
+        gen = torch.Generator().manual_seed(5)
+        unif = torch.rand(S, 4, generator=gen, dtype=torch.float64)
+        noise = torch.randn(S, 4, cfg['output_dim'], generator=gen, dtype=torch.float64)
+        outs = m.sample_model_device(lab, lm.float(), spk, 4, S, unif=unif.float(), noise=noise.float())
+        assert_close(outs[0], g('sample_x'), 3e-4, f"{name} sample_x")
+        assert_close(outs[1], g('sample_k'), 3e-4, f"{name} sample_k")
+        m.close()

@@ -95,3 +95,19 @@ def test_param_shapes_count_matches_survey():
         H, E, A = 1024, 256, 10
         n = sum((H + E + l * H) * 3 * H for l in range(L)) + 3 * A * H
         assert abs(n - expect) / expect < 0.01
+
+
+def test_parrot_oracle_reproduces_frozen_vectors():
+    """tests/golden/parrot_golden.npz was written by tests/golden/make_parrot_golden.py from this oracle: any
+    later edit of oracle/parrot_ref.py that changes its arithmetic shows up here (GRU, GMM, LSTM, layer_norm)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(here, "golden", "make_parrot_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = np.load(os.path.join(here, "golden", "parrot_golden.npz"))
+    for name, kw in mk.CASES.items():
+        out = mk.run_case(kw)
+        for k, v in out.items():
+            np.testing.assert_allclose(v, gold[f"{name}|{k}"], rtol=1e-10, atol=1e-12, err_msg=f"{name}|{k}")
