@@ -228,6 +228,10 @@ typedef struct ParrotDecoderDesc {
     const float* Wc_f[PARROT_MAX_LAYERS];
     const float* Wg_r[PARROT_MAX_LAYERS];
     const float* Wc_r[PARROT_MAX_LAYERS];
+    /* Optional [T,B,2] int32 scratch: per step and row the first / last context position whose window weight phi is
+     * not exactly 0.0f (written by seq_fwd, read by seq_bwd).  Rows outside it are multiplied by exact zeros in
+     * model.py:675-690 and its gradient, so the scan does not read them; NULL: all U rows are read. */
+    int* att_sup;
 } ParrotDecoderDesc;
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);

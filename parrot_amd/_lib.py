@@ -68,6 +68,7 @@ class DecoderDesc(C.Structure):
         ("ln_sg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_sc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
         ("Wg_f", C.c_void_p * MAX_LAYERS), ("Wc_f", C.c_void_p * MAX_LAYERS),
         ("Wg_r", C.c_void_p * MAX_LAYERS), ("Wc_r", C.c_void_p * MAX_LAYERS),
+        ("att_sup", C.c_void_p),
     ]
 
 

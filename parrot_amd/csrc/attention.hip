@@ -190,6 +190,10 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
         u_lo = reinterpret_cast<int*>(s_red)[6];
         u_hi = reinterpret_cast<int*>(s_red)[7];
     }
+    if (g.sup_out && es == 0 && t == 0) {  // saved for the backward step (dense mode saves the full range)
+        g.sup_out[2 * b] = u_lo;
+        g.sup_out[2 * b + 1] = u_hi;
+    }
 
     // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
     if (g.dbg & 4) return;
@@ -251,6 +255,13 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
     constexpr int NWB = ATTB_THREADS / 64;
     constexpr int RPW = 16, SEG = 4;  // rows per wave / 64-float segments per row covered by the preload
     const bool use_pre = (U <= NWB * RPW) && (E <= 64 * SEG) && !(g.dbg & 1);
+    // Support of the window saved by the forward step: outside [u_lo, u_hi] every exp(-b (kappa-u)^2) is exactly
+    // 0.0f, so dphi[u] is multiplied by zero in all three mixture gradients and its context row is not needed.
+    int u_lo = 0, u_hi = U - 1;
+    if (g.sup) {
+        u_lo = g.sup[2 * b];
+        u_hi = g.sup[2 * b + 1];
+    }
     float cpre[RPW][SEG];
     if (use_pre) {
 #pragma unroll
@@ -259,7 +270,7 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
 #pragma unroll
             for (int sg = 0; sg < SEG; ++sg) {
                 const int e = lane + 64 * sg;
-                cpre[q][sg] = (u < U && e < E) ? ctx[(size_t)u * E + e] : 0.f;
+                cpre[q][sg] = (u >= u_lo && u <= u_hi && e < E) ? ctx[(size_t)u * E + e] : 0.f;
             }
         }
     }
@@ -295,7 +306,7 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
 #pragma unroll
             for (int sg = 0; sg < SEG; ++sg) acc += dseg[sg] * cpre[q][sg];
             if (u < U) {  // wave-uniform
-                const float r = wave_sum(acc);
+                const float r = (u >= u_lo && u <= u_hi) ? wave_sum(acc) : 0.f;
                 if (lane == 0) s_dphi[u] = r;
             }
         }
@@ -325,16 +336,17 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
         for (int j = 0; j < WPRE; ++j) wpre[j] = (j < 3 * A) ? g.WattT[(size_t)j * H + t] : 0.f;
     }
 
-    // da, db, dkappa: reduce over u for every mixture j.  Each wave first reduces its lanes with
-    // shuffles and parks 3A partial sums in LDS; one barrier later 3A threads add the per-wave rows.
-    // (s_part reuses the dw staging area, which is dead after the dphi pass.)
+    // da, db, dkappa: reduce over the support of the window for every mixture j, one wave per mixture
+    // (lanes over u, three wave reductions per mixture, results straight into s_dp).
     {
         constexpr int NWB2 = ATTB_THREADS / 64;
-        float* s_part = s_dw;  // needs NWB2 * 3A floats <= E (checked on the host)
-        for (int j = 0; j < ((g.dbg & 2) ? 0 : A); ++j) {
+        if (g.dbg & 2) {
+            if (t < 3 * A) s_dp[t] = 0.f;
+        } else
+        for (int j = wave; j < A; j += NWB2) {
             const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
             float da = 0.f, db = 0.f, dk = 0.f;
-            for (int u = t; u < U; u += ATTB_THREADS) {
+            for (int u = u_lo + lane; u <= u_hi; u += 64) {
                 const float d = kj - (float)u;
                 const float dph = s_dphi[u];
                 if (g.att_type == 1) {
@@ -355,17 +367,10 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
             db = wave_sum(db);
             dk = wave_sum(dk);
             if (lane == 0) {
-                s_part[wave * 3 * A + j] = da;
-                s_part[wave * 3 * A + A + j] = db;
-                s_part[wave * 3 * A + 2 * A + j] = dk;
+                s_dp[j] = da;            // [da | db | dkappa (without carry)]
+                s_dp[A + j] = db;
+                s_dp[2 * A + j] = dk;
             }
-        }
-        __syncthreads();
-        if (t < 3 * A) {
-            float acc = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWB2; ++w) acc += s_part[w * 3 * A + t];
-            s_dp[t] = acc;  // [da | db | dkappa (without carry)]
         }
     }
     __syncthreads();
@@ -483,12 +488,14 @@ int att_bwd_launch(const AttBwdArgs& gin, hipStream_t stream) {
 }
 
 int att_state_bwd_launch(const AttBwdArgs* gin, const GruStateBwdArgs& sa, int l0_chain, hipStream_t stream) {
-    AttBwdArgs g;
+    AttBwdArgs g{};
     int att_rows = 0;
     size_t lds = 0;
     if (gin) {
         g = *gin;
-        g.dbg = 0;
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("PARROT_ATTB_DBG"); dbg = e ? atoi(e) : 0; }
+        g.dbg = dbg;
         if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.B != sa.B) return PH_ERR_BADARG;
         lds = att_bwd_lds(g.U, g.E);
         if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;

@@ -177,7 +177,7 @@ int parrot_gmm_attention_fwd(const float* h1, const float* WattT, const float* b
                              int H, int A, int U, int E, int att_type, float eps, float alignment,
                              float sharpening, float timing, void* stream) {
     if (!h1 || !WattT || !kappa_prev || !ctx || !a || !b || !kappa || !phi || !w) return PARROT_ERR_BADARG;
-    AttFwdArgs g;
+    AttFwdArgs g{};
     g.h1 = h1; g.ldh = H; g.WattT = WattT; g.batt = batt; g.kappa_prev = kappa_prev; g.ctx = ctx;
     g.a_out = a; g.b_out = b; g.kappa_out = kappa; g.phi_out = phi; g.w_out = w; g.ldw = E;
     g.B = B; g.H = H; g.A = A; g.U = U; g.E = E; g.esplit = att_default_esplit(B, E);
@@ -191,7 +191,7 @@ int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, 
                              void* stream) {
     if (!dw || !ctx || !a || !b || !kappa || !kappa_prev || !WattT || !dkappa || !dp || !dh1)
         return PARROT_ERR_BADARG;
-    AttBwdArgs g;
+    AttBwdArgs g{};
     g.dw = const_cast<float*>(dw); g.dw2 = nullptr; g.lddw = E; g.ctx = ctx; g.a = a; g.b = b; g.kappa = kappa; g.kappa_prev = kappa_prev;
     g.WattT = WattT; g.dkappa = dkappa; g.dp_out = dp; g.dh1 = dh1; g.lddh = H;
     g.B = B; g.H = H; g.A = A; g.U = U; g.E = E; g.att_type = att_type; g.eps = eps;

@@ -315,7 +315,7 @@ struct DecoderPlan : PlanBase {
 
     int att_fwd_step(int t, hipStream_t st) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
-        AttFwdArgs g;
+        AttFwdArgs g{};
         g.h1 = d.h[0] + (t + 1) * BH; g.ldh = d.H;
         g.WattT = d.WattT; g.batt = d.batt;
         g.kappa_prev = d.kappa + t * BA;
@@ -326,6 +326,7 @@ struct DecoderPlan : PlanBase {
         g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.esplit = esplit;
         g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
         g.sharpening = d.sharpening; g.timing = d.timing;
+        g.sup_out = d.att_sup ? d.att_sup + (size_t)t * d.B * 2 : nullptr;
         return att_fwd_launch(g, st);
     }
 
@@ -375,7 +376,7 @@ struct DecoderPlan : PlanBase {
             for (int l = 0; l < d.L; ++l) tl[l] = d.T - 1 - (q - (d.L - 1 - l));
             const int t0 = tl[0];
             const bool att_on = t0 >= 0 && t0 < d.T;
-            AttBwdArgs g;
+            AttBwdArgs g{};
             if (att_on) {
                 g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
                 g.ctx = d.ctx;
@@ -384,6 +385,7 @@ struct DecoderPlan : PlanBase {
                 g.WattT = d.WattT;
                 g.dkappa = d.dkappa;
                 g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
+        g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
                 g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
                 g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
                 g.dbg = 0;
@@ -596,7 +598,7 @@ struct DecoderPlan : PlanBase {
 
     int att_bwd_step(int t0, hipStream_t st) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
-        AttBwdArgs g;
+        AttBwdArgs g{};
         g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = d.E;
         g.ctx = d.ctx;
         g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
@@ -604,6 +606,7 @@ struct DecoderPlan : PlanBase {
         g.WattT = d.WattT;
         g.dkappa = d.dkappa;
         g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
+        g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
         g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = d.H;
         g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
         return att_bwd_launch(g, st);
@@ -752,7 +755,7 @@ struct DecoderPlan : PlanBase {
                     tl[l] = (cl[l] >= 0 && cl[l] < C && t < d.T) ? t : -1;
                 }
                 const int t0 = tl[0];
-                AttBwdArgs g;
+                AttBwdArgs g{};
                 if (t0 >= 0) {
                     g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
                     g.ctx = d.ctx;
@@ -761,6 +764,7 @@ struct DecoderPlan : PlanBase {
                     g.WattT = d.WattT;
                     g.dkappa = d.dkappa;
                     g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
+        g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
                     g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
                     g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
                     g.dbg = 0;
@@ -1009,7 +1013,7 @@ struct DecoderPlan : PlanBase {
                 hipStream_t st = stream_of(l, main);
                 if (l + 1 < d.L) PL_TRY((int)hipStreamWaitEvent(st, done[l + 1], 0));
                 if (l == 0) {
-                    AttBwdArgs g;
+                    AttBwdArgs g{};
                     g.dw = d.dw + (t + 1) * BE; g.dw2 = d.dw0 + (t + 1) * BE; g.lddw = E;
                     g.ctx = d.ctx;
                     g.a = d.a + t * BA; g.b = d.b + t * BA;
@@ -1017,6 +1021,7 @@ struct DecoderPlan : PlanBase {
                     g.WattT = d.WattT;
                     g.dkappa = d.dkappa;
                     g.dp_out = d.dp + (size_t)t * d.B * 3 * d.A;
+                    g.sup = d.att_sup ? d.att_sup + (size_t)t * d.B * 2 : nullptr;
                     g.dh1 = d.dh[0] + (t + 1) * BH; g.lddh = H;
                     g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
                     PL_TRY(att_bwd_launch(g, st));
@@ -1247,7 +1252,7 @@ struct SamplePlan : PlanBase {
                 }
 
                 if (l == 0) {
-                    AttFwdArgs g;
+                    AttFwdArgs g{};
                     g.h1 = d.h[0] + nxt * BH; g.ldh = H;
                     g.WattT = d.WattT; g.batt = d.batt;
                     g.kappa_prev = d.kappa + t * BA;

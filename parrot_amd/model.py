@@ -505,6 +505,8 @@ class Parrot(Brick):
                 for key, wd, suf, mat, rec in self._groups:
                     getattr(d, f'W{key}_f')[l] = tl[(l, key, 'f')].data_ptr()
                     getattr(d, f'W{key}_r')[l] = tl[(l, key, 'r')].data_ptr()
+        ws['att_sup'] = torch.zeros(T, B, 2, device=self._dev(), dtype=torch.int32)
+        d.att_sup = ws['att_sup'].data_ptr()
         d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
         for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dw0', 'dkappa', 'dp'):
             setattr(d, n, ws[n].data_ptr())
