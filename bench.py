@@ -239,7 +239,11 @@ def main():
                                    "batch=64 per GPU, T_enc=200, T_dec=800, fp32, N(0,0.01) init",
                        "layers": a.L, "hidden": a.H, "batch_per_gpu": a.B, "global_batch": a.B * world,
                        "T_enc": a.U, "T_dec": a.T, "parallelism": f"dp{world}",
-                       "params": int(model.store.numel)},
+                       "params": int(model.store.numel),
+                       "attention_rows": ("all U context rows (PARROT_ATT_DENSE=1)"
+                                          if os.environ.get("PARROT_ATT_DENSE", "0") not in ("", "0") else
+                                          "rows whose window weight phi is exactly 0.0f are not read "
+                                          "(bit-identical results; PARROT_ATT_DENSE=1 reads all)")},
             "final_cost": round(final_cost, 5),
             "roofline": roof, "cpu_baseline": cpu,
         }
