@@ -18,10 +18,11 @@ ap.add_argument("--H", type=int, default=1024)
 ap.add_argument("--L", type=int, default=2)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--cell", default="gru")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 m = Parrot(device=dev, num_layers=a.L, rnn_h_dim=a.H, readouts_dim=a.H, encoder_type='bidirectional',
-           use_graph=bool(a.graph)).initialize()
+           use_graph=bool(a.graph), cell_type=a.cell).initialize()
 g = torch.Generator().manual_seed(1234)
 feat = torch.randn(a.T + 1, a.B, 63, generator=g).to(dev)
 fm = torch.ones(a.T + 1, a.B, device=dev)
