@@ -214,14 +214,14 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc += s_phi[u + q * G] * v[q];
+                for (int q = 0; q < 8; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
             }
             float v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (u + q * G <= u_hi) ? ctx[(size_t)(u + q * G) * E + e] : 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (u + q * G <= u_hi) acc += s_phi[u + q * G] * v[q];
+                if (u + q * G <= u_hi) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);  // same rounding as above
         }
         __syncthreads();
         s_acc[t] = acc;
@@ -465,9 +465,10 @@ int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("PARROT_ATT_DBG"); dbg = e ? atoi(e) : 0; }
     g.dbg = dbg;
-    static int dense = -1;
-    if (dense < 0) { const char* e = getenv("PARROT_ATT_DENSE"); dense = e ? atoi(e) : 0; }
-    g.dense = dense;
+    {   // read per launch (launches happen once, at graph capture): tests toggle it between two plans
+        const char* e = getenv("PARROT_ATT_DENSE");
+        g.dense = e ? atoi(e) : 0;
+    }
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.esplit < 1) return PH_ERR_BADARG;
     const size_t lds = att_fwd_lds(g.U);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;

@@ -642,7 +642,7 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
     for (int q = 0; q < L.njobs; ++q) {
         maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
         tiles += L.tile_end[q];
-        if (!L.job[q].aligned || L.job[q].epi == SK_EPI_LSTM) nb2_ok = false;
+        if (!L.job[q].aligned) nb2_ok = false;
     }
     // Tile shape per workgroup: (16*mb rows) x (16*nb columns).  Per-CU load bandwidth (~50 GB/s measured)
     // is what limits this kernel, so prefer the shape with the fewest operand bytes per flop
