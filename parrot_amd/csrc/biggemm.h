@@ -15,10 +15,13 @@ struct BgArgs {
     int ldc;
     long long batchA, batchB, batchC;  // element strides between batch entries
     int nbatch;
-    int splitk;      // >1: K is split over grid.z and results are combined with f32 atomics
+    int splitk;      // >1: K is split over grid.y; the slices' partial tiles go to `ws` and are summed in slice
+                     // order by a second kernel (deterministic), or -- ws == null -- combined with f32 atomics
+    float* ws;       // [nbatch * splitk, M, N] partial sums or null
     int accumulate;  // C += result (C must hold valid data; with splitk>1 always accumulates)
     float alpha;
     int act;         // SkAct-compatible activation, only when splitk == 1
 };
 
 int bg_launch(const BgArgs& a, hipStream_t stream);
+int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of the deterministic split-K

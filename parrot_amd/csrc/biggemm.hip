@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
     kchunk = (kchunk + BK - 1) / BK * BK;
     const int kbeg = ks * kchunk;
     const int kend = min(a.K, kbeg + kchunk);
-    if (kbeg >= kend && ks > 0) return;
+    if (kbeg >= kend && ks > 0 && !a.ws) return;  // (deterministic split-K: empty slices still write their zeros)
 
     const float* A = a.A + (long long)batch * a.batchA;
     const float* B = a.B + (long long)batch * a.batchB;
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
                 float v = a.alpha * acc[i][j][q] + bias;
                 float* c = C + (long long)m * a.ldc + n;
                 if (a.splitk > 1) {
-                    unsafeAtomicAdd(c, v);
+                    if (a.ws) a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][j][q];  // bias added by the reducer
+                    else unsafeAtomicAdd(c, v);
                 } else {
                     if (a.accumulate) v += *c;
                     if (a.act == 1) v = fmaxf(v, 0.f);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
     kchunk = (kchunk + BK - 1) / BK * BK;
     const int kbeg = ks * kchunk;
     const int kend = min(a.K, kbeg + kchunk);
-    if (kbeg >= kend && ks > 0) return;
+    if (kbeg >= kend && ks > 0 && !a.ws) return;  // (deterministic split-K: empty slices still write their zeros)
     const float* A = a.A + (long long)batch * a.batchA;
     const float* B = a.B + (long long)batch * a.batchB;
     float* C = a.C + (long long)batch * a.batchC;
@@ -300,7 +301,8 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
             float v = a.alpha * acc[i][q] + bias;
             float* c = C + (long long)m * a.ldc + n;
             if (a.splitk > 1) {
-                unsafeAtomicAdd(c, v);
+                if (a.ws) a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][q];  // bias added by the reducer
+                else unsafeAtomicAdd(c, v);
             } else {
                 if (a.accumulate) v += *c;
                 if (a.act == 1) v = fmaxf(v, 0.f);
@@ -312,7 +314,32 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
     }
 }
 
+// C[b][m][n] (+)= bias[n] + sum over the K slices, in slice order (deterministic split-K).
+__global__ __launch_bounds__(256) void bg_reduce_kernel(const BgArgs a) {
+    const long long mn = (long long)a.M * a.N;
+    const long long total = mn * a.nbatch;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int batch = (int)(i / mn);
+        const long long r = i % mn;
+        const int m = (int)(r / a.N), n = (int)(r % a.N);
+        float* c = a.C + (long long)batch * a.batchC + (long long)m * a.ldc + n;
+        float v = a.accumulate ? *c : 0.f;
+        if (a.bias) v += a.bias[n];
+        const float* w = a.ws + ((long long)batch * a.splitk) * mn + r;
+        for (int ks = 0; ks < a.splitk; ++ks) v += w[(long long)ks * mn];
+        *c = v;
+    }
+}
+
 }  // namespace
+
+int bg_reduce_launch(const BgArgs& a, hipStream_t stream) {
+    const long long total = (long long)a.M * a.N * a.nbatch;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bg_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}
 
 int bg_launch(const BgArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch < 1 || a.splitk < 1) return PH_ERR_BADARG;

@@ -13,7 +13,7 @@ static int gemm_target_wgs() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("PARROT_GEMM_TARGET_WGS");
-        v = e ? atoi(e) : 2048;
+        v = e ? atoi(e) : 1024;  // 8-wave kernel: 1024..4096 measure the same; fewer slices = less partial-sum traffic
     }
     return v;
 }
@@ -72,8 +72,43 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
         }
     }
     a.splitk = split;
+    a.ws = nullptr;
     if (a.splitk > 1) {
         if (act != 0) return PARROT_ERR_BADARG;
+        // Deterministic split-K: the slices write partial tiles to a library-owned workspace and a second kernel
+        // adds them in slice order (results do not depend on scheduling; PARROT_GEMM_ATOMIC=1 restores the
+        // single-pass float-atomic combine).  The workspace grows on demand and is reused by later calls on the
+        // same stream order; calls are not captured into graphs (the scan plans use split_k = 1).
+        static int use_atomic = -1;
+        if (use_atomic < 0) {
+            const char* e = getenv("PARROT_GEMM_ATOMIC");
+            use_atomic = e ? atoi(e) : 0;
+        }
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (!use_atomic && cs == hipStreamCaptureStatusNone) {
+            static float* ws = nullptr;
+            static size_t ws_floats = 0;
+            const size_t need = (size_t)nbatch * a.splitk * M * N;
+            if (need > ws_floats) {
+                if (ws) {
+                    (void)hipDeviceSynchronize();
+                    (void)hipFree(ws);
+                    ws = nullptr;
+                    ws_floats = 0;
+                }
+                if (hipMalloc(&ws, need * sizeof(float)) == hipSuccess) ws_floats = need;
+                else ws = nullptr;
+            }
+            if (ws) {
+                a.ws = ws;
+                a.bias = nullptr;  // the reducer adds it
+                int rc = bg_launch(a, st);
+                if (rc) return rc;
+                a.bias = bias;
+                return bg_reduce_launch(a, st);
+            }
+        }
         if (!accumulate) {  // atomics accumulate into C: clear it first
             for (int b = 0; b < nbatch; ++b) {
                 hipError_t e = hipMemset2DAsync(C + (long long)b * strideC, sizeof(float) * (size_t)ldc, 0,

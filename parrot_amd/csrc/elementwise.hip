@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     __syncthreads();
     if (rg == 0 && n < N) {
         const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (gridDim.y > 1) unsafeAtomicAdd(out + n, s);
+        if (gridDim.y > 1) out[(size_t)blockIdx.y * N + n] = s;  // `out` is the partial buffer [ysplit, N] here
         else if (accumulate) out[n] += s;
         else out[n] = s;
     }
@@ -51,7 +51,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];  // per-block partial (no atomics)
+}
+
+// out[0] = sum of n partials, fixed order: the global norm (and with it every clipped update) is reproducible.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[n] (+)= sum over the row slices' partial column sums, slice order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int N, int ysplit,
+                                                            float* __restrict__ out, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float v = accumulate ? out[n] : 0.f;
+    for (int y = 0; y < ysplit; ++y) v += part[(size_t)y * N + n];
+    out[n] = v;
 }
 
 // StepClipping(threshold) then Adam (Blocks 0.2 semantics):
@@ -224,6 +245,29 @@ __global__ __launch_bounds__(256) void norm_sum_kernel(const NormSumArgs a, floa
 
 }  // namespace
 
+// Library-owned scratch for the two-stage reductions (grown on demand; the calls that use it are issued eagerly
+// on one stream, never from inside a captured scan plan).
+static float* ew_scratch(size_t floats, hipStream_t stream) {
+    static float* buf = nullptr;
+    static size_t cap = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cs);
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    if (floats > cap) {
+        if (buf) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(buf);
+            buf = nullptr;
+            cap = 0;
+        }
+        const size_t want = floats < (1u << 20) ? (1u << 20) : floats;
+        if (hipMalloc(&buf, want * sizeof(float)) != hipSuccess) return nullptr;
+        cap = want;
+    }
+    return buf;
+}
+
+
 int norm_sum_launch(const NormSumGroup* groups, int ngroups, int R, float eps, hipStream_t stream) {
     if (ngroups < 1 || ngroups > 2 || R < 1) return PH_ERR_BADARG;
     NormSumArgs a;
@@ -279,9 +323,15 @@ int colsum_launch(const float* x, long long M, int N, int ld, float* out, int ac
     int ysplit = 1;
     const int bx = ceil_div(N, 64);
     while (bx * ysplit < 512 && M / (ysplit * 2) >= 256) ysplit *= 2;
-    if (ysplit > 1 && !accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, stream);
-        if (e != hipSuccess) return (int)e;
+    if (ysplit > 1) {  // row slices -> partial sums -> fixed-order finish (deterministic, no float atomics)
+        float* part = ew_scratch((size_t)ysplit * N, stream);
+        if (!part) ysplit = 1;
+        else {
+            hipLaunchKernelGGL(colsum_kernel, dim3(bx, ysplit), dim3(256), 0, stream, x, M, N, ld, part, 0);
+            hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, stream, part, N, ysplit, out,
+                               accumulate);
+            return (int)hipGetLastError();
+        }
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(bx, ysplit), dim3(256), 0, stream, x, M, N, ld, out, accumulate);
     return (int)hipGetLastError();
@@ -289,12 +339,13 @@ int colsum_launch(const float* x, long long M, int N, int ld, float* out, int ac
 
 int sumsq_launch(const float* x, size_t n, float* out, hipStream_t stream) {
     if (((uintptr_t)x & 15) != 0) return PH_ERR_BADARG;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
     int bx = (int)((n / 4 + 255) / 256);
     if (bx < 1) bx = 1;
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(bx), dim3(256), 0, stream, x, n, out);
+    float* part = ew_scratch((size_t)bx, stream);
+    if (!part) return PH_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(bx), dim3(256), 0, stream, x, n, part);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, part, bx, out);
     return (int)hipGetLastError();
 }
 

@@ -430,8 +430,8 @@ class Parrot(Brick):
         demb = dx.view(Te, Be, -1)
         if not self.encoder_literal:
             demb = demb.transpose(0, 1)
-        self._g('/encoder/embed_label.W').index_add_(0, labels.long().reshape(-1),
-                                                     demb.reshape(-1, demb.shape[-1]))
+        self._scatter_rows_add(self._g('/encoder/embed_label.W'), labels.long().reshape(-1),
+                               demb.reshape(-1, demb.shape[-1]))
 
     # ------------------------------------------------------------------ training workspace
     def _train_workspace(self, T, B, U):
@@ -515,6 +515,14 @@ class Parrot(Brick):
         ws['plan'], ws['desc'] = plan, d
         self._train_ws[key] = ws
         return ws
+
+    @staticmethod
+    def _scatter_rows_add(grad, idx, src):
+        """grad[idx[i]] += src[i] (LookupTable gradient) as onehot^T . src on the HIP GEMM: same result as
+        index_add_, but summed in a fixed order (no float atomics), so gradients are reproducible bit for bit."""
+        onehot = torch.zeros(idx.numel(), grad.shape[0], device=grad.device, dtype=torch.float32)
+        onehot.scatter_(1, idx.reshape(-1, 1), 1.0)
+        ops.gemm(onehot.t(), src.contiguous(), out=grad, accumulate=True)
 
     def _tiled_weights(self, refresh=False):
         """Fragment-major copies of the packed layer matrices for the scan kernels (parrot_tile_weights);
@@ -859,7 +867,7 @@ class Parrot(Brick):
         _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
                   dctx.data_ptr(), E, U, E, T, None, 1.0, 0, 0, B, U, E, U * E, 1, ops._stream())
         if self.use_speaker:
-            self._g('/lookuptable.W').index_add_(0, save['spk_idx'], demb_spk)
+            self._scatter_rows_add(self._g('/lookuptable.W'), save['spk_idx'], demb_spk)
         self._encoder_backward(dctx, save)
         self._saved = None
 
