@@ -165,6 +165,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; it has to be in the process BEFORE this library is dlopen'ed, so that
+    # the loader binds our DT_NEEDED libamdhip64.so to that one.  Loaded the other way round the process ends up
+    # with two HIP runtimes and our launches on torch's pointers fail with hipErrorNoDevice (100).
+    import torch  # noqa: F401
     path = os.environ.get('PARROT_HIP_LIB', LIB_PATH)  # development knob: alternative builds of the same ABI
     if not os.path.exists(path):
         raise HipLibraryMissing(

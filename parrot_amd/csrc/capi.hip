@@ -20,20 +20,20 @@ static int gemm_target_wgs() {
 
 extern "C" {
 
-const char* parrot_hip_version(void) { return "parrot_hip 0.1.0 gfx950"; }
+const char* parrot_hip_version(void) { PH_ENTRY(); return "parrot_hip 0.1.0 gfx950"; }
 
-int parrot_profile_begin(void) {
+int parrot_profile_begin(void) { PH_ENTRY();
     sk_profile_begin();
     return 0;
 }
 
-long long parrot_profile_end(double* total_us, double* flops, double* bytes) {
+long long parrot_profile_end(double* total_us, double* flops, double* bytes) { PH_ENTRY();
     return sk_profile_end(total_us, flops, bytes);
 }
 
 int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
                 int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
-                long long strideA, long long strideB, long long strideC, int split_k, void* stream) {
+                long long strideA, long long strideB, long long strideC, int split_k, void* stream) { PH_ENTRY();
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || nbatch < 1) return PARROT_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (M <= 64 && !transA && nbatch == 1 && split_k <= 1 && alpha == 1.0f) {
@@ -120,30 +120,30 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     return bg_launch(a, st);
 }
 
-int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream) {
+int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream) { PH_ENTRY();
     if (mode != 0 && mode != 1) return PARROT_ERR_BADARG;
     return sk_tile_weights_launch(W, rows, cols, ld, out, mode, lstm_H, (hipStream_t)stream);
 }
 
 int parrot_simple_norm_fwd(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,
-                           float* add_dst, int ld_add, void* stream) {
+                           float* add_dst, int ld_add, void* stream) { PH_ENTRY();
     if (!x || !y || !sigma) return PARROT_ERR_BADARG;
     return simple_norm_fwd_launch(x, ldx, y, ldy, sigma, R, N, eps, add_dst, ld_add, (hipStream_t)stream);
 }
 
 int parrot_simple_norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* sigma, float* dx,
-                           int lddx, long long R, int N, float eps, int accumulate, void* stream) {
+                           int lddx, long long R, int N, float eps, int accumulate, void* stream) { PH_ENTRY();
     if (!dy || !y || !sigma || !dx) return PARROT_ERR_BADARG;
     return simple_norm_bwd_launch(dy, lddy, y, ldy, sigma, dx, lddx, R, N, eps, accumulate, (hipStream_t)stream);
 }
 
-int parrot_colsum(const float* x, long long M, int N, int ld, float* out, int accumulate, void* stream) {
+int parrot_colsum(const float* x, long long M, int N, int ld, float* out, int accumulate, void* stream) { PH_ENTRY();
     return colsum_launch(x, M, N, ld, out, accumulate, (hipStream_t)stream);
 }
 
 int parrot_gru_step_fwd(const float* h, const float* inputs, const float* gate_inputs, const float* mask,
                         const float* Wg, const float* Wc, float* h_out, float* z, float* r, float* rh,
-                        float* c, int B, int H, void* stream) {
+                        float* c, int B, int H, void* stream) { PH_ENTRY();
     if (!h || !Wg || !Wc || !h_out || !z || !r || !rh || B < 1 || H < 1) return PARROT_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
     SkJob j;
@@ -173,7 +173,7 @@ int parrot_gru_step_fwd(const float* h, const float* inputs, const float* gate_i
 
 int parrot_gru_step_bwd(const float* dh_out, const float* h, const float* mask, const float* Wg,
                         const float* Wc, const float* z, const float* r, const float* c, float* dh,
-                        float* d_inputs, float* d_gate_inputs, int B, int H, void* stream) {
+                        float* d_inputs, float* d_gate_inputs, int B, int H, void* stream) { PH_ENTRY();
     if (!dh_out || !h || !Wg || !Wc || !z || !r || !c || !dh || !d_inputs || !d_gate_inputs)
         return PARROT_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
@@ -210,7 +210,7 @@ int parrot_gru_step_bwd(const float* dh_out, const float* h, const float* mask, 
 int parrot_gmm_attention_fwd(const float* h1, const float* WattT, const float* batt, const float* kappa_prev,
                              const float* ctx, float* a, float* b, float* kappa, float* phi, float* w, int B,
                              int H, int A, int U, int E, int att_type, float eps, float alignment,
-                             float sharpening, float timing, void* stream) {
+                             float sharpening, float timing, void* stream) { PH_ENTRY();
     if (!h1 || !WattT || !kappa_prev || !ctx || !a || !b || !kappa || !phi || !w) return PARROT_ERR_BADARG;
     AttFwdArgs g{};
     g.h1 = h1; g.ldh = H; g.WattT = WattT; g.batt = batt; g.kappa_prev = kappa_prev; g.ctx = ctx;
@@ -223,7 +223,7 @@ int parrot_gmm_attention_fwd(const float* h1, const float* WattT, const float* b
 int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, const float* b,
                              const float* kappa, const float* kappa_prev, const float* WattT, float* dkappa,
                              float* dp, float* dh1, int B, int H, int A, int U, int E, int att_type, float eps,
-                             void* stream) {
+                             void* stream) { PH_ENTRY();
     if (!dw || !ctx || !a || !b || !kappa || !kappa_prev || !WattT || !dkappa || !dp || !dh1)
         return PARROT_ERR_BADARG;
     AttBwdArgs g{};
@@ -233,13 +233,13 @@ int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, 
     return att_bwd_launch(g, (hipStream_t)stream);
 }
 
-int parrot_sumsq(const float* x, size_t n, float* out, void* stream) {
+int parrot_sumsq(const float* x, size_t n, float* out, void* stream) { PH_ENTRY();
     return sumsq_launch(x, n, out, (hipStream_t)stream);
 }
 
 int parrot_adam_clip_step(float* param, const float* grad, float* m, float* v, size_t n,
                           const float* gnorm_sq, float grad_scale, float clip_threshold, float lr,
-                          float beta1, float beta2, float eps, int step, void* stream) {
+                          float beta1, float beta2, float eps, int step, void* stream) { PH_ENTRY();
     if (!param || !grad || !m || !v || step < 1) return PARROT_ERR_BADARG;
     if (clip_threshold > 0.f && !gnorm_sq) return PARROT_ERR_BADARG;
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
@@ -248,12 +248,12 @@ int parrot_adam_clip_step(float* param, const float* grad, float* m, float* v, s
 }
 
 int parrot_batch_quantize(const float* x, int rows, int n, int ld, double* ws, void* out, int ldo, int mode,
-                          int q_levels, void* stream) {
+                          int q_levels, void* stream) { PH_ENTRY();
     if (!x || !ws || !out) return PARROT_ERR_BADARG;
     return quantize_launch(x, rows, n, ld, ws, out, ldo, mode, q_levels, (hipStream_t)stream);
 }
 
-int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream) {
+int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream) { PH_ENTRY();
     if (!q || !out) return PARROT_ERR_BADARG;
     return mu2linear_launch(q, n, out, (hipStream_t)stream);
 }

@@ -12,6 +12,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         if (e__ != hipSuccess) return (int)e__;       \
     } while (0)
 
+// First statement of every extern "C" entry point: the launch wrappers report `hipGetLastError()`, which is sticky
+// per thread across ALL users of the runtime in the process -- an error left behind by somebody else's call (seen
+// on the GPU box: 100 after PyTorch's own start-up probing) must not be blamed on our first launch.
+#define PH_ENTRY() (void)hipGetLastError()
+
 // Error codes returned by the C-ABI on bad arguments (hipError_t values are
 // returned unchanged for runtime failures).
 #define PH_ERR_BADARG 10001

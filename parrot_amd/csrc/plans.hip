@@ -1325,7 +1325,7 @@ bool bad_dims(int L) { return L < 1 || L > PARROT_MAX_LAYERS; }
 
 extern "C" {
 
-int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan) {
+int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan) { PH_ENTRY();
     if (!desc || !plan || desc->T < 1 || desc->B < 1 || desc->H < 1 || desc->nchain < 1 || desc->nchain > 4)
         return PARROT_ERR_BADARG;
     GruSeqPlan* p = new (std::nothrow) GruSeqPlan();
@@ -1335,14 +1335,14 @@ int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan) {
     *plan = p;
     return 0;
 }
-int parrot_gru_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
-int parrot_gru_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
-int parrot_gru_seq_destroy(void* plan) {
+int parrot_gru_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_gru_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_gru_seq_destroy(void* plan) { PH_ENTRY();
     delete static_cast<PlanBase*>(plan);
     return 0;
 }
 
-int parrot_lstm_seq_create(const ParrotLstmSeqDesc* desc, void** plan) {
+int parrot_lstm_seq_create(const ParrotLstmSeqDesc* desc, void** plan) { PH_ENTRY();
     if (!desc || !plan || desc->T < 1 || desc->B < 1 || desc->H < 4 || (desc->H & 3)) return PARROT_ERR_BADARG;
     LstmSeqPlan* p = new (std::nothrow) LstmSeqPlan();
     if (!p) return PARROT_ERR_BADARG;
@@ -1351,14 +1351,14 @@ int parrot_lstm_seq_create(const ParrotLstmSeqDesc* desc, void** plan) {
     *plan = p;
     return 0;
 }
-int parrot_lstm_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
-int parrot_lstm_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
-int parrot_lstm_seq_destroy(void* plan) {
+int parrot_lstm_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_lstm_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_lstm_seq_destroy(void* plan) { PH_ENTRY();
     delete static_cast<PlanBase*>(plan);
     return 0;
 }
 
-int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
+int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY();
     if (!desc || !plan || desc->T < 1 || desc->B < 1 || bad_dims(desc->L)) return PARROT_ERR_BADARG;
     DecoderPlan* p = new (std::nothrow) DecoderPlan();
     if (!p) return PARROT_ERR_BADARG;
@@ -1391,14 +1391,14 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) {
     *plan = p;
     return 0;
 }
-int parrot_decoder_seq_fwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
-int parrot_decoder_seq_bwd(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
-int parrot_decoder_destroy(void* plan) {
+int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_decoder_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_decoder_destroy(void* plan) { PH_ENTRY();
     delete static_cast<PlanBase*>(plan);
     return 0;
 }
 
-int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) {
+int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) { PH_ENTRY();
     if (!desc || !plan || desc->S < 1 || desc->B < 1 || bad_dims(desc->L) || desc->ldx < desc->O)
         return PARROT_ERR_BADARG;
     SamplePlan* p = new (std::nothrow) SamplePlan();
@@ -1417,12 +1417,12 @@ int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) {
     *plan = p;
     return 0;
 }
-int parrot_sample_run(void* plan, void* stream) { return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
-int parrot_sample_destroy(void* plan) {
+int parrot_sample_run(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
+int parrot_sample_destroy(void* plan) { PH_ENTRY();
     delete static_cast<PlanBase*>(plan);
     return 0;
 }
 
-int parrot_plan_last_error(void* plan) { return plan ? static_cast<PlanBase*>(plan)->last_error : PARROT_ERR_BADARG; }
+int parrot_plan_last_error(void* plan) { PH_ENTRY(); return plan ? static_cast<PlanBase*>(plan)->last_error : PARROT_ERR_BADARG; }
 
 }  // extern "C"

@@ -241,7 +241,7 @@ struct SrPlan {
 
 extern "C" {
 
-int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) {
+int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_ENTRY();
     if (!desc || !plan || desc->B < 1 || desc->T < 2 || desc->D < 4 || (desc->D & 3) || desc->FS < 1 ||
         desc->BFS % desc->FS != 0 || desc->Q < 2)
         return PARROT_ERR_BADARG;
@@ -252,14 +252,14 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) {
     return 0;
 }
 
-int samplernn_generate_run(void* plan, void* stream) {
+int samplernn_generate_run(void* plan, void* stream) { PH_ENTRY();
     SrPlan* p = static_cast<SrPlan*>(plan);
     const int rc = p->run((hipStream_t)stream);
     if (rc != 0 && p->last_error == 0) p->last_error = rc;
     return rc;
 }
 
-int samplernn_generate_destroy(void* plan) {
+int samplernn_generate_destroy(void* plan) { PH_ENTRY();
     delete static_cast<SrPlan*>(plan);
     return 0;
 }
