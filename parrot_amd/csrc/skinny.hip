@@ -662,7 +662,10 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
             int wgx = 0;
             for (int q = 0; q < L.njobs; ++q) wgx += ceil_div(L.tile_end[q], nb);
             const int wg = wgx * ceil_div(maxM, 16 * mb);
-            const double cost = 1.0 / mb + 1.0 / nb;
+            // operand bytes per flop ~ 1/mb + 1/nb, but 48/64-row tiles measured slower than 32-row ones whenever both
+            // fill the chip (cfg2 merged launches, and the 2300-workgroup launches of a 3 x LSTM-1536 decoder:
+            // <2,2> 183 k frames/s vs <4,2> 154 k, <4,1> 162 k, <3,2> 152 k), so rows beyond 32 earn no credit
+            const double cost = 1.0 / (mb > 2 ? 2 : mb) + 1.0 / nb + (mb > 2 ? 0.1 : 0.0);
             const bool full = wg >= 224, best_full = best_wg >= 224;
             bool better;
             if (full != best_full) better = full;
