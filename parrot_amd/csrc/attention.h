@@ -38,4 +38,6 @@ int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream);
 struct GruStateBwdArgs;
 // att (or null) + the GRU state backward of all chains in one launch; l0_chain = index of layer 0's chain or -1.
 int att_state_bwd_launch(const AttBwdArgs* g, const GruStateBwdArgs& sa, int l0_chain, hipStream_t stream);
+struct LstmStateBwdArgs;
+int att_state_bwd_launch(const AttBwdArgs* g, const LstmStateBwdArgs& sa, int l0_chain, hipStream_t stream);
 int att_default_esplit(int B, int E);

@@ -436,20 +436,28 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs 
 // active in this tick of the backward wavefront (plans.hip): blocks [0, att_rows) take one attention row each
 // and then, with the same threads (thread k updated dh1[b][k] itself), layer 0's state backward for that row;
 // the remaining blocks take one (chain, row) pair of the other layers.  Saves a kernel boundary per step.
-__global__ __launch_bounds__(ATTB_THREADS) void att_state_bwd_kernel(const AttBwdArgs g, const GruStateBwdArgs sa,
-                                                                      int att_rows, int l0_chain) {
+__device__ __forceinline__ void state_bwd_row(const GruStateBwdChain& c, int m, int H, int tid, int nthr) {
+    gru_state_bwd_row(c, m, H, tid, nthr);
+}
+__device__ __forceinline__ void state_bwd_row(const LstmStateBwdChain& c, int m, int H, int tid, int nthr) {
+    lstm_state_bwd_row(c, m, H, tid, nthr);
+}
+
+template <class SA>
+__global__ __launch_bounds__(ATTB_THREADS) void att_state_bwd_kernel(const AttBwdArgs g, const SA sa, int att_rows,
+                                                                      int l0_chain) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bx = blockIdx.x;
     if (bx < att_rows) {
         att_bwd_row(g, bx, sm);
-        if (l0_chain >= 0) gru_state_bwd_row(sa.chain[l0_chain], bx, sa.H, threadIdx.x, ATTB_THREADS);
+        if (l0_chain >= 0) state_bwd_row(sa.chain[l0_chain], bx, sa.H, threadIdx.x, ATTB_THREADS);
         return;
     }
     const int idx = bx - att_rows;
     int ch = idx / sa.B;
     const int m = idx % sa.B;
     if (att_rows > 0 && l0_chain >= 0 && ch >= l0_chain) ++ch;  // skip the chain fused above
-    if (ch < sa.nchain) gru_state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
+    if (ch < sa.nchain) state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
 }
 
 }  // namespace
@@ -488,7 +496,8 @@ int att_bwd_launch(const AttBwdArgs& gin, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-int att_state_bwd_launch(const AttBwdArgs* gin, const GruStateBwdArgs& sa, int l0_chain, hipStream_t stream) {
+template <class SA>
+static int att_state_bwd_launch_t(const AttBwdArgs* gin, const SA& sa, int l0_chain, hipStream_t stream) {
     AttBwdArgs g{};
     int att_rows = 0;
     size_t lds = 0;
@@ -509,8 +518,16 @@ int att_state_bwd_launch(const AttBwdArgs* gin, const GruStateBwdArgs& sa, int l
     const int others = sa.nchain - ((att_rows > 0 && l0_chain >= 0) ? 1 : 0);
     const int blocks = att_rows + others * sa.B;
     if (blocks < 1) return 0;
-    hipLaunchKernelGGL(att_state_bwd_kernel, dim3(blocks), dim3(ATTB_THREADS), lds, stream, g, sa, att_rows, l0_chain);
+    hipLaunchKernelGGL((att_state_bwd_kernel<SA>), dim3(blocks), dim3(ATTB_THREADS), lds, stream, g, sa, att_rows,
+                       l0_chain);
     return (int)hipGetLastError();
+}
+
+int att_state_bwd_launch(const AttBwdArgs* gin, const GruStateBwdArgs& sa, int l0_chain, hipStream_t stream) {
+    return att_state_bwd_launch_t(gin, sa, l0_chain, stream);
+}
+int att_state_bwd_launch(const AttBwdArgs* gin, const LstmStateBwdArgs& sa, int l0_chain, hipStream_t stream) {
+    return att_state_bwd_launch_t(gin, sa, l0_chain, stream);
 }
 
 int att_default_esplit(int B, int E) {

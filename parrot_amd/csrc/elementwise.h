@@ -52,6 +52,38 @@ int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat
                       float eps, const float* unif, const float* noise, float* x, int ldx, float* pi_out,
                       hipStream_t stream);
 
+struct LstmStateBwdChain {
+    const float* dh;      // [B,H] gradient wrt s_t
+    const float* dh2;     // [B,H] optional second share of it or null
+    float* dc;            // [B,H] carry: in gradient wrt c_t (from step t+1), out gradient wrt c_{t-1}
+    const float* gates;   // [B,4H] saved activations i|f|o|g
+    const float* c_prev;  // [B,H]
+    const float* c_new;   // [B,H]
+    float* dP;            // [B,4H] out: gradient wrt the pre-activations
+};
+struct LstmStateBwdArgs {
+    LstmStateBwdChain chain[4];
+    int nchain, B, H;
+};
+
+// Row m of one chain of the LSTM state backward (same arithmetic as lstm_state_bwd_kernel).
+__device__ __forceinline__ void lstm_state_bwd_row(const LstmStateBwdChain& c, int m, int H, int tid, int nthr) {
+    for (int k = tid; k < H; k += nthr) {
+        const size_t idx = (size_t)m * H + k;
+        const float* g = c.gates + (size_t)m * 4 * H;
+        const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
+        const float tc = tanhf(c.c_new[idx]);
+        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f);
+        const float dcv = dhv * go * (1.f - tc * tc) + c.dc[idx];
+        float* o = c.dP + (size_t)m * 4 * H;
+        o[k] = dcv * gg * gi * (1.f - gi);
+        o[H + k] = dcv * c.c_prev[idx] * gf * (1.f - gf);
+        o[2 * H + k] = dhv * tc * go * (1.f - go);
+        o[3 * H + k] = dcv * gi * (1.f - gg * gg);
+        c.dc[idx] = dcv * gf;
+    }
+}
+
 // Elementwise half of the LSTM backward step (ops.py:505-553 reversed).  dh: gradient wrt s_t; dc: carry
 // (in: gradient wrt c_t from step t+1, out: gradient wrt c_{t-1}); gates [B,4H] = i|f|o|g; dP [B,4H] out.
 int lstm_state_bwd_launch(const float* dh, const float* dh2, float* dc, const float* gates, const float* c_prev, const float* c_new,

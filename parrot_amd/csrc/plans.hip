@@ -389,18 +389,29 @@ struct DecoderPlan : PlanBase {
                 g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
                 g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
                 g.dbg = 0;
-                if (d.cell == 1) PL_TRY(att_bwd_launch(g, st));  // GRU: fused with the state backward below
             }
             if (d.cell == 1) {
                 SkJob jl[SK_MAXJOB];
                 int nl = 0;
+                LstmStateBwdArgs la;
+                la.nchain = 0; la.B = d.B; la.H = H;
+                for (int l = d.L - 1; l >= 0; --l) {  // state updates of all active layers + attention: one launch
+                    const int t = tl[l];
+                    if (t < 0 || t >= d.T) continue;
+                    LstmStateBwdChain& c = la.chain[la.nchain++];
+                    c.dh = d.dh[l] + (t + 1) * BH;
+                    c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
+                    c.dc = d.dcell[l];
+                    c.gates = d.gate4[l] + (size_t)t * 4 * BH;
+                    c.c_prev = d.cst[l] + t * BH;
+                    c.c_new = d.cst[l] + (t + 1) * BH;
+                    c.dP = d.dG[l] + (size_t)t * 4 * BH;
+                }
+                if (la.nchain > 0) PL_TRY(att_state_bwd_launch(att_on ? &g : nullptr, la, att_on ? la.nchain - 1 : -1, st));
                 for (int l = d.L - 1; l >= 0; --l) {
                     const int t = tl[l];
                     if (t < 0 || t >= d.T) continue;
                     float* dP = d.dG[l] + (size_t)t * 4 * BH;
-                    PL_TRY(lstm_state_bwd_launch(d.dh[l] + (t + 1) * BH, (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr,
-                                                 d.dcell[l], d.gate4[l] + (size_t)t * 4 * BH, d.cst[l] + t * BH,
-                                                 d.cst[l] + (t + 1) * BH, dP, d.B, H, st));
                     {   // previous state of this layer
                         SkJob& j = jl[nl++];
                         sk_job_init(j);
