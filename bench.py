@@ -74,8 +74,14 @@ def model_kwargs(a):
 def roofline_leg(a, dev, flat_params):
     """One extra, untimed training step with eager launches, every recurrent-step dispatch timed."""
     from parrot_amd import _lib, ops
+    from parrot_amd import dist as pdist
     from parrot_amd.model import Parrot
     from parrot_amd.trainer import Trainer
+    with pdist.local_only():  # rank 0 measures alone: no collective may be issued here (N > 1)
+        return _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer)
+
+
+def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
     m = Parrot(device=dev, use_graph=False, **model_kwargs(a)).initialize()
     m.flat_parameters.copy_(flat_params)
     tr = Trainer(m)
@@ -193,7 +199,8 @@ def main():
     rank, local_rank, world = pdist.init_process_group()
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    # (ranks wrap around the visible devices only in the gloo plumbing test, PARROT_DIST_BACKEND=gloo)
+    dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     from parrot_amd.model import Parrot

@@ -33,16 +33,37 @@ def init_process_group(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PARROT_DIST_BACKEND=gloo: plumbing test of the N > 1 path on a box with fewer GPUs than ranks
+            backend = os.environ.get("PARROT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
+_LOCAL_ONLY = 0
+
+
+class local_only:
+    """Context manager: inside it this rank behaves like a single process (no collective is issued), e.g. for a
+    measurement that only rank 0 performs while the other ranks wait at a barrier."""
+
+    def __enter__(self):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _LOCAL_ONLY
+        _LOCAL_ONLY -= 1
+        return False
+
+
 def is_distributed():
+    if _LOCAL_ONLY:
+        return False
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 

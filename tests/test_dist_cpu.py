@@ -71,3 +71,36 @@ def test_shard_batch_covers_batch():
             spans = [shard_batch(B, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _worker_local_only(rank, world, port, ret):
+    """bench.py's shape: rank 0 does extra single-rank work (the roofline leg) while the others wait at a barrier."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from parrot_amd import dist as pdist
+    pdist.init_process_group(backend="gloo")
+    x = torch.full((4,), float(rank + 1))
+    if rank == 0:
+        with pdist.local_only():
+            assert not pdist.is_distributed()
+            y = x.clone()
+            pdist.allreduce_flat_(y)                      # must NOT talk to rank 1 (which is at the barrier below)
+            pdist.broadcast_parameters_(y)
+            scale, den = pdist.global_cost_scale(torch.tensor(3.0))
+            assert torch.equal(y, x) and float(den) == 3.0
+        assert pdist.is_distributed()
+    pdist.barrier()
+    pdist.allreduce_flat_(x)                              # the collectives are still in step afterwards
+    if rank == 0:
+        ret["sum"] = x.tolist()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_local_only_issues_no_collectives():
+    world, port = 2, 29519
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_local_only, args=(world, port, ret), nprocs=world, join=True)
+    assert ret["sum"] == [3.0, 3.0, 3.0, 3.0]
