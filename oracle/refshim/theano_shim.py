@@ -642,8 +642,14 @@ def builtins_min(it):
 
 
 def ifelse(condition, then_branch, else_branch, name=None):
+    """Lazy conditional.  The chosen branch's value is returned, but the node keeps BOTH branches as inputs: in a
+    symbolic Theano graph both are reachable from the result whatever the condition's run-time value, which is what
+    lib.get_params walks (three_tier.py:595-600: the learned h0 is a parameter of the cost for reset = 0 too)."""
     c = bool(_t(condition).item() != 0)
-    return then_branch if c else else_branch
+    chosen = then_branch if c else else_branch
+    if isinstance(chosen, (list, tuple)):
+        return chosen
+    return _mk(_t(chosen), condition, then_branch, else_branch)
 
 
 def function(*a, **k):

@@ -115,8 +115,8 @@ class DataStream:
         return it
 
 
-def _pad(seqs, dtype):
-    n = max(len(s) for s in seqs)
+def _pad(seqs, dtype, n=None):
+    n = max(len(s) for s in seqs) if n is None else n
     out = numpy.zeros((len(seqs), n) + seqs[0].shape[1:], dtype=dtype)
     mask = numpy.zeros((len(seqs), n), dtype='float32')
     for i, s in enumerate(seqs):
@@ -128,10 +128,15 @@ def _pad(seqs, dtype):
 def parrot_stream(voice, use_speaker=False, which_sets=('train',), batch_size=32, seq_size=50,
                   num_examples=None, sorting_mult=4, noise_level=None, labels_type='full_labels',
                   check_ratio=False, raw_data=True, q_type='mu-law', q_level=256, dataset=None,
-                  quantizer=None, seed=1234):
+                  quantizer=None, seed=1234, shard=None):
     """datasets.parrot_stream (datasets.py:206-298).  Returns a DataStream whose epoch iterator yields
     tuples in `sources` order: features [S,B,63], features_mask [S,B], [raw_audio [S,B,80]], labels
-    [B,U], [labels_mask [B,U]], [speaker_index [B,1]], start_flag, [feedback_noise_level]."""
+    [B,U], [labels_mask [B,U]], [speaker_index [B,1]], start_flag, [feedback_noise_level].
+
+    shard = (rank, world): data-parallel producer.  Batches are formed exactly as for one process (same shuffle,
+    same length-bucket sort, same drop rule on the GLOBAL batch) but only this rank's contiguous rows are
+    padded / quantised / materialised; padding lengths are the global batch's, so every rank cuts the same
+    number of TBPTT windows (= issues the same number of gradient all-reduces)."""
     assert labels_type in ['full_labels', 'phonemes', 'unconditional', 'unaligned_phonemes', 'text']
     if labels_type in ('full_labels', 'phonemes'):
         raise NotImplementedError(
@@ -164,13 +169,19 @@ def parrot_stream(voice, use_speaker=False, which_sets=('train',), batch_size=32
                 batch = chunk[b:b + batch_size]
                 if len(batch) != batch_size:  # Filter(_check_batch_size)
                     continue
-                feats, fmask = _pad([e['features'] for e in batch], 'float32')
+                t_max = max(len(e['features']) for e in batch)
+                u_max = max(len(e['labels']) for e in batch)
+                if shard is not None:
+                    from .dist import shard_batch
+                    lo, hi = shard_batch(batch_size, shard[0], shard[1])
+                    batch = batch[lo:hi]
+                feats, fmask = _pad([e['features'] for e in batch], 'float32', t_max)
                 out = [feats.swapaxes(0, 1), fmask.swapaxes(0, 1)]  # time-major (datasets.py:274-275)
                 if raw_data:
-                    raw, _ = _pad([e['raw_audio'] for e in batch], 'float32')
+                    raw, _ = _pad([e['raw_audio'] for e in batch], 'float32', t_max * 80)
                     out.append(raw_tf(_chunk(raw)))
                 if labels_type != 'unconditional':
-                    lab, lmask = _pad([e['labels'] for e in batch], 'int32')
+                    lab, lmask = _pad([e['labels'] for e in batch], 'int32', u_max)
                     out += [lab, lmask]
                 if use_speaker:
                     out.append(numpy.stack([e['speaker_index'] for e in batch]))
@@ -190,14 +201,32 @@ def parrot_stream(voice, use_speaker=False, which_sets=('train',), batch_size=32
 
 class PinnedAsyncLoader:
     """Double-buffered host->device feeder: a background thread pulls numpy batches from a stream, stages
-    them in pinned host memory and issues non-blocking copies on a side HIP stream, so the next window's
-    H2D transfer overlaps the current window's scan."""
+    them in a RING of pinned host buffers (depth + 2 slots, reused; a slot is rewritten only after the H2D
+    copies issued from it have completed) and the consumer issues non-blocking copies on a side HIP stream, so
+    the next window's H2D transfer overlaps the current window's scan."""
 
     def __init__(self, stream: DataStream, device, depth=2):
         import torch
         self.stream, self.device, self.depth = stream, torch.device(device), depth
         self.sources = stream.sources
         self._copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self._slots = [dict(bufs={}, event=None) for _ in range(depth + 2)]
+        self.pinned_allocations = 0  # how many pinned buffers were ever created (tests: stays bounded)
+
+    def _stage(self, slot, i, x):
+        import torch
+        if self._copy_stream is None:
+            return torch.from_numpy(numpy.ascontiguousarray(x))
+        src = torch.from_numpy(numpy.ascontiguousarray(x))
+        key = (i, src.dtype)
+        buf = slot['bufs'].get(key)
+        if buf is None or buf.numel() < src.numel():
+            buf = torch.empty(max(src.numel(), 1), dtype=src.dtype).pin_memory()
+            slot['bufs'][key] = buf
+            self.pinned_allocations += 1
+        view = buf[:src.numel()].view(src.shape)
+        view.copy_(src)
+        return view
 
     def __iter__(self):
         import torch
@@ -206,24 +235,25 @@ class PinnedAsyncLoader:
 
         def worker():
             try:
+                k = 0
                 for item in self.stream.get_epoch_iterator():
-                    staged = []
-                    for x in item:
-                        if isinstance(x, numpy.ndarray):
-                            t = torch.from_numpy(numpy.ascontiguousarray(x))
-                            staged.append(t.pin_memory() if self._copy_stream is not None else t)
-                        else:
-                            staged.append(x)
-                    q.put(staged)
+                    slot = self._slots[k % len(self._slots)]
+                    k += 1
+                    if slot['event'] is not None:
+                        slot['event'].synchronize()  # copies issued from this slot's buffers are done
+                    staged = [self._stage(slot, i, x) if isinstance(x, numpy.ndarray) else x
+                              for i, x in enumerate(item)]
+                    q.put((slot, staged))
             finally:
                 q.put(sentinel)
 
         th = threading.Thread(target=worker, daemon=True)
         th.start()
         while True:
-            staged = q.get()
-            if staged is sentinel:
+            got = q.get()
+            if got is sentinel:
                 break
+            slot, staged = got
             out, ev = [], None
             if self._copy_stream is not None:
                 with torch.cuda.stream(self._copy_stream):
@@ -231,6 +261,7 @@ class PinnedAsyncLoader:
                         out.append(x.to(self.device, non_blocking=True) if isinstance(x, torch.Tensor) else x)
                     ev = torch.cuda.Event()
                     ev.record(self._copy_stream)
+                slot['event'] = ev
                 torch.cuda.current_stream(self.device).wait_event(ev)
                 for x in out:  # the consumer stream now owns the buffers
                     if isinstance(x, torch.Tensor):

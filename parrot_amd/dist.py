@@ -107,3 +107,27 @@ def broadcast_parameters_(flat: torch.Tensor, src=0, group=None):
 def barrier():
     if is_distributed():
         dist.barrier()
+
+
+def any_rank(flag: bool, device=None) -> bool:
+    """Collective OR: every rank gets True when any rank passed True (stop / time-limit decisions must be the same
+    everywhere, or the ranks that continue hang in the next gradient all-reduce)."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device or _coll_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
+def sum_over_ranks(values, device=None):
+    """Sum-all-reduce of a few python floats (validation numerator / denominator); returns a list of floats."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or _coll_device())
+    if is_distributed():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def _coll_device():
+    if dist.is_initialized() and dist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')

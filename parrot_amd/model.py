@@ -15,12 +15,15 @@ drives the HIP library directly:
 
 Generalisations beyond the reference (flagged in SURVEY.md 8a): ``num_layers`` in {1,2,3} (the
 reference hard-wires 3) and ``encoder_literal`` (True reproduces the reference's encoder scan over
-the batch axis).  Not built yet on the HIP path and therefore rejected loudly: ``layer_norm=True`` and
-``raw_output=True`` inside compute_cost (the SampleRNN head is driven separately).
+the batch axis), ``cell_type='lstm'`` (BASELINE configs[3]).  ``layer_norm=True`` runs on the chunk-skewed scan
+schedule (in-scan normalised projections); ``raw_output=True`` trains the SampleRNN head on the predicted frames
+inside compute_cost (model.py:793-820).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy
@@ -70,6 +73,33 @@ class _CostFn(torch.autograd.Function):
     def backward(ctx, g):
         ctx.engine._backward(ctx.token, g)
         return None, None, None, None
+
+
+class _LRU(collections.OrderedDict):
+    """Bounded cache: `get` refreshes an entry, inserting beyond `cap` entries evicts the least recently used one
+    through `on_evict` (which frees the plan / graph the entry owns)."""
+
+    def __init__(self, cap, on_evict):
+        super().__init__()
+        self.cap, self.on_evict = max(1, cap), on_evict
+
+    def get(self, key, default=None):
+        if key in self:
+            self.move_to_end(key)
+            return super().__getitem__(key)
+        return default
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        self.move_to_end(key)
+        while len(self) > self.cap:
+            _, old = self.popitem(last=False)
+            self.on_evict(old)
+
+    def clear(self):
+        while len(self):
+            _, old = self.popitem(last=False)
+            self.on_evict(old)
 
 
 class Parrot(Brick):
@@ -125,8 +155,15 @@ class Parrot(Brick):
         self.store = ParamStore()
         self._declare_parameters()
         self._allocated = False
-        self._train_ws = {}
-        self._sample_ws = {}
+        # Workspaces + instantiated hipGraph plans are cached per shape (T, B, U) -- with real data U changes every
+        # batch and the last TBPTT window of a batch has its own T, so the caches are LRU-bounded (PARROT_WS_CACHE
+        # entries each, default 6) and an evicted entry destroys its plan: HBM use stays bounded however many
+        # distinct shapes a run sees.  Only the most recent compute_cost can have a backward pending (self._saved is
+        # a single slot) and its encoder + decoder workspaces are the two most recently used entries, so an
+        # eviction never touches a workspace that is still needed (cap >= 4).
+        cap = max(4, int(os.environ.get('PARROT_WS_CACHE', '6')))
+        self._train_ws = _LRU(cap, self._evict_train_ws)
+        self._sample_ws = _LRU(max(2, cap // 2), self._evict_sample_ws)
         self._carry = {}
         self._token = 0
         self._saved = None
@@ -1045,16 +1082,21 @@ class Parrot(Brick):
                                             t('speaker_index'), data_tr.get('start_flag', 1), num_samples)
         return [a.detach().cpu().numpy().copy() for a in av]
 
+    @staticmethod
+    def _evict_train_ws(ws):
+        if 'plan' in ws:
+            _lib.load().parrot_decoder_destroy(ws.pop('plan'))
+        if 'run' in ws:
+            ws.pop('run').close()
+
+    @staticmethod
+    def _evict_sample_ws(ws):
+        if 'plan' in ws:
+            _lib.load().parrot_sample_destroy(ws.pop('plan'))
+
     def close(self):
-        lib = _lib.load()
-        for ws in self._train_ws.values():
-            if 'plan' in ws:
-                lib.parrot_decoder_destroy(ws['plan'])
-            if 'run' in ws:
-                ws['run'].close()
-        for ws in self._sample_ws.values():
-            lib.parrot_sample_destroy(ws['plan'])
-        self._train_ws, self._sample_ws = {}, {}
+        self._train_ws.clear()
+        self._sample_ws.clear()
 
 
 class SampleRnn(Brick):

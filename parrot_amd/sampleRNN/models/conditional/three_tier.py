@@ -146,9 +146,12 @@ def compute_cost(sequences, features, h0, big_h0, reset, mask):
     cost = ce_bits(sample_level_outputs)
     ip_cost = ce_bits(big_frame_independent_preds.reshape(-1, Q_LEVELS))
     all_named = lib.named_params()
-    ip_params = [p for n, p in all_named.items() if 'BigFrameLevel' in n and getattr(p, 'param', False)]
-    other_params = [p for n, p in all_named.items() if 'BigFrameLevel' not in n and getattr(p, 'param', False)
-                    and 'IndependentPreds' not in n]
+    # three_tier.py:595-600: ip_params = the BigFrameLevel parameters the independent-prediction cost is a function of
+    # (everything in that tier except its Output projection, which only feeds the frame tier); other_params = the
+    # remaining parameters of `cost`; all_params = ip_params + other_params (so IndependentPreds is in, via ip_params).
+    trainable = [(n, p) for n, p in all_named.items() if getattr(p, 'param', False)]
+    ip_params = [p for n, p in trainable if 'BigFrameLevel' in n and not n.startswith('BigFrameLevel.Output.')]
+    other_params = [p for n, p in trainable if 'BigFrameLevel' not in n or n.startswith('BigFrameLevel.Output.')]
     all_params = ip_params + other_params
     return cost, ip_cost, all_params, ip_params, other_params, new_h0, new_big_h0
 

@@ -31,7 +31,8 @@ class Trainer:
         self.gnorm_sq = torch.zeros(1, device=parrot.flat_parameters.device, dtype=torch.float32)
         self.step_count = 0
         self.last_grad_norm = None
-        pdist.broadcast_parameters_(parrot.flat_parameters)
+        for p_, _ in self.groups:  # identical replicas: every parameter group starts from rank 0's values
+            pdist.broadcast_parameters_(p_)
 
     def step(self, features, features_mask, labels, labels_mask, speaker=None, start_flag=1,
              feedback_noise=None, raw_audio=None):
@@ -74,8 +75,48 @@ class Trainer:
         self.step_count = 0
 
     def state_dict(self):
-        return dict(m=self.m.clone(), v=self.v.clone(), step=self.step_count, lr=self.lr)
+        """Adam moments of EVERY parameter group (decoder + SampleRNN head), step count and learning rate."""
+        return dict(ms=[m_.clone() for m_ in self.ms], vs=[v_.clone() for v_ in self.vs], step=self.step_count,
+                    lr=self.lr)
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd['m']); self.v.copy_(sd['v'])
+        ms = sd['ms'] if 'ms' in sd else [sd['m']]
+        vs = sd['vs'] if 'vs' in sd else [sd['v']]
+        assert len(ms) == len(self.ms), "checkpoint and trainer disagree on the number of parameter groups"
+        for dst, src in zip(self.ms + self.vs, list(ms) + list(vs)):
+            dst.copy_(src)
         self.step_count, self.lr = int(sd['step']), float(sd['lr'])
+
+
+class LearningRateSchedule:
+    """extensions.py:83-152 (wired at train.py:175-182 with patience=10, num_cuts=5, cut_size=.5): tracks the
+    validation cost every `save_every` iterations; after `patience` checks without a new best (or at once on NaN)
+    it reloads the best parameters, zeroes the optimiser buffers, multiplies the learning rate by `cut_size`, and
+    asks for the end of training after `num_cuts` cuts.
+
+    `update(value)` returns (cut, finish).  The caller supplies `reload_best()` (loads best_<exp>.tar into the model
+    on every rank) -- the Blocks main-loop plumbing is not part of the arithmetic."""
+
+    def __init__(self, trainer, reload_best, patience=5, num_cuts=3, cut_size=.5):
+        self.trainer, self.reload_best = trainer, reload_best
+        self.patience, self.num_cuts, self.cut_size = patience, num_cuts, cut_size
+        self.counter = self.count_cuts = 0
+        self.best_value = float('inf')
+
+    def update(self, current_value):
+        if current_value is None:
+            return False, False
+        current_value = float(current_value)
+        if current_value < self.best_value:
+            self.best_value, self.counter = current_value, 0
+        else:
+            self.counter += 1
+        if current_value != current_value:  # NaN: skip the remaining patience (extensions.py:126-128)
+            self.counter = self.patience + 1
+        if self.counter < self.patience:
+            return False, False
+        self.counter = 0
+        self.count_cuts += 1
+        self.reload_best()
+        self.trainer.cut_learning_rate(self.cut_size)
+        return True, self.count_cuts >= self.num_cuts

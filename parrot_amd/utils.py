@@ -41,7 +41,7 @@ def train_parse(argv=None):
     parser.add_argument('--full_feedback', type=bool, default=False)
     parser.add_argument('--feedback_noise_level', type=float, default=None)
     parser.add_argument('--layer_norm', type=bool, default=False)
-    parser.add_argument('--labels_type', type=str, default='full_labels')
+    parser.add_argument('--labels_type', type=str, default='text')  # reference default 'full_labels' cannot feed model.py:511 (imatrix)
     parser.add_argument('--which_cost', type=str, default='MSE')
     parser.add_argument('--attention_type', type=str, default='graves')
     parser.add_argument('--attention_alignment', type=float, default=1.)

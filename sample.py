@@ -22,8 +22,15 @@ def main(argv=None):
     params_mode = 'last_' if args.use_last else 'best_'
     args.samples_name = params_mode + args.samples_name
     parameters = load_parameters(os.path.join(args.save_dir, 'pkl', params_mode + args.experiment_name + '.tar'))
+    srn_parameters = {k[len('/parrot/samplernn/'):]: v for k, v in parameters.items()
+                      if k.startswith('/parrot/samplernn/')}
+    parameters = {k: v for k, v in parameters.items() if not k.startswith('/parrot/samplernn/')}
 
-    labels_type = saved_args.labels_type if saved_args.labels_type in ('text', 'unaligned_phonemes') else 'text'
+    labels_type = saved_args.labels_type
+    if labels_type not in ('text', 'unaligned_phonemes'):
+        raise SystemExit("saved config has labels_type %r: only 'text' / 'unaligned_phonemes' fit Parrot's integer "
+                         "label matrix (model.py:511)" % labels_type)
+    raw_output = bool(getattr(saved_args, 'raw_output', False))  # sample.py:92-93
     test_stream = parrot_stream(args.dataset, saved_args.use_speaker, ('test',), args.num_samples,
                                 args.num_steps, sorting_mult=1, labels_type=labels_type, raw_data=False,
                                 num_examples=max(args.synthetic_examples, args.num_samples))
@@ -47,11 +54,14 @@ def main(argv=None):
         num_characters=saved_args.num_characters, attention_type=saved_args.attention_type,
         attention_alignment=saved_args.attention_alignment, sampling_bias=args.sampling_bias,
         sharpening_coeff=args.sharpening_coeff, timing_coeff=args.timing_coeff,
-        encoder_type=saved_args.encoder_type, raw_output=False, name='parrot',
+        encoder_type=saved_args.encoder_type, raw_output=raw_output, name='parrot',
         num_layers=getattr(saved_args, 'num_layers', 3),
         encoder_literal=bool(getattr(saved_args, 'encoder_literal', 1)), device=device)
     parrot.allocate()
     parrot.set_parameter_values(parameters)
+    if raw_output and srn_parameters:
+        from parrot_amd.sampleRNN import lib as srn_lib
+        srn_lib.set_params(srn_parameters)
     print("Successfully loaded the parameters.")
 
     if args.sample_one_step:
@@ -66,6 +76,12 @@ def main(argv=None):
     for idx in range(args.num_samples):
         ll = int(labels_mask_tr[idx].sum())
         features_lengths.append(end_of_utterance(gen_phi[idx], min(ll, gen_phi.shape[2] - 1), args.num_steps))
+    if raw_output:  # sample.py:165-173: SampleRNN vocoder on the generated frames
+        print("Sampling and saving raw audio...")
+        to_save_path = os.path.join(args.save_dir, 'samples', 'new_raw')
+        os.makedirs(to_save_path, exist_ok=True)
+        parrot.sampleRnn.sample_raw(gen_x.swapaxes(0, 1).copy(), features_lengths, args.samples_name, to_save_path)
+        print("Successfully sampled raw audio...")
     out_dir = os.path.join(args.save_dir, 'samples')
     for idx, this_sample in enumerate(gen_x):
         generate_wav(this_sample[:features_lengths[idx]], out_dir, args.samples_name + '_' + str(idx),
