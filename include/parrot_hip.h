@@ -232,7 +232,21 @@ typedef struct ParrotDecoderDesc {
      * not exactly 0.0f (written by seq_fwd, read by seq_bwd).  Rows outside it are multiplied by exact zeros in
      * model.py:675-690 and its gradient, so the scan does not read them; NULL: all U rows are read. */
     int* att_sup;
+    /* Optional workspace of the persistent forward scan (PARROT_SCHEDULE=4): at least
+     * parrot_decoder_persist_floats(desc) floats, ZERO-FILLED by the caller once.  It holds the machine's
+     * fragment-major activation slabs, pre-activation buffers, unit table and barrier words.  With it (and GRU layers,
+     * B <= 64, H and E multiples of 16, U <= 800, fragment-major weight copies present) seq_fwd runs the whole window as
+     * one resident kernel: weights stationary in LDS, phases separated by grid barriers (parrot_amd/csrc/persist.h).
+     * NULL, too small or a non-qualifying configuration: the launch schedules are used. */
+    float* persist_ws;
+    long long persist_ws_floats;
 } ParrotDecoderDesc;
+
+/* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify for the persistent
+ * scan (see above).  Only T, B, H, E, A, U, L, cell, layer_norm and the Wg_f / Wc_f pointers are read. */
+long long parrot_decoder_persist_floats(const ParrotDecoderDesc* desc);
+/* 1 when the plan's forward scan runs on the persistent phase machine. */
+int parrot_decoder_is_persistent(void* plan);
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
 int parrot_decoder_seq_fwd(void* plan, void* stream);

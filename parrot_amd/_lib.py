@@ -69,6 +69,7 @@ class DecoderDesc(C.Structure):
         ("Wg_f", C.c_void_p * MAX_LAYERS), ("Wc_f", C.c_void_p * MAX_LAYERS),
         ("Wg_r", C.c_void_p * MAX_LAYERS), ("Wc_r", C.c_void_p * MAX_LAYERS),
         ("att_sup", C.c_void_p),
+        ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
     ]
 
 
@@ -138,6 +139,8 @@ SIGNATURES = {
     "parrot_gmm_attention_fwd": (_i, [_vp] * 10 + [_i] * 6 + [_f] * 4 + [_vp]),
     "parrot_gmm_attention_bwd": (_i, [_vp] * 10 + [_i] * 6 + [_f, _vp]),
     "parrot_decoder_create": (_i, [C.POINTER(DecoderDesc), C.POINTER(C.c_void_p)]),
+    "parrot_decoder_persist_floats": (C.c_longlong, [C.POINTER(DecoderDesc)]),
+    "parrot_decoder_is_persistent": (_i, [_vp]),
     "parrot_decoder_seq_fwd": (_i, [_vp, _vp]),
     "parrot_decoder_seq_bwd": (_i, [_vp, _vp]),
     "parrot_decoder_destroy": (_i, [_vp]),

@@ -18,7 +18,7 @@ OBJDIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 
 SOURCES = ["skinny.hip", "biggemm.hip", "attention.hip", "elementwise.hip", "quantize.hip",
-           "plans.hip", "capi.hip", "samplernn.hip"]
+           "plans.hip", "capi.hip", "samplernn.hip", "persist.hip"]
 EXTRA_FLAGS = {"quantize.hip": ["-ffp-contract=off"]}
 
 

@@ -1,0 +1,95 @@
+// Persistent phase machine: the decoder scan as ONE resident kernel (gfx950).
+//
+// Replaces the thousands of per-step launches of the wavefront schedules (plans.hip) for the scan of
+// Parrot.compute_cost (reference model.py:651-737).  One workgroup per CU stays resident for the whole window; a
+// tick = PM_SLOTS phases separated by grid barriers; in a phase every workgroup runs up to PM_MAXU work units from a
+// host-built table.  A unit is a 16-column tile of a recurrent-step GEMM over all batch rows with the GRU gate math
+// fused (the same algebra as sk_kernel's epilogues, Blocks GatedRecurrent / sampleRNN/lib/ops.py:364-393), or the
+// GMM-window attention of one batch row (model.py:664-690).  What the launches could not do:
+//   * weights are STATIONARY: a unit's [K,16] weight slab is copied into the CU's LDS once per window (up to 144 KB per
+//     CU) and every step reads it from there; only what does not fit is streamed from the fragment-major copies;
+//   * activations travel between workgroups in fragment-major slabs (1 KB blocks in MFMA operand order), stored
+//     write-through (sc1) by the producing epilogue and read with sc1 loads by the consumers, so the only inter-phase
+//     cost is the barrier (XCD-hierarchical, ~2.4 us measured, tools/persist_probe.hip) -- no launch, no cold start;
+//   * the projections of lower-layer outputs into a layer (Fork h{j}_to_h{l}, inp_to_h{l}; model.py:692-722) run as
+//     separate units one tick ahead of the layer's recurrent units, so every phase's longest dependent GEMM has
+//     K = H instead of K = (l+1) H + E.
+#pragma once
+#include "common.h"
+
+enum { PM_MAXSEG = 4, PM_MAXU = 3, PM_SLOTS = 3, PM_THREADS = 512, PM_MAXINIT = 8 };
+enum { PM_NONE = 0, PM_GEMM = 1, PM_ATT = 2 };
+enum { PM_EPI_LINEAR = 0, PM_EPI_GATES = 1, PM_EPI_CAND = 2 };
+
+// LDS map (floats): resident weights | split-K reduction scratch | attention scratch.  160 KB in total.
+enum {
+    PM_LDS_W = 36864,                 // 144 KB = 2304 K-rows of a 16-column tile
+    PM_LDS_RED = 8 * 16 * 20,         // 8 partial 16x16 tiles, rows padded to 20 floats
+    PM_LDS_ATT = 1536,                // 6 KB
+    PM_LDS_FLOATS = PM_LDS_W + PM_LDS_RED + PM_LDS_ATT,
+    PM_ATT_MAXU = 800,                // context length limit of the in-kernel attention (LDS: 208 + U + 512 + 16 <= 1536)
+    PM_ATT_MAXA = 32,
+};
+
+// Row-major operand at step t: p + t * st (floats), leading dimension ld; p already points at the unit's first column.
+struct PmRM {
+    float* p;
+    long long st;
+    int ld, pad;
+};
+
+// Fragment-major activation slab of one step: [MB row blocks][K/16 chunks][256 floats]; block (rb, c) holds, for lane
+// l = kk*16 + r, the four values X[16 rb + r][16 c + 4 kk + 0..3] -- the A operand of four 16x16x4 MFMAs.
+struct PmSeg {
+    const float* A;
+    long long st;  // floats per step
+    int K, pad;
+};
+
+struct PmUnit {
+    int kind, lag, nseg, w_lds;  // w_lds >= 0: float offset of the resident weight slab in LDS; -1: stream from W
+    PmSeg seg[PM_MAXSEG];
+    const float* W;              // fragment-major weights of the unit: [sum K/16][256] floats, chunks in segment order
+    int epi, M, rtile, row;      // rtile: GATES tile of the reset gate; row: batch row of an ATT unit
+    const float* bias;           // 16 floats (the tile's columns) or null
+    PmRM add0, add1;             // additive pre-activation inputs or null
+    PmRM e0, e1;                 // GATES (r tile): e0 = h_prev;  CAND: e0 = h_prev, e1 = z
+    PmRM out, o1, o2;            // LINEAR: out;  GATES: o1 = z | o2 = r, out = r*h_prev;  CAND: o1 = c, out = h_new
+    float* out_fm;               // fragment-major copy of `out` for the consuming units (or null)
+    long long out_fm_st;
+    int out_fm_nch, out_fm_chunk;  // chunks per row block of that slab / this tile's chunk in it
+};
+
+struct PmAtt {
+    PmRM h1;                      // layer-0 state history [T+1,B,H]: row-major, p = slot 0
+    const float* WattT; const float* batt; const float* ctx;
+    float* kappa;                 // [T+1,B,A]
+    float* a; float* b;           // [T,B,A]
+    float* phi;                   // [T,B,U]
+    float* w;                     // [T+1,B,E] row-major
+    float* wfm; long long wfm_st; // fragment-major copy, slot per step
+    int* sup;                     // [T,B,2] or null
+    int B, H, A, U, E, att_type, dense, pad;
+    float eps, alignment, sharpening, timing;
+};
+
+struct PmInit {  // prologue: row-major [M,K] (ld) -> fragment-major slab
+    const float* src;
+    float* dst;
+    int ld, K;
+};
+
+struct PmProgram {
+    int T, n_ticks, nwg, MB, M, ninit, pad0, pad1;
+    const PmUnit* units;  // device: [PM_SLOTS][nwg][PM_MAXU]
+    unsigned* sync;       // device: PM_SYNC_WORDS unsigned, zeroed before every launch
+    PmAtt att;
+    PmInit init[PM_MAXINIT];
+};
+
+enum { PM_SYNC_WORDS = 1024 };
+// word offsets inside `sync` (128 B apart)
+enum { PM_S_XCNT = 0, PM_S_XGEN = 256, PM_S_TOP = 512, PM_S_CENSUS = 544, PM_S_TOTAL = 800, PM_S_ABORT = 832 };
+
+int pm_launch(const PmProgram& prog, hipStream_t stream);
+int pm_max_workgroups();  // number of workgroups the machine runs with on this device (one per CU, <= 256)

@@ -1,0 +1,509 @@
+// Persistent phase machine for the decoder scan (see persist.h).  gfx950 only.
+#include "persist.h"
+
+#include <stdlib.h>
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+#define PM_RLX __ATOMIC_RELAXED
+#define PM_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ unsigned pm_ld(unsigned* p) { return __hip_atomic_load(p, PM_RLX, PM_AGENT); }
+__device__ __forceinline__ void pm_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, PM_RLX, PM_AGENT); }
+__device__ __forceinline__ unsigned pm_add(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, PM_RLX, PM_AGENT); }
+
+// 4-byte agent-scope (write-through / L1-bypassing) accesses for the few scalar hand-offs (kappa, w fragments)
+__device__ __forceinline__ float pm_ldf(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), PM_RLX, PM_AGENT));
+}
+__device__ __forceinline__ void pm_stf(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), PM_RLX, PM_AGENT);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pm_rsrc(const void* p) {
+    // raw buffer over [p, p + 2 GB); p is wave-uniform
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
+}
+// 16-byte sc1 (agent-coherent) load / store: aux bit 4 = sc1 on gfx950
+__device__ __forceinline__ f32x4 pm_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+__device__ __forceinline__ void pm_st16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, 16);
+}
+
+__device__ __forceinline__ int pm_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 7);
+}
+
+// one lane: wait until *p >= target; gives up after ~200 ms (sets the abort word) or when somebody else did
+__device__ __forceinline__ bool pm_spin_ge(unsigned* p, unsigned target, unsigned* sync) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned it = 0;
+    while (pm_ld(p) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 255) == 0) {
+            if (pm_ld(sync + PM_S_ABORT)) return false;
+            if (wall_clock64() - t0 > 20000000ull) {
+                pm_st(sync + PM_S_ABORT, 1u);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+struct PmBar {
+    int xcc;
+    unsigned n_x, n_xcc;
+};
+
+// XCD-hierarchical grid barrier.  Payload protocol: every wave has drained its write-through (sc1) stores before the
+// workgroup barrier; one lane arrives; consumers read the payload with sc1 loads afterwards (no fences needed: the
+// payload buffers are write-once per launch, so no cache can hold a stale copy).  epoch = 1, 2, ...
+__device__ __forceinline__ bool pm_barrier(unsigned* sync, const PmBar& c, unsigned epoch, int* ok_sh) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool ok;
+        const unsigned old = pm_add(sync + PM_S_XCNT + c.xcc * 32, 1u);
+        if (old == c.n_x * epoch - 1u) {  // last arriver of this XCC: on to the top counter
+            pm_add(sync + PM_S_TOP, 1u);
+            ok = pm_spin_ge(sync + PM_S_TOP, c.n_xcc * epoch, sync);
+            pm_st(sync + PM_S_XGEN + c.xcc * 32, epoch);
+        } else {
+            ok = pm_spin_ge(sync + PM_S_XGEN + c.xcc * 32, epoch, sync);
+        }
+        *ok_sh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *ok_sh != 0;
+}
+
+__device__ __forceinline__ f32x4 pm_rm_load(const PmRM& o, int t, int m, int n0) {
+    // 16 B of row m at columns n0..n0+3 (sc1: written by another workgroup in an earlier phase)
+    const float* p = o.p + (long long)t * o.st + (long long)m * o.ld + n0;
+    const unsigned long long a = (unsigned long long)p;
+    // per-lane address: use a global sc1 load through the flat-address buffer trick is not possible -> two 8-byte
+    // agent-scope loads (L1-bypassing); these operands are a few KB per unit
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(a);
+    const unsigned long long x0 = __hip_atomic_load(q, PM_RLX, PM_AGENT);
+    const unsigned long long x1 = __hip_atomic_load(q + 1, PM_RLX, PM_AGENT);
+    f32x4 v;
+    v[0] = __uint_as_float((unsigned)x0); v[1] = __uint_as_float((unsigned)(x0 >> 32));
+    v[2] = __uint_as_float((unsigned)x1); v[3] = __uint_as_float((unsigned)(x1 >> 32));
+    return v;
+}
+__device__ __forceinline__ void pm_rm_store(const PmRM& o, int t, int m, int n0, f32x4 v) {
+    float* p = o.p + (long long)t * o.st + (long long)m * o.ld + n0;
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), PM_RLX, PM_AGENT);
+    __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), PM_RLX, PM_AGENT);
+}
+
+__device__ __forceinline__ f32x4 pm_sigmoid4(f32x4 x) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = ph_sigmoid(x[i]);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM unit
+// 8 waves = MB row blocks x KS = 8/MB contiguous K ranges.  Wave (rb, ks) owns row block rb of the 16-column tile
+// over its K range: per 16-deep chunk one fragment-major A block (1 KB, sc1 global load) and one B block (1 KB from
+// LDS, shared by the MB waves of the same ks; or a global load when the slab is streamed) feed 4 MFMA 16x16x4.
+template <int MB>
+__device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds_w, float* lds_red) {
+    constexpr int KS = 8 / MB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rb = wave % MB, ks = wave / MB;
+
+    int cend[PM_MAXSEG], snch[PM_MAXSEG];
+    __amdgpu_buffer_rsrc_t srs[PM_MAXSEG];
+    int total = 0;
+#pragma unroll
+    for (int s = 0; s < PM_MAXSEG; ++s) {
+        const bool on = s < u.nseg;
+        const int ss = on ? s : 0;
+        const int nch = on ? (u.seg[ss].K >> 4) : 0;
+        snch[s] = on ? nch : 1;
+        total += nch;
+        cend[s] = total;
+        srs[s] = pm_rsrc(u.seg[ss].A + (long long)t * u.seg[ss].st);
+    }
+    const int c0 = (ks * total) / KS, c1 = ((ks + 1) * total) / KS;
+    const bool resident = u.w_lds >= 0;
+    const float* wl = lds_w + (resident ? u.w_lds : 0);
+    const float* wg = u.W;
+
+    // finalising waves (ks == 0) request their epilogue operands now: they were published in earlier phases
+    const bool fin = wave < MB;
+    const int kk = lane >> 4, r16 = lane & 15;
+    const int m = 16 * rb + r16, n0 = 4 * kk;
+    const bool row_ok = m < u.M;
+    f32x4 p_bias = {0.f, 0.f, 0.f, 0.f}, p_add = {0.f, 0.f, 0.f, 0.f}, p_e0 = {0.f, 0.f, 0.f, 0.f},
+          p_e1 = {0.f, 0.f, 0.f, 0.f};
+    if (fin && row_ok) {
+        if (u.bias) p_bias = *reinterpret_cast<const f32x4*>(u.bias + n0);
+        if (u.add0.p) p_add = pm_rm_load(u.add0, t, m, n0);
+        if (u.add1.p) p_add += pm_rm_load(u.add1, t, m, n0);
+        if (u.e0.p) p_e0 = pm_rm_load(u.e0, t, m, n0);
+        if (u.e1.p) p_e1 = pm_rm_load(u.e1, t, m, n0);
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    auto loadA = [&](int c) -> f32x4 {
+        int beg = 0, s_nch = snch[0];
+        __amdgpu_buffer_rsrc_t rs = srs[0];
+#pragma unroll
+        for (int s = 0; s < PM_MAXSEG - 1; ++s) {
+            const bool nx = c >= cend[s];
+            rs = nx ? srs[s + 1] : rs;
+            s_nch = nx ? snch[s + 1] : s_nch;
+            beg = nx ? cend[s] : beg;
+        }
+        const unsigned off = ((unsigned)(rb * s_nch + (c - beg)) << 10) + ((unsigned)lane << 4);
+        return pm_ld16(rs, off);
+    };
+    auto loadB = [&](int c) -> f32x4 {
+        if (resident) return *reinterpret_cast<const f32x4*>(wl + ((size_t)c << 8) + (lane << 2));
+        return *reinterpret_cast<const f32x4*>(wg + ((size_t)c << 8) + (lane << 2));
+    };
+    auto mma = [&](const f32x4& a, const f32x4& b, f32x4& acc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc, 0, 0, 0);
+    };
+    if (c1 > c0) {
+        constexpr int D = 4;
+        f32x4 ra[D], rbv[D];
+        const int last = c1 - 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int c = min(c0 + d, last);
+            ra[d] = loadA(c);
+            rbv[d] = loadB(c);
+        }
+        int c = c0;
+        for (; c + D <= c1; c += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                mma(ra[d], rbv[d], (d & 1) ? acc1 : acc0);
+                const int cn = min(c + D + d, last);
+                ra[d] = loadA(cn);
+                rbv[d] = loadB(cn);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+            if (c + d < c1) mma(ra[d], rbv[d], (d & 1) ? acc1 : acc0);
+    }
+    const f32x4 part = acc0 + acc1;
+
+    // split-K reduction through LDS: C layout (col = lane & 15, row = 4 (lane >> 4) + reg) -> [row][col] tiles, rows
+    // padded to 20 floats; the finalising wave reads 16-byte row quads = the fragment-major lane order
+    {
+        float* dst = lds_red + (ks * MB + rb) * 320;
+        const int g = lane >> 4, jj = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[(4 * g + i) * 20 + jj] = part[i];
+    }
+    __syncthreads();
+    if (fin) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+            v += *reinterpret_cast<const f32x4*>(lds_red + (q * MB + rb) * 320 + r16 * 20 + n0);
+        f32x4 fm = {0.f, 0.f, 0.f, 0.f};  // value published to the consumers (zero in the padding rows)
+        if (row_ok) {
+            const f32x4 pre = v + p_bias + p_add;
+            if (u.epi == PM_EPI_LINEAR) {
+                fm = pre;
+                pm_rm_store(u.out, t, m, n0, pre);
+            } else if (u.epi == PM_EPI_GATES) {
+                const f32x4 gt = pm_sigmoid4(pre);
+                if (!u.rtile) {
+                    pm_rm_store(u.o1, t, m, n0, gt);  // update gate z
+                } else {
+                    pm_rm_store(u.o2, t, m, n0, gt);  // reset gate r
+                    fm = gt * p_e0;                   // r * h_prev
+                    pm_rm_store(u.out, t, m, n0, fm);
+                }
+            } else {  // PM_EPI_CAND
+                f32x4 c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = tanhf(pre[i]);
+                const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+                fm = p_e1 * c + (one - p_e1) * p_e0;  // z*c + (1-z)*h_prev
+                pm_rm_store(u.o1, t, m, n0, c);
+                pm_rm_store(u.out, t, m, n0, fm);
+            }
+        }
+        if (u.out_fm) {
+            float* f = u.out_fm + (long long)t * u.out_fm_st + ((size_t)(rb * u.out_fm_nch + u.out_fm_chunk) << 8);
+            pm_st16(pm_rsrc(f), (unsigned)lane << 4, fm);
+        }
+    }
+    __syncthreads();  // lds_red is reused by the next unit
+}
+
+// ------------------------------------------------------------------------------------------------ attention row
+// GMM-window attention of batch row b at step t (model.py:664-690) by the whole workgroup (512 threads):
+// projection h1 . Watt, window parameters, phi over the context, w = sum_u phi[u] ctx[b,u,:] over the support of the
+// window.  Same formulas as att_fwd_kernel (attention.hip); the summation order over u differs (two row groups).
+__device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* sm) {
+    const int A = g.A, U = g.U, E = g.E, H = g.H;
+    float* s_p = sm;                        // [3A]
+    float* s_a = s_p + 3 * PM_ATT_MAXA;     // [A]
+    float* s_b = s_a + PM_ATT_MAXA;
+    float* s_k = s_b + PM_ATT_MAXA;
+    float* s_red = s_k + PM_ATT_MAXA;       // [16]
+    float* s_phi = s_red + 16;              // [U]
+    float* s_acc = s_phi + ((U + 3) & ~3);  // [512]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* h = g.h1.p + (long long)(t + 1) * g.h1.st + (long long)b * g.h1.ld;
+    const size_t BA = (size_t)g.B * A;
+
+    // 1) projection: wave w owns outputs j = w, w+8, w+16, w+24
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const __amdgpu_buffer_rsrc_t hr = pm_rsrc(h);
+        for (int k = 4 * lane; k < H; k += 256) {
+            const f32x4 hv = pm_ld16(hr, (unsigned)k << 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = wave + 8 * q;
+                if (j < 3 * A) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(g.WattT + (size_t)j * H + k);
+                    acc[q] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float r = wave_sum(acc[q]);
+            const int j = wave + 8 * q;
+            if (lane == 0 && j < 3 * A) s_p[j] = r + (g.batt ? g.batt[j] : 0.f);
+        }
+    }
+    __syncthreads();
+    // 2) window parameters
+    if (g.att_type == 1) {
+        if (tid == 0) {
+            float mx = -INFINITY;
+            for (int j = 0; j < A; ++j) mx = fmaxf(mx, s_p[j]);
+            float s = 0.f;
+            for (int j = 0; j < A; ++j) s += expf(s_p[j] - mx);
+            s_red[4] = mx;
+            s_red[5] = s;
+        }
+        __syncthreads();
+    }
+    if (tid < A) {
+        float av;
+        if (g.att_type == 1) av = expf(s_p[tid] - s_red[4]) / s_red[5] + g.eps;
+        else av = expf(s_p[tid]) + g.eps;
+        const float bv = expf(s_p[A + tid]) * g.sharpening + g.eps;
+        const float kp = pm_ldf(g.kappa + (size_t)t * BA + (size_t)b * A + tid);
+        const float kv = kp + g.alignment * expf(s_p[2 * A + tid]) / g.timing;
+        s_a[tid] = av; s_b[tid] = bv; s_k[tid] = kv;
+        g.a[(size_t)t * BA + (size_t)b * A + tid] = av;
+        g.b[(size_t)t * BA + (size_t)b * A + tid] = bv;
+        pm_stf(g.kappa + (size_t)(t + 1) * BA + (size_t)b * A + tid, kv);
+    }
+    if (tid == 0) {
+        reinterpret_cast<int*>(s_red)[6] = U;
+        reinterpret_cast<int*>(s_red)[7] = -1;
+    }
+    __syncthreads();
+    // 3) phi
+    float* phi_out = g.phi + ((size_t)t * g.B + b) * U;
+    for (int u = tid; u < U; u += PM_THREADS) {
+        float ph = 0.f;
+        const float uf = (float)u;
+        if (g.att_type == 1) {
+            for (int j = 0; j < A; ++j) {
+                const float d = s_k[j] - uf;
+                ph += s_a[j] * sqrtf(s_b[j]) * expf(-0.5f * s_b[j] * d * d);
+            }
+            ph *= 0.3989422917366028f;
+        } else {
+            for (int j = 0; j < A; ++j) {
+                const float d = s_k[j] - uf;
+                ph += s_a[j] * expf(-s_b[j] * d * d);
+            }
+        }
+        s_phi[u] = ph;
+        if (ph != 0.f) {
+            atomicMin(&reinterpret_cast<int*>(s_red)[6], u);
+            atomicMax(&reinterpret_cast<int*>(s_red)[7], u);
+        }
+        phi_out[u] = ph;
+    }
+    __syncthreads();
+    int u_lo = 0, u_hi = U - 1;
+    if (!g.dense) {
+        u_lo = reinterpret_cast<int*>(s_red)[6];
+        u_hi = reinterpret_cast<int*>(s_red)[7];
+    }
+    if (g.sup && tid == 0) {
+        g.sup[((size_t)t * g.B + b) * 2] = u_lo;
+        g.sup[((size_t)t * g.B + b) * 2 + 1] = u_hi;
+    }
+    // 4) w[e] = sum_u phi[u] ctx[b,u,e] over the support: CW columns x G row groups per pass
+    int CW = 1;
+    while (CW < E && CW < PM_THREADS) CW <<= 1;
+    const int G = PM_THREADS / CW;
+    const int c = tid % CW, ug = tid / CW;
+    const float* ctx = g.ctx + (size_t)b * U * E;
+    float* w_rm = g.w + ((size_t)(t + 1) * g.B + b) * E;
+    float* w_fm = g.wfm + (long long)(t + 1) * g.wfm_st;
+    const int nch = E >> 4;
+    for (int eb = 0; eb < E; eb += CW) {
+        const int e = eb + c;
+        float acc = 0.f;
+        if (e < E && u_lo <= u_hi) {
+            int u = u_lo + ug;
+            for (; u + 3 * G <= u_hi; u += 4 * G) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
+            }
+            for (; u <= u_hi; u += G) acc = __builtin_fmaf(s_phi[u], ctx[(size_t)u * E + e], acc);
+        }
+        __syncthreads();
+        s_acc[tid] = acc;
+        __syncthreads();
+        if (ug == 0 && e < E) {
+            float s = 0.f;
+            for (int q = 0; q < G; ++q) s += s_acc[q * CW + c];
+            w_rm[e] = s;
+            // fragment-major copy: block (b / 16, e / 16), lane (e % 16) / 4 * 16 + b % 16, element e % 4
+            pm_stf(w_fm + (((size_t)((b >> 4) * nch + (e >> 4))) << 8) + ((((e & 15) >> 2) * 16 + (b & 15)) << 2) + (e & 3), s);
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ kernel
+template <int MB>
+__global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lds_w = lds;
+    float* lds_red = lds + PM_LDS_W;
+    float* lds_att = lds_red + PM_LDS_RED;
+    // all scratch lives in the dynamic region (a static __shared__ would push the total over the 160 KB limit)
+    unsigned* cen = reinterpret_cast<unsigned*>(lds_att + PM_LDS_ATT - 16);
+    int& ok_sh = *reinterpret_cast<int*>(lds_att + PM_LDS_ATT - 8);
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned* sync = P.sync;
+
+    // census of the workgroup -> XCC placement (not architecturally defined), then the first rendezvous
+    PmBar bar;
+    bar.xcc = pm_xcc_id();
+    if (tid == 0) {
+        pm_add(sync + PM_S_CENSUS + bar.xcc * 32, 1u);
+        pm_add(sync + PM_S_TOTAL, 1u);
+        const bool ok = pm_spin_ge(sync + PM_S_TOTAL, (unsigned)nwg, sync);
+        for (int x = 0; x < 8; ++x) cen[x] = pm_ld(sync + PM_S_CENSUS + x * 32);
+        ok_sh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ok_sh) return;
+    bar.n_x = cen[bar.xcc];
+    bar.n_xcc = 0;
+    for (int x = 0; x < 8; ++x) bar.n_xcc += cen[x] ? 1u : 0u;
+
+    // resident weight slabs -> LDS (once per window)
+    for (int s = 0; s < PM_SLOTS; ++s)
+        for (int q = 0; q < PM_MAXU; ++q) {
+            const PmUnit& u = P.units[((size_t)s * nwg + wg) * PM_MAXU + q];
+            if (u.kind != PM_GEMM || u.w_lds < 0) continue;
+            int nch = 0;
+            for (int i = 0; i < u.nseg; ++i) nch += u.seg[i].K >> 4;
+            const f32x4* src = reinterpret_cast<const f32x4*>(u.W);
+            f32x4* dst = reinterpret_cast<f32x4*>(lds_w + u.w_lds);
+            for (int i = tid; i < nch * 64; i += PM_THREADS) dst[i] = src[i];
+        }
+    // prologue: the states entering the window (row-major, written by the host side) -> fragment-major slabs
+    {
+        int base = 0;
+        for (int q = 0; q < P.ninit; ++q) {
+            const PmInit in = P.init[q];
+            const int nch = in.K >> 4, nblk = MB * nch;
+            for (int blk = wg * 8 + wave - base; blk < nblk; blk += nwg * 8) {
+                if (blk < 0) continue;
+                const int rb = blk / nch, c = blk % nch;
+                const int m = 16 * rb + (lane & 15), k = 16 * c + 4 * (lane >> 4);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (m < P.M) v = *reinterpret_cast<const f32x4*>(in.src + (size_t)m * in.ld + k);
+                pm_st16(pm_rsrc(in.dst + ((size_t)blk << 8)), (unsigned)lane << 4, v);
+            }
+            base = (base + nblk) % (nwg * 8);
+        }
+    }
+    unsigned epoch = 1;
+    if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
+
+    for (int tick = 0; tick < P.n_ticks; ++tick) {
+        for (int s = 0; s < PM_SLOTS; ++s) {
+            for (int q = 0; q < PM_MAXU; ++q) {
+                const PmUnit& u = P.units[((size_t)s * nwg + wg) * PM_MAXU + q];
+                const int kind = __builtin_amdgcn_readfirstlane(u.kind);
+                if (kind == PM_NONE) continue;
+                const int t = tick - __builtin_amdgcn_readfirstlane(u.lag);
+                if (t < 0 || t >= P.T) continue;
+                if (kind == PM_GEMM) pm_gemm<MB>(u, t, lds_w, lds_red);
+                else pm_att_row(P.att, u.row, t, lds_att);
+            }
+            if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
+        }
+    }
+}
+
+}  // namespace
+
+int pm_max_workgroups() {
+    static int n = -1;
+    if (n < 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
+        const char* e = getenv("PARROT_PM_WGS");  // development knob
+        if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
+    }
+    return n;
+}
+
+int pm_launch(const PmProgram& P, hipStream_t stream) {
+    if (P.nwg < 1 || P.nwg > pm_max_workgroups() || !P.units || !P.sync) return PH_ERR_BADARG;
+    if (P.att.U > PM_ATT_MAXU || P.att.A > PM_ATT_MAXA) return PH_ERR_UNSUPPORTED;
+    PH_CHECK(hipMemsetAsync(P.sync, 0, PM_SYNC_WORDS * sizeof(unsigned), stream));
+    const size_t lds = (size_t)PM_LDS_FLOATS * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    switch (P.MB) {
+        case 1: hipLaunchKernelGGL(pm_kernel<1>, dim3(P.nwg), dim3(PM_THREADS), lds, stream, P); break;
+        case 2: hipLaunchKernelGGL(pm_kernel<2>, dim3(P.nwg), dim3(PM_THREADS), lds, stream, P); break;
+        case 4: hipLaunchKernelGGL(pm_kernel<4>, dim3(P.nwg), dim3(PM_THREADS), lds, stream, P); break;
+        default: return PH_ERR_BADARG;
+    }
+    return (int)hipGetLastError();
+}

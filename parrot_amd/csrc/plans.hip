@@ -4,12 +4,16 @@
 // plan are fixed, so a replay costs one hipGraphLaunch instead of thousands of host launches).
 #include <stdlib.h>
 
+#include <string.h>
+
+#include <algorithm>
 #include <new>
 #include <vector>
 
 #include "../../include/parrot_hip.h"
 #include "attention.h"
 #include "elementwise.h"
+#include "persist.h"
 #include "skinny.h"
 
 namespace {
@@ -213,8 +217,10 @@ struct DecoderPlan : PlanBase {
     // the extra kernels / GEMMs cost.  2 and 3 are what layer_norm needs (the projections that must be normalised
     // are the hoisted ones); layer_norm with L >= 2 therefore runs on 3.
     int schedule = 0, chunk = 50;
+    bool try_persist = false;
 
     int enqueue(int which, hipStream_t s) override {
+        if (which == 0 && persist_ok) return pm_launch(pm_prog, s);  // schedule 4: the persistent phase machine
         if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
         return which == 0 ? fwd(s) : bwd(s);
@@ -227,13 +233,213 @@ struct DecoderPlan : PlanBase {
         bool pipe_ok = d.L >= 2;
         for (int l = 1; l < d.L; ++l)
             if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
+        // 4 = persistent forward scan (resolved in parrot_decoder_create; everything it does not cover -- the backward
+        // scan, LSTM layers, layer_norm, B > 64 -- runs on the launch schedules chosen below)
+        const bool want_persist = want == 4;
+        if (want_persist) want = -1;
         if (want < 0) want = 0;
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
         if (want >= 2 && !pipe_ok) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
         schedule = want;
+        try_persist = want_persist && d.cell == 0 && !d.layer_norm;
         const char* c = getenv("PARROT_CHUNK");
         if (c && atoi(c) > 0) chunk = atoi(c);
+    }
+
+
+    // ---- schedule 4: persistent phase machine for the forward scan (persist.h) ---------------------------------
+    // Units per step t: layer 0: G0 = gates over [h0[t]; w[t]], C0 = candidate over [r*h0; w[t]], ATT (one per batch
+    // row); layer l >= 1: IG_l / IC_l = the projections of [w[t+1]; h_0[t+1] .. h_{l-1}[t+1]] into the layer's gates /
+    // candidate (written to pre-activation buffers), G_l / C_l = the recurrent products over h_l[t] / r*h_l.
+    // Tick q runs slot 0: G0(q), G_l(q - 2l);  slot 1: C0(q), C_l(q - 2l), IC_l(q - 2l + 1);  slot 2: ATT(q),
+    // IG_l(q - 2l + 1).  Every unit's inputs were published at least one barrier earlier (see the lag arithmetic in
+    // DESIGN.md).  Units are spread over the workgroups greedily; a unit's weight slab stays in the workgroup's LDS
+    // for the whole window when it fits (critical recurrent units first), otherwise it is streamed.
+    bool persist_ok = false;
+    PmProgram pm_prog;
+    static long long persist_floats(const ParrotDecoderDesc& d, int nwg) {
+        const int MB = d.B <= 16 ? 1 : (d.B <= 32 ? 2 : 4);
+        const long long slab_h = (long long)MB * 16 * d.H, slab_e = (long long)MB * 16 * d.E;
+        long long n = PM_SYNC_WORDS;
+        n += ((long long)PM_SLOTS * nwg * PM_MAXU * sizeof(PmUnit) + 3) / 4 + 64;
+        n += (long long)d.L * (d.T + 1) * slab_h + (long long)d.L * d.T * slab_h + (long long)(d.T + 1) * slab_e;
+        n += (long long)(d.L - 1) * d.T * d.B * 3 * d.H;
+        return n + 1024;
+    }
+    static bool persist_eligible(const ParrotDecoderDesc& d) {
+        if (d.cell != 0 || d.layer_norm || d.B > 64 || (d.H % 16) || (d.E % 16) || d.U > PM_ATT_MAXU ||
+            d.A > PM_ATT_MAXA || d.T < 1)
+            return false;
+        for (int l = 0; l < d.L; ++l)
+            if (!d.Wg_f[l] || !d.Wc_f[l]) return false;
+        return pm_max_workgroups() >= 64;
+    }
+
+    int build_persist() {
+        persist_ok = false;
+        if (!persist_eligible(d) || !tiled || !d.persist_ws) return 0;
+        const int nwg = pm_max_workgroups();
+        if (d.persist_ws_floats < persist_floats(d, nwg)) return 0;
+        const int H = d.H, E = d.E, B = d.B, L = d.L, T = d.T;
+        const int MB = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+        const long long slab_h = (long long)MB * 16 * H, slab_e = (long long)MB * 16 * E;
+        const long long BH = (long long)B * H, BE = (long long)B * E;
+        // carve the workspace (16-byte aligned pieces)
+        float* ws = d.persist_ws;
+        auto take = [&](long long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
+        unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS));
+        const size_t unit_bytes = (size_t)PM_SLOTS * nwg * PM_MAXU * sizeof(PmUnit);
+        PmUnit* units_dev = reinterpret_cast<PmUnit*>(take((long long)(unit_bytes + 3) / 4 + 16));
+        float* hfm[PARROT_MAX_LAYERS];
+        float* rhfm[PARROT_MAX_LAYERS];
+        float* preg[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+        float* prec[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+        for (int l = 0; l < L; ++l) hfm[l] = take((long long)(T + 1) * slab_h);
+        for (int l = 0; l < L; ++l) rhfm[l] = take((long long)T * slab_h);
+        float* wfm = take((long long)(T + 1) * slab_e);
+        for (int l = 1; l < L; ++l) {
+            preg[l] = take((long long)T * B * 2 * H);
+            prec[l] = take((long long)T * B * H);
+        }
+
+        struct Req { PmUnit u; int slot, krows, crit; };
+        std::vector<Req> reqs;
+        auto rm = [](float* p, long long st, int ld) { PmRM r; r.p = p; r.st = st; r.ld = ld; r.pad = 0; return r; };
+        auto seg = [](const float* A, long long st, int K) { PmSeg g; g.A = A; g.st = st; g.K = K; g.pad = 0; return g; };
+        auto seq_on = [&](int l, const float* p) { return p && ((d.seq_init >> l) & 1); };
+        for (int l = 0; l < L; ++l) {
+            const int Kl = krows(l), nchK = Kl / 16;
+            for (int g = 0; g < 2; ++g) {                      // g = 0: gates (2H wide), 1: candidate (H wide)
+                const int wd = g == 0 ? 2 * H : H;
+                const float* Wf = g == 0 ? d.Wg_f[l] : d.Wc_f[l];
+                const float* bias = g == 0 ? d.bg[l] : d.bc[l];
+                float* sq = g == 0 ? d.seq_g[l] : d.seq_c[l];
+                float* pre = g == 0 ? preg[l] : prec[l];
+                for (int ct = 0; ct < wd / 16; ++ct) {
+                    // recurrent unit (layer 0: the whole product)
+                    Req q;
+                    memset(&q, 0, sizeof(q));
+                    PmUnit& u = q.u;
+                    u.kind = PM_GEMM; u.lag = 2 * l; u.M = B; u.w_lds = -1;
+                    const float* first = g == 0 ? hfm[l] : rhfm[l];
+                    u.seg[0] = seg(first, slab_h, H);
+                    u.nseg = 1;
+                    if (l == 0) { u.seg[1] = seg(wfm, slab_e, E); u.nseg = 2; }
+                    u.W = Wf + (size_t)ct * nchK * 256;
+                    if (l == 0) {
+                        u.bias = bias ? bias + 16 * ct : nullptr;
+                        if (seq_on(l, sq)) u.add0 = rm(sq + 16 * ct, (long long)B * wd, wd);
+                    } else {
+                        u.add0 = rm(pre + 16 * ct, (long long)B * wd, wd);
+                    }
+                    if (g == 0) {
+                        u.epi = PM_EPI_GATES;
+                        u.rtile = 16 * ct >= H;
+                        if (!u.rtile) {
+                            u.o1 = rm(d.z[l] + 16 * ct, BH, H);
+                        } else {
+                            const int j0 = 16 * ct - H;
+                            u.o2 = rm(d.r[l] + j0, BH, H);
+                            u.e0 = rm(d.h[l] + j0, BH, H);
+                            u.out = rm(d.rh[l] + j0, BH, H);
+                            u.out_fm = rhfm[l]; u.out_fm_st = slab_h; u.out_fm_nch = H / 16; u.out_fm_chunk = j0 / 16;
+                        }
+                    } else {
+                        u.epi = PM_EPI_CAND;
+                        u.e0 = rm(d.h[l] + 16 * ct, BH, H);
+                        u.e1 = rm(d.z[l] + 16 * ct, BH, H);
+                        u.o1 = rm(d.c[l] + 16 * ct, BH, H);
+                        u.out = rm(d.h[l] + BH + 16 * ct, BH, H);
+                        u.out_fm = hfm[l] + slab_h; u.out_fm_st = slab_h; u.out_fm_nch = H / 16; u.out_fm_chunk = ct;
+                    }
+                    q.slot = g; q.crit = 1;
+                    q.krows = l == 0 ? H + E : H;
+                    reqs.push_back(q);
+                    if (l == 0) continue;
+                    // input projection of the layer, one tick ahead of its consumer
+                    Req qi;
+                    memset(&qi, 0, sizeof(qi));
+                    PmUnit& v = qi.u;
+                    v.kind = PM_GEMM; v.lag = 2 * l - 1; v.M = B; v.w_lds = -1;
+                    v.seg[0] = seg(wfm + slab_e, slab_e, E);
+                    v.nseg = 1;
+                    for (int j = 0; j < l; ++j) v.seg[v.nseg++] = seg(hfm[j] + slab_h, slab_h, H);
+                    v.W = Wf + ((size_t)ct * nchK + H / 16) * 256;
+                    v.bias = bias ? bias + 16 * ct : nullptr;
+                    if (seq_on(l, sq)) v.add0 = rm(sq + 16 * ct, (long long)B * wd, wd);
+                    v.epi = PM_EPI_LINEAR;
+                    v.out = rm(pre + 16 * ct, (long long)B * wd, wd);
+                    qi.slot = g == 0 ? 2 : 1; qi.crit = 0;
+                    qi.krows = E + l * H;
+                    reqs.push_back(qi);
+                }
+            }
+        }
+        for (int b = 0; b < B; ++b) {
+            Req q;
+            memset(&q, 0, sizeof(q));
+            q.u.kind = PM_ATT; q.u.lag = 0; q.u.row = b; q.u.w_lds = -1;
+            q.slot = 2; q.crit = 1; q.krows = 0;
+            reqs.push_back(q);
+        }
+        // greedy placement
+        std::vector<PmUnit> table((size_t)PM_SLOTS * nwg * PM_MAXU);
+        memset(table.data(), 0, table.size() * sizeof(PmUnit));
+        std::vector<int> lds_used(nwg, 0), load(nwg, 0);
+        std::vector<int> cnt((size_t)PM_SLOTS * nwg, 0);
+        std::vector<int> order(reqs.size());
+        for (size_t i = 0; i < reqs.size(); ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            if (reqs[a].slot != reqs[b].slot) return reqs[a].slot < reqs[b].slot;
+            if (reqs[a].crit != reqs[b].crit) return reqs[a].crit > reqs[b].crit;
+            return reqs[a].krows > reqs[b].krows;
+        });
+        for (int idx : order) {
+            Req& q = reqs[idx];
+            const int need = q.krows * 16;
+            int best = -1;
+            long long best_key = 0;
+            for (int w = 0; w < nwg; ++w) {
+                const int c = cnt[(size_t)q.slot * nwg + w];
+                if (c >= PM_MAXU) continue;
+                const bool fits = need > 0 && lds_used[w] + need <= PM_LDS_W;
+                const long long key = ((long long)c << 40) | ((long long)(need > 0 && !fits ? 1 : 0) << 36) | (long long)load[w];
+                if (best < 0 || key < best_key) { best = w; best_key = key; }
+            }
+            if (best < 0) return 0;  // more units than slots: not eligible (falls back to the launch schedules)
+            if (need > 0 && lds_used[best] + need <= PM_LDS_W) {
+                q.u.w_lds = lds_used[best];
+                lds_used[best] += need;
+            }
+            load[best] += q.krows;
+            int& c = cnt[(size_t)q.slot * nwg + best];
+            table[((size_t)q.slot * nwg + best) * PM_MAXU + c] = q.u;
+            ++c;
+        }
+        if (hipMemcpy(units_dev, table.data(), unit_bytes, hipMemcpyHostToDevice) != hipSuccess) return 0;
+
+        PmProgram& P = pm_prog;
+        memset(&P, 0, sizeof(P));
+        P.T = T; P.n_ticks = T + 2 * (L - 1); P.nwg = nwg; P.MB = MB; P.M = B;
+        P.units = units_dev; P.sync = sync;
+        PmAtt& a = P.att;
+        a.h1 = rm(d.h[0], BH, H);
+        a.WattT = d.WattT; a.batt = d.batt; a.ctx = d.ctx;
+        a.kappa = d.kappa; a.a = d.a; a.b = d.b; a.phi = d.phi; a.w = d.w;
+        a.wfm = wfm; a.wfm_st = slab_e; a.sup = d.att_sup;
+        a.B = B; a.H = H; a.A = d.A; a.U = d.U; a.E = E; a.att_type = d.att_type;
+        {
+            const char* e = getenv("PARROT_ATT_DENSE");
+            a.dense = e ? atoi(e) : 0;
+        }
+        a.eps = d.eps; a.alignment = d.alignment; a.sharpening = d.sharpening; a.timing = d.timing;
+        int ni = 0;
+        for (int l = 0; l < L; ++l) { P.init[ni].src = d.h[l]; P.init[ni].dst = hfm[l]; P.init[ni].ld = H; P.init[ni].K = H; ++ni; }
+        P.init[ni].src = d.w; P.init[ni].dst = wfm; P.init[ni].ld = E; P.init[ni].K = E; ++ni;
+        P.ninit = ni;
+        persist_ok = true;
+        return 0;
     }
 
     // ---- weight operands: plain packed matrices, or their fragment-major copies when the caller gave them
@@ -1386,6 +1592,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         const char* e = getenv("PARROT_TILED_WEIGHTS");
         p->tiled = all && !(e && atoi(e) == 0);
     }
+    if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule >= 2;
         for (int l = 1; l < desc->L && ok; ++l)
@@ -1402,6 +1609,13 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     *plan = p;
     return 0;
 }
+long long parrot_decoder_persist_floats(const ParrotDecoderDesc* desc) { PH_ENTRY();
+    if (!desc || !DecoderPlan::persist_eligible(*desc)) return 0;
+    return DecoderPlan::persist_floats(*desc, pm_max_workgroups());
+}
+
+int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
+
 int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_decoder_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
 int parrot_decoder_destroy(void* plan) { PH_ENTRY();

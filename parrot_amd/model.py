@@ -472,8 +472,8 @@ class Parrot(Brick):
 
     # ------------------------------------------------------------------ training workspace
     def _train_workspace(self, T, B, U):
-        key = ('dec', T, B, U)
-        ws = self._train_ws.get(key)
+        ws_key = ('dec', T, B, U)
+        ws = self._train_ws.get(ws_key)
         if ws is not None:
             return ws
         H, E, A, L, R = self.rnn_h_dim, self.encoded_input_dim, self.attention_size, self.num_layers, self.readouts_dim
@@ -544,13 +544,19 @@ class Parrot(Brick):
                     getattr(d, f'W{key}_r')[l] = tl[(l, key, 'r')].data_ptr()
         ws['att_sup'] = torch.zeros(T, B, 2, device=self._dev(), dtype=torch.int32)
         d.att_sup = ws['att_sup'].data_ptr()
+        if os.environ.get('PARROT_SCHEDULE', '') == '4' and tl is not None:
+            # persistent forward scan: zero-filled workspace for the machine's slabs / unit table / barrier words
+            n = int(_lib.load().parrot_decoder_persist_floats(C.byref(d)))
+            if n > 0:
+                ws['persist_ws'] = torch.zeros(n, **f)
+                d.persist_ws, d.persist_ws_floats = ws['persist_ws'].data_ptr(), n
         d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
         for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dw0', 'dkappa', 'dp'):
             setattr(d, n, ws[n].data_ptr())
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
-        self._train_ws[key] = ws
+        self._train_ws[ws_key] = ws  # (`key` is the group key of the loops above)
         return ws
 
     @staticmethod
@@ -917,8 +923,8 @@ class Parrot(Brick):
 
     # ------------------------------------------------------------------ sampling
     def _sample_workspace(self, S, N, U):
-        key = (S, N, U)
-        ws = self._sample_ws.get(key)
+        ws_key = (S, N, U)
+        ws = self._sample_ws.get(ws_key)
         if ws is not None:
             return ws
         H, E, A, L, R, O = (self.rnn_h_dim, self.encoded_input_dim, self.attention_size, self.num_layers,
@@ -1007,7 +1013,7 @@ class Parrot(Brick):
         plan = C.c_void_p()
         _lib.call('parrot_sample_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
-        self._sample_ws[key] = ws
+        self._sample_ws[ws_key] = ws  # (`key` is the group key of the loops above)
         return ws
 
     def sample_model_device(self, labels, labels_mask, speaker, num_samples, num_steps, unif=None, noise=None,

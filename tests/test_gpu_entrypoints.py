@@ -66,3 +66,53 @@ def test_raw_audio_stream_uses_hip_quantiser(dev):
     ref = Q.batch_quantize(padded, 256, 'mu-law')
     got = raw.transpose(1, 0, 2).reshape(4, -1)
     assert np.array_equal(got, ref[:, :got.shape[1]])
+
+
+def test_train_raw_output_then_sample_raw(dev, tmp_path, monkeypatch):
+    """--raw_output (train.py:36,46,76,92-93; sample.py:165-173): the raw-audio stream feeds the SampleRNN head inside
+    Parrot.compute_cost, both parameter groups are clipped + stepped and checkpointed, and sample.py runs
+    parrot.sampleRnn.sample_raw on the generated frames."""
+    monkeypatch.setenv("RESULTS_DIR", str(tmp_path))
+    sys.path.insert(0, ROOT)
+    import importlib
+    from parrot_amd.checkpoint import load_parameters
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    train = importlib.import_module("train")
+    sample = importlib.import_module("sample")
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=32, EMB_SIZE=8)
+    try:
+        argv = ["--experiment_name", "raw", "--rnn_h_dim", "64", "--readouts_dim", "64", "--batch_size", "2",
+                "--seq_size", "20", "--num_layers", "1", "--labels_type", "text", "--synthetic_examples", "4",
+                "--save_every", "3", "--max_steps", "6", "--save_dir", str(tmp_path), "--raw_output", "1",
+                "--lr_schedule", "1"]
+        train.main(argv)
+        best = os.path.join(str(tmp_path), "vctk", "pkl", "best_raw.tar")
+        vals = load_parameters(best)
+        assert any(k.startswith('/parrot/samplernn/SampleLevel.') for k in vals), "SampleRNN group checkpointed"
+        assert '/parrot/rnn1.state_to_gates' in vals
+        gen_x, lengths = sample.main(["--experiment_name", "raw", "--num_samples", "2", "--num_steps", "12",
+                                      "--save_dir", str(tmp_path)])
+        assert gen_x.shape == (2, 12, 63)
+        raw_dir = os.path.join(str(tmp_path), "vctk", "samples", "new_raw")
+        assert len([f for f in os.listdir(raw_dir) if f.endswith('.wav')]) == 2
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256)
+
+
+def test_pinned_loader_reuses_a_bounded_ring(dev):
+    from parrot_amd.datasets import PinnedAsyncLoader, parrot_stream
+    stream = parrot_stream('vctk', batch_size=4, seq_size=20, labels_type='text', raw_data=False, num_examples=16,
+                           sorting_mult=1)
+    loader = PinnedAsyncLoader(stream, dev, depth=2)
+    n = 0
+    for epoch in range(3):
+        for b in loader:
+            assert b['features'].is_cuda and torch.isfinite(b['features']).all()
+            n += 1
+    assert n >= 12
+    # 4 slots x 4 array sources: independent of how many batches went through
+    assert loader.pinned_allocations <= 4 * 4 * 2, loader.pinned_allocations

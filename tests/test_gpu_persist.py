@@ -1,0 +1,165 @@
+"""The persistent phase machine (PARROT_SCHEDULE=4, parrot_amd/csrc/persist.hip): the forward scan of
+Parrot.compute_cost as ONE resident kernel with LDS-stationary weights.  Parity against the oracle -- cost, frames,
+window state and every gradient (the backward runs on the launch schedule from the buffers the machine saved) -- plus
+run-to-run bitwise reproducibility, hipGraph replay, TBPTT carry and the abort word."""
+import pytest
+import torch
+
+from tests.util import assert_close, make_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(rnn_h_dim=64, readouts_dim=48, encoder_dim=16, input_dim=24, speaker_dim=8, num_speakers=5,
+             encoder_type='bidirectional')
+
+
+def _is_persistent(m, T, B, U):
+    from parrot_amd import _lib
+    ws = m._train_ws.get(('dec', T, B, U))
+    assert ws is not None
+    if 'persist_ws' in ws:
+        assert int(ws['persist_ws'][832:833].view(torch.int32).item()) == 0, "a spin timed out inside the machine"
+    return bool(_lib.load().parrot_decoder_is_persistent(ws['plan']))
+
+
+def _check(dev, monkeypatch, T, B, U, kw, use_graph=True, expect_persistent=True, tol_grad=1e-3, seed=3):
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    monkeypatch.setenv("PARROT_SCHEDULE", "4")
+    full = dict(SMALL, **kw)
+    cfg = R.default_config(**full)
+    p = R.init_params(cfg, seed=7, scale_by_fan_in=True)
+    m = Parrot(device=dev, use_graph=use_graph, **full).allocate()
+    m.set_parameter_values(p)
+    feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=seed, ragged=True, speaker=cfg['use_speaker'])
+    for v in p.values():
+        v.requires_grad_()
+    rc, _, rav, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, spk, 1)
+    rc.backward()
+    outs = []
+    for rep in range(2):
+        m.zero_grad()
+        cost, upd, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev),
+                                          None if spk is None else spk.to(dev), 1, B)
+        cost.backward()
+        assert _is_persistent(m, T, B, U) == expect_persistent
+        assert_close(cost, rc, 1e-4, "cost")
+        assert_close(av[0], rav[0], 1e-4, "frames")
+        assert_close(av[1], rav[1], 1e-4, "kappa")
+        assert_close(av[2], rav[2], 1e-4, "w")
+        assert_close(av[4], rav[4], 1e-4, "phi")
+        assert_close(av[5], rav[5], 1e-4, "pi_att")
+        grads = m.get_gradient_dict()
+        for name, ref in p.items():
+            if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+                continue
+            e = rel_err(grads[name], ref.grad)
+            assert e <= tol_grad, f"grad {name}: rel err {e:.3e}"
+        outs.append((cost.detach().clone(), av[0].clone(), av[1].clone(), m.flat_gradients.clone()))
+    # no float atomics, fixed reduction orders: two passes (the second replays the captured graph) agree bit for bit
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    m.close()
+
+
+@pytest.mark.parametrize("L,B", [(1, 5), (2, 20), (2, 64), (3, 37), (3, 64)])
+def test_persistent_forward_layers_and_row_blocks(dev, monkeypatch, L, B):
+    """1, 2 and 4 row blocks (B <= 16 / 32 / 64), 1-3 layers; T = 9 covers the lagging layers' fill and drain."""
+    _check(dev, monkeypatch, T=9, B=B, U=11, kw=dict(num_layers=L))
+
+
+def test_persistent_forward_feedback_speaker_softmax(dev, monkeypatch):
+    _check(dev, monkeypatch, T=8, B=6, U=9, kw=dict(num_layers=3, full_feedback=True, use_speaker=True))
+    _check(dev, monkeypatch, T=7, B=5, U=8, kw=dict(num_layers=2, weak_feedback=True, attention_type='softmax'),
+           use_graph=False)
+
+
+def test_non_qualifying_configurations_fall_back(dev, monkeypatch):
+    """LSTM layers / layer_norm / B > 64 are not covered by the machine: the launch schedules run instead."""
+    _check(dev, monkeypatch, T=6, B=4, U=7, kw=dict(num_layers=2, cell_type='lstm'), expect_persistent=False)
+    _check(dev, monkeypatch, T=6, B=4, U=7, kw=dict(num_layers=2, layer_norm=True, weak_feedback=True),
+           expect_persistent=False, tol_grad=2e-3)
+    _check(dev, monkeypatch, T=4, B=70, U=7, kw=dict(num_layers=2), expect_persistent=False)
+
+
+def test_persistent_forward_tbptt_carry_and_launch_path_agreement(dev, monkeypatch):
+    """One window == two windows with the carried state; and the machine's frames agree with the launch schedule's to
+    rounding (different summation order of the same products)."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(SMALL, num_layers=2, weak_feedback=True)
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=7, scale_by_fan_in=True)
+    T, B, U = 12, 9, 7
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=5)
+    args = [t.to(dev) for t in (feat.float(), fm.float(), lab, lm.float())]
+    res = {}
+    for sched in ("0", "4"):
+        monkeypatch.setenv("PARROT_SCHEDULE", sched)
+        m = Parrot(device=dev, use_graph=True, **kw).allocate()
+        m.set_parameter_values(p)
+        c, upd, av, _ = m.compute_cost(args[0], args[1], args[2], args[3], None, 1, B)
+        full = av[0].clone()
+        c1, u1, av1, _ = m.compute_cost(args[0][:7], args[1][:7], args[2], args[3], None, 1, B)
+        m.apply_updates(u1)
+        c2, u2, av2, _ = m.compute_cost(args[0][6:], args[1][6:], args[2], args[3], None, 0, B)
+        assert_close(torch.cat([av1[0], av2[0]], 0), full, 1e-5, f"schedule {sched}: TBPTT carry")
+        res[sched] = full
+        m.close()
+    assert_close(res["4"], res["0"], 1e-5, "machine vs launches")
+
+
+def test_persistent_forward_cfg2_width(dev, monkeypatch):
+    """BASELINE configs[1] widths (H = R = 1024, B = 64, U = 200): LDS-resident and streamed units, 4 row blocks."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    monkeypatch.setenv("PARROT_SCHEDULE", "4")
+    kw = dict(num_layers=2, encoder_type='bidirectional', rnn_h_dim=1024, readouts_dim=1024)
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=11, scale_by_fan_in=True)
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.5)
+    m = Parrot(device=dev, use_graph=True, **kw).allocate()
+    m.set_parameter_values(p)
+    T, B, U = 6, 64, 200
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=12, ragged=True)
+    for v in p.values():
+        v.requires_grad_()
+    rc, _, rav, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
+    rc.backward()
+    m.zero_grad()
+    cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+    cost.backward()
+    assert _is_persistent(m, T, B, U)
+    assert_close(cost, rc, 1e-4, "cost")
+    for i, n in ((0, "frames"), (1, "kappa"), (2, "w"), (4, "phi")):
+        assert_close(av[i], rav[i], 1e-4, n)
+    grads = m.get_gradient_dict()
+    for name, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+            continue
+        assert rel_err(grads[name], ref.grad) <= 1e-3, name
+    m.close()
+
+
+def test_workspaces_and_plans_are_reused_between_calls(dev):
+    """A second compute_cost / sample_model call with the same shapes must reuse the cached workspace and replay its
+    instantiated hipGraph (round 1 stored the cache entry under a shadowed key and rebuilt both on every call)."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(SMALL, num_layers=2, weak_feedback=True)
+    cfg = R.default_config(**kw)
+    m = Parrot(device=dev, use_graph=True, **kw).initialize()
+    feat, fm, lab, lm, _ = make_batch(cfg, 6, 4, 7, seed=5)
+    args = (feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev))
+    plans = []
+    for _ in range(3):
+        c, upd, av, _ = m.compute_cost(*args, None, 1, 4)
+        c.backward()
+        ws = m._train_ws.get(('dec', 6, 4, 7))
+        assert ws is not None
+        plans.append(ws['plan'].value)
+    assert len(set(plans)) == 1 and len(m._train_ws) == 2  # encoder runner + decoder workspace
+    for _ in range(2):
+        m.sample_model_device(lab, lm.float(), None, 4, 5)
+    assert len(m._sample_ws) == 1
+    m.close()
