@@ -20,6 +20,8 @@ ARCH = "gfx950"
 SOURCES = ["skinny.hip", "biggemm.hip", "attention.hip", "elementwise.hip", "quantize.hip",
            "plans.hip", "capi.hip", "samplernn.hip", "persist.hip"]
 EXTRA_FLAGS = {"quantize.hip": ["-ffp-contract=off"]}
+if os.environ.get("PARROT_PM_DEPTH"):  # development: ring depth of the persistent machine's K loop
+    EXTRA_FLAGS["persist.hip"] = ["-DPM_DEPTH=" + os.environ["PARROT_PM_DEPTH"]]
 
 
 def _hipcc() -> str:

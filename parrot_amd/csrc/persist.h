@@ -17,17 +17,19 @@
 #pragma once
 #include "common.h"
 
-enum { PM_MAXSEG = 4, PM_MAXU = 3, PM_SLOTS = 3, PM_THREADS = 512, PM_MAXINIT = 8 };
+enum { PM_MAXU = 3, PM_SLOTS = 3, PM_THREADS = 512, PM_MAXINIT = 8, PM_MAXDST = 4 };
 enum { PM_NONE = 0, PM_GEMM = 1, PM_ATT = 2 };
 enum { PM_EPI_LINEAR = 0, PM_EPI_GATES = 1, PM_EPI_CAND = 2 };
 
-// LDS map (floats): resident weights | split-K reduction scratch | attention scratch.  160 KB in total.
+// LDS map (floats): resident weights | scratch shared by the split-K reduction (8 partial 16x16 tiles, rows padded
+// to 20 floats) and the attention row (never live at the same time) | the workgroup's unit table | misc.
 enum {
     PM_LDS_W = 36864,                 // 144 KB = 2304 K-rows of a 16-column tile
-    PM_LDS_RED = 8 * 16 * 20,         // 8 partial 16x16 tiles, rows padded to 20 floats
-    PM_LDS_ATT = 1536,                // 6 KB
-    PM_LDS_FLOATS = PM_LDS_W + PM_LDS_RED + PM_LDS_ATT,
-    PM_ATT_MAXU = 800,                // context length limit of the in-kernel attention (LDS: 208 + U + 512 + 16 <= 1536)
+    PM_LDS_RED = 8 * 16 * 20,         // 10 KB
+    PM_LDS_UNITS = 1024,              // 4 KB: PM_SLOTS * PM_MAXU unit descriptors
+    PM_LDS_MISC = 32,
+    PM_LDS_FLOATS = PM_LDS_W + PM_LDS_RED + PM_LDS_UNITS + PM_LDS_MISC,
+    PM_ATT_MAXU = 800,                // context length limit of the in-kernel attention (208 + U + 512 floats <= PM_LDS_RED)
     PM_ATT_MAXA = 32,
 };
 
@@ -40,24 +42,26 @@ struct PmRM {
 
 // Fragment-major activation slab of one step: [MB row blocks][K/16 chunks][256 floats]; block (rb, c) holds, for lane
 // l = kk*16 + r, the four values X[16 rb + r][16 c + 4 kk + 0..3] -- the A operand of four 16x16x4 MFMAs.
-struct PmSeg {
-    const float* A;
-    long long st;  // floats per step
-    int K, pad;
+// Every unit reads ONE slab (its whole K range, e.g. [h0[t] ; w[t]] for the layer-0 gates): the producers write their
+// tiles into every slab that contains them (PmDst), so the consumer's K loop needs no segment lookup.
+// Slabs are addressed as BYTE offsets from PmProgram::fm_base (one buffer resource for the whole region, < 4 GB).
+struct PmDst {
+    unsigned off, st;   // slab of step t = fm_base + off + t * st
+    int nch, chunk;     // chunks per row block of that slab / chunk of the producer's first column
 };
 
 struct PmUnit {
-    int kind, lag, nseg, w_lds;  // w_lds >= 0: float offset of the resident weight slab in LDS; -1: stream from W
-    PmSeg seg[PM_MAXSEG];
-    const float* W;              // fragment-major weights of the unit: [sum K/16][256] floats, chunks in segment order
+    int kind, lag, K, w_lds;     // w_lds >= 0: float offset of the resident weight slab in LDS; -1: stream from W
+    unsigned a_off, a_st;        // the activation slab the unit reads
+    int a_nch, a_c0;             // chunks per row block of that slab / the unit's first chunk in it (K/16 chunks are read)
+    const float* W;              // fragment-major weights of the unit: [K/16][256] floats
     int epi, M, rtile, row;      // rtile: GATES tile of the reset gate; row: batch row of an ATT unit
     const float* bias;           // 16 floats (the tile's columns) or null
-    PmRM add0, add1;             // additive pre-activation inputs or null
+    PmRM add[4];                 // additive pre-activation inputs (p == null: unused)
     PmRM e0, e1;                 // GATES (r tile): e0 = h_prev;  CAND: e0 = h_prev, e1 = z
     PmRM out, o1, o2;            // LINEAR: out;  GATES: o1 = z | o2 = r, out = r*h_prev;  CAND: o1 = c, out = h_new
-    float* out_fm;               // fragment-major copy of `out` for the consuming units (or null)
-    long long out_fm_st;
-    int out_fm_nch, out_fm_chunk;  // chunks per row block of that slab / this tile's chunk in it
+    int ndst, pad2;              // fragment-major copies of `out` for the consuming units
+    PmDst dst[PM_MAXDST];
 };
 
 struct PmAtt {
@@ -67,27 +71,29 @@ struct PmAtt {
     float* a; float* b;           // [T,B,A]
     float* phi;                   // [T,B,U]
     float* w;                     // [T+1,B,E] row-major
-    float* wfm; long long wfm_st; // fragment-major copy, slot per step
+    int nwdst, pad3;              // fragment-major copies of w[t+1] (slab of step t+1 for layer 0, step t above)
+    PmDst wdst[PM_MAXDST];        // off already points at the slab the value of step t goes to (t * st is added)
     int* sup;                     // [T,B,2] or null
     int B, H, A, U, E, att_type, dense, pad;
     float eps, alignment, sharpening, timing;
 };
 
-struct PmInit {  // prologue: row-major [M,K] (ld) -> fragment-major slab
+struct PmInit {  // prologue: row-major [M,K] (ld) -> chunks [chunk, chunk + K/16) of a fragment-major slab
     const float* src;
-    float* dst;
-    int ld, K;
+    unsigned dst_off;
+    int nch, chunk, ld, K, pad;
 };
 
 struct PmProgram {
     int T, n_ticks, nwg, MB, M, ninit, pad0, pad1;
     const PmUnit* units;  // device: [PM_SLOTS][nwg][PM_MAXU]
-    unsigned* sync;       // device: PM_SYNC_WORDS unsigned, zeroed before every launch
+    unsigned* sync;       // device: PM_SYNC_WORDS + PM_DBG_WORDS unsigned, zeroed before every launch
+    float* fm_base;       // start of the fragment-major slab region (all PmDst / a_off offsets are relative to it)
     PmAtt att;
     PmInit init[PM_MAXINIT];
 };
 
-enum { PM_SYNC_WORDS = 1024 };
+enum { PM_SYNC_WORDS = 1024, PM_DBG_WORDS = 256 * 16 + 256 * 8 };  // dbg: per workgroup 8 x u64 phase timers (100 MHz ticks)
 // word offsets inside `sync` (128 B apart)
 enum { PM_S_XCNT = 0, PM_S_XGEN = 256, PM_S_TOP = 512, PM_S_CENSUS = 544, PM_S_TOTAL = 800, PM_S_ABORT = 832 };
 

@@ -3,7 +3,22 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// 16-deep K chunks in flight per wave (1 KB of activations + 1 KB of weights each).  The sc1 activation loads miss the
+// XCD's L2 by construction (another XCD wrote them through), ~0.5 us per round trip: with 4 in flight a [64, 1280]
+// operand took ~10 round trips; 12 keeps 96 KB per CU in flight.
+#ifndef PM_DEPTH
+#define PM_DEPTH 16
+#endif
+#ifndef PM_SDEPTH
+#define PM_SDEPTH 8  // streamed units: activation and weight chunks both come from global memory
+#endif
+#ifndef PM_WDEPTH
+#define PM_WDEPTH 4
+#endif
 
 namespace {
 
@@ -36,6 +51,13 @@ __device__ __forceinline__ f32x4 pm_ld16(__amdgpu_buffer_rsrc_t r, unsigned byte
 }
 __device__ __forceinline__ void pm_st16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, 16);
+}
+
+// 100 MHz wall clock, not reorderable (the builtin has no side effects as far as the optimiser is concerned)
+__device__ __forceinline__ unsigned long long pm_clock() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
 }
 
 __device__ __forceinline__ int pm_xcc_id() {
@@ -102,11 +124,15 @@ __device__ __forceinline__ f32x4 pm_rm_load(const PmRM& o, int t, int m, int n0)
     v[2] = __uint_as_float((unsigned)x1); v[3] = __uint_as_float((unsigned)(x1 >> 32));
     return v;
 }
+// 16-byte row-major stores.  WT = true: write-through (sc1) for values another workgroup reads later in this launch
+// (z, h_new, pre-activation partials); false: plain store for values only the backward pass / the host side reads.
+// Issued as inline asm (no C++ construct yields a 16-byte sc1 global store); every phase ends with an explicit
+// s_waitcnt vmcnt(0) before the barrier, which is what orders them.
+template <bool WT>
 __device__ __forceinline__ void pm_rm_store(const PmRM& o, int t, int m, int n0, f32x4 v) {
     float* p = o.p + (long long)t * o.st + (long long)m * o.ld + n0;
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]), PM_RLX, PM_AGENT);
-    __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]), PM_RLX, PM_AGENT);
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<f32x4*>(p) = v;
 }
 
 __device__ __forceinline__ f32x4 pm_sigmoid4(f32x4 x) {
@@ -121,29 +147,23 @@ __device__ __forceinline__ f32x4 pm_sigmoid4(f32x4 x) {
 // over its K range: per 16-deep chunk one fragment-major A block (1 KB, sc1 global load) and one B block (1 KB from
 // LDS, shared by the MB waves of the same ks; or a global load when the slab is streamed) feed 4 MFMA 16x16x4.
 template <int MB>
-__device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds_w, float* lds_red) {
+__device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds_w, float* lds_red,
+                                        const __amdgpu_buffer_rsrc_t fm, unsigned long long* stage) {
+    const unsigned long long ts0 = pm_clock();
     constexpr int KS = 8 / MB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rb = wave % MB, ks = wave / MB;
 
-    int cend[PM_MAXSEG], snch[PM_MAXSEG];
-    __amdgpu_buffer_rsrc_t srs[PM_MAXSEG];
-    int total = 0;
-#pragma unroll
-    for (int s = 0; s < PM_MAXSEG; ++s) {
-        const bool on = s < u.nseg;
-        const int ss = on ? s : 0;
-        const int nch = on ? (u.seg[ss].K >> 4) : 0;
-        snch[s] = on ? nch : 1;
-        total += nch;
-        cend[s] = total;
-        srs[s] = pm_rsrc(u.seg[ss].A + (long long)t * u.seg[ss].st);
-    }
+    const int total = __builtin_amdgcn_readfirstlane(u.K >> 4);  // 16-deep chunks of the unit's slab
+    const unsigned abase = __builtin_amdgcn_readfirstlane(u.a_off + (unsigned)t * u.a_st) +
+                           ((unsigned)(rb * __builtin_amdgcn_readfirstlane(u.a_nch) + __builtin_amdgcn_readfirstlane(u.a_c0)) << 10);
     const int c0 = (ks * total) / KS, c1 = ((ks + 1) * total) / KS;
     const bool resident = u.w_lds >= 0;
-    const float* wl = lds_w + (resident ? u.w_lds : 0);
-    const float* wg = u.W;
+    const float* wl = lds_w + (resident ? u.w_lds : 0);  // stays an LDS (address space 3) pointer
+    // global (address space 1) pointer: the descriptor lives in LDS, so the compiler cannot infer it
+    typedef const __attribute__((address_space(1))) f32x4* gptr4;
+    gptr4 wg = (gptr4)(unsigned long long)u.W;
 
     // finalising waves (ks == 0) request their epilogue operands now: they were published in earlier phases
     const bool fin = wave < MB;
@@ -154,59 +174,62 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
           p_e1 = {0.f, 0.f, 0.f, 0.f};
     if (fin && row_ok) {
         if (u.bias) p_bias = *reinterpret_cast<const f32x4*>(u.bias + n0);
-        if (u.add0.p) p_add = pm_rm_load(u.add0, t, m, n0);
-        if (u.add1.p) p_add += pm_rm_load(u.add1, t, m, n0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (u.add[q].p) p_add += pm_rm_load(u.add[q], t, m, n0);
         if (u.e0.p) p_e0 = pm_rm_load(u.e0, t, m, n0);
         if (u.e1.p) p_e1 = pm_rm_load(u.e1, t, m, n0);
     }
 
+    const unsigned long long ts1 = pm_clock();
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    auto loadA = [&](int c) -> f32x4 {
-        int beg = 0, s_nch = snch[0];
-        __amdgpu_buffer_rsrc_t rs = srs[0];
-#pragma unroll
-        for (int s = 0; s < PM_MAXSEG - 1; ++s) {
-            const bool nx = c >= cend[s];
-            rs = nx ? srs[s + 1] : rs;
-            s_nch = nx ? snch[s + 1] : s_nch;
-            beg = nx ? cend[s] : beg;
-        }
-        const unsigned off = ((unsigned)(rb * s_nch + (c - beg)) << 10) + ((unsigned)lane << 4);
-        return pm_ld16(rs, off);
-    };
-    auto loadB = [&](int c) -> f32x4 {
-        if (resident) return *reinterpret_cast<const f32x4*>(wl + ((size_t)c << 8) + (lane << 2));
-        return *reinterpret_cast<const f32x4*>(wg + ((size_t)c << 8) + (lane << 2));
+    auto loadA = [&](int c) -> f32x4 {  // block (rb, c): scalar offset + lane * 16
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fm, (unsigned)lane << 4,
+                                                                               abase + ((unsigned)c << 10), 16));
     };
     auto mma = [&](const f32x4& a, const f32x4& b, f32x4& acc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc, 0, 0, 0);
     };
-    if (c1 > c0) {
-        constexpr int D = 4;
-        f32x4 ra[D], rbv[D];
+    // two copies of the K loop: weights from LDS (ds_read_b128) or streamed from global memory.  One loop with a
+    // run-time pointer would turn both into flat loads (conservative waits on both counters).
+    auto run = [&](auto res_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        auto loadB = [&](int c) -> f32x4 {
+            if (RES) return *reinterpret_cast<const f32x4*>(wl + ((size_t)c << 8) + (lane << 2));
+            return __builtin_nontemporal_load(wg + ((size_t)c << 6) + lane);
+        };
+        // activation ring: PM_DEPTH chunks in flight (global, ~1 us away); weight ring: PM_WDEPTH (LDS is close)
+        constexpr int D = RES ? PM_DEPTH : PM_SDEPTH, DB = RES ? PM_WDEPTH : PM_SDEPTH;
+        static_assert(D % DB == 0, "");
+        f32x4 ra[D], rbv[DB];
         const int last = c1 - 1;
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int c = min(c0 + d, last);
-            ra[d] = loadA(c);
-            rbv[d] = loadB(c);
-        }
+        for (int d = 0; d < D; ++d) ra[d] = loadA(min(c0 + d, last));
+#pragma unroll
+        for (int d = 0; d < DB; ++d) rbv[d] = loadB(min(c0 + d, last));
         int c = c0;
         for (; c + D <= c1; c += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                mma(ra[d], rbv[d], (d & 1) ? acc1 : acc0);
-                const int cn = min(c + D + d, last);
-                ra[d] = loadA(cn);
-                rbv[d] = loadB(cn);
+                mma(ra[d], rbv[d % DB], (d & 1) ? acc1 : acc0);
+                ra[d] = loadA(min(c + D + d, last));
+                rbv[d % DB] = loadB(min(c + DB + d, last));
             }
         }
 #pragma unroll
         for (int d = 0; d < D - 1; ++d)
-            if (c + d < c1) mma(ra[d], rbv[d], (d & 1) ? acc1 : acc0);
+            if (c + d < c1) {
+                mma(ra[d], rbv[d % DB], (d & 1) ? acc1 : acc0);
+                rbv[d % DB] = loadB(min(c + DB + d, last));
+            }
+    };
+    if (c1 > c0) {
+        if (resident) run(std::true_type{});
+        else run(std::false_type{});
     }
     const f32x4 part = acc0 + acc1;
+    const unsigned long long ts2 = pm_clock();
 
     // split-K reduction through LDS: C layout (col = lane & 15, row = 4 (lane >> 4) + reg) -> [row][col] tiles, rows
     // padded to 20 floats; the finalising wave reads 16-byte row quads = the fragment-major lane order
@@ -217,41 +240,51 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
         for (int i = 0; i < 4; ++i) dst[(4 * g + i) * 20 + jj] = part[i];
     }
     __syncthreads();
+    const unsigned long long ts3 = pm_clock();
     if (fin) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < KS; ++q)
             v += *reinterpret_cast<const f32x4*>(lds_red + (q * MB + rb) * 320 + r16 * 20 + n0);
-        f32x4 fm = {0.f, 0.f, 0.f, 0.f};  // value published to the consumers (zero in the padding rows)
+        f32x4 fmv = {0.f, 0.f, 0.f, 0.f};  // value published to the consumers (zero in the padding rows)
         if (row_ok) {
             const f32x4 pre = v + p_bias + p_add;
             if (u.epi == PM_EPI_LINEAR) {
-                fm = pre;
-                pm_rm_store(u.out, t, m, n0, pre);
+                fmv = pre;
+                pm_rm_store<true>(u.out, t, m, n0, pre);
             } else if (u.epi == PM_EPI_GATES) {
                 const f32x4 gt = pm_sigmoid4(pre);
                 if (!u.rtile) {
-                    pm_rm_store(u.o1, t, m, n0, gt);  // update gate z
+                    pm_rm_store<true>(u.o1, t, m, n0, gt);  // update gate z (read by the candidate units)
                 } else {
-                    pm_rm_store(u.o2, t, m, n0, gt);  // reset gate r
-                    fm = gt * p_e0;                   // r * h_prev
-                    pm_rm_store(u.out, t, m, n0, fm);
+                    pm_rm_store<false>(u.o2, t, m, n0, gt);  // reset gate r (backward only)
+                    fmv = gt * p_e0;                   // r * h_prev
+                    pm_rm_store<false>(u.out, t, m, n0, fmv);  // row-major r*h: backward only (consumers read the slab)
                 }
             } else {  // PM_EPI_CAND
                 f32x4 c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = tanhf(pre[i]);
                 const f32x4 one = {1.f, 1.f, 1.f, 1.f};
-                fm = p_e1 * c + (one - p_e1) * p_e0;  // z*c + (1-z)*h_prev
-                pm_rm_store(u.o1, t, m, n0, c);
-                pm_rm_store(u.out, t, m, n0, fm);
+                fmv = p_e1 * c + (one - p_e1) * p_e0;  // z*c + (1-z)*h_prev
+                pm_rm_store<false>(u.o1, t, m, n0, c);
+                pm_rm_store<true>(u.out, t, m, n0, fmv);  // h_new: next step's epilogues and the attention read it
             }
         }
-        if (u.out_fm) {
-            float* f = u.out_fm + (long long)t * u.out_fm_st + ((size_t)(rb * u.out_fm_nch + u.out_fm_chunk) << 8);
-            pm_st16(pm_rsrc(f), (unsigned)lane << 4, fm);
+        const int ndst = __builtin_amdgcn_readfirstlane(u.ndst);
+#pragma unroll
+        for (int q = 0; q < PM_MAXDST; ++q) {
+            if (q < ndst) {
+                const PmDst ds = u.dst[q];
+                const unsigned so = ds.off + (unsigned)t * ds.st + ((unsigned)(rb * ds.nch + ds.chunk) << 10);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fmv), fm, (unsigned)lane << 4,
+                                                       __builtin_amdgcn_readfirstlane(so), 16);
+            }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts4 = pm_clock();
+    stage[0] += ts1 - ts0; stage[1] += ts2 - ts1; stage[2] += ts3 - ts2; stage[3] += ts4 - ts3;
     __syncthreads();  // lds_red is reused by the next unit
 }
 
@@ -259,7 +292,7 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
 // GMM-window attention of batch row b at step t (model.py:664-690) by the whole workgroup (512 threads):
 // projection h1 . Watt, window parameters, phi over the context, w = sum_u phi[u] ctx[b,u,:] over the support of the
 // window.  Same formulas as att_fwd_kernel (attention.hip); the summation order over u differs (two row groups).
-__device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* sm) {
+__device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* sm, float* fm_base) {
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_p = sm;                        // [3A]
     float* s_a = s_p + 3 * PM_ATT_MAXA;     // [A]
@@ -365,13 +398,13 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
     const int c = tid % CW, ug = tid / CW;
     const float* ctx = g.ctx + (size_t)b * U * E;
     float* w_rm = g.w + ((size_t)(t + 1) * g.B + b) * E;
-    float* w_fm = g.wfm + (long long)(t + 1) * g.wfm_st;
-    const int nch = E >> 4;
     for (int eb = 0; eb < E; eb += CW) {
         const int e = eb + c;
         float acc = 0.f;
         if (e < E && u_lo <= u_hi) {
-            int u = u_lo + ug;
+            // row group ug takes u = ug (mod G), as in the walk over all rows: skipping the rows with phi == 0 then
+            // leaves every partial sum bit-identical (PARROT_ATT_DENSE=1 reads them all)
+            int u = u_lo + ((ug - u_lo % G + G) % G);
             for (; u + 3 * G <= u_hi; u += 4 * G) {
                 float v[4];
 #pragma unroll
@@ -388,8 +421,13 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
             float s = 0.f;
             for (int q = 0; q < G; ++q) s += s_acc[q * CW + c];
             w_rm[e] = s;
-            // fragment-major copy: block (b / 16, e / 16), lane (e % 16) / 4 * 16 + b % 16, element e % 4
-            pm_stf(w_fm + (((size_t)((b >> 4) * nch + (e >> 4))) << 8) + ((((e & 15) >> 2) * 16 + (b & 15)) << 2) + (e & 3), s);
+            // fragment-major copies: block (b / 16, chunk + e / 16), lane (e % 16) / 4 * 16 + b % 16, element e % 4
+            for (int q = 0; q < g.nwdst; ++q) {
+                const PmDst ds = g.wdst[q];
+                float* slab = fm_base + ((size_t)ds.off + (size_t)t * ds.st) / 4;
+                pm_stf(slab + (((size_t)((b >> 4) * ds.nch + ds.chunk + (e >> 4))) << 8) +
+                           ((((e & 15) >> 2) * 16 + (b & 15)) << 2) + (e & 3), s);
+            }
         }
     }
     __syncthreads();
@@ -401,13 +439,17 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds;
     float* lds_red = lds + PM_LDS_W;
-    float* lds_att = lds_red + PM_LDS_RED;
+    float* lds_att = lds_red;  // the attention row reuses the reduction scratch
+    // the workgroup's unit descriptors: read once from global memory, then from LDS every phase
+    PmUnit* lds_units = reinterpret_cast<PmUnit*>(lds_red + PM_LDS_RED);
+    static_assert(sizeof(PmUnit) * PM_SLOTS * PM_MAXU <= PM_LDS_UNITS * sizeof(float), "unit table does not fit");
     // all scratch lives in the dynamic region (a static __shared__ would push the total over the 160 KB limit)
-    unsigned* cen = reinterpret_cast<unsigned*>(lds_att + PM_LDS_ATT - 16);
-    int& ok_sh = *reinterpret_cast<int*>(lds_att + PM_LDS_ATT - 8);
+    unsigned* cen = reinterpret_cast<unsigned*>(lds_red + PM_LDS_RED + PM_LDS_UNITS);
+    int& ok_sh = *reinterpret_cast<int*>(lds_red + PM_LDS_RED + PM_LDS_UNITS + 16);
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     unsigned* sync = P.sync;
+    const __amdgpu_buffer_rsrc_t fmr = __builtin_amdgcn_make_buffer_rsrc(P.fm_base, 0, 0xffffffff, 0x00020000);
 
     // census of the workgroup -> XCC placement (not architecturally defined), then the first rendezvous
     PmBar bar;
@@ -425,13 +467,23 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     bar.n_xcc = 0;
     for (int x = 0; x < 8; ++x) bar.n_xcc += cen[x] ? 1u : 0u;
 
+    {
+        static_assert(sizeof(PmUnit) % 4 == 0, "");
+        constexpr int words = (int)(sizeof(PmUnit) / 4);
+        for (int s = 0; s < PM_SLOTS; ++s)
+            for (int q = 0; q < PM_MAXU; ++q) {
+                const unsigned* src = reinterpret_cast<const unsigned*>(&P.units[((size_t)s * nwg + wg) * PM_MAXU + q]);
+                unsigned* dst = reinterpret_cast<unsigned*>(&lds_units[s * PM_MAXU + q]);
+                for (int i = tid; i < words; i += PM_THREADS) dst[i] = src[i];
+            }
+    }
+    __syncthreads();
     // resident weight slabs -> LDS (once per window)
     for (int s = 0; s < PM_SLOTS; ++s)
         for (int q = 0; q < PM_MAXU; ++q) {
-            const PmUnit& u = P.units[((size_t)s * nwg + wg) * PM_MAXU + q];
+            const PmUnit& u = lds_units[s * PM_MAXU + q];
             if (u.kind != PM_GEMM || u.w_lds < 0) continue;
-            int nch = 0;
-            for (int i = 0; i < u.nseg; ++i) nch += u.seg[i].K >> 4;
+            const int nch = u.K >> 4;
             const f32x4* src = reinterpret_cast<const f32x4*>(u.W);
             f32x4* dst = reinterpret_cast<f32x4*>(lds_w + u.w_lds);
             for (int i = tid; i < nch * 64; i += PM_THREADS) dst[i] = src[i];
@@ -448,7 +500,9 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
                 const int m = 16 * rb + (lane & 15), k = 16 * c + 4 * (lane >> 4);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (m < P.M) v = *reinterpret_cast<const f32x4*>(in.src + (size_t)m * in.ld + k);
-                pm_st16(pm_rsrc(in.dst + ((size_t)blk << 8)), (unsigned)lane << 4, v);
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(i32x4, v), fmr, (unsigned)lane << 4,
+                    __builtin_amdgcn_readfirstlane(in.dst_off + ((unsigned)(rb * in.nch + in.chunk + c) << 10)), 16);
             }
             base = (base + nblk) % (nwg * 8);
         }
@@ -456,19 +510,32 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     unsigned epoch = 1;
     if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
 
+    // phase timers (work / barrier wait per slot, summed over the ticks): a handful of s_memrealtime reads per phase
+    unsigned long long t_work[PM_SLOTS] = {0, 0, 0}, t_wait[PM_SLOTS] = {0, 0, 0}, stage[4] = {0, 0, 0, 0};
     for (int tick = 0; tick < P.n_ticks; ++tick) {
         for (int s = 0; s < PM_SLOTS; ++s) {
+            const unsigned long long ta = pm_clock();
             for (int q = 0; q < PM_MAXU; ++q) {
-                const PmUnit& u = P.units[((size_t)s * nwg + wg) * PM_MAXU + q];
+                const PmUnit& u = lds_units[s * PM_MAXU + q];
                 const int kind = __builtin_amdgcn_readfirstlane(u.kind);
                 if (kind == PM_NONE) continue;
                 const int t = tick - __builtin_amdgcn_readfirstlane(u.lag);
                 if (t < 0 || t >= P.T) continue;
-                if (kind == PM_GEMM) pm_gemm<MB>(u, t, lds_w, lds_red);
-                else pm_att_row(P.att, u.row, t, lds_att);
+                if (kind == PM_GEMM) pm_gemm<MB>(u, t, lds_w, lds_red, fmr, stage);
+                else pm_att_row(P.att, u.row, t, lds_att, P.fm_base);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long tb = pm_clock();
             if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
+            t_work[s] += tb - ta;
+            t_wait[s] += pm_clock() - tb;
         }
+    }
+    if (tid == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(sync + PM_SYNC_WORDS) + (size_t)wg * 8;
+        for (int s = 0; s < PM_SLOTS; ++s) { dbg[s] = t_work[s]; dbg[3 + s] = t_wait[s]; }
+        unsigned long long* dbg2 = reinterpret_cast<unsigned long long*>(sync + PM_SYNC_WORDS) + 2048 + (size_t)wg * 4;
+        for (int q = 0; q < 4; ++q) dbg2[q] = stage[q];
     }
 }
 
@@ -490,7 +557,7 @@ int pm_max_workgroups() {
 int pm_launch(const PmProgram& P, hipStream_t stream) {
     if (P.nwg < 1 || P.nwg > pm_max_workgroups() || !P.units || !P.sync) return PH_ERR_BADARG;
     if (P.att.U > PM_ATT_MAXU || P.att.A > PM_ATT_MAXA) return PH_ERR_UNSUPPORTED;
-    PH_CHECK(hipMemsetAsync(P.sync, 0, PM_SYNC_WORDS * sizeof(unsigned), stream));
+    PH_CHECK(hipMemsetAsync(P.sync, 0, (PM_SYNC_WORDS + PM_DBG_WORDS) * sizeof(unsigned), stream));
     const size_t lds = (size_t)PM_LDS_FLOATS * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

@@ -235,7 +235,7 @@ struct DecoderPlan : PlanBase {
             if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
         // 4 = persistent forward scan (resolved in parrot_decoder_create; everything it does not cover -- the backward
         // scan, LSTM layers, layer_norm, B > 64 -- runs on the launch schedules chosen below)
-        const bool want_persist = want == 4;
+        const bool want_persist = want == 4;  // opt-in: measured at cfg2 it only matches the launch schedules
         if (want_persist) want = -1;
         if (want < 0) want = 0;
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
@@ -257,14 +257,17 @@ struct DecoderPlan : PlanBase {
     // DESIGN.md).  Units are spread over the workgroups greedily; a unit's weight slab stays in the workgroup's LDS
     // for the whole window when it fits (critical recurrent units first), otherwise it is streamed.
     bool persist_ok = false;
+    enum { PERSIST_MAXPIECES = 4 };
     PmProgram pm_prog;
     static long long persist_floats(const ParrotDecoderDesc& d, int nwg) {
         const int MB = d.B <= 16 ? 1 : (d.B <= 32 ? 2 : 4);
-        const long long slab_h = (long long)MB * 16 * d.H, slab_e = (long long)MB * 16 * d.E;
-        long long n = PM_SYNC_WORDS;
+        const long long rows = (long long)MB * 16;
+        long long n = PM_SYNC_WORDS + PM_DBG_WORDS;
         n += ((long long)PM_SLOTS * nwg * PM_MAXU * sizeof(PmUnit) + 3) / 4 + 64;
-        n += (long long)d.L * (d.T + 1) * slab_h + (long long)d.L * d.T * slab_h + (long long)(d.T + 1) * slab_e;
-        n += (long long)(d.L - 1) * d.T * d.B * 3 * d.H;
+        n += 2 * (long long)(d.T + 1) * rows * (d.H + d.E);                       // XG0, XC0
+        for (int l = 1; l < d.L; ++l)
+            n += 2 * (long long)(d.T + 1) * rows * d.H + (long long)d.T * rows * (d.E + l * d.H);  // XG_l, XC_l, XI_l
+        for (int l = 1; l < d.L; ++l) n += (long long)d.T * d.B * 3 * d.H * PERSIST_MAXPIECES / (l == 1 ? 2 : 1);  // partials
         return n + 1024;
     }
     static bool persist_eligible(const ParrotDecoderDesc& d) {
@@ -283,30 +286,64 @@ struct DecoderPlan : PlanBase {
         if (d.persist_ws_floats < persist_floats(d, nwg)) return 0;
         const int H = d.H, E = d.E, B = d.B, L = d.L, T = d.T;
         const int MB = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
-        const long long slab_h = (long long)MB * 16 * H, slab_e = (long long)MB * 16 * E;
-        const long long BH = (long long)B * H, BE = (long long)B * E;
+        const long long rows = (long long)MB * 16;
+        const long long BH = (long long)B * H;
         // carve the workspace (16-byte aligned pieces)
         float* ws = d.persist_ws;
         auto take = [&](long long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
-        unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS));
+        unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS + PM_DBG_WORDS));
         const size_t unit_bytes = (size_t)PM_SLOTS * nwg * PM_MAXU * sizeof(PmUnit);
         PmUnit* units_dev = reinterpret_cast<PmUnit*>(take((long long)(unit_bytes + 3) / 4 + 16));
-        float* hfm[PARROT_MAX_LAYERS];
-        float* rhfm[PARROT_MAX_LAYERS];
-        float* preg[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-        float* prec[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-        for (int l = 0; l < L; ++l) hfm[l] = take((long long)(T + 1) * slab_h);
-        for (int l = 0; l < L; ++l) rhfm[l] = take((long long)T * slab_h);
-        float* wfm = take((long long)(T + 1) * slab_e);
-        for (int l = 1; l < L; ++l) {
-            preg[l] = take((long long)T * B * 2 * H);
-            prec[l] = take((long long)T * B * H);
+        // activation slabs (fragment-major, one per consumer kind and step):
+        //   XG[l][t] = A operand of G_l(t):  l = 0: [h_0[t] ; w[t]],  l >= 1: [h_l[t]]
+        //   XC[l][t] = A operand of C_l(t):  l = 0: [r*h_0 ; w[t]],   l >= 1: [r*h_l]
+        //   XI[l][t] = A operand of IG_l(t) / IC_l(t), l >= 1: [w[t+1] ; h_0[t+1] ; .. ; h_{l-1}[t+1]]
+        float* XG[PARROT_MAX_LAYERS];
+        float* XC[PARROT_MAX_LAYERS];
+        float* XI[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+        long long kx[PARROT_MAX_LAYERS], ki[PARROT_MAX_LAYERS] = {0, 0, 0};
+        float* fm_base = ws;
+        for (int l = 0; l < L; ++l) {
+            kx[l] = l == 0 ? H + E : H;
+            XG[l] = take((long long)(T + 1) * rows * kx[l]);
+            XC[l] = take((long long)(T + 1) * rows * kx[l]);
+            if (l >= 1) {
+                ki[l] = E + (long long)l * H;
+                XI[l] = take((long long)T * rows * ki[l]);
+            }
         }
+        const long long fm_bytes = (long long)(ws - fm_base) * 4;
+        if (fm_bytes >= 0xfff00000ll) return 0;  // one 32-bit buffer resource addresses the slab region
+        // Input projections of the layers l >= 1 are cut into pieces (K ranges of the XI slab) that write separate
+        // partial pre-activation buffers; the consuming recurrent unit adds them.  Pieces: the w rows, then per lower
+        // layer its H rows -- whole when the slab can stay LDS-resident, otherwise (streamed) in two halves so that
+        // no streamed unit is longer than a resident recurrent one.
+        float* pre[PARROT_MAX_LAYERS][2][PERSIST_MAXPIECES];
+        memset(pre, 0, sizeof(pre));
+        for (int l = 1; l < L; ++l)
+            for (int g = 0; g < 2; ++g)
+                for (int q = 0; q < (l == 1 ? PERSIST_MAXPIECES / 2 : PERSIST_MAXPIECES); ++q)
+                    pre[l][g][q] = take((long long)T * B * (g == 0 ? 2 * H : H));
+        auto boff = [&](const float* p) { return (unsigned)((p - fm_base) * 4); };
+        auto mkdst = [&](float* slab, long long step0, long long kslab, int chunk) {
+            PmDst q;
+            q.off = boff(slab + step0 * rows * kslab);
+            q.st = (unsigned)(rows * kslab * 4);
+            q.nch = (int)(kslab / 16);
+            q.chunk = chunk;
+            return q;
+        };
 
+        // When the chip's LDS (nwg x PM_LDS_W) cannot hold all weights, some input-projection pieces are streamed:
+        // cut the H-row pieces in halves then (see above).
+        long long all_rows = 0;
+        for (int l = 0; l < L; ++l) all_rows += (long long)krows(l) * 3 * H / 16;
+        // (measured at cfg2: halves do not pay -- every unit carries ~3.5 us of fixed latency -- so off unless asked for)
+        const bool stream_split = getenv("PARROT_PM_SPLIT") && atoi(getenv("PARROT_PM_SPLIT")) &&
+                                  all_rows * 16 > (long long)nwg * PM_LDS_W;
         struct Req { PmUnit u; int slot, krows, crit; };
         std::vector<Req> reqs;
         auto rm = [](float* p, long long st, int ld) { PmRM r; r.p = p; r.st = st; r.ld = ld; r.pad = 0; return r; };
-        auto seg = [](const float* A, long long st, int K) { PmSeg g; g.A = A; g.st = st; g.K = K; g.pad = 0; return g; };
         auto seq_on = [&](int l, const float* p) { return p && ((d.seq_init >> l) & 1); };
         for (int l = 0; l < L; ++l) {
             const int Kl = krows(l), nchK = Kl / 16;
@@ -315,23 +352,19 @@ struct DecoderPlan : PlanBase {
                 const float* Wf = g == 0 ? d.Wg_f[l] : d.Wc_f[l];
                 const float* bias = g == 0 ? d.bg[l] : d.bc[l];
                 float* sq = g == 0 ? d.seq_g[l] : d.seq_c[l];
-                float* pre = g == 0 ? preg[l] : prec[l];
                 for (int ct = 0; ct < wd / 16; ++ct) {
                     // recurrent unit (layer 0: the whole product)
                     Req q;
                     memset(&q, 0, sizeof(q));
                     PmUnit& u = q.u;
                     u.kind = PM_GEMM; u.lag = 2 * l; u.M = B; u.w_lds = -1;
-                    const float* first = g == 0 ? hfm[l] : rhfm[l];
-                    u.seg[0] = seg(first, slab_h, H);
-                    u.nseg = 1;
-                    if (l == 0) { u.seg[1] = seg(wfm, slab_e, E); u.nseg = 2; }
+                    float* slab = g == 0 ? XG[l] : XC[l];
+                    u.a_off = boff(slab); u.a_st = (unsigned)(rows * kx[l] * 4); u.K = (int)kx[l];
+                    u.a_nch = (int)(kx[l] / 16); u.a_c0 = 0;
                     u.W = Wf + (size_t)ct * nchK * 256;
                     if (l == 0) {
                         u.bias = bias ? bias + 16 * ct : nullptr;
-                        if (seq_on(l, sq)) u.add0 = rm(sq + 16 * ct, (long long)B * wd, wd);
-                    } else {
-                        u.add0 = rm(pre + 16 * ct, (long long)B * wd, wd);
+                        if (seq_on(l, sq)) u.add[0] = rm(sq + 16 * ct, (long long)B * wd, wd);
                     }
                     if (g == 0) {
                         u.epi = PM_EPI_GATES;
@@ -343,7 +376,7 @@ struct DecoderPlan : PlanBase {
                             u.o2 = rm(d.r[l] + j0, BH, H);
                             u.e0 = rm(d.h[l] + j0, BH, H);
                             u.out = rm(d.rh[l] + j0, BH, H);
-                            u.out_fm = rhfm[l]; u.out_fm_st = slab_h; u.out_fm_nch = H / 16; u.out_fm_chunk = j0 / 16;
+                            u.dst[u.ndst++] = mkdst(XC[l], 0, kx[l], j0 / 16);
                         }
                     } else {
                         u.epi = PM_EPI_CAND;
@@ -351,28 +384,45 @@ struct DecoderPlan : PlanBase {
                         u.e1 = rm(d.z[l] + 16 * ct, BH, H);
                         u.o1 = rm(d.c[l] + 16 * ct, BH, H);
                         u.out = rm(d.h[l] + BH + 16 * ct, BH, H);
-                        u.out_fm = hfm[l] + slab_h; u.out_fm_st = slab_h; u.out_fm_nch = H / 16; u.out_fm_chunk = ct;
+                        u.dst[u.ndst++] = mkdst(XG[l], 1, kx[l], ct);               // h_l[t+1] for G_l(t+1)
+                        for (int m2 = l + 1; m2 < L; ++m2)                            // ... and for the layers above
+                            u.dst[u.ndst++] = mkdst(XI[m2], 0, ki[m2], E / 16 + l * (H / 16) + ct);
                     }
                     q.slot = g; q.crit = 1;
-                    q.krows = l == 0 ? H + E : H;
+                    q.krows = (int)kx[l];
+                    if (l == 0) { reqs.push_back(q); continue; }
+                    // input projection of the layer, one tick ahead of its consumer, in pieces
+                    struct Piece { int c0, K; };
+                    std::vector<Piece> pieces;
+                    pieces.push_back({0, E});
+                    for (int j = 0; j < l; ++j) {
+                        const int cj = E / 16 + j * (H / 16);
+                        const bool split = stream_split && l >= 2 && (H % 32 == 0) &&
+                                           (int)pieces.size() + 2 <= PERSIST_MAXPIECES - (l - 1 - j);
+                        if (split) { pieces.push_back({cj, H / 2}); pieces.push_back({cj + H / 32, H / 2}); }
+                        else pieces.push_back({cj, H});
+                    }
+                    int na = 0;
+                    for (size_t pi = 0; pi < pieces.size(); ++pi) {
+                        Req qi;
+                        memset(&qi, 0, sizeof(qi));
+                        PmUnit& v = qi.u;
+                        v.kind = PM_GEMM; v.lag = 2 * l - 1; v.M = B; v.w_lds = -1;
+                        v.a_off = boff(XI[l]); v.a_st = (unsigned)(rows * ki[l] * 4);
+                        v.a_nch = (int)(ki[l] / 16); v.a_c0 = pieces[pi].c0; v.K = pieces[pi].K;
+                        v.W = Wf + ((size_t)ct * nchK + H / 16 + pieces[pi].c0) * 256;
+                        if (pi == 0) {
+                            v.bias = bias ? bias + 16 * ct : nullptr;
+                            if (seq_on(l, sq)) v.add[0] = rm(sq + 16 * ct, (long long)B * wd, wd);
+                        }
+                        v.epi = PM_EPI_LINEAR;
+                        v.out = rm(pre[l][g][pi] + 16 * ct, (long long)B * wd, wd);
+                        u.add[na++] = rm(pre[l][g][pi] + 16 * ct, (long long)B * wd, wd);
+                        qi.slot = g == 0 ? 2 : 1; qi.crit = 0;
+                        qi.krows = pieces[pi].K;
+                        reqs.push_back(qi);
+                    }
                     reqs.push_back(q);
-                    if (l == 0) continue;
-                    // input projection of the layer, one tick ahead of its consumer
-                    Req qi;
-                    memset(&qi, 0, sizeof(qi));
-                    PmUnit& v = qi.u;
-                    v.kind = PM_GEMM; v.lag = 2 * l - 1; v.M = B; v.w_lds = -1;
-                    v.seg[0] = seg(wfm + slab_e, slab_e, E);
-                    v.nseg = 1;
-                    for (int j = 0; j < l; ++j) v.seg[v.nseg++] = seg(hfm[j] + slab_h, slab_h, H);
-                    v.W = Wf + ((size_t)ct * nchK + H / 16) * 256;
-                    v.bias = bias ? bias + 16 * ct : nullptr;
-                    if (seq_on(l, sq)) v.add0 = rm(sq + 16 * ct, (long long)B * wd, wd);
-                    v.epi = PM_EPI_LINEAR;
-                    v.out = rm(pre + 16 * ct, (long long)B * wd, wd);
-                    qi.slot = g == 0 ? 2 : 1; qi.crit = 0;
-                    qi.krows = E + l * H;
-                    reqs.push_back(qi);
                 }
             }
         }
@@ -383,11 +433,14 @@ struct DecoderPlan : PlanBase {
             q.slot = 2; q.crit = 1; q.krows = 0;
             reqs.push_back(q);
         }
-        // greedy placement
+        // greedy placement: per slot, longest units first; a unit goes to the workgroup whose slot would end earliest
+        // (measured unit cost: ~3.5 us fixed + ~3.5 us per 1024 K-rows from LDS, ~2x the K term when streamed; an
+        // attention row ~9 us), ties broken towards workgroups whose LDS can still hold the unit's weights.
         std::vector<PmUnit> table((size_t)PM_SLOTS * nwg * PM_MAXU);
         memset(table.data(), 0, table.size() * sizeof(PmUnit));
-        std::vector<int> lds_used(nwg, 0), load(nwg, 0);
+        std::vector<int> lds_used(nwg, 0);
         std::vector<int> cnt((size_t)PM_SLOTS * nwg, 0);
+        std::vector<double> busy((size_t)PM_SLOTS * nwg, 0.0), load(nwg, 0.0);
         std::vector<int> order(reqs.size());
         for (size_t i = 0; i < reqs.size(); ++i) order[i] = (int)i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
@@ -398,21 +451,25 @@ struct DecoderPlan : PlanBase {
         for (int idx : order) {
             Req& q = reqs[idx];
             const int need = q.krows * 16;
+            const bool is_att = q.u.kind == PM_ATT;
             int best = -1;
-            long long best_key = 0;
+            double best_key = 0;
             for (int w = 0; w < nwg; ++w) {
-                const int c = cnt[(size_t)q.slot * nwg + w];
-                if (c >= PM_MAXU) continue;
-                const bool fits = need > 0 && lds_used[w] + need <= PM_LDS_W;
-                const long long key = ((long long)c << 40) | ((long long)(need > 0 && !fits ? 1 : 0) << 36) | (long long)load[w];
+                if (cnt[(size_t)q.slot * nwg + w] >= PM_MAXU) continue;
+                const bool fits = lds_used[w] + need <= PM_LDS_W;
+                const double cost = is_att ? 9.0 : 3.5 + (fits ? 3.5 : 7.0) * q.krows / 1024.0;
+                const double key = (busy[(size_t)q.slot * nwg + w] + cost) * 1e3 + load[w];
                 if (best < 0 || key < best_key) { best = w; best_key = key; }
             }
             if (best < 0) return 0;  // more units than slots: not eligible (falls back to the launch schedules)
-            if (need > 0 && lds_used[best] + need <= PM_LDS_W) {
+            const bool fits = lds_used[best] + need <= PM_LDS_W;
+            if (need > 0 && fits) {
                 q.u.w_lds = lds_used[best];
                 lds_used[best] += need;
             }
-            load[best] += q.krows;
+            const double cost = is_att ? 9.0 : 3.5 + (fits ? 3.5 : 7.0) * q.krows / 1024.0;
+            busy[(size_t)q.slot * nwg + best] += cost;
+            load[best] += cost;
             int& c = cnt[(size_t)q.slot * nwg + best];
             table[((size_t)q.slot * nwg + best) * PM_MAXU + c] = q.u;
             ++c;
@@ -422,12 +479,15 @@ struct DecoderPlan : PlanBase {
         PmProgram& P = pm_prog;
         memset(&P, 0, sizeof(P));
         P.T = T; P.n_ticks = T + 2 * (L - 1); P.nwg = nwg; P.MB = MB; P.M = B;
-        P.units = units_dev; P.sync = sync;
+        P.units = units_dev; P.sync = sync; P.fm_base = fm_base;
         PmAtt& a = P.att;
         a.h1 = rm(d.h[0], BH, H);
         a.WattT = d.WattT; a.batt = d.batt; a.ctx = d.ctx;
         a.kappa = d.kappa; a.a = d.a; a.b = d.b; a.phi = d.phi; a.w = d.w;
-        a.wfm = wfm; a.wfm_st = slab_e; a.sup = d.att_sup;
+        a.sup = d.att_sup;
+        a.wdst[a.nwdst++] = mkdst(XG[0], 1, kx[0], H / 16);   // w[t+1] for G_0(t+1) and C_0(t+1) ...
+        a.wdst[a.nwdst++] = mkdst(XC[0], 1, kx[0], H / 16);
+        for (int l = 1; l < L; ++l) a.wdst[a.nwdst++] = mkdst(XI[l], 0, ki[l], 0);  // ... and for the layers above
         a.B = B; a.H = H; a.A = d.A; a.U = d.U; a.E = E; a.att_type = d.att_type;
         {
             const char* e = getenv("PARROT_ATT_DENSE");
@@ -435,8 +495,14 @@ struct DecoderPlan : PlanBase {
         }
         a.eps = d.eps; a.alignment = d.alignment; a.sharpening = d.sharpening; a.timing = d.timing;
         int ni = 0;
-        for (int l = 0; l < L; ++l) { P.init[ni].src = d.h[l]; P.init[ni].dst = hfm[l]; P.init[ni].ld = H; P.init[ni].K = H; ++ni; }
-        P.init[ni].src = d.w; P.init[ni].dst = wfm; P.init[ni].ld = E; P.init[ni].K = E; ++ni;
+        auto add_init = [&](const float* src, int ld, int K, float* slab, long long kslab, int chunk) {
+            PmInit& in = P.init[ni++];
+            in.src = src; in.ld = ld; in.K = K; in.dst_off = boff(slab); in.nch = (int)(kslab / 16); in.chunk = chunk;
+            in.pad = 0;
+        };
+        for (int l = 0; l < L; ++l) add_init(d.h[l], H, H, XG[l], kx[l], 0);  // states entering the window (slot 0)
+        add_init(d.w, E, E, XG[0], kx[0], H / 16);
+        add_init(d.w, E, E, XC[0], kx[0], H / 16);
         P.ninit = ni;
         persist_ok = true;
         return 0;

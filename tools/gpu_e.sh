@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02e
+cd $GRAFT_REPO_ROOT
+timeout 300 python tools/pm_timing.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02e/pm_timing16.log
