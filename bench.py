@@ -41,7 +41,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound on timed CPU-baseline work")
+    ap.add_argument("--cpu-T", type=int, default=100, help="decoder frames per window of the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU-baseline iterations (after 3 warm-ups)")
+    ap.add_argument("--kappa-bias", type=float, default=-1.5,
+                    help="bias of the attention's kappa projection: exp(-1.5) = 0.22 positions per frame keeps the "
+                         "window inside the 200-character context for all 800 frames (with the plain N(0, 0.01) init "
+                         "kappa advances ~1 per frame and leaves the text after ~210 frames, after which no context row "
+                         "is read at all -- a favourable, unrealistic case)")
+    ap.add_argument("--no-dense", action="store_true", help="skip the second timed run that reads all context rows")
     return ap.parse_args()
 
 
@@ -71,6 +78,15 @@ def model_kwargs(a):
     return dict(num_layers=a.L, rnn_h_dim=a.H, readouts_dim=a.H, encoder_type='bidirectional')
 
 
+def build_model(a, dev, use_graph=True):
+    """BASELINE configs[1] model: train.py's init (N(0, 0.01) weights, zero biases) except the kappa bias (--kappa-bias)."""
+    from parrot_amd.model import Parrot
+    m = Parrot(device=dev, use_graph=use_graph, seed=1234, **model_kwargs(a)).initialize()
+    with torch.no_grad():
+        m.get_parameter_dict()['/parrot/h1_to_att/fork_kappa.b'].fill_(a.kappa_bias)
+    return m
+
+
 def roofline_leg(a, dev, flat_params):
     """One extra, untimed training step with eager launches, every recurrent-step dispatch timed."""
     from parrot_amd import _lib, ops
@@ -82,7 +98,7 @@ def roofline_leg(a, dev, flat_params):
 
 
 def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
-    m = Parrot(device=dev, use_graph=False, **model_kwargs(a)).initialize()
+    m = build_model(a, dev, use_graph=False)
     m.flat_parameters.copy_(flat_params)
     tr = Trainer(m)
     batch = make_batch(a, dev, 4321)
@@ -99,17 +115,23 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
         return None
     peak = 157.3  # f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
     ach = fl.value / us.value * 1e-6  # TFLOP/s
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass
+    # with the timed run); the number is the committed measurement of the session named next to it, not of this run
+    traffic, traffic_src = None, None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            try:
+                blob = json.load(open(tpath))
+                traffic = blob.get("hbm_bytes_per_launch")
+                traffic_src = f"profiles/{name} ({blob.get('session', 'round-1 session r01e')}; tools/pmc_traffic.py)"
+                break
+            except Exception:
+                traffic = None
     return {
         "kernel": "sk_kernel (fused GRU gate/candidate step GEMM, fwd + bwd)",
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(ach / peak, 4), "traffic": traffic,
+        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_step": int(n), "avg_launch_us": round(us.value / n, 3),
         "alg_flops_per_launch": round(fl.value / n), "alg_bytes_per_launch": round(by.value / n),
         "alg_GBps": round(by.value / us.value * 1e-3, 1), "hbm_peak_GBps": 8000,
@@ -118,57 +140,56 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
 
 
 def cpu_baseline_leg(a):
-    """Oracle (port of the reference equations, torch-CPU fp32, all cores): fwd + bwd + clip/Adam on
-    cfg2 shapes with a short T; frames/s is per-frame-linear in T so it is reported as is."""
+    """Oracle (port of the reference equations, torch-CPU fp32, all cores): fwd + bwd + clip/Adam, BASELINE.md section 2
+    protocol: the cfg2 shapes at T_dec = --cpu-T (100) timed directly -- 3 warm-ups, >= 10 iterations, median + IQR --
+    and configs[0] (1-layer GRU h=256, batch 4, 50-frame windows) exactly."""
     from oracle import parrot_ref as R
     nthreads = host_cores()
     torch.set_num_threads(nthreads)
-    cfg = R.default_config(**model_kwargs(a))
-    p = R.init_params(cfg, seed=1234, dtype=torch.float32)
-    for v in p.values():
-        v.requires_grad_()
-    mom = {k: torch.zeros_like(v) for k, v in p.items()}
-    var = {k: torch.zeros_like(v) for k, v in p.items()}
-    g = torch.Generator().manual_seed(99)
-    lab = torch.randint(0, 43, (a.B, a.U), generator=g)
-    lm = torch.ones(a.B, a.U)
-    Ts = (4, 12)
-    data = {Tc: (torch.randn(Tc + 1, a.B, 63, generator=g), torch.ones(Tc + 1, a.B)) for Tc in Ts}
-    state = {"step": 0}
 
-    def one(Tc):
-        feat, fm = data[Tc]
+    def time_config(kw, B, U, Tc, iters, warm):
+        cfg = R.default_config(**kw)
+        p = R.init_params(cfg, seed=1234, dtype=torch.float32)
+        p['/parrot/h1_to_att/fork_kappa.b'].fill_(a.kappa_bias)
         for v in p.values():
-            v.grad = None
-        cost, _, _, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
-        cost.backward()
-        state["step"] += 1
-        with torch.no_grad():
-            R.clip_adam_step({k: v.data for k, v in p.items()}, {k: v.grad for k, v in p.items()}, mom, var,
-                             state["step"])
+            v.requires_grad_()
+        mom = {k: torch.zeros_like(v) for k, v in p.items()}
+        var = {k: torch.zeros_like(v) for k, v in p.items()}
+        g = torch.Generator().manual_seed(99)
+        lab = torch.randint(0, 43, (B, U), generator=g)
+        lm = torch.ones(B, U)
+        feat, fm = torch.randn(Tc + 1, B, 63, generator=g), torch.ones(Tc + 1, B)
+        times = []
+        for it in range(warm + iters):
+            t0 = time.perf_counter()
+            for v in p.values():
+                v.grad = None
+            cost, _, _, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, None, 1)
+            cost.backward()
+            with torch.no_grad():
+                R.clip_adam_step({k: v.data for k, v in p.items()}, {k: v.grad for k, v in p.items()}, mom, var, it + 1)
+            if it >= warm:
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        n = len(times)
+        med = times[n // 2] if n % 2 else 0.5 * (times[n // 2 - 1] + times[n // 2])
+        q1, q3 = times[n // 4], times[(3 * n) // 4]
+        return dict(frames_per_s=round(B * Tc / med, 1), median_s=round(med, 4), iqr_s=round(q3 - q1, 4), iters=n,
+                    cpu_work_s=round(sum(times), 1))
 
-    one(Ts[0])  # warm-up
-    times = {Tc: [] for Tc in Ts}
-    t_start = time.time()
-    while True:
-        for Tc in Ts:
-            t0 = time.time()
-            one(Tc)
-            times[Tc].append(time.time() - t0)
-        if time.time() - t_start >= a.cpu_seconds or len(times[Ts[0]]) >= 20:
-            break
-    el = time.time() - t_start
-    med = {Tc: sorted(v)[len(v) // 2] for Tc, v in times.items()}
-    per_frame_step = (med[Ts[1]] - med[Ts[0]]) / (Ts[1] - Ts[0])   # seconds per decoder timestep (B frames)
-    fixed = max(0.0, med[Ts[0]] - Ts[0] * per_frame_step)            # encoder + optimiser + overhead per window
-    window = fixed + a.T * per_frame_step
-    fps = a.B * a.T / window
-    return {"value": round(fps, 1), "unit": "frames/s", "cores": nthreads, "kind": "port",
-            "sample": f"{len(times[Ts[0]])} training steps each at T_dec={Ts[0]} and T_dec={Ts[1]} of the cfg2 shapes "
-                      f"(L={a.L}, H={a.H}, B={a.B}, T_enc={a.U}; {el:.1f} s of CPU work); per-timestep cost "
-                      f"{1e3 * per_frame_step:.1f} ms and per-window cost {1e3 * fixed:.0f} ms extrapolated "
-                      f"linearly to T_dec={a.T}; oracle/parrot_ref.py (torch-CPU fp32, autograd backward, "
-                      f"clip+Adam), {nthreads} threads"}
+    t_all = time.time()
+    main = time_config(model_kwargs(a), a.B, a.U, a.cpu_T, a.cpu_iters, 3)
+    cfg1 = time_config(dict(num_layers=1, rnn_h_dim=256, readouts_dim=256, encoder_type='bidirectional'), 4, 15, 50,
+                       a.cpu_iters, 3)
+    return {"value": main["frames_per_s"], "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "median_s": main["median_s"], "iqr_s": main["iqr_s"], "iters": main["iters"],
+            "configs0": {"frames_per_s": cfg1["frames_per_s"], "median_s": cfg1["median_s"], "iqr_s": cfg1["iqr_s"],
+                         "workload": "BASELINE configs[0]: 1-layer GRU h=256, batch 4, 50-frame windows, T_enc=15"},
+            "sample": f"{main['iters']} training steps (after 3 warm-ups) of the cfg2 shapes (L={a.L}, H={a.H}, B={a.B}, "
+                      f"T_enc={a.U}) at T_dec={a.cpu_T}, timed directly, median + IQR ({time.time() - t_all:.0f} s of CPU "
+                      f"work incl. configs[0]); the per-window costs (encoder, optimiser) are amortised over {a.cpu_T} "
+                      f"instead of {a.T} frames, which understates the CPU rate at T_dec={a.T} by a few percent; "
+                      f"oracle/parrot_ref.py (torch-CPU fp32, autograd backward, clip+Adam), {nthreads} threads"}
 
 
 def cpu_baseline_subprocess(a):
@@ -176,9 +197,10 @@ def cpu_baseline_subprocess(a):
     never stall the GPU job."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--T", str(a.T), "--B", str(a.B),
-           "--U", str(a.U), "--H", str(a.H), "--L", str(a.L), "--cpu-seconds", str(a.cpu_seconds)]
+           "--U", str(a.U), "--H", str(a.H), "--L", str(a.L), "--cpu-T", str(a.cpu_T), "--cpu-iters", str(a.cpu_iters),
+           "--kappa-bias", str(a.kappa_bias)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)
@@ -186,7 +208,7 @@ def cpu_baseline_subprocess(a):
                 "sample": "cpu leg produced no result: " + r.stderr[-200:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "frames/s", "cores": host_cores(), "kind": "port",
-                "sample": "cpu leg exceeded its 240 s limit"}
+                "sample": "cpu leg exceeded its 300 s limit"}
 
 
 def main():
@@ -203,28 +225,39 @@ def main():
     dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    from parrot_amd.model import Parrot
     from parrot_amd.trainer import Trainer
 
-    model = Parrot(device=dev, use_graph=True, seed=1234, **model_kwargs(a)).initialize()
+    model = build_model(a, dev)
     trainer = Trainer(model)
     batch = make_batch(a, dev, 1234 + rank)
 
-    for _ in range(a.warmup):
-        trainer.step(*batch, None, 1)
-    pdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        cost = trainer.step(*batch, None, 1)
-    torch.cuda.synchronize()
-    pdist.barrier()
-    el = time.perf_counter() - t0
-    tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    el = float(tmax)
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            trainer.step(*batch, None, 1)
+        pdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c = trainer.step(*batch, None, 1)
+        torch.cuda.synchronize()
+        pdist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t), c
+
+    el, cost = timed(a.steps, a.warmup)
     final_cost = float(cost)
+    kappa_end = float(model._carry[a.B]['k'].mean()) if a.B in model._carry else None
+    # second timed run, outside the headline region: the attention kernels read ALL context rows (no window support)
+    dense = None
+    if not a.no_dense and os.environ.get("PARROT_ATT_DENSE", "0") in ("", "0"):
+        os.environ["PARROT_ATT_DENSE"] = "1"
+        model.close()  # plans read the switch when they are built
+        el_d, _ = timed(a.steps, 1)
+        os.environ["PARROT_ATT_DENSE"] = "0"
+        dense = {"value": round(world * a.B * a.T * a.steps / el_d, 1), "ms_per_step": round(1e3 * el_d / a.steps, 3)}
+        model.close()
 
     roof = cpu = None
     if rank == 0:
@@ -243,14 +276,19 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 2-layer attention-GRU decoder, h=1024, "
-                                   "batch=64 per GPU, T_enc=200, T_dec=800, fp32, N(0,0.01) init",
+                                   "batch=64 per GPU, T_enc=200, T_dec=800, fp32",
                        "layers": a.L, "hidden": a.H, "batch_per_gpu": a.B, "global_batch": a.B * world,
                        "T_enc": a.U, "T_dec": a.T, "parallelism": f"dp{world}",
                        "params": int(model.store.numel),
+                       "init": f"train.py:30-31 (N(0,0.01) weights, zero biases) with the kappa bias at {a.kappa_bias}: the "
+                               f"window ends the 800 frames at mean position {kappa_end and round(kappa_end, 1)} of "
+                               f"{a.U}, i.e. inside the text, as for a trained model",
                        "attention_rows": ("all U context rows (PARROT_ATT_DENSE=1)"
                                           if os.environ.get("PARROT_ATT_DENSE", "0") not in ("", "0") else
-                                          "rows whose window weight phi is exactly 0.0f are not read "
-                                          "(bit-identical results; PARROT_ATT_DENSE=1 reads all)")},
+                                          "support: rows whose window weight phi is exactly 0.0f are not read "
+                                          "(bit-identical results); `dense` = the same step reading all rows"),
+                       "scan_schedule": os.environ.get("PARROT_SCHEDULE", "0 (merged wavefront launches)")},
+            "dense": dense,
             "final_cost": round(final_cost, 5),
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -118,7 +118,7 @@ class SampleRnnGenDesc(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/parrot_hip.h declares must be listed here
-# (tests/test_capi_symbols.py cross-checks this table against the header).
+# (tests/test_capi_cpu.py cross-checks this table against the header).
 _vp, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
 SIGNATURES = {
     "parrot_hip_version": (C.c_char_p, []),

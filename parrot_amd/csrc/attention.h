@@ -13,7 +13,6 @@ struct AttFwdArgs {
     float* w_out; int ldw;         // [B,E]
     int B, H, A, U, E, esplit, att_type;
     float eps, alignment, sharpening, timing;
-    int dbg;  // development only: bit0 skip projection, bit1 skip phi, bit2 skip weighted sum
     int* sup_out;  // [B,2] or null: first / last context position with phi != 0 (saved for the backward step)
     int dense;  // set by att_fwd_launch (PARROT_ATT_DENSE=1): read all U context rows, also those with phi == 0
 };
@@ -29,7 +28,6 @@ struct AttBwdArgs {
     float* dh1; int lddh;          // [B,H] accumulated (+=)
     int B, H, A, U, E, att_type;
     float eps;
-    int dbg;  // development only: bit0 skip dphi, bit1 skip mixture reductions, bit2 skip dh1 update
     const int* sup;  // [B,2] or null: the forward step's window support
 };
 

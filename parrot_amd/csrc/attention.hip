@@ -86,7 +86,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     const int c = t % CW, ug = t / CW;
     const float* ctx = g.ctx + (size_t)b * U * E;
     constexpr int NPRE = 32;
-    const bool use_pre = ATT_FWD_PRELOAD && (EW <= CW) && ((U + G - 1) / G <= NPRE) && !(g.dbg & 4);
+    const bool use_pre = ATT_FWD_PRELOAD && (EW <= CW) && ((U + G - 1) / G <= NPRE);
     float pre[NPRE];
     if (use_pre) {
         const int e = e0 + c;
@@ -100,7 +100,6 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
     // Wave w owns outputs j = w, w+4, ... (up to 8 per pass); the loads of all its outputs for one k-slab
     // are issued together (8 rows + h in flight), instead of one output after the other.
-    if (g.dbg & 1) { if (t < 3 * A) s_p[t] = 0.01f * t; } else
     for (int jb = wave; jb < 3 * A; jb += 32) {
         float acc[8];
 #pragma unroll
@@ -158,7 +157,6 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     __syncthreads();
 
     // 3) phi[u]
-    if (g.dbg & 2) { for (int u = t; u < U; u += ATT_THREADS) s_phi[u] = 0.001f * u; } else
     for (int u = t; u < U; u += ATT_THREADS) {
         float ph = 0.f;
         const float uf = (float)u;
@@ -186,7 +184,7 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     // zero weight adds exactly nothing to w: rows outside [lo, hi] are not read.  Same sums, same order, minus
     // the +0 terms -- bit-identical to reading all U rows (PARROT_ATT_DENSE=1 reads them all).
     int u_lo = 0, u_hi = U - 1;
-    if (!g.dense && !(g.dbg & 2)) {
+    if (!g.dense) {
         u_lo = reinterpret_cast<int*>(s_red)[6];
         u_hi = reinterpret_cast<int*>(s_red)[7];
     }
@@ -196,7 +194,6 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
     }
 
     // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
-    if (g.dbg & 4) return;
     for (int eb = e0; eb < e1; eb += CW) {
         const int e = eb + c;
         float acc = 0.f;
@@ -254,7 +251,7 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
     // chain of four dependent ones.
     constexpr int NWB = ATTB_THREADS / 64;
     constexpr int RPW = 16, SEG = 4;  // rows per wave / 64-float segments per row covered by the preload
-    const bool use_pre = (U <= NWB * RPW) && (E <= 64 * SEG) && !(g.dbg & 1);
+    const bool use_pre = (U <= NWB * RPW) && (E <= 64 * SEG);
     // Support of the window saved by the forward step: outside [u_lo, u_hi] every exp(-b (kappa-u)^2) is exactly
     // 0.0f, so dphi[u] is multiplied by zero in all three mixture gradients and its context row is not needed.
     int u_lo = 0, u_hi = U - 1;
@@ -275,7 +272,7 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
         }
     }
     constexpr int WPRE = 32;
-    const bool use_wpre = (H <= ATTB_THREADS) && (3 * A <= WPRE) && !(g.dbg & 4);
+    const bool use_wpre = (H <= ATTB_THREADS) && (3 * A <= WPRE);
     float wpre[WPRE];
 
     for (int e = t; e < E; e += ATTB_THREADS) {
@@ -294,7 +291,6 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
     __syncthreads();
 
     // dphi[u] = sum_e dw[e] ctx[u][e]: one wave per u, lanes over e (coalesced row reads).
-    if (g.dbg & 1) { for (int u = t; u < U; u += ATTB_THREADS) s_dphi[u] = 0.01f; } else
     if (use_pre) {
         float dseg[SEG];
 #pragma unroll
@@ -340,9 +336,6 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
     // (lanes over u, three wave reductions per mixture, results straight into s_dp).
     {
         constexpr int NWB2 = ATTB_THREADS / 64;
-        if (g.dbg & 2) {
-            if (t < 3 * A) s_dp[t] = 0.f;
-        } else
         for (int j = wave; j < A; j += NWB2) {
             const float aj = s_a[j], bj = s_b[j], kj = s_k[j];
             float da = 0.f, db = 0.f, dk = 0.f;
@@ -408,7 +401,6 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
 
     // dh1[b][k] += sum_j dp[j] Watt[k][j]
     float* dh = g.dh1 + (size_t)b * g.lddh;
-    if (g.dbg & 4) return;
     if (use_wpre) {
         if (t < H) {
             float acc = 0.f;
@@ -470,9 +462,6 @@ static size_t att_bwd_lds(int U, int E) {
 
 int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
     AttFwdArgs g = gin;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("PARROT_ATT_DBG"); dbg = e ? atoi(e) : 0; }
-    g.dbg = dbg;
     {   // read per launch (launches happen once, at graph capture): tests toggle it between two plans
         const char* e = getenv("PARROT_ATT_DENSE");
         g.dense = e ? atoi(e) : 0;
@@ -486,9 +475,6 @@ int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
 
 int att_bwd_launch(const AttBwdArgs& gin, hipStream_t stream) {
     AttBwdArgs g = gin;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("PARROT_ATTB_DBG"); dbg = e ? atoi(e) : 0; }
-    g.dbg = dbg;
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1) return PH_ERR_BADARG;
     const size_t lds = att_bwd_lds(g.U, g.E);
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
@@ -503,9 +489,6 @@ static int att_state_bwd_launch_t(const AttBwdArgs* gin, const SA& sa, int l0_ch
     size_t lds = 0;
     if (gin) {
         g = *gin;
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("PARROT_ATTB_DBG"); dbg = e ? atoi(e) : 0; }
-        g.dbg = dbg;
         if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.B != sa.B) return PH_ERR_BADARG;
         lds = att_bwd_lds(g.U, g.E);
         if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;

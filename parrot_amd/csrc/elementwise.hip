@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
     if (threshold > 0.f) {
         const float nrm = sqrtf(*gnorm_sq) * grad_scale;
         if (nrm > threshold) scale *= threshold / nrm;
-        if (!(nrm == nrm) || nrm > 3.0e38f) scale = 0.f;  // NaN / inf guard: skip the step
+        // Non-finite gradient norm: skip the step entirely -- no write to p, m or v (g[i] * 0 would still be NaN and
+        // poison the moments).  Blocks' StepClipping has no such guard (the NaN reaches the parameters and the
+        // LearningRateSchedule reloads the best checkpoint, extensions.py:126-140); skipping keeps the replicas finite
+        // and the schedule still sees the non-finite validation cost.
+        if (!(nrm == nrm) || nrm > 3.0e38f) return;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * scale;

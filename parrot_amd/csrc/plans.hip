@@ -649,19 +649,7 @@ struct DecoderPlan : PlanBase {
             const int t0 = tl[0];
             const bool att_on = t0 >= 0 && t0 < d.T;
             AttBwdArgs g{};
-            if (att_on) {
-                g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
-                g.ctx = d.ctx;
-                g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
-                g.kappa = d.kappa + (t0 + 1) * BA; g.kappa_prev = d.kappa + t0 * BA;
-                g.WattT = d.WattT;
-                g.dkappa = d.dkappa;
-                g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
-        g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
-                g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
-                g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
-                g.dbg = 0;
-            }
+            if (att_on) g = att_bwd_args(t0);
             if (d.cell == 1) {
                 SkJob jl[SK_MAXJOB];
                 int nl = 0;
@@ -879,7 +867,8 @@ struct DecoderPlan : PlanBase {
         return 0;
     }
 
-    int att_bwd_step(int t0, hipStream_t st) const {
+    // Arguments of the attention backward of step t0 (one place: four schedules use it).
+    AttBwdArgs att_bwd_args(int t0) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
         AttBwdArgs g{};
         g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = d.E;
@@ -892,8 +881,9 @@ struct DecoderPlan : PlanBase {
         g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
         g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = d.H;
         g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
-        return att_bwd_launch(g, st);
+        return g;
     }
+    int att_bwd_step(int t0, hipStream_t st) const { return att_bwd_launch(att_bwd_args(t0), st); }
 
     int bwd_piece(int l, int c, hipStream_t st) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -1040,17 +1030,7 @@ struct DecoderPlan : PlanBase {
                 const int t0 = tl[0];
                 AttBwdArgs g{};
                 if (t0 >= 0) {
-                    g.dw = d.dw + (t0 + 1) * BE; g.dw2 = d.dw0 + (t0 + 1) * BE; g.lddw = E;
-                    g.ctx = d.ctx;
-                    g.a = d.a + t0 * BA; g.b = d.b + t0 * BA;
-                    g.kappa = d.kappa + (t0 + 1) * BA; g.kappa_prev = d.kappa + t0 * BA;
-                    g.WattT = d.WattT;
-                    g.dkappa = d.dkappa;
-                    g.dp_out = d.dp + (size_t)t0 * d.B * 3 * d.A;
-        g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
-                    g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = H;
-                    g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
-                    g.dbg = 0;
+                    g = att_bwd_args(t0);
                     if (d.cell == 1) PL_TRY(att_bwd_launch(g, st));
                 }
                 GruStateBwdArgs ga;
@@ -1295,20 +1275,7 @@ struct DecoderPlan : PlanBase {
             for (int l = d.L - 1; l >= 0; --l) {
                 hipStream_t st = stream_of(l, main);
                 if (l + 1 < d.L) PL_TRY((int)hipStreamWaitEvent(st, done[l + 1], 0));
-                if (l == 0) {
-                    AttBwdArgs g{};
-                    g.dw = d.dw + (t + 1) * BE; g.dw2 = d.dw0 + (t + 1) * BE; g.lddw = E;
-                    g.ctx = d.ctx;
-                    g.a = d.a + t * BA; g.b = d.b + t * BA;
-                    g.kappa = d.kappa + (t + 1) * BA; g.kappa_prev = d.kappa + t * BA;
-                    g.WattT = d.WattT;
-                    g.dkappa = d.dkappa;
-                    g.dp_out = d.dp + (size_t)t * d.B * 3 * d.A;
-                    g.sup = d.att_sup ? d.att_sup + (size_t)t * d.B * 2 : nullptr;
-                    g.dh1 = d.dh[0] + (t + 1) * BH; g.lddh = H;
-                    g.B = d.B; g.H = H; g.A = d.A; g.U = d.U; g.E = E; g.att_type = d.att_type; g.eps = d.eps;
-                    PL_TRY(att_bwd_launch(g, st));
-                }
+                if (l == 0) PL_TRY(att_bwd_step(t, st));
                 GruStateBwdArgs ga;
                 ga.nchain = 1; ga.B = d.B; ga.H = H;
                 GruStateBwdChain& c = ga.chain[0];

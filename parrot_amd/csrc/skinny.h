@@ -34,7 +34,7 @@ struct SkSeg {
 struct SkJob {
     SkSeg seg[SK_MAXSEG];
     int nseg, M, N, epi;
-    int act, accumulate, H, aligned;  // accumulate: 0 store, 1 out += (exclusive owner), 2 atomic add
+    int act, accumulate, H, aligned;  // accumulate: 0 store, 1 out += (the job is the exclusive owner of its tiles)
                                       // aligned: every segment allows the branch-free 16-byte fetch
     const float* bias;  // [N] or null
     const float* add;   // [M, N] additive pre-activation input or null

@@ -59,19 +59,10 @@ __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M,
     for (int rb = 0; rb < MB; ++rb) {
         const int m = m0 + rb * 16 + i;
         a[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifndef SK_DBG_NO_A
         if (m < M) a[rb] = ld4k<AL>(sg.A + (size_t)m * sg.lda + k, k, sg.K);
-#else
-        a[rb][0] = (float)m;
-#endif
     }
     b = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifdef SK_DBG_NO_B
-    b[0] = (float)ncol;
-    if (false) {
-#else
     if (ncol_ok) {
-#endif
         if (sg.b_kcontig) {
             b = ld4k<AL>(sg.B + (size_t)ncol * sg.ldb + k, k, sg.K);
         } else {
@@ -101,11 +92,7 @@ __device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int rb = 0; rb < MB; ++rb)
-#ifndef SK_DBG_NO_MMA
             acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[u], acc[rb], 0, 0, 0);
-#else
-            acc[rb][u] += a[rb][u] * b[u];
-#endif
 }
 
 // Branch-free operand fetch of the fast path: every segment has K % 16 == 0 and 16-byte aligned
@@ -118,13 +105,7 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
     const int k = kc + 4 * kk;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) {
-#ifdef SK_DBG_NO_A
-        a[rb] = (f32x4){(float)k, 1.f, 2.f, (float)mrow[rb]};
-#elif defined(SK_DBG_TILED) && !defined(SK_DBG_TILED_B_ONLY)
-        // probe only (wrong values): same bytes, but the 64 lanes read one contiguous 1 KB block
-        a[rb] = *reinterpret_cast<const f32x4*>(A + ((size_t)(mrow[rb] >> 4) * (lda >> 4) + (kc >> 4)) * 256 +
-                                                (threadIdx.x & 63) * 4);
-#elif SK_A_PERMUTE
+#if SK_A_PERMUTE
         // quad-contiguous mapping: lane l reads 16 B of row (l >> 2) at k-offset 4 * (l & 3), so every quad of
         // lanes covers one contiguous 64-B segment; sk_a_unpermute moves the quads to the MFMA lanes later.
         a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + kc + 4 * (threadIdx.x & 3));
@@ -134,15 +115,6 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-#ifdef SK_DBG_NO_B
-        b[nb] = (f32x4){(float)k, 1.f, 2.f, (float)ncol[nb]};
-        continue;
-#elif defined(SK_DBG_TILED)
-        b[nb] = *reinterpret_cast<const f32x4*>(B + (BM == 1 ? ((size_t)(ncol[nb] >> 4) * (ldb >> 4) + (kc >> 4)) * 256
-                                                        : (size_t)(kc >> 4) * ldb * 16 + (size_t)(ncol[nb] >> 4) * 256) +
-                                                (threadIdx.x & 63) * 4);
-        continue;
-#endif
         if (BM == 2) {
             // fragment-major weights (sk_tile_weights): the 64 lanes read one contiguous 1 KB block
             b[nb] = *reinterpret_cast<const f32x4*>(B + (size_t)btile[nb] * ldb + ((size_t)(kc >> 4) << 8) +
@@ -179,11 +151,7 @@ __device__ __forceinline__ void sk_mma2(const f32x4 (&a)[MB], const f32x4 (&b)[N
         for (int rb = 0; rb < MB; ++rb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
-#ifndef SK_DBG_NO_MMA
                 acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[nb][u], acc[rb][nb], 0, 0, 0);
-#else
-                acc[rb][nb][u] += a[rb][u] * b[nb][u];
-#endif
 }
 
 // One workgroup: (16*MB rows) x (16*NB columns) output tile, K split over the SK_NW waves.
@@ -420,12 +388,8 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
                 float* o = job.out + (size_t)m * job.ldo + n;
-                if (job.accumulate == 2) {
-                    unsafeAtomicAdd(o, x);  // another job of the same launch adds into this tile too
-                } else {
-                    if (job.accumulate) x += p_oc[r];
-                    *o = x;
-                }
+                if (job.accumulate) x += p_oc[r];  // exclusive owner of the tile: no two jobs of a launch share one
+                *o = x;
             } break;
             case SK_EPI_GRU_GATES: {
                 x += bias + p_add[r];
