@@ -316,7 +316,24 @@ typedef struct ParrotSampleDesc {
     const float* br_l[PARROT_MAX_LAYERS];
     float* ln_scratch;
     long long ln_scratch_floats;
+    /* Optional: decode on the persistent phase machine (parrot_amd/csrc/persist.h) -- the whole S-step loop as one
+     * resident kernel, 2L + 3 barrier-separated phases per step instead of 2L + 3 launches.  GRU layers, MSE head, no
+     * layer_norm, B <= 64, O <= 64 <= ldx.  The caller provides fragment-major copies (parrot_tile_weights, mode 0) of
+     *   Wg_t[l] / Wc_t[l]: [K_l + F_l, 2H] / [K_l + F_l, H] = the packed layer matrix with the feedback rows Wfg / Wfc
+     *                      appended and zero-padded to F_l = 64 rows (F_l = 0 without feedback into the layer),
+     *   Wr_t: [L*H + E, R],   Wo_t: [R, 64] (columns >= O zero),
+     * bo_pad [64] (zeros beyond O), oadd_pad [B, 64] when oadd is used, and a ZERO-FILLED workspace of
+     * parrot_sample_persist_floats(desc) floats.  Anything missing or non-qualifying: the per-step launches run.
+     * The h ping-pong buffers keep the initial state (slot 0) only; PARROT_SAMPLE_PERSIST=0 disables the machine. */
+    const float* Wg_t[PARROT_MAX_LAYERS];
+    const float* Wc_t[PARROT_MAX_LAYERS];
+    const float* Wr_t; const float* Wo_t; const float* bo_pad; const float* oadd_pad;
+    float* persist_ws;
+    long long persist_ws_floats;
 } ParrotSampleDesc;
+
+long long parrot_sample_persist_floats(const ParrotSampleDesc* desc);
+int parrot_sample_is_persistent(void* plan);
 
 int parrot_sample_create(const ParrotSampleDesc* desc, void** plan);
 int parrot_sample_run(void* plan, void* stream);

@@ -103,6 +103,9 @@ class SampleDesc(C.Structure):
         ("ln_bg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_bc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
         ("br_l", C.c_void_p * MAX_LAYERS),
         ("ln_scratch", C.c_void_p), ("ln_scratch_floats", C.c_longlong),
+        ("Wg_t", C.c_void_p * MAX_LAYERS), ("Wc_t", C.c_void_p * MAX_LAYERS),
+        ("Wr_t", C.c_void_p), ("Wo_t", C.c_void_p), ("bo_pad", C.c_void_p), ("oadd_pad", C.c_void_p),
+        ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
     ]
 
 
@@ -145,6 +148,8 @@ SIGNATURES = {
     "parrot_decoder_seq_bwd": (_i, [_vp, _vp]),
     "parrot_decoder_destroy": (_i, [_vp]),
     "parrot_sample_create": (_i, [C.POINTER(SampleDesc), C.POINTER(C.c_void_p)]),
+    "parrot_sample_persist_floats": (C.c_longlong, [C.POINTER(SampleDesc)]),
+    "parrot_sample_is_persistent": (_i, [_vp]),
     "parrot_sample_run": (_i, [_vp, _vp]),
     "parrot_sample_destroy": (_i, [_vp]),
     "parrot_plan_last_error": (_i, [_vp]),

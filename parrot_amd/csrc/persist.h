@@ -2,7 +2,7 @@
 //
 // Replaces the thousands of per-step launches of the wavefront schedules (plans.hip) for the scan of
 // Parrot.compute_cost (reference model.py:651-737).  One workgroup per CU stays resident for the whole window; a
-// tick = PM_SLOTS phases separated by grid barriers; in a phase every workgroup runs up to PM_MAXU work units from a
+// tick = n_slots phases separated by grid barriers; in a phase every workgroup runs up to maxu work units from a
 // host-built table.  A unit is a 16-column tile of a recurrent-step GEMM over all batch rows with the GRU gate math
 // fused (the same algebra as sk_kernel's epilogues, Blocks GatedRecurrent / sampleRNN/lib/ops.py:364-393), or the
 // GMM-window attention of one batch row (model.py:664-690).  What the launches could not do:
@@ -17,7 +17,8 @@
 #pragma once
 #include "common.h"
 
-enum { PM_MAXU = 3, PM_SLOTS = 3, PM_THREADS = 512, PM_MAXINIT = 8, PM_MAXDST = 4 };
+enum { PM_MAXENT = 12,   // unit descriptors per workgroup: n_slots * maxu <= PM_MAXENT (training 3 x 3, decode 9 x 1)
+       PM_MAXSLOTS = 9, PM_THREADS = 512, PM_MAXINIT = 8, PM_MAXDST = 6, PM_MAXWDST = 8 };
 enum { PM_NONE = 0, PM_GEMM = 1, PM_ATT = 2 };
 enum { PM_EPI_LINEAR = 0, PM_EPI_GATES = 1, PM_EPI_CAND = 2 };
 
@@ -26,10 +27,10 @@ enum { PM_EPI_LINEAR = 0, PM_EPI_GATES = 1, PM_EPI_CAND = 2 };
 enum {
     PM_LDS_W = 36864,                 // 144 KB = 2304 K-rows of a 16-column tile
     PM_LDS_RED = 8 * 16 * 20,         // 10 KB
-    PM_LDS_UNITS = 1024,              // 4 KB: PM_SLOTS * PM_MAXU unit descriptors
-    PM_LDS_MISC = 32,
+    PM_LDS_UNITS = 1280,              // 5 KB: PM_MAXENT unit descriptors
+    PM_LDS_MISC = 64,                 // census, flags, phase timers
     PM_LDS_FLOATS = PM_LDS_W + PM_LDS_RED + PM_LDS_UNITS + PM_LDS_MISC,
-    PM_ATT_MAXU = 800,                // context length limit of the in-kernel attention (208 + U + 512 floats <= PM_LDS_RED)
+    PM_ATT_MAXU = 800,                // context length limit of the in-kernel attention (208 + U + 512 + 512 floats <= PM_LDS_RED)
     PM_ATT_MAXA = 32,
 };
 
@@ -72,7 +73,7 @@ struct PmAtt {
     float* phi;                   // [T,B,U]
     float* w;                     // [T+1,B,E] row-major
     int nwdst, pad3;              // fragment-major copies of w[t+1] (slab of step t+1 for layer 0, step t above)
-    PmDst wdst[PM_MAXDST];        // off already points at the slab the value of step t goes to (t * st is added)
+    PmDst wdst[PM_MAXWDST];       // off already points at the slab the value of step t goes to (t * st is added)
     int* sup;                     // [T,B,2] or null
     int B, H, A, U, E, att_type, dense, pad;
     float eps, alignment, sharpening, timing;
@@ -85,15 +86,15 @@ struct PmInit {  // prologue: row-major [M,K] (ld) -> chunks [chunk, chunk + K/1
 };
 
 struct PmProgram {
-    int T, n_ticks, nwg, MB, M, ninit, pad0, pad1;
-    const PmUnit* units;  // device: [PM_SLOTS][nwg][PM_MAXU]
+    int T, n_ticks, nwg, MB, M, ninit, n_slots, maxu;  // a tick = n_slots phases of up to maxu units per workgroup
+    const PmUnit* units;  // device: [n_slots][nwg][maxu]
     unsigned* sync;       // device: PM_SYNC_WORDS + PM_DBG_WORDS unsigned, zeroed before every launch
     float* fm_base;       // start of the fragment-major slab region (all PmDst / a_off offsets are relative to it)
     PmAtt att;
     PmInit init[PM_MAXINIT];
 };
 
-enum { PM_SYNC_WORDS = 1024, PM_DBG_WORDS = 256 * 16 + 256 * 8 };  // dbg: per workgroup 8 x u64 phase timers (100 MHz ticks)
+enum { PM_SYNC_WORDS = 1024, PM_DBG_WORDS = 256 * 24 * 2 };  // dbg: per workgroup 24 x u64: work[9], wait[9] per slot, 4 gemm stages (100 MHz ticks)
 // word offsets inside `sync` (128 B apart)
 enum { PM_S_XCNT = 0, PM_S_XGEN = 256, PM_S_TOP = 512, PM_S_CENSUS = 544, PM_S_TOTAL = 800, PM_S_ABORT = 832 };
 

@@ -14,7 +14,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define PM_DEPTH 16
 #endif
 #ifndef PM_SDEPTH
-#define PM_SDEPTH 8  // streamed units: activation and weight chunks both come from global memory
+#define PM_SDEPTH 12  // streamed units: activation and weight chunks both come from global memory
 #endif
 #ifndef PM_WDEPTH
 #define PM_WDEPTH 4
@@ -71,7 +71,9 @@ __device__ __forceinline__ bool pm_spin_ge(unsigned* p, unsigned target, unsigne
     const unsigned long long t0 = wall_clock64();
     unsigned it = 0;
     while (pm_ld(p) < target) {
-        __builtin_amdgcn_s_sleep(1);
+        // back off: idle workgroups (decode: most of them in every phase) must not hammer the counter's L2 channel
+        if (it < 16) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(6);
         if ((++it & 255) == 0) {
             if (pm_ld(sync + PM_S_ABORT)) return false;
             if (wall_clock64() - t0 > 20000000ull) {
@@ -257,9 +259,9 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
                 if (!u.rtile) {
                     pm_rm_store<true>(u.o1, t, m, n0, gt);  // update gate z (read by the candidate units)
                 } else {
-                    pm_rm_store<false>(u.o2, t, m, n0, gt);  // reset gate r (backward only)
+                    if (u.o2.p) pm_rm_store<false>(u.o2, t, m, n0, gt);  // reset gate r (backward only)
                     fmv = gt * p_e0;                   // r * h_prev
-                    pm_rm_store<false>(u.out, t, m, n0, fmv);  // row-major r*h: backward only (consumers read the slab)
+                    if (u.out.p) pm_rm_store<false>(u.out, t, m, n0, fmv);  // row-major r*h: backward only
                 }
             } else {  // PM_EPI_CAND
                 f32x4 c;
@@ -267,7 +269,7 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
                 for (int i = 0; i < 4; ++i) c[i] = tanhf(pre[i]);
                 const f32x4 one = {1.f, 1.f, 1.f, 1.f};
                 fmv = p_e1 * c + (one - p_e1) * p_e0;  // z*c + (1-z)*h_prev
-                pm_rm_store<false>(u.o1, t, m, n0, c);
+                if (u.o1.p) pm_rm_store<false>(u.o1, t, m, n0, c);
                 pm_rm_store<true>(u.out, t, m, n0, fmv);  // h_new: next step's epilogues and the attention read it
             }
         }
@@ -301,6 +303,7 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
     float* s_red = s_k + PM_ATT_MAXA;       // [16]
     float* s_phi = s_red + 16;              // [U]
     float* s_acc = s_phi + ((U + 3) & ~3);  // [512]
+    float* s_stage = s_acc + PM_THREADS;    // [<= 512] one column block of w, staged for 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* h = g.h1.p + (long long)(t + 1) * g.h1.st + (long long)b * g.h1.ld;
     const size_t BA = (size_t)g.B * A;
@@ -420,15 +423,25 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
         if (ug == 0 && e < E) {
             float s = 0.f;
             for (int q = 0; q < G; ++q) s += s_acc[q * CW + c];
-            w_rm[e] = s;
-            // fragment-major copies: block (b / 16, chunk + e / 16), lane (e % 16) / 4 * 16 + b % 16, element e % 4
-            for (int q = 0; q < g.nwdst; ++q) {
+            s_stage[c] = s;
+        }
+        __syncthreads();
+        // 16-byte stores of the block's columns: row-major w, and one piece per fragment-major destination
+        // (block (b / 16, chunk + e / 16), lane (e % 16) / 4 * 16 + b % 16 holds columns e .. e + 3)
+        const int ncol = min(CW, E - eb);
+        if (4 * tid < ncol) {
+            const int e4 = eb + 4 * tid;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(s_stage + 4 * tid);
+            *reinterpret_cast<f32x4*>(w_rm + e4) = v;
+            for (int q = 0; q < g.nwdst && q < PM_MAXWDST; ++q) {
                 const PmDst ds = g.wdst[q];
                 float* slab = fm_base + ((size_t)ds.off + (size_t)t * ds.st) / 4;
-                pm_stf(slab + (((size_t)((b >> 4) * ds.nch + ds.chunk + (e >> 4))) << 8) +
-                           ((((e & 15) >> 2) * 16 + (b & 15)) << 2) + (e & 3), s);
+                float* p = slab + (((size_t)((b >> 4) * ds.nch + ds.chunk + (e4 >> 4))) << 8) +
+                           ((((e4 & 15) >> 2) * 16 + (b & 15)) << 2);
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
             }
         }
+        __syncthreads();
     }
     __syncthreads();
 }
@@ -442,7 +455,8 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     float* lds_att = lds_red;  // the attention row reuses the reduction scratch
     // the workgroup's unit descriptors: read once from global memory, then from LDS every phase
     PmUnit* lds_units = reinterpret_cast<PmUnit*>(lds_red + PM_LDS_RED);
-    static_assert(sizeof(PmUnit) * PM_SLOTS * PM_MAXU <= PM_LDS_UNITS * sizeof(float), "unit table does not fit");
+    static_assert(sizeof(PmUnit) * PM_MAXENT <= PM_LDS_UNITS * sizeof(float), "unit table does not fit");
+    const int n_slots = P.n_slots, maxu = P.maxu;
     // all scratch lives in the dynamic region (a static __shared__ would push the total over the 160 KB limit)
     unsigned* cen = reinterpret_cast<unsigned*>(lds_red + PM_LDS_RED + PM_LDS_UNITS);
     int& ok_sh = *reinterpret_cast<int*>(lds_red + PM_LDS_RED + PM_LDS_UNITS + 16);
@@ -470,18 +484,18 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     {
         static_assert(sizeof(PmUnit) % 4 == 0, "");
         constexpr int words = (int)(sizeof(PmUnit) / 4);
-        for (int s = 0; s < PM_SLOTS; ++s)
-            for (int q = 0; q < PM_MAXU; ++q) {
-                const unsigned* src = reinterpret_cast<const unsigned*>(&P.units[((size_t)s * nwg + wg) * PM_MAXU + q]);
-                unsigned* dst = reinterpret_cast<unsigned*>(&lds_units[s * PM_MAXU + q]);
+        for (int s = 0; s < n_slots; ++s)
+            for (int q = 0; q < maxu; ++q) {
+                const unsigned* src = reinterpret_cast<const unsigned*>(&P.units[((size_t)s * nwg + wg) * maxu + q]);
+                unsigned* dst = reinterpret_cast<unsigned*>(&lds_units[s * maxu + q]);
                 for (int i = tid; i < words; i += PM_THREADS) dst[i] = src[i];
             }
     }
     __syncthreads();
     // resident weight slabs -> LDS (once per window)
-    for (int s = 0; s < PM_SLOTS; ++s)
-        for (int q = 0; q < PM_MAXU; ++q) {
-            const PmUnit& u = lds_units[s * PM_MAXU + q];
+    for (int s = 0; s < n_slots; ++s)
+        for (int q = 0; q < maxu; ++q) {
+            const PmUnit& u = lds_units[s * maxu + q];
             if (u.kind != PM_GEMM || u.w_lds < 0) continue;
             const int nch = u.K >> 4;
             const f32x4* src = reinterpret_cast<const f32x4*>(u.W);
@@ -511,12 +525,16 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
 
     // phase timers (work / barrier wait per slot, summed over the ticks): a handful of s_memrealtime reads per phase
-    unsigned long long t_work[PM_SLOTS] = {0, 0, 0}, t_wait[PM_SLOTS] = {0, 0, 0}, stage[4] = {0, 0, 0, 0};
+    unsigned long long* t_work = reinterpret_cast<unsigned long long*>(lds_red + PM_LDS_RED + PM_LDS_UNITS + 20);
+    unsigned long long* t_wait = t_work + PM_MAXSLOTS;  // 20 + 2 * 18 floats <= PM_LDS_MISC
+    unsigned long long stage[4] = {0, 0, 0, 0};
+    if (tid < 2 * PM_MAXSLOTS) t_work[tid] = 0;
+    __syncthreads();
     for (int tick = 0; tick < P.n_ticks; ++tick) {
-        for (int s = 0; s < PM_SLOTS; ++s) {
+        for (int s = 0; s < n_slots; ++s) {
             const unsigned long long ta = pm_clock();
-            for (int q = 0; q < PM_MAXU; ++q) {
-                const PmUnit& u = lds_units[s * PM_MAXU + q];
+            for (int q = 0; q < maxu; ++q) {
+                const PmUnit& u = lds_units[s * maxu + q];
                 const int kind = __builtin_amdgcn_readfirstlane(u.kind);
                 if (kind == PM_NONE) continue;
                 const int t = tick - __builtin_amdgcn_readfirstlane(u.lag);
@@ -527,15 +545,16 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long tb = pm_clock();
             if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
-            t_work[s] += tb - ta;
-            t_wait[s] += pm_clock() - tb;
+            if (tid == 0) {
+                t_work[s] += tb - ta;
+                t_wait[s] += pm_clock() - tb;
+            }
         }
     }
     if (tid == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(sync + PM_SYNC_WORDS) + (size_t)wg * 8;
-        for (int s = 0; s < PM_SLOTS; ++s) { dbg[s] = t_work[s]; dbg[3 + s] = t_wait[s]; }
-        unsigned long long* dbg2 = reinterpret_cast<unsigned long long*>(sync + PM_SYNC_WORDS) + 2048 + (size_t)wg * 4;
-        for (int q = 0; q < 4; ++q) dbg2[q] = stage[q];
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(sync + PM_SYNC_WORDS) + (size_t)wg * 24;
+        for (int s = 0; s < PM_MAXSLOTS; ++s) { dbg[s] = t_work[s]; dbg[PM_MAXSLOTS + s] = t_wait[s]; }
+        for (int q = 0; q < 4; ++q) dbg[18 + q] = stage[q];
     }
 }
 
@@ -555,7 +574,9 @@ int pm_max_workgroups() {
 }
 
 int pm_launch(const PmProgram& P, hipStream_t stream) {
-    if (P.nwg < 1 || P.nwg > pm_max_workgroups() || !P.units || !P.sync) return PH_ERR_BADARG;
+    if (P.nwg < 1 || P.nwg > pm_max_workgroups() || !P.units || !P.sync || P.n_slots < 1 || P.n_slots > PM_MAXSLOTS ||
+        P.maxu < 1 || P.n_slots * P.maxu > PM_MAXENT)
+        return PH_ERR_BADARG;
     if (P.att.U > PM_ATT_MAXU || P.att.A > PM_ATT_MAXA) return PH_ERR_UNSUPPORTED;
     PH_CHECK(hipMemsetAsync(P.sync, 0, (PM_SYNC_WORDS + PM_DBG_WORDS) * sizeof(unsigned), stream));
     const size_t lds = (size_t)PM_LDS_FLOATS * sizeof(float);

@@ -201,6 +201,57 @@ struct LstmSeqPlan : PlanBase {
     }
 };
 
+// ----------------------------------------------------------------------------- persistent machine: unit placement
+struct PmReq { PmUnit u; int slot, krows, crit; };
+
+// Greedy placement of the units of one tick on the workgroups: per slot, critical and long units first; a unit goes
+// to the workgroup whose slot would end earliest (measured unit cost: ~3.5 us fixed + ~3.5 us per 1024 K-rows from
+// LDS, ~2x the K term when streamed; an attention row ~9 us), ties broken towards the least loaded workgroup.  A
+// unit's weight slab becomes LDS-resident when the workgroup still has room for it.
+bool pm_place(std::vector<PmReq>& reqs, int n_slots, int maxu, int nwg, std::vector<PmUnit>& table) {
+    table.assign((size_t)n_slots * nwg * maxu, PmUnit());
+    memset(table.data(), 0, table.size() * sizeof(PmUnit));
+    std::vector<int> lds_used(nwg, 0);
+    std::vector<int> cnt((size_t)n_slots * nwg, 0);
+    std::vector<double> busy((size_t)n_slots * nwg, 0.0), load(nwg, 0.0);
+    std::vector<int> order(reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) order[i] = (int)i;
+    // critical units first, then the longest K first across ALL slots: LDS residency is handed out in this order, and
+    // it pays most where the weight slab is largest
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (reqs[a].crit != reqs[b].crit) return reqs[a].crit > reqs[b].crit;
+        if (reqs[a].krows != reqs[b].krows) return reqs[a].krows > reqs[b].krows;
+        return reqs[a].slot < reqs[b].slot;
+    });
+    for (int idx : order) {
+        PmReq& q = reqs[idx];
+        const int need = q.krows * 16;
+        const bool is_att = q.u.kind == PM_ATT;
+        int best = -1;
+        double best_key = 0;
+        for (int w = 0; w < nwg; ++w) {
+            if (cnt[(size_t)q.slot * nwg + w] >= maxu) continue;
+            const bool fits = lds_used[w] + need <= PM_LDS_W;
+            const double cost = is_att ? 9.0 : 3.5 + (fits ? 3.5 : 7.0) * q.krows / 1024.0;
+            const double key = (busy[(size_t)q.slot * nwg + w] + cost) * 1e3 + load[w];
+            if (best < 0 || key < best_key) { best = w; best_key = key; }
+        }
+        if (best < 0) return false;  // more units than places
+        const bool fits = lds_used[best] + need <= PM_LDS_W;
+        if (need > 0 && fits) {
+            q.u.w_lds = lds_used[best];
+            lds_used[best] += need;
+        }
+        const double cost = is_att ? 9.0 : 3.5 + (fits ? 3.5 : 7.0) * q.krows / 1024.0;
+        busy[(size_t)q.slot * nwg + best] += cost;
+        load[best] += cost;
+        int& c = cnt[(size_t)q.slot * nwg + best];
+        table[((size_t)q.slot * nwg + best) * maxu + c] = q.u;
+        ++c;
+    }
+    return true;
+}
+
 // ----------------------------------------------------------------------------- decoder (training)
 struct DecoderPlan : PlanBase {
     ParrotDecoderDesc d;
@@ -257,13 +308,13 @@ struct DecoderPlan : PlanBase {
     // DESIGN.md).  Units are spread over the workgroups greedily; a unit's weight slab stays in the workgroup's LDS
     // for the whole window when it fits (critical recurrent units first), otherwise it is streamed.
     bool persist_ok = false;
-    enum { PERSIST_MAXPIECES = 4 };
+    enum { PERSIST_MAXPIECES = 4, TR_SLOTS = 3, TR_MAXU = 3 };
     PmProgram pm_prog;
     static long long persist_floats(const ParrotDecoderDesc& d, int nwg) {
         const int MB = d.B <= 16 ? 1 : (d.B <= 32 ? 2 : 4);
         const long long rows = (long long)MB * 16;
         long long n = PM_SYNC_WORDS + PM_DBG_WORDS;
-        n += ((long long)PM_SLOTS * nwg * PM_MAXU * sizeof(PmUnit) + 3) / 4 + 64;
+        n += ((long long)TR_SLOTS * nwg * TR_MAXU * sizeof(PmUnit) + 3) / 4 + 64;
         n += 2 * (long long)(d.T + 1) * rows * (d.H + d.E);                       // XG0, XC0
         for (int l = 1; l < d.L; ++l)
             n += 2 * (long long)(d.T + 1) * rows * d.H + (long long)d.T * rows * (d.E + l * d.H);  // XG_l, XC_l, XI_l
@@ -292,7 +343,7 @@ struct DecoderPlan : PlanBase {
         float* ws = d.persist_ws;
         auto take = [&](long long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
         unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS + PM_DBG_WORDS));
-        const size_t unit_bytes = (size_t)PM_SLOTS * nwg * PM_MAXU * sizeof(PmUnit);
+        const size_t unit_bytes = (size_t)TR_SLOTS * nwg * TR_MAXU * sizeof(PmUnit);
         PmUnit* units_dev = reinterpret_cast<PmUnit*>(take((long long)(unit_bytes + 3) / 4 + 16));
         // activation slabs (fragment-major, one per consumer kind and step):
         //   XG[l][t] = A operand of G_l(t):  l = 0: [h_0[t] ; w[t]],  l >= 1: [h_l[t]]
@@ -341,8 +392,8 @@ struct DecoderPlan : PlanBase {
         // (measured at cfg2: halves do not pay -- every unit carries ~3.5 us of fixed latency -- so off unless asked for)
         const bool stream_split = getenv("PARROT_PM_SPLIT") && atoi(getenv("PARROT_PM_SPLIT")) &&
                                   all_rows * 16 > (long long)nwg * PM_LDS_W;
-        struct Req { PmUnit u; int slot, krows, crit; };
-        std::vector<Req> reqs;
+        std::vector<PmReq> reqs;
+        typedef PmReq Req;
         auto rm = [](float* p, long long st, int ld) { PmRM r; r.p = p; r.st = st; r.ld = ld; r.pad = 0; return r; };
         auto seq_on = [&](int l, const float* p) { return p && ((d.seq_init >> l) & 1); };
         for (int l = 0; l < L; ++l) {
@@ -433,52 +484,13 @@ struct DecoderPlan : PlanBase {
             q.slot = 2; q.crit = 1; q.krows = 0;
             reqs.push_back(q);
         }
-        // greedy placement: per slot, longest units first; a unit goes to the workgroup whose slot would end earliest
-        // (measured unit cost: ~3.5 us fixed + ~3.5 us per 1024 K-rows from LDS, ~2x the K term when streamed; an
-        // attention row ~9 us), ties broken towards workgroups whose LDS can still hold the unit's weights.
-        std::vector<PmUnit> table((size_t)PM_SLOTS * nwg * PM_MAXU);
-        memset(table.data(), 0, table.size() * sizeof(PmUnit));
-        std::vector<int> lds_used(nwg, 0);
-        std::vector<int> cnt((size_t)PM_SLOTS * nwg, 0);
-        std::vector<double> busy((size_t)PM_SLOTS * nwg, 0.0), load(nwg, 0.0);
-        std::vector<int> order(reqs.size());
-        for (size_t i = 0; i < reqs.size(); ++i) order[i] = (int)i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-            if (reqs[a].slot != reqs[b].slot) return reqs[a].slot < reqs[b].slot;
-            if (reqs[a].crit != reqs[b].crit) return reqs[a].crit > reqs[b].crit;
-            return reqs[a].krows > reqs[b].krows;
-        });
-        for (int idx : order) {
-            Req& q = reqs[idx];
-            const int need = q.krows * 16;
-            const bool is_att = q.u.kind == PM_ATT;
-            int best = -1;
-            double best_key = 0;
-            for (int w = 0; w < nwg; ++w) {
-                if (cnt[(size_t)q.slot * nwg + w] >= PM_MAXU) continue;
-                const bool fits = lds_used[w] + need <= PM_LDS_W;
-                const double cost = is_att ? 9.0 : 3.5 + (fits ? 3.5 : 7.0) * q.krows / 1024.0;
-                const double key = (busy[(size_t)q.slot * nwg + w] + cost) * 1e3 + load[w];
-                if (best < 0 || key < best_key) { best = w; best_key = key; }
-            }
-            if (best < 0) return 0;  // more units than slots: not eligible (falls back to the launch schedules)
-            const bool fits = lds_used[best] + need <= PM_LDS_W;
-            if (need > 0 && fits) {
-                q.u.w_lds = lds_used[best];
-                lds_used[best] += need;
-            }
-            const double cost = is_att ? 9.0 : 3.5 + (fits ? 3.5 : 7.0) * q.krows / 1024.0;
-            busy[(size_t)q.slot * nwg + best] += cost;
-            load[best] += cost;
-            int& c = cnt[(size_t)q.slot * nwg + best];
-            table[((size_t)q.slot * nwg + best) * PM_MAXU + c] = q.u;
-            ++c;
-        }
+        std::vector<PmUnit> table;
+        if (!pm_place(reqs, TR_SLOTS, TR_MAXU, nwg, table)) return 0;
         if (hipMemcpy(units_dev, table.data(), unit_bytes, hipMemcpyHostToDevice) != hipSuccess) return 0;
 
         PmProgram& P = pm_prog;
         memset(&P, 0, sizeof(P));
-        P.T = T; P.n_ticks = T + 2 * (L - 1); P.nwg = nwg; P.MB = MB; P.M = B;
+        P.T = T; P.n_ticks = T + 2 * (L - 1); P.nwg = nwg; P.MB = MB; P.M = B; P.n_slots = TR_SLOTS; P.maxu = TR_MAXU;
         P.units = units_dev; P.sync = sync; P.fm_base = fm_base;
         PmAtt& a = P.att;
         a.h1 = rm(d.h[0], BH, H);
@@ -1349,7 +1361,214 @@ struct SamplePlan : PlanBase {
     ParrotSampleDesc d;
     int esplit = 1;
 
-    int enqueue(int, hipStream_t s) override { return run_all(s); }
+    int enqueue(int, hipStream_t s) override { return persist_ok ? run_persist(s) : run_all(s); }
+
+    // ---- persistent phase machine for the decode loop (persist.h) ------------------------------------------------
+    // One resident kernel runs all S steps; a step = 2L + 3 phases: G_0, C_0, ATT, (G_l, C_l for l >= 1), readout,
+    // output.  With output feedback (x_{t-1} -> layer inputs, model.py:899-924) the whole step is one dependency chain,
+    // so every phase is on the critical path and costs its fixed latency (~4 us) instead of a launch (~16 us at
+    // M = 16).  Each unit reads ONE fragment-major slab assembled by its producers:
+    //   XG[l][t] / XC[l][t] = [h_l[t] or r*h_l ; w ; h_0[t+1] .. h_{l-1}[t+1] ; x[t] (64 columns, zero padded)]
+    //   XR[t] = [h_0[t+1] .. h_{L-1}[t+1] ; w[t+1]]      XO[t] = readout[t]
+    // Weights: fragment-major copies prepared by the caller (Wg_t / Wc_t: packed layer matrix with the feedback rows
+    // appended and padded to 64; Wr_t; Wo_t with the columns padded to 64).
+    bool persist_ok = false;
+    PmProgram pm_prog;
+    float* hist_h[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
+
+    static bool persist_eligible(const ParrotSampleDesc& d) {
+        if (d.cell != 0 || d.layer_norm || d.gmm_K > 0 || d.B > 64 || (d.H % 16) || (d.E % 16) || (d.R % 16) ||
+            d.U > PM_ATT_MAXU || d.A > PM_ATT_MAXA || d.S < 1 || d.O > 64 || d.ldx < 64 || (d.ldx % 4))
+            return false;
+        if (2 * d.L + 3 > PM_MAXSLOTS || !d.Wr_t || !d.Wo_t || !d.bo_pad) return false;
+        for (int l = 0; l < d.L; ++l)
+            if (!d.Wg_t[l] || !d.Wc_t[l]) return false;
+        if ((d.oadd != nullptr) != (d.oadd_pad != nullptr)) return false;
+        return pm_max_workgroups() >= 64;
+    }
+    static int fb_rows(const ParrotSampleDesc& d, int l) { return d.Wfg[l] ? 64 : 0; }
+    static long long kslab(const ParrotSampleDesc& d, int l) { return d.H + d.E + (long long)l * d.H + fb_rows(d, l); }
+    static long long persist_floats(const ParrotSampleDesc& d, int nwg) {
+        const int MB = d.B <= 16 ? 1 : (d.B <= 32 ? 2 : 4);
+        const long long rows = (long long)MB * 16, S = d.S;
+        long long n = PM_SYNC_WORDS + PM_DBG_WORDS;
+        n += ((long long)(2 * d.L + 3) * nwg * sizeof(PmUnit) + 3) / 4 + 64;
+        for (int l = 0; l < d.L; ++l) n += 2 * (S + 1) * rows * kslab(d, l);
+        n += S * rows * ((long long)d.L * d.H + d.E) + S * rows * d.R;
+        n += (long long)d.L * (S + 1) * d.B * d.H + (long long)d.L * S * d.B * d.H;   // h and z histories (row-major)
+        n += S * d.B * d.R + S * d.B * d.A;
+        return n + 4096;
+    }
+
+    int build_persist() {
+        persist_ok = false;
+        const char* e = getenv("PARROT_SAMPLE_PERSIST");
+        if (e && atoi(e) == 0) return 0;
+        if (!persist_eligible(d) || !d.persist_ws) return 0;
+        const int nwg = pm_max_workgroups();
+        if (d.persist_ws_floats < persist_floats(d, nwg)) return 0;
+        const int H = d.H, E = d.E, B = d.B, L = d.L, S = d.S, R = d.R;
+        const int MB = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+        const long long rows = (long long)MB * 16, BH = (long long)B * H;
+        const int n_slots = 2 * L + 3;
+        float* ws = d.persist_ws;
+        auto take = [&](long long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
+        unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS + PM_DBG_WORDS));
+        const size_t unit_bytes = (size_t)n_slots * nwg * sizeof(PmUnit);
+        PmUnit* units_dev = reinterpret_cast<PmUnit*>(take((long long)(unit_bytes + 3) / 4 + 16));
+        float* fm_base = ws;
+        float* XG[PARROT_MAX_LAYERS];
+        float* XC[PARROT_MAX_LAYERS];
+        long long kx[PARROT_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) {
+            kx[l] = kslab(d, l);
+            XG[l] = take((S + 1) * rows * kx[l]);
+            XC[l] = take((S + 1) * rows * kx[l]);
+        }
+        const long long kr = (long long)L * H + E;
+        float* XR = take(S * rows * kr);
+        float* XO = take(S * rows * R);
+        if ((long long)(ws - fm_base) * 4 >= 0xfff00000ll) return 0;
+        float* zh[PARROT_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) hist_h[l] = take((S + 1) * BH);
+        for (int l = 0; l < L; ++l) zh[l] = take(S * BH);
+        float* ro_hist = take((long long)S * B * R);
+        float* b_hist = take((long long)S * B * d.A);
+
+        auto boff = [&](const float* p) { return (unsigned)((p - fm_base) * 4); };
+        auto mkdst = [&](float* slab, long long step0, long long ks, int chunk) {
+            PmDst q;
+            q.off = boff(slab + step0 * rows * ks); q.st = (unsigned)(rows * ks * 4); q.nch = (int)(ks / 16); q.chunk = chunk;
+            return q;
+        };
+        auto rm = [](const float* p, long long st, int ld) { PmRM r; r.p = const_cast<float*>(p); r.st = st; r.ld = ld; r.pad = 0; return r; };
+        std::vector<PmReq> reqs;
+        auto gemm_unit = [&](int slot, float* slab, long long ks) {
+            PmReq q;
+            memset(&q, 0, sizeof(q));
+            q.u.kind = PM_GEMM; q.u.M = B; q.u.w_lds = -1;
+            q.u.a_off = boff(slab); q.u.a_st = (unsigned)(rows * ks * 4); q.u.a_nch = (int)(ks / 16); q.u.K = (int)ks;
+            q.slot = slot; q.crit = 1; q.krows = (int)ks;
+            return q;
+        };
+        for (int l = 0; l < L; ++l) {
+            const int sg = l == 0 ? 0 : 2 * l + 1, sc = sg + 1;
+            const int nch = (int)(kx[l] / 16);
+            for (int ct = 0; ct < 2 * H / 16; ++ct) {     // gates
+                PmReq q = gemm_unit(sg, XG[l], kx[l]);
+                PmUnit& u = q.u;
+                u.W = d.Wg_t[l] + (size_t)ct * nch * 256;
+                u.bias = d.bg[l] ? d.bg[l] + 16 * ct : nullptr;
+                if (d.seq_g[l]) u.add[0] = rm(d.seq_g[l] + 16 * ct, 0, 2 * H);
+                u.epi = PM_EPI_GATES;
+                u.rtile = 16 * ct >= H;
+                if (!u.rtile) {
+                    u.o1 = rm(zh[l] + 16 * ct, BH, H);
+                } else {
+                    const int j0 = 16 * ct - H;
+                    u.e0 = rm(hist_h[l] + j0, BH, H);
+                    u.dst[u.ndst++] = mkdst(XC[l], 0, kx[l], j0 / 16);
+                }
+                reqs.push_back(q);
+            }
+            for (int ct = 0; ct < H / 16; ++ct) {         // candidate -> h_l[t+1]
+                PmReq q = gemm_unit(sc, XC[l], kx[l]);
+                PmUnit& u = q.u;
+                u.W = d.Wc_t[l] + (size_t)ct * nch * 256;
+                u.bias = d.bc[l] ? d.bc[l] + 16 * ct : nullptr;
+                if (d.seq_c[l]) u.add[0] = rm(d.seq_c[l] + 16 * ct, 0, H);
+                u.epi = PM_EPI_CAND;
+                u.e0 = rm(hist_h[l] + 16 * ct, BH, H);
+                u.e1 = rm(zh[l] + 16 * ct, BH, H);
+                u.out = rm(hist_h[l] + BH + 16 * ct, BH, H);
+                u.dst[u.ndst++] = mkdst(XG[l], 1, kx[l], ct);
+                for (int m2 = l + 1; m2 < L; ++m2) {
+                    const int ch = (H + E) / 16 + l * (H / 16) + ct;
+                    u.dst[u.ndst++] = mkdst(XG[m2], 0, kx[m2], ch);
+                    u.dst[u.ndst++] = mkdst(XC[m2], 0, kx[m2], ch);
+                }
+                u.dst[u.ndst++] = mkdst(XR, 0, kr, l * (H / 16) + ct);
+                if (u.ndst > PM_MAXDST) return 0;
+                reqs.push_back(q);
+            }
+        }
+        for (int b = 0; b < B; ++b) {
+            PmReq q;
+            memset(&q, 0, sizeof(q));
+            q.u.kind = PM_ATT; q.u.row = b; q.u.w_lds = -1;
+            q.slot = 2; q.crit = 1; q.krows = 0;
+            reqs.push_back(q);
+        }
+        for (int ct = 0; ct < R / 16; ++ct) {             // readout
+            PmReq q = gemm_unit(2 * L + 1, XR, kr);
+            PmUnit& u = q.u;
+            u.W = d.Wr_t + (size_t)ct * (kr / 16) * 256;
+            u.bias = d.br ? d.br + 16 * ct : nullptr;
+            if (d.radd) u.add[0] = rm(d.radd + 16 * ct, 0, R);
+            u.epi = PM_EPI_LINEAR;
+            u.out = rm(ro_hist + 16 * ct, (long long)B * R, R);
+            u.dst[u.ndst++] = mkdst(XO, 0, R, ct);
+            reqs.push_back(q);
+        }
+        for (int ct = 0; ct < 4; ++ct) {                  // output frame x[t+1] (63 columns, padded to 64)
+            PmReq q = gemm_unit(2 * L + 2, XO, R);
+            PmUnit& u = q.u;
+            u.W = d.Wo_t + (size_t)ct * (R / 16) * 256;
+            u.bias = d.bo_pad + 16 * ct;
+            if (d.oadd_pad) u.add[0] = rm(d.oadd_pad + 16 * ct, 0, 64);
+            u.epi = PM_EPI_LINEAR;
+            u.out = rm(d.x + (size_t)B * d.ldx + 16 * ct, (long long)B * d.ldx, d.ldx);
+            for (int l = 0; l < L; ++l) {
+                if (!fb_rows(d, l)) continue;
+                const int ch = (int)((kx[l] - 64) / 16) + ct;
+                u.dst[u.ndst++] = mkdst(XG[l], 1, kx[l], ch);
+                u.dst[u.ndst++] = mkdst(XC[l], 1, kx[l], ch);
+            }
+            if (u.ndst > PM_MAXDST) return 0;
+            reqs.push_back(q);
+        }
+        std::vector<PmUnit> table;
+        if (!pm_place(reqs, n_slots, 1, nwg, table)) return 0;
+        if (hipMemcpy(units_dev, table.data(), unit_bytes, hipMemcpyHostToDevice) != hipSuccess) return 0;
+
+        PmProgram& P = pm_prog;
+        memset(&P, 0, sizeof(P));
+        P.T = S; P.n_ticks = S; P.nwg = nwg; P.MB = MB; P.M = B; P.n_slots = n_slots; P.maxu = 1;
+        P.units = units_dev; P.sync = sync; P.fm_base = fm_base;
+        PmAtt& a = P.att;
+        a.h1 = rm(hist_h[0], BH, H);
+        a.WattT = d.WattT; a.batt = d.batt; a.ctx = d.ctx;
+        a.kappa = d.kappa; a.a = d.a; a.b = b_hist; a.phi = d.phi; a.w = d.w; a.sup = nullptr;
+        a.B = B; a.H = H; a.A = d.A; a.U = d.U; a.E = E; a.att_type = d.att_type; a.dense = 0;
+        a.eps = d.eps; a.alignment = d.alignment; a.sharpening = d.sharpening; a.timing = d.timing;
+        a.wdst[a.nwdst++] = mkdst(XG[0], 1, kx[0], H / 16);
+        a.wdst[a.nwdst++] = mkdst(XC[0], 1, kx[0], H / 16);
+        for (int l = 1; l < L; ++l) {
+            a.wdst[a.nwdst++] = mkdst(XG[l], 0, kx[l], H / 16);
+            a.wdst[a.nwdst++] = mkdst(XC[l], 0, kx[l], H / 16);
+        }
+        a.wdst[a.nwdst++] = mkdst(XR, 0, kr, L * (H / 16));
+        if (a.nwdst > PM_MAXWDST) return 0;
+        int ni = 0;
+        auto add_init = [&](const float* src, int ld, int K, float* slab, long long ks, int chunk) {
+            PmInit& in = P.init[ni++];
+            in.src = src; in.ld = ld; in.K = K; in.dst_off = boff(slab); in.nch = (int)(ks / 16); in.chunk = chunk; in.pad = 0;
+        };
+        for (int l = 0; l < L; ++l) add_init(d.h[l], H, H, XG[l], kx[l], 0);   // initial states (slot 0 of the ping-pong)
+        add_init(d.w, E, E, XG[0], kx[0], H / 16);
+        add_init(d.w, E, E, XC[0], kx[0], H / 16);
+        P.ninit = ni;   // x[0] = 0 (model.py:834-835): the x chunks of slot 0 stay at their zero fill
+        persist_ok = true;
+        return 0;
+    }
+
+    int run_persist(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H;
+        for (int l = 0; l < d.L; ++l)  // row-major initial state for the epilogues (r * h_prev, state blend)
+            PL_TRY((int)hipMemcpyAsync(hist_h[l], d.h[l], BH * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return pm_launch(pm_prog, st);
+    }
+
 
     void layer_segs(SkJob& j, int l, int t, const float* first, const float* W, int ldw, const float* Wf) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -1647,6 +1866,12 @@ long long parrot_decoder_persist_floats(const ParrotDecoderDesc* desc) { PH_ENTR
     return DecoderPlan::persist_floats(*desc, pm_max_workgroups());
 }
 
+long long parrot_sample_persist_floats(const ParrotSampleDesc* desc) { PH_ENTRY();
+    if (!desc || !SamplePlan::persist_eligible(*desc)) return 0;
+    return SamplePlan::persist_floats(*desc, pm_max_workgroups());
+}
+int parrot_sample_is_persistent(void* plan) { return static_cast<SamplePlan*>(plan)->persist_ok ? 1 : 0; }
+
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
 
 int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
@@ -1672,6 +1897,7 @@ int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) { PH_ENTRY()
             return PARROT_ERR_BADARG;
         }
     }
+    p->build_persist();  // decode on the persistent phase machine when the configuration qualifies
     *plan = p;
     return 0;
 }

@@ -1010,6 +1010,31 @@ class Parrot(Brick):
         d.ctx = ws['ctx'].data_ptr()
         for n in ('x', 'w', 'kappa', 'a', 'bwork', 'phi', 'zwork', 'rwork', 'rhwork', 'readout'):
             setattr(d, n, ws[n].data_ptr())
+        # Persistent phase machine (csrc/persist.h): the decode loop as one resident kernel.  It wants fragment-major
+        # copies of the packed layer matrices with the fed-back-output rows appended (padded to 64 rows), of the
+        # readout stack and of the output projection (63 -> 64 columns); sample_model_device refreshes them per call.
+        if (not lstm and not gmm and not self.layer_norm and N <= 64 and H % 16 == 0 and E % 16 == 0 and R % 16 == 0
+                and O <= 64 <= ldx and os.environ.get('PARROT_SAMPLE_PERSIST', '1') != '0'):
+            pm = dict(cat={}, tiled={})
+            for l in range(L):
+                fb = 64 if (l + 1) in self._fb_layers else 0
+                for key, wd, suf, mat, rec in self._groups:
+                    rows = H + E + l * H + fb
+                    pm['cat'][(l, key)] = torch.zeros(rows, wd, **f)
+                    pm['tiled'][(l, key)] = torch.empty(rows, wd, **f)
+                    getattr(d, f'W{key}_t')[l] = pm['tiled'][(l, key)].data_ptr()
+            pm['Wr_t'] = torch.empty(L * H + E, R, **f)
+            pm['Wo_pad'], pm['Wo_t'] = torch.zeros(R, 64, **f), torch.empty(R, 64, **f)
+            pm['bo_pad'] = torch.zeros(64, **f)
+            d.Wr_t, d.Wo_t, d.bo_pad = pm['Wr_t'].data_ptr(), pm['Wo_t'].data_ptr(), pm['bo_pad'].data_ptr()
+            if ws['oadd'] is not None:
+                pm['oadd_pad'] = torch.zeros(N, 64, **f)
+                d.oadd_pad = pm['oadd_pad'].data_ptr()
+            n = int(_lib.load().parrot_sample_persist_floats(C.byref(d)))
+            if n > 0:
+                pm['ws'] = torch.zeros(n, **f)
+                d.persist_ws, d.persist_ws_floats = pm['ws'].data_ptr(), n
+                ws['pm'] = pm
         plan = C.c_void_p()
         _lib.call('parrot_sample_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
@@ -1067,10 +1092,36 @@ class Parrot(Brick):
                 noise = torch.randn(S, N, O, device=dev, generator=g)
             ws['unif'].copy_(torch.as_tensor(unif).to(dev, torch.float32))
             ws['noise'].copy_(torch.as_tensor(noise).to(dev, torch.float32))
+        if 'pm' in ws:
+            self._refresh_sample_machine_weights(ws)
         _lib.call('parrot_sample_run', ws['plan'], ops._stream())
         sx = ws['x'][1:, :, :O]
         pi = ws['pi_out'] if self.which_cost == 'GMM' else sx
         return [sx, ws['kappa'][1:], ws['w'][1:], pi, ws['phi'], ws['a']]
+
+    def _refresh_sample_machine_weights(self, ws):
+        """Fragment-major weight copies of the decode machine from the current parameters."""
+        pm, st = ws['pm'], self.store.storage
+        H, E, L, O = self.rnn_h_dim, self.encoded_input_dim, self.num_layers, self.output_dim
+
+        def tile(W, out):
+            _lib.call('parrot_tile_weights', W.data_ptr(), W.shape[0], W.shape[1], W.shape[1], out.data_ptr(), 0, 0,
+                      ops._stream())
+        with torch.no_grad():
+            for l in range(L):
+                for key, wd, suf, mat, rec in self._groups:
+                    cat = pm['cat'][(l, key)]
+                    kl = H + E + l * H
+                    cat[:kl].copy_(st[f'{mat}{l + 1}'])
+                    if (l + 1) in self._fb_layers:
+                        cat[kl:kl + O].copy_(self._p(f'/out_to_h{l + 1}/fork_rnn{l + 1}_{suf}.W'))
+                    tile(cat, pm['tiled'][(l, key)])
+            tile(st['dec.Wr'], pm['Wr_t'])
+            pm['Wo_pad'][:, :O].copy_(self._p('/readout_to_output.W'))
+            tile(pm['Wo_pad'], pm['Wo_t'])
+            pm['bo_pad'][:O].copy_(self._p('/readout_to_output.b'))
+            if 'oadd_pad' in pm:
+                pm['oadd_pad'][:, :O].copy_(ws['oadd'])
 
     def sample_model(self, labels_tr, labels_mask_tr, features_mask_tr, speaker_tr, num_samples, num_steps):
         """Parrot.sample_model (model.py:1061-1083): numpy in, list of numpy arrays out

@@ -163,3 +163,40 @@ def test_workspaces_and_plans_are_reused_between_calls(dev):
         m.sample_model_device(lab, lm.float(), None, 4, 5)
     assert len(m._sample_ws) == 1
     m.close()
+
+
+@pytest.mark.parametrize("kw", [dict(num_layers=2, weak_feedback=True),
+                                dict(num_layers=3, full_feedback=True, use_speaker=True),
+                                dict(num_layers=1),
+                                dict(num_layers=2, weak_feedback=True, sharpening_coeff=1.2, timing_coeff=0.9,
+                                     attention_type='softmax')])
+def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
+    """sample_model as one resident kernel (2L + 3 phases per step): every output vs the oracle, the machine really
+    ran, a second call replays it, and the per-step launch path (PARROT_SAMPLE_PERSIST=0) agrees to rounding."""
+    from oracle import parrot_ref as R
+    from parrot_amd import _lib
+    from parrot_amd.model import Parrot
+    full = dict(SMALL, **kw)
+    cfg = R.default_config(**full)
+    p = R.init_params(cfg, seed=7, scale_by_fan_in=True)
+    N, U, S = 5, 9, 14
+    _, _, lab, lm, spk = make_batch(cfg, 2, N, U, seed=9, speaker=cfg['use_speaker'])
+    with torch.no_grad():
+        ref = R.sample_model(p, cfg, lab, lm, spk, S)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PARROT_SAMPLE_PERSIST", mode)
+        m = Parrot(device=dev, use_graph=True, **full).allocate()
+        m.set_parameter_values(p)
+        for rep in range(2):
+            outs = m.sample_model_device(lab, lm.float(), spk, N, S)
+            for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+                assert_close(o, r, 1e-4, f"persist={mode} pass {rep}: {n}")
+        ws = m._sample_ws.get((S, N, U))
+        assert bool(_lib.load().parrot_sample_is_persistent(ws['plan'])) == (mode == "1")
+        if mode == "1":
+            assert int(ws['pm']['ws'][832:833].view(torch.int32).item()) == 0, "a spin timed out inside the machine"
+        res[mode] = [o.clone() for o in outs]
+        m.close()
+    for a, b, n in zip(res["1"], res["0"], ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+        assert_close(a, b, 2e-5, f"machine vs launches: {n}")
