@@ -409,6 +409,20 @@ typedef struct SampleRnnGenDesc {
     float* xf_big; float* xf_frm; float* feat_cur; float* gru_in; float* P; float* z; float* r; float* rh;
     float* big_out; float* frame_out; float* o1; float* o2; float* o3; float* logits;
     int* tbase;
+    /* Stacked / LSTM tiers (three_tier.py:147-169 allows RNN_TYPE = 'LSTM' and N_RNN in 1..5; stackedGRU / stackedLSTM,
+     * sampleRNN/lib/ops.py:612-777, 823-989, without skip connections).  n_rnn = 0 keeps the single-GRU fields above.
+     * Otherwise, per tier and layer k < n_rnn, four pointers:
+     *   GRU  (lstm = 0): { Input.W [D,3D], Input.b [3D], Recurrent_Gates [D,2D], Recurrent_Candidate [D,D] }
+     *   LSTM (lstm = 1): { Input.W [D,4D], b [4D], Recurrent_Gates [D,4D], NULL }   (gate order i | f | o | g)
+     * and the layer states big_hs / frm_hs [k] ([B,D]; initial state on entry, final on return) plus, for LSTM, the cell
+     * states big_cs / frm_cs [k].  P must then hold B*4D floats, gate_ws B*4D floats (LSTM gate scratch), and
+     * layer_tmp B*D floats. */
+    int n_rnn, lstm;
+    const float* big_L[5][4];
+    const float* frm_L[5][4];
+    float* big_hs[5]; float* big_cs[5];
+    float* frm_hs[5]; float* frm_cs[5];
+    float* gate_ws; float* layer_tmp;
 } SampleRnnGenDesc;
 
 int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan);

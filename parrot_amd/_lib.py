@@ -117,7 +117,12 @@ class SampleRnnGenDesc(C.Structure):
                     "big_Wout", "big_bout", "frm_Win", "frm_bin", "frm_U", "frm_bU", "frm_Wg", "frm_Wc",
                     "frm_Wout", "frm_bout", "emb_tbl", "W2", "b2", "W3", "b3", "W4", "b4", "features",
                     "samples", "big_h", "frm_h", "xf_big", "xf_frm", "feat_cur", "gru_in", "P", "z", "r", "rh",
-                    "big_out", "frame_out", "o1", "o2", "o3", "logits", "tbase")])
+                    "big_out", "frame_out", "o1", "o2", "o3", "logits", "tbase")] +
+                [("n_rnn", C.c_int), ("lstm", C.c_int),
+                 ("big_L", (C.c_void_p * 4) * 5), ("frm_L", (C.c_void_p * 4) * 5),
+                 ("big_hs", C.c_void_p * 5), ("big_cs", C.c_void_p * 5),
+                 ("frm_hs", C.c_void_p * 5), ("frm_cs", C.c_void_p * 5),
+                 ("gate_ws", C.c_void_p), ("layer_tmp", C.c_void_p)])
 
 
 # name -> (restype, argtypes); every symbol include/parrot_hip.h declares must be listed here

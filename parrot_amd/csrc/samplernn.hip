@@ -164,6 +164,46 @@ struct SrPlan {
         return sk_launch(L, st);
     }
 
+    // LSTM step of a tier layer (ops.py:505-553): pre = x . Win + b; gates = s . Wrec + pre (i | f | o | g);
+    // c' = c*f + g*i; s' = tanh(c')*o.  s is the A operand of the step GEMM, so s' goes to a temporary first.
+    int lstm_layer(const float* x, const float* Win, const float* b, const float* Wrec, float* s, float* c, hipStream_t st) {
+        const int D = d.D;
+        SR_TRY(linear(x, D, Win, 4 * D, D, 4 * D, b, nullptr, 0, d.P, 4 * D, 0, st));
+        SkJob j;
+        SkLaunch L;
+        sk_job_init(j);
+        j.nseg = 1;
+        j.seg[0] = sk_seg(s, D, Wrec, 4 * D, D, 0);
+        j.M = d.B; j.N = 4 * D; j.H = D; j.epi = SK_EPI_LSTM;
+        j.add = d.P; j.ld_add = 4 * D;
+        j.e1 = c; j.lde1 = D;
+        j.o1 = c; j.ldo1 = D;
+        j.o2 = d.gate_ws; j.ldo2 = 4 * D;
+        j.out = d.layer_tmp; j.ldo = D;
+        SR_TRY(sk_make_launch(L, &j, 1));
+        SR_TRY(sk_launch(L, st));
+        return (int)hipMemcpyAsync(s, d.layer_tmp, (size_t)d.B * D * sizeof(float), hipMemcpyDeviceToDevice, st);
+    }
+
+    // One step of a tier's RNN stack on input x [B,D]; returns the top layer's output (state) pointer.
+    int stack_step(bool big, const float* x, const float** top, hipStream_t st) {
+        if (d.n_rnn == 0) {  // single GRU layer, original fields
+            if (big) SR_TRY(gru(x, d.big_U, d.big_bU, d.big_Wg, d.big_Wc, d.big_h, st));
+            else SR_TRY(gru(x, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st));
+            *top = big ? d.big_h : d.frm_h;
+            return 0;
+        }
+        for (int k = 0; k < d.n_rnn; ++k) {
+            const float* const* Lk = big ? d.big_L[k] : d.frm_L[k];
+            float* hs = big ? d.big_hs[k] : d.frm_hs[k];
+            if (d.lstm) SR_TRY(lstm_layer(x, Lk[0], Lk[1], Lk[2], hs, big ? d.big_cs[k] : d.frm_cs[k], st));
+            else SR_TRY(gru(x, Lk[0], Lk[1], Lk[2], Lk[3], hs, st));
+            x = hs;
+        }
+        *top = x;
+        return 0;
+    }
+
     int period(hipStream_t st) {
         const int B = d.B, D = d.D, FS = d.FS, BFS = d.BFS, len = BFS * d.T;
         const float half_q = (float)(d.Q / 2);
@@ -175,8 +215,9 @@ struct SrPlan {
                                half_q, d.xf_big, B, d.features, d.feat_cur, d.feat_dim, BFS);
             SR_TRY(linear(d.xf_big, BFS, d.big_Win_frames, D, BFS, D, d.big_bin, nullptr, 0, d.gru_in, D, 0, st,
                           d.feat_cur, d.feat_dim, d.big_Win_feats, d.feat_dim));
-            SR_TRY(gru(d.gru_in, d.big_U, d.big_bU, d.big_Wg, d.big_Wc, d.big_h, st));
-            SR_TRY(linear(d.big_h, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st));
+            const float* top = nullptr;
+            SR_TRY(stack_step(true, d.gru_in, &top, st));
+            SR_TRY(linear(top, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st));
         }
         for (int f = 0; f < nfr; ++f) {
             // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
@@ -185,8 +226,9 @@ struct SrPlan {
                                FS, half_q, d.xf_frm, B, (const float*)nullptr, (float*)nullptr, 0, BFS);
             SR_TRY(linear(d.xf_frm, FS, d.frm_Win, D, FS, D, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D, 0,
                           st));
-            SR_TRY(gru(d.gru_in, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st));
-            SR_TRY(linear(d.frm_h, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st));
+            const float* ftop = nullptr;
+            SR_TRY(stack_step(false, d.gru_in, &ftop, st));
+            SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st));
             for (int i = 0; i < FS; ++i) {
                 // ---- sample-level MLP (three_tier.py:452-515) + pick (ops.py:268-297)
                 const int to = toff + i;
@@ -243,8 +285,17 @@ extern "C" {
 
 int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_ENTRY();
     if (!desc || !plan || desc->B < 1 || desc->T < 2 || desc->D < 4 || (desc->D & 3) || desc->FS < 1 ||
-        desc->BFS % desc->FS != 0 || desc->Q < 2)
+        desc->BFS % desc->FS != 0 || desc->Q < 2 || desc->n_rnn < 0 || desc->n_rnn > 5)
         return PARROT_ERR_BADARG;
+    if (desc->n_rnn > 0) {
+        if (desc->lstm && (!desc->gate_ws || !desc->layer_tmp)) return PARROT_ERR_BADARG;
+        for (int k = 0; k < desc->n_rnn; ++k) {
+            if (!desc->big_hs[k] || !desc->frm_hs[k] || (desc->lstm && (!desc->big_cs[k] || !desc->frm_cs[k])))
+                return PARROT_ERR_BADARG;
+            for (int q = 0; q < (desc->lstm ? 3 : 4); ++q)
+                if (!desc->big_L[k][q] || !desc->frm_L[k][q]) return PARROT_ERR_BADARG;
+        }
+    }
     SrPlan* p = new (std::nothrow) SrPlan();
     if (!p) return PARROT_ERR_BADARG;
     p->d = *desc;

@@ -189,7 +189,8 @@ class DeviceGenerator:
     """Device-resident generation loop (samplernn_generate_*, include/parrot_hip.h)."""
 
     def __init__(self, batch, n_frames, temperature=0.0, seed=234, use_graph=True):
-        assert RNN_TYPE == 'GRU' and N_RNN == 1 and not SKIP_CONN
+        """GRU or LSTM tiers, 1..5 stacked layers (three_tier.py:147-169); skip connections are not built."""
+        assert not SKIP_CONN
         self.B, self.T = batch, n_frames
         dev = lib.device()
         f = dict(device=dev, dtype=torch.float32)
@@ -198,15 +199,12 @@ class DeviceGenerator:
         ew = lambda n, i=0: lops.effective_weight(n, i, WEIGHT_NORM).detach().contiguous()
         pb = lambda n: lib.param(n + '.b').detach().contiguous()
         with torch.no_grad():
+            single = RNN_TYPE == 'GRU' and N_RNN == 1
             w = dict(
                 big_Win_frames=ew('BigFrameLevel.rnn_inp_fusion', 0), big_Win_feats=ew('BigFrameLevel.rnn_inp_fusion', 1),
                 big_bin=pb('BigFrameLevel.rnn_inp_fusion'),
-                big_U=ew('BigFrameLevel.GRU1.Step.Input'), big_bU=pb('BigFrameLevel.GRU1.Step.Input'),
-                big_Wg=ew('BigFrameLevel.GRU1.Step.Recurrent_Gates'), big_Wc=ew('BigFrameLevel.GRU1.Step.Recurrent_Candidate'),
                 big_Wout=ew('BigFrameLevel.Output'), big_bout=pb('BigFrameLevel.Output'),
                 frm_Win=ew('FrameLevel.InputExpand'), frm_bin=pb('FrameLevel.InputExpand'),
-                frm_U=ew('FrameLevel.GRU1.Step.Input'), frm_bU=pb('FrameLevel.GRU1.Step.Input'),
-                frm_Wg=ew('FrameLevel.GRU1.Step.Recurrent_Gates'), frm_Wc=ew('FrameLevel.GRU1.Step.Recurrent_Candidate'),
                 frm_Wout=ew('FrameLevel.Output'), frm_bout=pb('FrameLevel.Output'),
                 W2=ew('SampleLevel.L2'), b2=pb('SampleLevel.L2'), W3=ew('SampleLevel.L3'), b3=pb('SampleLevel.L3'),
                 W4=ew('SampleLevel.Output'), b4=pb('SampleLevel.Output'))
@@ -217,14 +215,31 @@ class DeviceGenerator:
             for pos in range(FS):
                 hip.gemm(emb, W1[pos * EMB_SIZE:(pos + 1) * EMB_SIZE], out=tbl[pos])
             w['emb_tbl'] = tbl
+            # the RNN stacks of the two tiers: per layer (Input.W, Input.b | b, Recurrent_Gates, Recurrent_Candidate | -)
+            self.layers = {}
+            for tier, tag in (('BigFrameLevel', 'big'), ('FrameLevel', 'frm')):
+                for k in range(1, N_RNN + 1):
+                    if RNN_TYPE == 'GRU':
+                        pre = f'{tier}.GRU{k}.Step'
+                        self.layers[(tag, k - 1)] = [ew(pre + '.Input'), pb(pre + '.Input'), ew(pre + '.Recurrent_Gates'),
+                                                     ew(pre + '.Recurrent_Candidate')]
+                    else:
+                        pre = f'{tier}.LSTM{k}.Step'
+                        self.layers[(tag, k - 1)] = [ew(pre + '.Input'), lib.param(pre + '.b').detach().contiguous(),
+                                                     ew(pre + '.Recurrent_Gates')]
+            if single:
+                for tag in ('big', 'frm'):
+                    U_, bU_, Wg_, Wc_ = self.layers[(tag, 0)]
+                    w.update({f'{tag}_U': U_, f'{tag}_bU': bU_, f'{tag}_Wg': Wg_, f'{tag}_Wc': Wc_})
         self.w = w
+        self.single = single
         self.ws = dict(
             samples=torch.zeros(batch, BFS * n_frames, device=dev, dtype=torch.int32),
             features=torch.zeros(n_frames, batch, FEAT_DIM, **f),
             big_h=torch.zeros(batch, D, **f), frm_h=torch.zeros(batch, D, **f),
             xf_big=torch.zeros(batch, BFS, **f), xf_frm=torch.zeros(batch, FS, **f),
             feat_cur=torch.zeros(batch, FEAT_DIM, **f), gru_in=torch.zeros(batch, D, **f),
-            P=torch.zeros(batch, 3 * D, **f), z=torch.zeros(batch, D, **f), r=torch.zeros(batch, D, **f),
+            P=torch.zeros(batch, 4 * D, **f), z=torch.zeros(batch, D, **f), r=torch.zeros(batch, D, **f),
             rh=torch.zeros(batch, D, **f), big_out=torch.zeros(batch, nfr * D, **f),
             frame_out=torch.zeros(batch, FS * D, **f), o1=torch.zeros(batch, D, **f), o2=torch.zeros(batch, D, **f),
             o3=torch.zeros(batch, D, **f), logits=torch.zeros(batch, Q, **f),
@@ -234,6 +249,22 @@ class DeviceGenerator:
         d.temperature, d.seed = float(temperature), int(seed)
         for k, v in list(w.items()) + list(self.ws.items()):
             setattr(d, k, v.data_ptr())
+        if not self.single:
+            lstm = RNN_TYPE == 'LSTM'
+            d.n_rnn, d.lstm = N_RNN, int(lstm)
+            self.states = {}
+            for tag in ('big', 'frm'):
+                for k in range(N_RNN):
+                    for q, t in enumerate(self.layers[(tag, k)]):
+                        getattr(d, tag + '_L')[k][q] = t.data_ptr()
+                    self.states[(tag, 'h', k)] = torch.zeros(batch, D, **f)
+                    getattr(d, tag + '_hs')[k] = self.states[(tag, 'h', k)].data_ptr()
+                    if lstm:
+                        self.states[(tag, 'c', k)] = torch.zeros(batch, D, **f)
+                        getattr(d, tag + '_cs')[k] = self.states[(tag, 'c', k)].data_ptr()
+            self.ws['gate_ws'] = torch.zeros(batch, 4 * D, **f)
+            self.ws['layer_tmp'] = torch.zeros(batch, D, **f)
+            d.gate_ws, d.layer_tmp = self.ws['gate_ws'].data_ptr(), self.ws['layer_tmp'].data_ptr()
         self.desc = d
         self.plan = C.c_void_p()
         _lib.call('samplernn_generate_create', C.byref(d), C.byref(self.plan))
@@ -245,8 +276,16 @@ class DeviceGenerator:
         ws['samples'].zero_()
         ws['samples'][:, :BIG_FRAME_SIZE] = int(Q_ZERO)  # three_tier.py:795
         # reset = (t == BIG_FRAME_SIZE): the first step of both tiers starts from the learned h0 (:334-342, 411-419)
-        ws['big_h'].copy_(lib.param('BigFrameLevel.h0').detach()[0].unsqueeze(0).expand(self.B, -1))
-        ws['frm_h'].copy_(lib.param('FrameLevel.h0').detach()[0].unsqueeze(0).expand(self.B, -1))
+        if self.single:
+            ws['big_h'].copy_(lib.param('BigFrameLevel.h0').detach()[0].unsqueeze(0).expand(self.B, -1))
+            ws['frm_h'].copy_(lib.param('FrameLevel.h0').detach()[0].unsqueeze(0).expand(self.B, -1))
+        else:  # h0 [N_RNN, H0_MULT * D]: LSTM layers carry [s | c] (ops.py:552)
+            for tier, tag in (('BigFrameLevel', 'big'), ('FrameLevel', 'frm')):
+                h0 = lib.param(tier + '.h0').detach()
+                for k in range(N_RNN):
+                    self.states[(tag, 'h', k)].copy_(h0[k, :DIM].unsqueeze(0).expand(self.B, -1))
+                    if RNN_TYPE == 'LSTM':
+                        self.states[(tag, 'c', k)].copy_(h0[k, DIM:].unsqueeze(0).expand(self.B, -1))
         _lib.call('samplernn_generate_run', self.plan, hip._stream())
         return ws['samples']
 

@@ -143,3 +143,33 @@ def test_compute_cost_lstm_and_stacked(dev, rnn_type, n_rnn):
     finally:
         lib.delete_all_params()
         tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+
+
+@pytest.mark.parametrize("rnn_type,n_rnn", [("LSTM", 1), ("LSTM", 2), ("GRU", 2), ("GRU", 3)])
+def test_device_generation_lstm_and_stacked_tiers(dev, rnn_type, n_rnn):
+    """The device-resident sample loop for RNN_TYPE = 'LSTM' and stacked tiers (three_tier.py:147-169; stackedGRU /
+    stackedLSTM, ops.py:612-777, 823-989): greedy indices equal the fp64 oracle's, graph replay and eager launches."""
+    from oracle import samplernn_ref as S
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=32, EMB_SIZE=8, RNN_TYPE=rnn_type, N_RNN=n_rnn)
+    try:
+        c = S.config(DIM=32, EMB_SIZE=8, RNN_TYPE=rnn_type, N_RNN=n_rnn)
+        p = S.init_params(c, seed=9, perturb=0.3)
+        lib.set_params(p)
+        g = torch.Generator().manual_seed(4)
+        T, B = 4, 3
+        feats = torch.randn(T, B, 63, generator=g, dtype=torch.float64)
+        with torch.no_grad():
+            ref = S.generate(p, c, feats).numpy()
+        for use_graph in (True, False):
+            gen = tt.DeviceGenerator(B, T, temperature=0.0, use_graph=use_graph)
+            for rep in range(2):  # the second call starts again from the learned h0
+                out = gen.generate(feats.float().numpy()).cpu().numpy()
+                assert np.array_equal(out, ref), f"{(out != ref).sum()} of {out.size} greedy indices differ"
+            gen.close()
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
