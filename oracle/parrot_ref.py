@@ -1,7 +1,8 @@
 """torch-CPU restatement of reference model.py (test infrastructure, see oracle/__init__.py).
 
-PARITY UNPINNED: no reference test / golden vector exists for this path and Theano/Blocks cannot
-run here.  Every function cites the reference lines it restates.  Row-vector convention
+PINNED (round 2) to vectors produced by executing the reference's own model.py on eager Theano / Blocks
+stand-ins (oracle/refshim, tests/golden/make_ref_golden.py, tests/test_ref_golden_cpu.py: outputs and every gradient
+at 1e-10).  Every function cites the reference lines it restates.  Row-vector convention
 ``y = x . W + b`` with ``W [in, out]`` (Blocks Linear).  Default dtype float64 (the checker);
 ``dtype=torch.float32`` is used when this code is timed as the CPU baseline.
 

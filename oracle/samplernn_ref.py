@@ -1,5 +1,6 @@
 """torch-CPU restatement of the conditional three-tier SampleRNN (test infrastructure, see
-oracle/__init__.py).  PARITY UNPINNED (no reference tests / vectors; Theano cannot run here).
+oracle/__init__.py).  PINNED (round 2) to vectors produced by executing the reference's own ops.py / three_tier.py on
+an eager Theano stand-in (oracle/refshim, tests/golden/make_ref_golden.py; outputs and every gradient at 1e-10).
 
 Restates sampleRNN/lib/ops.py (Linear with weight norm :32-128, Embedding :252-266, GRU step
 :329-393, stackedGRU :612-777 for n_rnn = 1, softmax_and_argmax :268-297) and

@@ -1,5 +1,5 @@
 // Micro-benchmark of the recurrent-step kernel at BASELINE cfg2 shapes (development aid).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSK_DBG_...] tools/skbench.hip -o /tmp/skbench
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/skbench.hip -o /tmp/skbench
 #include "../parrot_amd/csrc/skinny.hip"
 
 #include <stdio.h>
