@@ -38,6 +38,13 @@ def parse():
     ap.add_argument("--U", type=int, default=200, help="encoder timesteps (T_enc)")
     ap.add_argument("--H", type=int, default=1024)
     ap.add_argument("--L", type=int, default=2)
+    ap.add_argument("--config", choices=("cfg2", "cfg4"), default="cfg2",
+                    help="cfg2 = BASELINE configs[1] (the headline; default).  cfg4 = BASELINE configs[3] per GPU: 3-layer "
+                         "LSTM h=1536 + attention, batch 64 per GPU (global 512 on 8), bf16 operands; sets --L/--H/--cell/--dtype")
+    ap.add_argument("--cell", choices=("gru", "lstm"), default="gru")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16: MFMA operands (weights and activations) rounded to bf16, f32 accumulation, f32 master "
+                         "weights / states / gradients")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -49,7 +56,12 @@ def parse():
                          "kappa advances ~1 per frame and leaves the text after ~210 frames, after which no context row "
                          "is read at all -- a favourable, unrealistic case)")
     ap.add_argument("--no-dense", action="store_true", help="skip the second timed run that reads all context rows")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.config == "cfg4":
+        a.L, a.H, a.cell = 3, 1536, "lstm"
+        if "--dtype" not in sys.argv:
+            a.dtype = "bf16"
+    return a
 
 
 def host_cores():
@@ -75,13 +87,14 @@ def make_batch(a, dev, seed):
 
 
 def model_kwargs(a):
-    return dict(num_layers=a.L, rnn_h_dim=a.H, readouts_dim=a.H, encoder_type='bidirectional')
+    return dict(num_layers=a.L, rnn_h_dim=a.H, readouts_dim=a.H, encoder_type='bidirectional', cell_type=a.cell)
 
 
 def build_model(a, dev, use_graph=True):
     """BASELINE configs[1] model: train.py's init (N(0, 0.01) weights, zero biases) except the kappa bias (--kappa-bias)."""
     from parrot_amd.model import Parrot
-    m = Parrot(device=dev, use_graph=use_graph, seed=1234, **model_kwargs(a)).initialize()
+    m = Parrot(device=dev, use_graph=use_graph, seed=1234,
+               compute_dtype='bf16' if a.dtype == 'bf16' else 'float32', **model_kwargs(a)).initialize()
     with torch.no_grad():
         m.get_parameter_dict()['/parrot/h1_to_att/fork_kappa.b'].fill_(a.kappa_bias)
     return m
@@ -113,8 +126,21 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
     m.close()
     if n <= 0 or us.value <= 0:
         return None
-    peak = 157.3  # f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
     ach = fl.value / us.value * 1e-6  # TFLOP/s
+    if a.dtype == "bf16":
+        # bf16 operands: 16 x the f32 matrix rate, half the weight bytes -- the step GEMMs (M = 64 rows per weight
+        # element) are bound by how fast the weights and the f32 activations arrive, so the roof is HBM / L2 bandwidth
+        gbps = by.value / us.value * 1e-3
+        return {
+            "kernel": "sk_kernel (fused LSTM/GRU step GEMM, bf16 operands, fwd + bwd)",
+            "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000, "unit": "GB/s", "frac": round(gbps / 8000, 4),
+            "traffic": None, "traffic_source": None,
+            "launches_per_step": int(n), "avg_launch_us": round(us.value / n, 3),
+            "alg_flops_per_launch": round(fl.value / n), "alg_bytes_per_launch": round(by.value / n),
+            "alg_TFLOPs": round(ach, 2), "bf16_mfma_peak_TFLOPs": 2516.6,
+            "kernel_time_ms_per_step": round(us.value * 1e-3, 3),
+        }
+    peak = 157.3  # f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass
     # with the timed run); the number is the committed measurement of the session named next to it, not of this run
     traffic, traffic_src = None, None
@@ -197,7 +223,7 @@ def cpu_baseline_subprocess(a):
     never stall the GPU job."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--T", str(a.T), "--B", str(a.B),
-           "--U", str(a.U), "--H", str(a.H), "--L", str(a.L), "--cpu-T", str(a.cpu_T), "--cpu-iters", str(a.cpu_iters),
+           "--U", str(a.U), "--H", str(a.H), "--L", str(a.L), "--cell", a.cell, "--cpu-T", str(a.cpu_T), "--cpu-iters", str(a.cpu_iters),
            "--kappa-bias", str(a.kappa_bias)]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -274,9 +300,13 @@ def main():
             "metric": "acoustic feature frames/sec (train fwd+bwd+allreduce+clip/Adam)",
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 2-layer attention-GRU decoder, h=1024, "
-                                   "batch=64 per GPU, T_enc=200, T_dec=800, fp32",
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[3] per GPU: 3-layer attention-LSTM decoder, h=1536, batch=64 per GPU "
+                                    "(global 512 on 8 GPUs), T_enc=200, T_dec=800, bf16 MFMA operands / f32 accumulate / "
+                                    "f32 master weights" if a.config == "cfg4" else
+                                    "BASELINE configs[1]: 2-layer attention-GRU decoder, h=1024, "
+                                    "batch=64 per GPU, T_enc=200, T_dec=800, fp32"),
+                       "cell": a.cell,
                        "layers": a.L, "hidden": a.H, "batch_per_gpu": a.B, "global_batch": a.B * world,
                        "T_enc": a.U, "T_dec": a.T, "parallelism": f"dp{world}",
                        "params": int(model.store.numel),

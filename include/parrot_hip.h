@@ -53,6 +53,15 @@ long long parrot_profile_end(double* total_us, double* flops, double* bytes);
  *   automatically (long reductions with few output tiles, e.g. deferred weight gradients).
  * M <= 64 with transA = 0 dispatches to the weight-streaming recurrent-step kernel.
  * ------------------------------------------------------------------------------------------ */
+#define PARROT_PRECISION_F32 0
+#define PARROT_PRECISION_BF16 1
+/* Operand precision of the batched path of parrot_gemm (M > 64, or transA / batched / split-K calls), process-wide:
+ * PARROT_PRECISION_F32 (default; the reference computes in floatX = float32, model.py:21) or PARROT_PRECISION_BF16:
+ * A and B are read as f32 and rounded to bf16 (nearest even) on their way into the matrix cores, products are
+ * accumulated in f32, C / bias / activation stay f32 (BASELINE configs[3]).  Not a per-stream setting: change it only
+ * between calls.  A decoder plan created with bf16 = 1 applies the mode to its own batched projections regardless. */
+int parrot_set_gemm_precision(int mode);
+int parrot_get_gemm_precision(void);
 int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
                 int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
                 long long strideA, long long strideB, long long strideC, int split_k, void* stream);
@@ -213,7 +222,11 @@ typedef struct ParrotDecoderDesc {
      * the normalised projection (ln_y*, [T,B,width]; seq_bwd overwrites it with the gradient wrt the
      * PRE-norm projection, which the caller turns into the weight/bias gradients) and the row std (ln_s*,
      * [T,B]).  Rows of Wg/Wc keep the packed layout. */
-    int layer_norm, reserved6;
+    /* bf16 = 1 (BASELINE configs[3]): Wg_f / Wc_f / Wg_r / Wc_r are bf16 copies made by parrot_tile_weights_bf16
+     * (mandatory then; H and E multiples of 32), the step GEMMs round the activations they read to bf16 and run on
+     * v_mfma_f32_16x16x32_bf16 with f32 accumulation, the batched lower-layer projections of the chunked schedule take
+     * the bf16 path of parrot_gemm.  States, gate activations, attention and all gradients buffers stay f32. */
+    int layer_norm, bf16;
     const float* ln_bg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
     const float* ln_bc[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
     float* ln_yg[PARROT_MAX_LAYERS * PARROT_MAX_LAYERS];
@@ -354,6 +367,10 @@ int parrot_sumsq(const float* x, size_t n, float* out, void* stream);
  * applies the gate-interleaved column order of the fused LSTM step, cols = 4*lstm_H); mode 1: for products
  * x . W^T (tiles over rows, chunks over columns).  out: rows*cols floats. */
 int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream);
+/* The same copy rounded to bf16 (round to nearest even) for the bf16 operand mode of the decoder scan
+ * (ParrotDecoderDesc::bf16): 1 KB blocks of 16 columns x 32 K-rows in v_mfma_f32_16x16x32_bf16 operand order.  The
+ * K extent (rows in mode 0, cols in mode 1) must be a multiple of 32, the other one of 16.  out: rows*cols bf16. */
+int parrot_tile_weights_bf16(const float* W, int rows, int cols, int ld, void* out, int mode, int lstm_H, void* stream);
 
 /* _simple_norm / _apply_norm of the reference (model.py:24-34; used when layer_norm=True on the Fork outputs
  * and readout projections, model.py:585-620, 703-722, 746): y = (x - mean) / (eps + std) over the last axis

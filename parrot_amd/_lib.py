@@ -62,7 +62,7 @@ class DecoderDesc(C.Structure):
         ("dG", C.c_void_p * MAX_LAYERS), ("dC", C.c_void_p * MAX_LAYERS), ("dp", C.c_void_p),
         ("cell", C.c_int), ("seq_init", C.c_int),
         ("cst", C.c_void_p * MAX_LAYERS), ("gate4", C.c_void_p * MAX_LAYERS), ("dcell", C.c_void_p * MAX_LAYERS),
-        ("layer_norm", C.c_int), ("reserved6", C.c_int),
+        ("layer_norm", C.c_int), ("bf16", C.c_int),
         ("ln_bg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_bc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
         ("ln_yg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_yc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
         ("ln_sg", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)), ("ln_sc", C.c_void_p * (MAX_LAYERS * MAX_LAYERS)),
@@ -160,6 +160,9 @@ SIGNATURES = {
     "parrot_plan_last_error": (_i, [_vp]),
     "parrot_sumsq": (_i, [_vp, _sz, _vp, _vp]),
     "parrot_tile_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "parrot_tile_weights_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "parrot_set_gemm_precision": (_i, [_i]),
+    "parrot_get_gemm_precision": (_i, []),
     "parrot_simple_norm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _ll, _i, _f, _vp, _i, _vp]),
     "parrot_simple_norm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     "parrot_adam_clip_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),

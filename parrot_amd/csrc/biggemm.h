@@ -21,7 +21,16 @@ struct BgArgs {
     int accumulate;  // C += result (C must hold valid data; with splitk>1 always accumulates)
     float alpha;
     int act;         // SkAct-compatible activation, only when splitk == 1
+    int bf16;        // 1: operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16, f32 accumulation
 };
 
 int bg_launch(const BgArgs& a, hipStream_t stream);
 int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of the deterministic split-K
+
+// Operand precision of parrot_gemm's batched path: the process-wide mode (parrot_set_gemm_precision) unless a scan
+// plan running on this thread pins its own (a plan built for bf16 operands keeps them whatever the caller's mode is).
+struct BgPrecisionScope {
+    explicit BgPrecisionScope(int bf16);
+    ~BgPrecisionScope();
+    int saved;
+};

@@ -9,7 +9,7 @@
 // images (row pitch 132 floats) so that an MFMA fragment read is 32 consecutive floats per half
 // wave (conflict-free ds_read_b32); the next K-tile is prefetched into registers while the
 // current one is consumed (double-buffered LDS, one barrier per K-tile).  Workgroup ids are
-// remapped so that each XCD (private 4 MiB L2) walks a contiguous band of tiles.
+// remapped so that each XCD (private 4 MiB L2) works on 8 x 8 blocks of tiles (bg_tile_of_block).
 #include "biggemm.h"
 
 #include <hip/hip_runtime.h>
@@ -18,6 +18,25 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, PITCH = 132;
+
+// Workgroup -> output tile.  Block b runs on XCD b % 8 (private 4 MiB L2 each).  Every XCD gets a contiguous range
+// of a tile order that walks column groups of 8 tiles row by row, so the ~64 workgroups an XCD runs at a time cover an
+// 8 x 8 block of tiles: 16 operand panels feed 64 tiles (8-fold reuse out of L2).  A plain row-major band gave 1 + 48
+// panels per 48 tiles on the 48-tile-wide weight gradients of a 3 x LSTM-1536 decoder, i.e. every tile row re-read the
+// whole [T*B, 4H] gradient matrix from HBM.
+__device__ __forceinline__ void bg_tile_of_block(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg / 8, r = nwg % 8;
+    const int xcd = bid % 8, idx = bid / 8;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GW = 8;
+    const int group = lin / (GW * tiles_m);
+    const int first = group * GW;
+    const int gsz = min(tiles_n - first, GW);
+    const int rem = lin - group * GW * tiles_m;
+    tm = rem / gsz;
+    tn = first + rem % gsz;
+}
 
 // Loads the 128 x 16 slab of an operand whose element (x, k) sits at p[x*sx + k*sk].
 // XC = true : x is the contiguous index (sx == 1).  thread -> (xq = t&31, kr = t>>5), 2 passes.
@@ -84,15 +103,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
     __shared__ __attribute__((aligned(16))) float As[2][BK * PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * PITCH];
 
-    // XCD-aware remap (8 XCDs; block b runs on XCD b % 8): give each XCD a contiguous band.
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8;
-        const int xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int z = blockIdx.y;
@@ -231,14 +243,8 @@ template <bool AXC, bool BXC>
 __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float As[2][BK * PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * PITCH];
-    const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8;
-        const int xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, tn;
+    bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.y;
     const int batch = z / a.splitk, ks = z % a.splitk;
@@ -314,6 +320,134 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
     }
 }
 
+// ---- bf16-operand variant (BgArgs::bf16): same 128 x 128 output tile and 2 x 4 wave grid, K-tile 32 ------------
+// The operands stay f32 in HBM (they are the scan's saved activations / gradients and the f32 master weights); each
+// thread rounds the 8 values it fetched to bf16 and writes them with one ds_write_b128 into an [x][k] image (row pitch
+// 40 bf16 = 80 B: the 16 lanes an LDS cycle serves hit 16 disjoint 4-bank groups, for the writes and for the
+// fragment reads).  A wave reads its MFMA fragments as ds_read_b128 (row li, k = 16s + 8kk .. +7) and issues
+// 4 v_mfma_f32_32x32x16_bf16 per K-tile (32 cycles each) where the f32 kernel issues 32 v_mfma_f32_32x32x2_f32
+// (64 cycles each) for the same K range: the matrix pipe stops being the limit and the kernel becomes bound by
+// the L2 -> LDS operand traffic (32 KB of f32 per K-tile and workgroup).
+constexpr int BK16 = 32, PITCH16 = 40;
+
+// XC = true : x contiguous (element (x,k) at p[k*sk + x]): thread -> (x = t & 127, kg = t >> 7), 8 dword loads down k.
+// XC = false: k contiguous (element (x,k) at p[x*sx + k]): thread -> (x = t >> 2, kg = t & 3), two 16-byte loads.
+template <bool XC>
+__device__ __forceinline__ void bg_load16(const float* __restrict__ p, int x0, int X, int k0, int kend,
+                                          long long sx, long long sk, bool vec, int t, f32x4 (&v)[2]) {
+    v[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (XC) {
+        const int x = x0 + (t & 127), k = k0 + 8 * (t >> 7);
+        if (x < X) {
+            const float* q = p + (long long)k * sk + x;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k + u < kend) v[u >> 2][u & 3] = q[(long long)u * sk];
+        }
+    } else {
+        const int x = x0 + (t >> 2), k = k0 + 8 * (t & 3);
+        if (x < X) {
+            const float* q = p + (long long)x * sx + k;
+            if (vec && k + 7 < kend) {
+                v[0] = *reinterpret_cast<const f32x4*>(q);
+                v[1] = *reinterpret_cast<const f32x4*>(q + 4);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k + u < kend) v[u >> 2][u & 3] = q[u];
+            }
+        }
+    }
+}
+
+template <bool XC>
+__device__ __forceinline__ void bg_store16(__bf16* __restrict__ s, int t, const f32x4 (&v)[2]) {
+    const int x = XC ? (t & 127) : (t >> 2), kg = XC ? (t >> 7) : (t & 3);
+    *reinterpret_cast<bf16x8*>(s + x * PITCH16 + 8 * kg) = ph_bf16x8(v[0], v[1]);
+}
+
+template <bool AXC, bool BXC>
+__global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * PITCH16];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * PITCH16];
+    int tm, tn;
+    bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int batch = z / a.splitk, ks = z % a.splitk;
+    int kchunk = (a.K + a.splitk - 1) / a.splitk;
+    kchunk = (kchunk + BK16 - 1) / BK16 * BK16;
+    const int kbeg = ks * kchunk;
+    const int kend = min(a.K, kbeg + kchunk);
+    if (kbeg >= kend && ks > 0 && !a.ws) return;
+    const float* A = a.A + (long long)batch * a.batchA;
+    const float* B = a.B + (long long)batch * a.batchB;
+    float* C = a.C + (long long)batch * a.batchC;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kk = lane >> 5, li = lane & 31;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    f32x4 ra[2], rb[2];
+    const int nk = (kend - kbeg + BK16 - 1) / BK16;
+    if (nk > 0) {
+        bg_load16<AXC>(A, m0, a.M, kbeg, kend, a.sam, a.sak, vecA, t, ra);
+        bg_load16<BXC>(B, n0, a.N, kbeg, kend, a.sbn, a.sbk, vecB, t, rb);
+        bg_store16<AXC>(As[0], t, ra);
+        bg_store16<BXC>(Bs[0], t, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            bg_load16<AXC>(A, m0, a.M, kbeg + (kt + 1) * BK16, kend, a.sam, a.sak, vecA, t, ra);
+            bg_load16<BXC>(B, n0, a.N, kbeg + (kt + 1) * BK16, kend, a.sbn, a.sbk, vecB, t, rb);
+        }
+        const __bf16* as = As[cur] + (wm * 64 + li) * PITCH16 + 8 * kk;
+        const __bf16* bs = Bs[cur] + (wn * 32 + li) * PITCH16 + 8 * kk;
+#pragma unroll
+        for (int s = 0; s < BK16 / 16; ++s) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(as + 16 * s);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(as + 32 * PITCH16 + 16 * s);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bs + 16 * s);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            bg_store16<AXC>(As[cur ^ 1], t, ra);
+            bg_store16<BXC>(Bs[cur ^ 1], t, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + wn * 32 + li;
+        if (n >= a.N) continue;
+        const float bias = (a.bias && ks == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+            if (m >= a.M) continue;
+            float v = a.alpha * acc[i][q] + bias;
+            float* c = C + (long long)m * a.ldc + n;
+            if (a.splitk > 1) {
+                if (a.ws) a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][q];  // bias added by the reducer
+                else unsafeAtomicAdd(c, v);
+            } else {
+                if (a.accumulate) v += *c;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = tanhf(v);
+                else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+                *c = v;
+            }
+        }
+    }
+}
+
 // C[b][m][n] (+)= bias[n] + sum over the K slices, in slice order (deterministic split-K).
 __global__ __launch_bounds__(256) void bg_reduce_kernel(const BgArgs a) {
     const long long mn = (long long)a.M * a.N;
@@ -355,6 +489,15 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
     dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
     dim3 block(256);
+    if (a.bf16) {
+        dim3 b8(512);
+        // vector loads of the k-contiguous layout take 8 consecutive k: both 16-byte halves must be aligned
+        if (axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<true, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel_bf16<true, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<false, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((bg_kernel_bf16<false, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        return (int)hipGetLastError();
+    }
     static int w8 = -1;
     if (w8 < 0) {
         const char* e = getenv("PARROT_GEMM_W8");

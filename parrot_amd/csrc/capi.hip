@@ -18,7 +18,20 @@ static int gemm_target_wgs() {
     return v;
 }
 
+static int g_gemm_bf16 = 0;                 // parrot_set_gemm_precision
+static thread_local int t_gemm_bf16 = -1;   // BgPrecisionScope (-1: follow the process-wide mode)
+BgPrecisionScope::BgPrecisionScope(int bf16) : saved(t_gemm_bf16) { t_gemm_bf16 = bf16 ? 1 : 0; }
+BgPrecisionScope::~BgPrecisionScope() { t_gemm_bf16 = saved; }
+
 extern "C" {
+
+int parrot_set_gemm_precision(int mode) { PH_ENTRY();
+    if (mode != PARROT_PRECISION_F32 && mode != PARROT_PRECISION_BF16) return PARROT_ERR_BADARG;
+    g_gemm_bf16 = mode;
+    return 0;
+}
+
+int parrot_get_gemm_precision(void) { PH_ENTRY(); return g_gemm_bf16; }
 
 const char* parrot_hip_version(void) { PH_ENTRY(); return "parrot_hip 0.1.0 gfx950"; }
 
@@ -58,6 +71,7 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     a.batchA = strideA; a.batchB = strideB; a.batchC = strideC;
     a.nbatch = nbatch;
     a.accumulate = accumulate; a.alpha = alpha; a.act = act;
+    a.bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16;
     int split = split_k;
     if (split <= 0) {
         // auto: few output tiles but a long reduction (deferred weight gradients: K = T*B rows)
@@ -123,6 +137,11 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
 int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream) { PH_ENTRY();
     if (mode != 0 && mode != 1) return PARROT_ERR_BADARG;
     return sk_tile_weights_launch(W, rows, cols, ld, out, mode, lstm_H, (hipStream_t)stream);
+}
+
+int parrot_tile_weights_bf16(const float* W, int rows, int cols, int ld, void* out, int mode, int lstm_H, void* stream) { PH_ENTRY();
+    if (mode != 0 && mode != 1) return PARROT_ERR_BADARG;
+    return sk_tile_weights_bf16_launch(W, rows, cols, ld, out, mode, lstm_H, (hipStream_t)stream);
 }
 
 int parrot_simple_norm_fwd(const float* x, int ldx, float* y, int ldy, float* sigma, long long R, int N, float eps,

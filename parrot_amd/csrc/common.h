@@ -5,6 +5,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define PH_CHECK(x)                                   \
     do {                                              \
@@ -21,6 +24,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // returned unchanged for runtime failures).
 #define PH_ERR_BADARG 10001
 #define PH_ERR_UNSUPPORTED 10002
+
+// Eight f32 -> eight bf16, round to nearest even (v_cvt_pk_bf16_f32 on gfx950): the operand rounding of the
+// bf16 compute mode (weights and activations are rounded where they enter an MFMA, accumulation stays f32).
+__device__ __forceinline__ bf16x8 ph_bf16x8(const f32x4& lo, const f32x4& hi) {
+    const f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_convertvector(v, bf16x8);
+}
 
 __device__ __forceinline__ float ph_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 

@@ -12,6 +12,7 @@
 
 #include "../../include/parrot_hip.h"
 #include "attention.h"
+#include "biggemm.h"
 #include "elementwise.h"
 #include "persist.h"
 #include "skinny.h"
@@ -271,6 +272,7 @@ struct DecoderPlan : PlanBase {
     bool try_persist = false;
 
     int enqueue(int which, hipStream_t s) override {
+        BgPrecisionScope precision(d.bf16);  // the hoisted projections follow the plan's operand mode
         if (which == 0 && persist_ok) return pm_launch(pm_prog, s);  // schedule 4: the persistent phase machine
         if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
@@ -293,7 +295,7 @@ struct DecoderPlan : PlanBase {
         if (want >= 2 && !pipe_ok) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
         schedule = want;
-        try_persist = want_persist && d.cell == 0 && !d.layer_norm;
+        try_persist = want_persist && d.cell == 0 && !d.layer_norm && !d.bf16;
         const char* c = getenv("PARROT_CHUNK");
         if (c && atoi(c) > 0) chunk = atoi(c);
     }
@@ -322,7 +324,7 @@ struct DecoderPlan : PlanBase {
         return n + 1024;
     }
     static bool persist_eligible(const ParrotDecoderDesc& d) {
-        if (d.cell != 0 || d.layer_norm || d.B > 64 || (d.H % 16) || (d.E % 16) || d.U > PM_ATT_MAXU ||
+        if (d.cell != 0 || d.layer_norm || d.bf16 || d.B > 64 || (d.H % 16) || (d.E % 16) || d.U > PM_ATT_MAXU ||
             d.A > PM_ATT_MAXA || d.T < 1)
             return false;
         for (int l = 0; l < d.L; ++l)
@@ -527,6 +529,7 @@ struct DecoderPlan : PlanBase {
     SkSeg fseg(const float* A, int lda, int l, int g, int r0, int K, int ldw) const {
         if (tiled) {
             const float* Wt = g == 0 ? d.Wg_f[l] : d.Wc_f[l];
+            if (d.bf16) return sk_seg(A, lda, Wt + (size_t)(r0 >> 5) * 256, (krows(l) >> 5) * 256, K, 3);
             return sk_seg(A, lda, Wt + (size_t)(r0 >> 4) * 256, (krows(l) >> 4) * 256, K, 2);
         }
         const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
@@ -536,6 +539,7 @@ struct DecoderPlan : PlanBase {
     SkSeg rseg(const float* A, int l, int g, int r0, int ldw) const {
         if (tiled) {
             const float* Wt = g == 0 ? d.Wg_r[l] : d.Wc_r[l];
+            if (d.bf16) return sk_seg(A, ldw, Wt + (size_t)(r0 >> 4) * (ldw >> 5) * 256, (ldw >> 5) * 256, ldw, 3);
             return sk_seg(A, ldw, Wt + (size_t)(r0 >> 4) * (ldw >> 4) * 256, (ldw >> 4) * 256, ldw, 2);
         }
         const float* W = g == 0 ? d.Wg[l] : d.Wc[l];
@@ -1188,6 +1192,7 @@ struct DecoderPlan : PlanBase {
     }
 
     int run(int which, hipStream_t s) override {
+        BgPrecisionScope precision(d.bf16);
         if (schedule != 2) return PlanBase::run(which, s);
         return note(run_pipe(which, s));
     }
@@ -1843,6 +1848,13 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         }
         const char* e = getenv("PARROT_TILED_WEIGHTS");
         p->tiled = all && !(e && atoi(e) == 0);
+        if (desc->bf16) {  // bf16 operands exist only as fragment-major copies; 32-deep K chunks
+            if (!all || desc->layer_norm || (desc->H % 32) || (desc->E % 32)) {
+                delete p;
+                return PARROT_ERR_BADARG;
+            }
+            p->tiled = true;
+        }
     }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     if (desc->layer_norm && desc->L >= 2) {

@@ -28,6 +28,8 @@ struct SkSeg {
     const float* B;  // b_kcontig: 0: B[k * ldb + n]   1: B[n * ldb + k]
                      //            2: fragment-major copy (sk_tile_weights): B = block of column tile 0 / this
                      //               segment's first chunk, ldb = floats between consecutive column tiles
+                     //            3: bf16 fragment-major copy (sk_tile_weights_bf16; 32-deep chunks): same addressing,
+                     //               B / ldb still counted in 4-byte units; the activations are rounded to bf16 too
     int lda, ldb, K, b_kcontig;
 };
 
@@ -66,6 +68,8 @@ static inline SkSeg sk_seg(const float* A, int lda, const float* B, int ldb, int
 }
 int sk_tile_weights_launch(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H,
                            hipStream_t stream);
+int sk_tile_weights_bf16_launch(const float* W, int rows, int cols, int ld, void* out, int mode, int lstm_H,
+                                hipStream_t stream);
 void sk_job_init(SkJob& j);
 void sk_finalize_job(SkJob& j);  // computes `aligned`
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs);

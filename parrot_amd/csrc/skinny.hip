@@ -154,6 +154,47 @@ __device__ __forceinline__ void sk_mma2(const f32x4 (&a)[MB], const f32x4 (&b)[N
                 acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rb][u], b[nb][u], acc[rb][nb], 0, 0, 0);
 }
 
+// ---- bf16 operand mode (b_kcontig == 3) --------------------------------------------------------------
+// Weights come from a bf16 fragment-major copy (sk_tile_weights_bf16: one 1 KB block = 16 columns x 32 K-rows in
+// v_mfma_f32_16x16x32_bf16 B-operand order), activations stay f32 in HBM and are rounded to bf16 in registers
+// (quad-contiguous 32-byte loads, v_cvt_pk_bf16_f32, then the same ds_bpermute move as the f32 path, on 4 dwords
+// instead of 8).  Per 32 K-rows a wave issues MB*NB MFMAs of 16 cycles instead of 8*MB*NB of 32 cycles: the f32
+// matrix pipe, 55 % busy in sk_kernel<2,2>, drops out of the picture and half the weight bytes move.
+template <int MB, int NB>
+__device__ __forceinline__ void sk_fetch_bf16(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              int kc, const int (&mrow)[MB], const int (&btile)[NB],
+                                              f32x4 (&a)[MB][2], f32x4 (&b)[NB]) {
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) {
+        const float* p = A + (size_t)mrow[rb] * lda + kc + 8 * (threadIdx.x & 3);
+        a[rb][0] = *reinterpret_cast<const f32x4*>(p);
+        a[rb][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+        b[nb] = *reinterpret_cast<const f32x4*>(B + (size_t)btile[nb] * ldb + ((size_t)(kc >> 5) << 8) +
+                                                ((threadIdx.x & 63) << 2));
+}
+
+template <int MB, int NB>
+__device__ __forceinline__ void sk_mma_bf16(const f32x4 (&a)[MB][2], const f32x4 (&b)[NB], f32x4 (&acc)[MB][NB]) {
+    const int lane = threadIdx.x & 63;
+    const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;  // MFMA lane (kk, i) takes the quad lane 4 * i + kk loaded
+    bf16x8 av[MB];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) {
+        i32x4 q = __builtin_bit_cast(i32x4, ph_bf16x8(a[rb][0], a[rb][1]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = __builtin_amdgcn_ds_bpermute(src, q[u]);
+        av[rb] = __builtin_bit_cast(bf16x8, q);
+    }
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb], __builtin_bit_cast(bf16x8, b[nb]), acc[rb][nb], 0, 0, 0);
+}
+
 // One workgroup: (16*MB rows) x (16*NB columns) output tile, K split over the SK_NW waves.
 template <int MB, int NB, bool FAST>
 __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red) {
@@ -222,11 +263,12 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         const float* sA[SK_MAXSEG];
         const float* sB[SK_MAXSEG];
         int total = 0;
+        const int csh = job.seg[0].b_kcontig == 3 ? 5 : 4;  // K rows per chunk: 32 (bf16 operands) or 16
 #pragma unroll
         for (int s = 0; s < SK_MAXSEG; ++s) {
             const bool on = s < job.nseg;
             const int ss = on ? s : 0;
-            if (on) total += job.seg[ss].K >> 4;
+            if (on) total += job.seg[ss].K >> csh;
             cend[s] = total;
             sA[s] = job.seg[ss].A; sB[s] = job.seg[ss].B; slda[s] = job.seg[ss].lda; sldb[s] = job.seg[ss].ldb;
         }
@@ -290,8 +332,40 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                     sk_mma2<MB, NB>(ra[dd], rb_[dd], acc);
                 }
         };
+        auto run_bf16 = [&]() {
+            auto fetch = [&](int g, f32x4 (&a)[MB][2], f32x4 (&b)[NB]) {
+                const float* A = sA[0];
+                const float* B = sB[0];
+                int lda = slda[0], ldb = sldb[0], beg = 0;
+#pragma unroll
+                for (int s = 0; s < SK_MAXSEG - 1; ++s) {
+                    const bool nx = g >= cend[s];
+                    A = nx ? sA[s + 1] : A; B = nx ? sB[s + 1] : B;
+                    lda = nx ? slda[s + 1] : lda; ldb = nx ? sldb[s + 1] : ldb; beg = nx ? cend[s] : beg;
+                }
+                sk_fetch_bf16<MB, NB>(A, lda, B, ldb, (g - beg) << 5, mrow, btile, a, b);
+            };
+            f32x4 ra[SK_DEPTH][MB][2], rb_[SK_DEPTH][NB];
+#pragma unroll
+            for (int dd = 0; dd < SK_DEPTH; ++dd) fetch(min(first + dd * STR, last), ra[dd], rb_[dd]);
+            int g = first;
+            const int ngroups = mine / SK_DEPTH;
+            for (int gr = 0; gr < ngroups; ++gr) {
+#pragma unroll
+                for (int dd = 0; dd < SK_DEPTH; ++dd) {
+                    sk_mma_bf16<MB, NB>(ra[dd], rb_[dd], acc);
+                    fetch(min(g + (SK_DEPTH + dd) * STR, last), ra[dd], rb_[dd]);
+                }
+                g += SK_DEPTH * STR;
+            }
+            const int rem = mine - ngroups * SK_DEPTH;
+#pragma unroll
+            for (int dd = 0; dd < SK_DEPTH - 1; ++dd)
+                if (dd < rem) sk_mma_bf16<MB, NB>(ra[dd], rb_[dd], acc);
+        };
         if (mine > 0) {
-            if (job.seg[0].b_kcontig == 2) run(std::integral_constant<int, 2>{});
+            if (job.seg[0].b_kcontig == 3) run_bf16();
+            else if (job.seg[0].b_kcontig == 2) run(std::integral_constant<int, 2>{});
             else if (job.seg[0].b_kcontig == 1) run(std::integral_constant<int, 1>{});
             else run(std::integral_constant<int, 0>{});
         }
@@ -457,7 +531,8 @@ void sk_finalize_job(SkJob& j) {
         const SkSeg& g = j.seg[s];
         if (((uintptr_t)g.A & 15) || (g.lda & 3) || (g.K & 15)) al = 0;
         if (g.b_kcontig && (((uintptr_t)g.B & 15) || (g.ldb & 3))) al = 0;
-        if (g.b_kcontig == 2 && (j.N & 15)) al = 0;
+        if (g.b_kcontig >= 2 && (j.N & 15)) al = 0;
+        if (g.b_kcontig == 3 && (g.K & 31)) al = 0;
         if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
@@ -472,7 +547,7 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
         sk_finalize_job(L.job[q]);
         const SkJob& j = L.job[q];
         if (j.nseg < 1 || j.nseg > SK_MAXSEG || j.M < 1 || j.N < 1) return PH_ERR_BADARG;
-        if (j.seg[0].b_kcontig == 2 && !j.aligned) return PH_ERR_BADARG;  // tiled weights: fast path only
+        if (j.seg[0].b_kcontig >= 2 && !j.aligned) return PH_ERR_BADARG;  // tiled weights: fast path only
         int tiles;
         if (j.epi == SK_EPI_LSTM) {
             if (j.N != 4 * j.H || (j.H & 3)) return PH_ERR_BADARG;
@@ -519,7 +594,48 @@ __global__ __launch_bounds__(256) void sk_tile_weights_kernel(const float* __res
         *reinterpret_cast<f32x4*>(out + it * 4) = v;
     }
 }
+// bf16 variant: block (column tile ct, 32-deep chunk c) holds, per lane (kk = lane >> 4, i = lane & 15), the 8
+// values k = 32c + 8kk .. +7 of column col(ct, i) (mode 0) / of W[16ct + i][k] (mode 1), rounded to nearest even;
+// 512 bf16 = 1 KB per block, blocks ordered [ct][c].
+__global__ __launch_bounds__(256) void sk_tile_weights_bf16_kernel(const float* __restrict__ W, int rows, int cols, int ld,
+                                                                   bf16x8* __restrict__ out, int mode, int lstm_H) {
+    const int nct = mode == 0 ? cols >> 4 : rows >> 4;
+    const int nch = mode == 0 ? rows >> 5 : cols >> 5;
+    const size_t total = (size_t)nct * nch * 64;
+    for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+        const int lane = (int)(it & 63);
+        const size_t blk = it >> 6;
+        const int c = (int)(blk % nch), ct = (int)(blk / nch);
+        const int i = lane & 15, kk = lane >> 4;
+        f32x4 lo, hi;
+        if (mode == 0) {
+            const int col = lstm_H > 0 ? (i >> 2) * lstm_H + ct * 4 + (i & 3) : ct * 16 + i;
+            const float* p = W + (size_t)(c * 32 + kk * 8) * ld + col;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { lo[u] = p[(size_t)u * ld]; hi[u] = p[(size_t)(u + 4) * ld]; }
+        } else {
+            const float* p = W + (size_t)(ct * 16 + i) * ld + c * 32 + kk * 8;
+            lo = *reinterpret_cast<const f32x4*>(p);
+            hi = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+        out[it] = ph_bf16x8(lo, hi);
+    }
+}
 }  // namespace
+
+int sk_tile_weights_bf16_launch(const float* W, int rows, int cols, int ld, void* out, int mode, int lstm_H,
+                                hipStream_t stream) {
+    const int K = mode == 0 ? rows : cols, N = mode == 0 ? cols : rows;
+    if (!W || !out || K < 32 || N < 16 || (K & 31) || (N & 15) || (ld & 3) || ((uintptr_t)W & 15) ||
+        ((uintptr_t)out & 15) || (lstm_H > 0 && (mode != 0 || cols != 4 * lstm_H)))
+        return PH_ERR_BADARG;
+    const size_t items = (size_t)rows * cols / 8;
+    int blocks = (int)((items + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sk_tile_weights_bf16_kernel, dim3(blocks), dim3(256), 0, stream, W, rows, cols, ld,
+                       reinterpret_cast<bf16x8*>(out), mode, lstm_H);
+    return (int)hipGetLastError();
+}
 
 int sk_tile_weights_launch(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H,
                            hipStream_t stream) {
@@ -547,6 +663,7 @@ void sk_account(const SkLaunch& L, double& flops, double& bytes) {
         const SkJob& j = L.job[q];
         double ksum = 0.0;
         for (int s = 0; s < j.nseg; ++s) ksum += j.seg[s].K;
+        const double wb = j.seg[0].b_kcontig == 3 ? 2.0 : 4.0;  // bytes per weight element
         flops += 2.0 * j.M * ksum * j.N;
         double epi = 1.0;  // values moved per output element by the epilogue
         switch (j.epi) {
@@ -556,7 +673,7 @@ void sk_account(const SkLaunch& L, double& flops, double& bytes) {
             case SK_EPI_LSTM: epi = 2.0; break;
             default: epi = 1.0 + (j.accumulate ? 1.0 : 0.0) + (j.add ? 1.0 : 0.0); break;
         }
-        bytes += 4.0 * (ksum * j.N + (double)j.M * ksum + epi * j.M * j.N);
+        bytes += wb * ksum * j.N + 4.0 * ((double)j.M * ksum + epi * j.M * j.N);
     }
 }
 }  // namespace

@@ -114,7 +114,7 @@ class Parrot(Brick):
             raw_output=False,
             # --- extensions (not in the reference) ---
             num_layers=3, encoder_literal=True, use_graph=True, seed=1234,
-            cell_type='gru', lstm_forget_bias=3.0,
+            cell_type='gru', lstm_forget_bias=3.0, compute_dtype='float32',
             **kwargs):
         kwargs.setdefault('name', 'parrot')
         kwargs.setdefault('weights_init', IsotropicGaussian(0.01))  # train.py:30
@@ -125,6 +125,11 @@ class Parrot(Brick):
         assert encoder_type in (None, 'bidirectional')  # model.py:209
         assert 1 <= num_layers <= _lib.MAX_LAYERS
         assert cell_type in ('gru', 'lstm')
+        assert compute_dtype in ('float32', 'bf16', 'bfloat16')
+        # bf16 (BASELINE configs[3]): bf16 MFMA operands (weights AND activations rounded where they enter a GEMM of
+        # the decoder: scan steps, batched projections, readouts, deferred weight gradients), f32 accumulation, f32
+        # master weights / states / gradients / optimiser.  Encoder, attention window and cost stay f32.
+        self.compute_bf16 = compute_dtype != 'float32'
         self.input_dim, self.output_dim = input_dim, output_dim
         self.rnn_h_dim, self.readouts_dim = rnn_h_dim, readouts_dim
         self.layer_norm, self.which_cost, self.use_speaker = layer_norm, which_cost, use_speaker
@@ -513,6 +518,7 @@ class Parrot(Brick):
         d = _lib.DecoderDesc()
         d.cell = 1 if lstm else 0
         d.layer_norm = 1 if ln else 0
+        d.bf16 = 1 if self.compute_bf16 else 0
         if ln:
             for key, wd, suf, mat, rec in self._groups:
                 for (l, j), t_ in ws['ln_y' + key].items():
@@ -565,12 +571,17 @@ class Parrot(Brick):
         index_add_, but summed in a fixed order (no float atomics), so gradients are reproducible bit for bit."""
         onehot = torch.zeros(idx.numel(), grad.shape[0], device=grad.device, dtype=torch.float32)
         onehot.scatter_(1, idx.reshape(-1, 1), 1.0)
-        ops.gemm(onehot.t(), src.contiguous(), out=grad, accumulate=True)
+        with ops.gemm_precision(ops.PRECISION_F32):  # a gather-sum, not a product: keep the addends exact
+            ops.gemm(onehot.t(), src.contiguous(), out=grad, accumulate=True)
 
     def _tiled_weights(self, refresh=False):
         """Fragment-major copies of the packed layer matrices for the scan kernels (parrot_tile_weights);
         None when the widths are not multiples of 16.  refresh=True re-derives them from the current weights."""
         H, E = self.rnn_h_dim, self.encoded_input_dim
+        bf = self.compute_bf16
+        if bf and (H % 32 or E % 32 or self.layer_norm):
+            raise ValueError("compute_dtype='bf16' needs rnn_h_dim and the encoder width to be multiples of 32 "
+                             "and layer_norm=False")
         if H % 16 or E % 16:
             return None
         if getattr(self, '_tiled', None) is None:
@@ -579,7 +590,8 @@ class Parrot(Brick):
             for l in range(self.num_layers):
                 for key, wd, suf, mat, rec in self._groups:
                     for which in ('f', 'r'):
-                        self._tiled[(l, key, which)] = torch.empty_like(st[f'{mat}{l + 1}'])
+                        self._tiled[(l, key, which)] = torch.empty_like(
+                            st[f'{mat}{l + 1}'], dtype=torch.bfloat16 if bf else torch.float32)
             refresh = True
         if refresh:
             st = self.store.storage
@@ -587,9 +599,10 @@ class Parrot(Brick):
                 for key, wd, suf, mat, rec in self._groups:
                     W = st[f'{mat}{l + 1}']
                     lstm_h = H if self.cell_type == 'lstm' else 0
-                    _lib.call('parrot_tile_weights', W.data_ptr(), W.shape[0], W.shape[1], W.shape[1],
+                    fn = 'parrot_tile_weights_bf16' if bf else 'parrot_tile_weights'
+                    _lib.call(fn, W.data_ptr(), W.shape[0], W.shape[1], W.shape[1],
                               self._tiled[(l, key, 'f')].data_ptr(), 0, lstm_h, ops._stream())
-                    _lib.call('parrot_tile_weights', W.data_ptr(), W.shape[0], W.shape[1], W.shape[1],
+                    _lib.call(fn, W.data_ptr(), W.shape[0], W.shape[1], W.shape[1],
                               self._tiled[(l, key, 'r')].data_ptr(), 1, 0, ops._stream())
         return self._tiled
 
@@ -612,8 +625,17 @@ class Parrot(Brick):
                     b.add_(self._p(f'/out_to_h{l}/fork_rnn{l}_{suf}.b'))
 
     # ------------------------------------------------------------------ compute_cost
-    def compute_cost(self, features, features_mask, labels, labels_mask, speaker, start_flag,
-                     batch_size, raw_audio=None, feedback_noise=None):
+    def compute_cost(self, *args, **kwargs):
+        """Parrot.compute_cost (model.py:551-824); see _compute_cost.  Runs under the model's operand precision."""
+        with ops.gemm_precision(ops.PRECISION_BF16 if self.compute_bf16 else ops.PRECISION_F32):
+            return self._compute_cost(*args, **kwargs)
+
+    def _backward(self, token, gscale):
+        with ops.gemm_precision(ops.PRECISION_BF16 if self.compute_bf16 else ops.PRECISION_F32):
+            return self._backward_f(token, gscale)
+
+    def _compute_cost(self, features, features_mask, labels, labels_mask, speaker, start_flag,
+                      batch_size, raw_audio=None, feedback_noise=None):
         """Parrot.compute_cost (model.py:551-824).
 
         features [T+1,B,O], features_mask [T+1,B] (time-major), labels [B,U] int, labels_mask [B,U],
@@ -786,7 +808,7 @@ class Parrot(Brick):
         return cost, updates, attention_vars, (cost_raw.detach() if cost_raw is not None else None)
 
     # ------------------------------------------------------------------ backward
-    def _backward(self, token, gscale):
+    def _backward_f(self, token, gscale):
         if self._saved is None or self._saved[0] != token:
             raise RuntimeError("backward() must follow the compute_cost() call that produced this cost "
                                "(workspaces are reused between calls)")

@@ -76,6 +76,26 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate=False
     return out
 
 
+PRECISION_F32, PRECISION_BF16 = 0, 1
+
+
+class gemm_precision:
+    """``with gemm_precision(PRECISION_BF16):`` -- operand precision of the batched path of ``gemm`` /
+    ``gemm_batched`` inside the block (parrot_set_gemm_precision); the previous mode is restored on exit."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = int(_lib.load().parrot_get_gemm_precision())
+        _lib.call("parrot_set_gemm_precision", self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.call("parrot_set_gemm_precision", self.prev)
+        return False
+
+
 def gemm_batched(a, b, out, transA=False, transB=False, accumulate=False):
     """a: [nb, M, K] (or [nb, K, M] if transA), b: [nb, K, N] (or [nb, N, K]); contiguous batches."""
     _chk(a, "a"); _chk(b, "b"); _chk(out, "out")

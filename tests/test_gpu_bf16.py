@@ -1,0 +1,156 @@
+"""bf16 operand mode (BASELINE configs[3]: "3-layer LSTM h=1536 + attention, bf16"): weights and activations are rounded to
+bf16 (nearest even) where they enter a matrix-core product, accumulation / states / gradients / master weights stay f32.
+
+Two kinds of checks:
+  * exact-arithmetic checks of the pieces against a torch emulation that rounds the same operands (tight tolerance:
+    only the f32 accumulation order differs) -- the bf16 fragment-major weight copy bit for bit, the batched GEMM in all
+    four operand layouts;
+  * the whole training step (cost, frames, every gradient) against the fp64 oracle with the tolerance a bf16 mantissa
+    (8 bits, 2^-9 relative rounding per operand) allows: 5e-3 on the cost, 2e-2 on frames / window state, 5e-2 norm-wise
+    per gradient.  The f32 path meets 1e-4 / 1e-3 on the same cases (test_gpu_fullshape.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, make_batch, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("rows,cols,mode,lstm_h", [(64, 48, 0, 0), (48, 64, 1, 0), (32, 32, 0, 8), (96, 128, 0, 32),
+                                                    (160, 96, 1, 0)])
+def test_tile_weights_bf16_layout(dev, rows, cols, mode, lstm_h):
+    from parrot_amd import _lib, ops
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    W = torch.randn(rows, cols, generator=g).to(dev)
+    out = torch.zeros(rows * cols, dtype=torch.bfloat16, device=dev)
+    _lib.call('parrot_tile_weights_bf16', W.data_ptr(), rows, cols, cols, out.data_ptr(), mode, lstm_h, ops._stream())
+    torch.cuda.synchronize()
+    Wb = W.to(torch.bfloat16).cpu()
+    got = out.cpu().view(-1, 64, 8)  # [block][lane][u]
+    K, N = (rows, cols) if mode == 0 else (cols, rows)
+    nch = K // 32
+    exp = torch.empty_like(got)
+    for ct in range(N // 16):
+        for c in range(nch):
+            for lane in range(64):
+                i, kk = lane & 15, lane >> 4
+                ks = torch.arange(8) + 32 * c + 8 * kk
+                if mode == 0:
+                    col = (i >> 2) * lstm_h + ct * 4 + (i & 3) if lstm_h else ct * 16 + i
+                    exp[ct * nch + c, lane] = Wb[ks, col]
+                else:
+                    exp[ct * nch + c, lane] = Wb[ct * 16 + i, ks]
+    assert torch.equal(got.view(torch.int16), exp.view(torch.int16))
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 100), (129, 257, 1000), (640, 384, 63), (96, 3072, 4096)])
+def test_gemm_bf16_matches_rounded_operands(dev, ta, tb, M, N, K):
+    from parrot_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + ta * 2 + tb)
+    a = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
+    b = torch.randn((N, K) if tb else (K, N), generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    av, bv = (a.t() if ta else a), (b.t() if tb else b)
+    ref = _bf(av.cpu()) @ _bf(bv.cpu()) + bias.cpu().double()
+    exact = av.cpu().double() @ bv.cpu().double() + bias.cpu().double()
+    with ops.gemm_precision(ops.PRECISION_BF16):
+        out = ops.gemm(av, bv, bias=bias)
+        acc = ops.gemm(av, bv, out=out.clone(), accumulate=True)
+        relu = ops.gemm(av, bv, bias=bias, act=ops.ACT_RELU, split_k=1)
+    assert ops._lib.load().parrot_get_gemm_precision() == 0  # restored
+    assert_close(out, ref, 2e-5, "bf16 gemm vs rounded-operand product")
+    assert_close(acc, 2 * ref - bias.cpu().double(), 2e-5, "accumulate")
+    assert_close(relu, ref.clamp_min(0), 2e-5, "relu epilogue")
+    assert rel_err(out, exact) > 1e-4, "operands were not rounded: the bf16 path did not run"
+    f32 = ops.gemm(av, bv, bias=bias)
+    assert_close(f32, exact, 1e-5, "f32 mode after the block")
+
+
+def test_gemm_batched_bf16(dev):
+    from parrot_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(3, 150, 70, generator=g).to(dev)
+    b = torch.randn(3, 70, 130, generator=g).to(dev)
+    out = torch.empty(3, 150, 130, device=dev)
+    with ops.gemm_precision(ops.PRECISION_BF16):
+        ops.gemm_batched(a, b, out)
+    assert_close(out, _bf(a.cpu()) @ _bf(b.cpu()), 2e-5, "batched")
+
+
+def _bf16_check(dev, kw, T, B, U, seed, kappa_bias=None):
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=seed, scale_by_fan_in=True)
+    if kappa_bias is not None:
+        p['/parrot/h1_to_att/fork_kappa.b'].fill_(kappa_bias)
+    feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=seed + 1, ragged=True, speaker=cfg['use_speaker'])
+    res = {}
+    for dt in ('bf16', 'float32'):
+        m = Parrot(device=dev, compute_dtype=dt, **kw).allocate()
+        m.set_parameter_values(p)
+        for rep in range(2):
+            m.zero_grad()
+            cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev),
+                                            None if spk is None else spk.to(dev), 1, B)
+            cost.backward()
+        res[dt] = (float(cost), [x.detach().cpu().double() for x in av[:3]],
+                   {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()})
+        m.close()
+    for v in p.values():
+        v.requires_grad_()
+    rc, _, rav, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, spk, 1)
+    rc.backward()
+    cost, av, grads = res['bf16']
+    assert abs(cost - float(rc)) <= 5e-3 * abs(float(rc)), (cost, float(rc))
+    assert_close(av[0], rav[0], 2e-2, "predicted frames")
+    assert_close(av[1], rav[1], 2e-2, "kappa")
+    assert_close(av[2], rav[2], 2e-2, "w")
+    worst, differs, n = 0.0, 0, 0
+    for name, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+            continue
+        e = rel_err(grads[name], ref.grad)
+        assert e <= 5e-2, f"grad {name}: rel err {e:.3e}"
+        worst = max(worst, e)
+        differs += rel_err(grads[name], res['float32'][2][name]) > 1e-5
+        n += 1
+    assert n >= 10
+    assert differs >= n // 2, "bf16 and f32 gradients coincide: the bf16 path did not run"
+    return worst
+
+
+@pytest.mark.parametrize("cell,L,H", [("gru", 2, 64), ("lstm", 3, 96), ("gru", 1, 32), ("lstm", 1, 64)])
+def test_compute_cost_bf16_small(dev, cell, L, H):
+    kw = dict(num_layers=L, rnn_h_dim=H, readouts_dim=H, encoder_type='bidirectional', encoder_dim=32, cell_type=cell,
+              weak_feedback=True)
+    _bf16_check(dev, kw, T=7, B=5, U=11, seed=31 + L)
+
+
+def test_compute_cost_bf16_cfg4_width(dev):
+    """BASELINE configs[3] widths: 3 x LSTM-1536, B = 64 per GPU (the <2,2> / <2,1> bf16 kernels, merged launches)."""
+    kw = dict(num_layers=3, rnn_h_dim=1536, readouts_dim=1536, encoder_type='bidirectional', cell_type='lstm')
+    _bf16_check(dev, kw, T=4, B=64, U=60, seed=77, kappa_bias=-1.5)
+
+
+def test_compute_cost_bf16_cfg2_width(dev):
+    kw = dict(num_layers=2, rnn_h_dim=1024, readouts_dim=1024, encoder_type='bidirectional', cell_type='gru')
+    _bf16_check(dev, kw, T=5, B=64, U=100, seed=78, kappa_bias=-1.5)
+
+
+def test_bf16_rejects_unsupported_shapes(dev):
+    from parrot_amd.model import Parrot
+    m = Parrot(device=dev, compute_dtype='bf16', num_layers=1, rnn_h_dim=48, readouts_dim=48,
+               encoder_type='bidirectional', encoder_dim=32).allocate()
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(4, 2, 63, generator=g).to(dev)
+    with pytest.raises(ValueError):
+        m.compute_cost(feat, torch.ones(4, 2, device=dev), torch.zeros(2, 5, dtype=torch.long, device=dev),
+                       torch.ones(2, 5, device=dev), None, 1, 2)
+    m.close()
