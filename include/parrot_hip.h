@@ -440,10 +440,24 @@ typedef struct SampleRnnGenDesc {
     float* big_hs[5]; float* big_cs[5];
     float* frm_hs[5]; float* frm_cs[5];
     float* gate_ws; float* layer_tmp;
+    /* Optional workspace of the persistent-thread sample kernel (parrot_amd/csrc/sr_persist.hip): at least
+     * samplernn_persist_floats(desc) floats, ZERO-FILLED by the caller once.  With it (B <= 32, D in {256, 512, 1024},
+     * Q = 256, a 256-CU device) the FS sample steps between two frame-tier steps run as ONE launch: each XCD takes four
+     * streams through the whole sample-level MLP with its weights held in LDS / registers and hand-offs that stay inside
+     * the XCD's L2.  NULL or a non-qualifying configuration: five launches per sample as before. */
+    float* persist_ws;
+    long long persist_ws_floats;
 } SampleRnnGenDesc;
 
+/* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify. */
+long long samplernn_persist_floats(const SampleRnnGenDesc* desc);
 int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan);
 int samplernn_generate_run(void* plan, void* stream);
+/* 1 when the plan's sample steps run on the persistent-thread kernel. */
+int samplernn_generate_is_persistent(void* plan);
+/* Waits for the device and returns 0, or a non-zero fault code when a persistent sample kernel gave up (a team of
+ * workgroups was incomplete or timed out): the samples of that run are invalid.  Always 0 on the launch path. */
+int samplernn_generate_status(void* plan);
 int samplernn_generate_destroy(void* plan);
 
 #ifdef __cplusplus

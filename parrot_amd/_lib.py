@@ -122,7 +122,8 @@ class SampleRnnGenDesc(C.Structure):
                  ("big_L", (C.c_void_p * 4) * 5), ("frm_L", (C.c_void_p * 4) * 5),
                  ("big_hs", C.c_void_p * 5), ("big_cs", C.c_void_p * 5),
                  ("frm_hs", C.c_void_p * 5), ("frm_cs", C.c_void_p * 5),
-                 ("gate_ws", C.c_void_p), ("layer_tmp", C.c_void_p)])
+                 ("gate_ws", C.c_void_p), ("layer_tmp", C.c_void_p),
+                 ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong)])
 
 
 # name -> (restype, argtypes); every symbol include/parrot_hip.h declares must be listed here
@@ -170,6 +171,9 @@ SIGNATURES = {
     "parrot_mu2linear": (_i, [_vp, _sz, _vp, _vp]),
     "samplernn_generate_create": (_i, [C.POINTER(SampleRnnGenDesc), C.POINTER(C.c_void_p)]),
     "samplernn_generate_run": (_i, [_vp, _vp]),
+    "samplernn_persist_floats": (C.c_longlong, [C.POINTER(SampleRnnGenDesc)]),
+    "samplernn_generate_is_persistent": (_i, [_vp]),
+    "samplernn_generate_status": (_i, [_vp]),
     "samplernn_generate_destroy": (_i, [_vp]),
 }
 

@@ -15,6 +15,7 @@
 
 #include "../../include/parrot_hip.h"
 #include "skinny.h"
+#include "sr_persist.h"
 
 namespace {
 
@@ -114,6 +115,7 @@ __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
 
 struct SrPlan {
     SampleRnnGenDesc d;
+    bool persist = false;  // sample steps on the persistent-thread kernel (sr_persist.hip)
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr;
     int last_error = 0;
@@ -229,6 +231,17 @@ struct SrPlan {
             const float* ftop = nullptr;
             SR_TRY(stack_step(false, d.gru_in, &ftop, st));
             SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st));
+            if (persist) {
+                // ---- all FS sample steps of this frame in one launch: XCD-local persistent-thread kernel
+                SrpArgs sa{};
+                sa.tbase = d.tbase; sa.toff = toff; sa.samples = d.samples; sa.len = len;
+                sa.B = B; sa.D = D; sa.Q = d.Q; sa.FS = FS; sa.nsteps = FS;
+                sa.emb_tbl = d.emb_tbl; sa.frame_out = d.frame_out; sa.ldf = FS * D;
+                sa.W2 = d.W2; sa.b2 = d.b2; sa.W3 = d.W3; sa.b3 = d.b3; sa.W4 = d.W4; sa.b4 = d.b4;
+                sa.logits = d.logits; sa.ws = d.persist_ws; sa.temperature = d.temperature; sa.seed = d.seed;
+                SR_TRY(srp_launch(sa, st));
+                continue;
+            }
             for (int i = 0; i < FS; ++i) {
                 // ---- sample-level MLP (three_tier.py:452-515) + pick (ops.py:268-297)
                 const int to = toff + i;
@@ -299,8 +312,28 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_EN
     SrPlan* p = new (std::nothrow) SrPlan();
     if (!p) return PARROT_ERR_BADARG;
     p->d = *desc;
+    p->persist = desc->persist_ws && srp_eligible(desc->B, desc->D, desc->Q, desc->FS) &&
+                 desc->persist_ws_floats >= srp_ws_floats(desc->D, desc->Q) && srp_prepare(desc->D) == 0;
     *plan = p;
     return 0;
+}
+
+long long samplernn_persist_floats(const SampleRnnGenDesc* desc) { PH_ENTRY();
+    if (!desc || !srp_eligible(desc->B, desc->D, desc->Q, desc->FS)) return 0;
+    return srp_ws_floats(desc->D, desc->Q);
+}
+
+int samplernn_generate_is_persistent(void* plan) { PH_ENTRY();
+    return plan && static_cast<SrPlan*>(plan)->persist ? 1 : 0;
+}
+
+int samplernn_generate_status(void* plan) { PH_ENTRY();
+    SrPlan* p = static_cast<SrPlan*>(plan);
+    if (!p) return PARROT_ERR_BADARG;
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return (int)e;
+    if (p->last_error) return p->last_error;
+    return p->persist ? srp_status(p->d.persist_ws) : 0;
 }
 
 int samplernn_generate_run(void* plan, void* stream) { PH_ENTRY();

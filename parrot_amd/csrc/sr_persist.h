@@ -1,0 +1,25 @@
+// Persistent-thread sample-level kernel of the SampleRNN generation loop (three_tier.py:452-515, 809-832): all
+// FRAME_SIZE sample steps between two frame-tier steps in ONE launch.  See sr_persist.hip.
+#pragma once
+#include "common.h"
+
+struct SrpArgs {
+    const int* tbase; int toff;        // first sample index of this launch: tbase[0] + toff
+    int* samples; int len;             // [B][len] sample history (read: the FS samples before t0; written: t0 .. t0+nsteps-1)
+    int B, D, Q, FS, nsteps;
+    const float* emb_tbl;              // [FS][Q][D]  (Embedding folded with L1_PrevSamples)
+    const float* frame_out; int ldf;   // [B][ldf]; step i adds columns [i*D, (i+1)*D)
+    const float* W2; const float* b2; const float* W3; const float* b3;   // [D][D], [D]
+    const float* W4; const float* b4;                                      // [D][Q], [Q]
+    float* logits;                     // [B][Q]: logits of the launch's last step (or null)
+    float* ws;                         // srp_ws_floats() floats, zero-filled once by the caller
+    float temperature; int pad;
+    unsigned long long seed;
+};
+
+bool srp_eligible(int B, int D, int Q, int FS);
+long long srp_ws_floats(int D, int Q);
+int srp_prepare(int D);  // once per process and width, outside stream capture (raises the kernel's LDS limit)
+int srp_launch(const SrpArgs& a, hipStream_t stream);
+// 0 when no launch on this workspace has timed out / mis-teamed so far
+int srp_status(const float* ws);

@@ -265,9 +265,15 @@ class DeviceGenerator:
             self.ws['gate_ws'] = torch.zeros(batch, 4 * D, **f)
             self.ws['layer_tmp'] = torch.zeros(batch, D, **f)
             d.gate_ws, d.layer_tmp = self.ws['gate_ws'].data_ptr(), self.ws['layer_tmp'].data_ptr()
+        # persistent-thread sample kernel (sr_persist.hip): zero-filled exchange / barrier workspace when the shape qualifies
+        n = int(_lib.load().samplernn_persist_floats(C.byref(d)))
+        if n > 0:
+            self.ws['persist_ws'] = torch.zeros(n, **f)
+            d.persist_ws, d.persist_ws_floats = self.ws['persist_ws'].data_ptr(), n
         self.desc = d
         self.plan = C.c_void_p()
         _lib.call('samplernn_generate_create', C.byref(d), C.byref(self.plan))
+        self.persistent = bool(_lib.load().samplernn_generate_is_persistent(self.plan))
 
     def generate(self, features):
         """features [T, B, 63] time-major (what generate_and_save_samples receives) -> samples [B, 80*T] int32."""
@@ -287,6 +293,8 @@ class DeviceGenerator:
                     if RNN_TYPE == 'LSTM':
                         self.states[(tag, 'c', k)].copy_(h0[k, DIM:].unsqueeze(0).expand(self.B, -1))
         _lib.call('samplernn_generate_run', self.plan, hip._stream())
+        if self.persistent:  # a team of the persistent kernel that gave up leaves invalid samples: fail loudly
+            _lib.call('samplernn_generate_status', self.plan)
         return ws['samples']
 
     def close(self):
