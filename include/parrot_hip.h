@@ -405,7 +405,8 @@ int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream);
  * temperature = 0 -> argmax (softmax_and_argmax, ops.py:296-297; lowest index on ties);
  * temperature > 0 -> multinomial draw from a seeded counter-based generator (not Theano's MRG stream).
  * samples: [B, BFS*T] int32, first BFS entries = Q/2 set by the caller; big_h / frm_h hold the
- * initial states (learned h0) on entry and the final states on return.
+ * initial states (learned h0) on entry and the final states on return.  The weight buffers must not change during a
+ * plan's life: create makes fragment-major copies of the tiers' matrices for the step kernel (single-GRU tiers).
  * ------------------------------------------------------------------------------------------ */
 typedef struct SampleRnnGenDesc {
     int B, D, T, Q, FS, BFS, feat_dim, use_graph;
@@ -441,7 +442,7 @@ typedef struct SampleRnnGenDesc {
     float* frm_hs[5]; float* frm_cs[5];
     float* gate_ws; float* layer_tmp;
     /* Optional workspace of the persistent-thread sample kernel (parrot_amd/csrc/sr_persist.hip): at least
-     * samplernn_persist_floats(desc) floats, ZERO-FILLED by the caller once.  With it (B <= 32, D in {256, 512, 1024},
+     * samplernn_persist_floats(desc) floats (create initialises it; it belongs to ONE plan).  With it (B <= 32, D in {256, 512, 1024},
      * Q = 256, a 256-CU device) the FS sample steps between two frame-tier steps run as ONE launch: each XCD takes four
      * streams through the whole sample-level MLP with its weights held in LDS / registers and hand-offs that stay inside
      * the XCD's L2.  NULL or a non-qualifying configuration: five launches per sample as before. */

@@ -12,6 +12,7 @@
 // sample-level Embedding (ops.py:252-266) is folded with SampleLevel.L1_PrevSamples into a
 // [FS, Q, D] table, which turns the K = FS*EMB GEMM into a 10-row gather-sum.
 #include <new>
+#include <stdlib.h>
 
 #include "../../include/parrot_hip.h"
 #include "skinny.h"
@@ -103,6 +104,24 @@ __global__ __launch_bounds__(256) void sr_pick_kernel(const float* __restrict__ 
     }
 }
 
+// Frame-tier input (three_tier.py:398-411): out[b][d] = bias[d] + add[b][d] + sum_i xf(b, i) * Win[i][d] with
+// xf = (sample / (Q/2) - 1) * 2 of the FS samples before t: the K = FS product is ten FMAs per output, taken
+// straight from the integer samples.
+__global__ __launch_bounds__(256) void sr_frame_in_kernel(const int* __restrict__ samples, int len, const int* __restrict__ tbase,
+                                                          int toff, int FS, float half_q, const float* __restrict__ Win,
+                                                          const float* __restrict__ bias, const float* __restrict__ add,
+                                                          int ld_add, float* __restrict__ out, int D) {
+    const int t = tbase[0] + toff;
+    const int b = blockIdx.y, dd = blockIdx.x * 256 + threadIdx.x;
+    if (dd >= D) return;
+    float acc = 0.f;
+    for (int i = 0; i < FS; ++i) {
+        const float xf = ((float)samples[(size_t)b * len + t - FS + i] / half_q - 1.0f) * 2.0f;
+        acc = fmaf(xf, Win[(size_t)i * D + dd], acc);
+    }
+    out[(size_t)b * D + dd] = acc + bias[dd] + add[(size_t)b * ld_add + dd];
+}
+
 __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
     if (threadIdx.x == 0 && blockIdx.x == 0) tbase[0] = set ? inc : tbase[0] + inc;
 }
@@ -116,21 +135,64 @@ __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
 struct SrPlan {
     SampleRnnGenDesc d;
     bool persist = false;  // sample steps on the persistent-thread kernel (sr_persist.hip)
+    // Fragment-major copies (sk_tile_weights, mode 0) of the single-GRU tiers' matrices, owned by the plan and made once
+    // at create time: the step kernel then reads its weights as contiguous 1 KB wave loads instead of 64-byte row pieces.
+    struct Tiled { float* U = nullptr; float* Wg = nullptr; float* Wc = nullptr; float* Wout = nullptr; };
+    Tiled t_big, t_frm;
+    float* tiled_slab = nullptr;
+    float* t2 = nullptr;  // [Q, D] = emb_tbl[FS-1] . W2 (persistent sample kernel)
+    int make_t2() {
+        if (hipMalloc(&t2, (size_t)d.Q * d.D * sizeof(float)) != hipSuccess) { t2 = nullptr; return 1; }
+        int rc = parrot_gemm(d.emb_tbl + (size_t)(d.FS - 1) * d.Q * d.D, d.D, 0, d.W2, d.D, 0, t2, d.D, d.Q, d.D, d.D, nullptr, 1.f,
+                             0, 0, 1, 0, 0, 0, 1, nullptr);
+        if (rc == 0) rc = (int)hipDeviceSynchronize();
+        return rc;
+    }
+    int make_tiled() {
+        const size_t D = d.D, nfr = d.BFS / d.FS;
+        if (d.n_rnn != 0 || (d.D & 15)) return 0;
+        {
+            const char* e = getenv("PARROT_SR_TILED");
+            if (e && atoi(e) == 0) return 0;
+        }
+        const size_t per = 3 * D * D + 2 * D * D + D * D;
+        const size_t total = 2 * per + D * nfr * D + D * d.FS * D;
+        if (hipMalloc(&tiled_slab, total * sizeof(float)) != hipSuccess) { tiled_slab = nullptr; return 0; }
+        float* p = tiled_slab;
+        auto tile = [&](const float* W, int rows, int cols, float*& dst) -> int {
+            dst = p;
+            p += (size_t)rows * cols;
+            return sk_tile_weights_launch(W, rows, cols, cols, dst, 0, 0, nullptr);
+        };
+        int rc = 0;
+        rc |= tile(d.big_U, d.D, 3 * d.D, t_big.U); rc |= tile(d.big_Wg, d.D, 2 * d.D, t_big.Wg);
+        rc |= tile(d.big_Wc, d.D, d.D, t_big.Wc); rc |= tile(d.big_Wout, d.D, (int)nfr * d.D, t_big.Wout);
+        rc |= tile(d.frm_U, d.D, 3 * d.D, t_frm.U); rc |= tile(d.frm_Wg, d.D, 2 * d.D, t_frm.Wg);
+        rc |= tile(d.frm_Wc, d.D, d.D, t_frm.Wc); rc |= tile(d.frm_Wout, d.D, d.FS * d.D, t_frm.Wout);
+        if (rc != 0 || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(tiled_slab);
+            tiled_slab = nullptr;
+            t_big = Tiled(); t_frm = Tiled();
+        }
+        return 0;
+    }
     hipGraphExec_t exec = nullptr;
     hipStream_t cap = nullptr;
     int last_error = 0;
     ~SrPlan() {
         if (exec) hipGraphExecDestroy(exec);
         if (cap) hipStreamDestroy(cap);
+        if (tiled_slab) (void)hipFree(tiled_slab);
+        if (t2) (void)hipFree(t2);
     }
 
     int linear(const float* A, int lda, const float* W, int ldw, int K, int N, const float* bias, const float* add,
                int ld_add, float* out, int ldo, int act, hipStream_t st, const float* A2 = nullptr, int lda2 = 0,
-               const float* W2 = nullptr, int K2 = 0) {
+               const float* W2 = nullptr, int K2 = 0, const float* Wt = nullptr) {
         SkJob j;
         sk_job_init(j);
         j.nseg = 1;
-        j.seg[0] = sk_seg(A, lda, W, ldw, K, 0);
+        j.seg[0] = Wt ? sk_seg(A, lda, Wt, (K >> 4) * 256, K, 2) : sk_seg(A, lda, W, ldw, K, 0);
         if (A2) { j.seg[1] = sk_seg(A2, lda2, W2, ldw, K2, 0); j.nseg = 2; }
         j.M = d.B; j.N = N; j.H = N; j.epi = SK_EPI_LINEAR; j.act = act;
         j.bias = bias; j.add = add; j.ld_add = ld_add;
@@ -140,26 +202,31 @@ struct SrPlan {
         return sk_launch(L, st);
     }
 
-    // GRU step of a tier (ops.py:356-393): P = x.U + b; gates = sigm(h.Wg + P[:, :2D]); cand; in-place h.
-    int gru(const float* x, const float* U, const float* bU, const float* Wg, const float* Wc, float* h, hipStream_t st) {
+    // GRU step of a tier (ops.py:356-393): gates = sigm(h.Wg + x.U[:, :2D] + b[:2D]); cand = tanh((r*h).Wc + x.U[:, 2D:] +
+    // b[2D:]); in-place h.  The Input linear rides in the step GEMMs as a second K segment: two launches, not three.
+    int gru(const float* x, const float* U, const float* bU, const float* Wg, const float* Wc, float* h, hipStream_t st,
+            const Tiled* t = nullptr) {
         const int D = d.D;
-        SR_TRY(linear(x, D, U, 3 * D, D, 3 * D, bU, nullptr, 0, d.P, 3 * D, 0, st));
+        const int blk = (D >> 4) * 256;  // floats per column tile of a [D, *] fragment-major copy
+        const bool tl = t && t->U;
         SkJob j;
         SkLaunch L;
         sk_job_init(j);
-        j.nseg = 1;
-        j.seg[0] = sk_seg(h, D, Wg, 2 * D, D, 0);
+        j.nseg = 2;
+        j.seg[0] = tl ? sk_seg(h, D, t->Wg, blk, D, 2) : sk_seg(h, D, Wg, 2 * D, D, 0);
+        j.seg[1] = tl ? sk_seg(x, D, t->U, blk, D, 2) : sk_seg(x, D, U, 3 * D, D, 0);
         j.M = d.B; j.N = 2 * D; j.H = D; j.epi = SK_EPI_GRU_GATES;
-        j.add = d.P; j.ld_add = 3 * D;
+        j.bias = bU;
         j.e0 = h; j.lde0 = D;
         j.o1 = d.z; j.ldo1 = D; j.o2 = d.r; j.ldo2 = D; j.out = d.rh; j.ldo = D;
         SR_TRY(sk_make_launch(L, &j, 1));
         SR_TRY(sk_launch(L, st));
         sk_job_init(j);
-        j.nseg = 1;
-        j.seg[0] = sk_seg(d.rh, D, Wc, D, D, 0);
+        j.nseg = 2;
+        j.seg[0] = tl ? sk_seg(d.rh, D, t->Wc, blk, D, 2) : sk_seg(d.rh, D, Wc, D, D, 0);
+        j.seg[1] = tl ? sk_seg(x, D, t->U + (size_t)(2 * D >> 4) * blk, blk, D, 2) : sk_seg(x, D, U + 2 * D, 3 * D, D, 0);
         j.M = d.B; j.N = D; j.H = D; j.epi = SK_EPI_GRU_CAND;
-        j.add = d.P + 2 * D; j.ld_add = 3 * D;
+        j.bias = bU + 2 * D;
         j.e0 = h; j.lde0 = D; j.e1 = d.z; j.lde1 = D;
         j.o1 = nullptr; j.out = h; j.ldo = D;
         SR_TRY(sk_make_launch(L, &j, 1));
@@ -190,8 +257,8 @@ struct SrPlan {
     // One step of a tier's RNN stack on input x [B,D]; returns the top layer's output (state) pointer.
     int stack_step(bool big, const float* x, const float** top, hipStream_t st) {
         if (d.n_rnn == 0) {  // single GRU layer, original fields
-            if (big) SR_TRY(gru(x, d.big_U, d.big_bU, d.big_Wg, d.big_Wc, d.big_h, st));
-            else SR_TRY(gru(x, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st));
+            if (big) SR_TRY(gru(x, d.big_U, d.big_bU, d.big_Wg, d.big_Wc, d.big_h, st, &t_big));
+            else SR_TRY(gru(x, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st, &t_frm));
             *top = big ? d.big_h : d.frm_h;
             return 0;
         }
@@ -219,26 +286,30 @@ struct SrPlan {
                           d.feat_cur, d.feat_dim, d.big_Win_feats, d.feat_dim));
             const float* top = nullptr;
             SR_TRY(stack_step(true, d.gru_in, &top, st));
-            SR_TRY(linear(top, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st));
+            SR_TRY(linear(top, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st,
+                          nullptr, 0, nullptr, 0, t_big.Wout));
         }
         for (int f = 0; f < nfr; ++f) {
             // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
             const int toff = f * FS;
-            hipLaunchKernelGGL(sr_prep_kernel, dim3(ceil_div(B * FS, 256)), dim3(256), 0, st, d.samples, len, d.tbase, toff,
-                               FS, half_q, d.xf_frm, B, (const float*)nullptr, (float*)nullptr, 0, BFS);
-            SR_TRY(linear(d.xf_frm, FS, d.frm_Win, D, FS, D, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D, 0,
-                          st));
+            hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(D, 256), B), dim3(256), 0, st, d.samples, len, d.tbase, toff,
+                               FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
             const float* ftop = nullptr;
             SR_TRY(stack_step(false, d.gru_in, &ftop, st));
-            SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st));
+            SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st,
+                          nullptr, 0, nullptr, 0, t_frm.Wout));
             if (persist) {
                 // ---- all FS sample steps of this frame in one launch: XCD-local persistent-thread kernel
                 SrpArgs sa{};
                 sa.tbase = d.tbase; sa.toff = toff; sa.samples = d.samples; sa.len = len;
                 sa.B = B; sa.D = D; sa.Q = d.Q; sa.FS = FS; sa.nsteps = FS;
-                sa.emb_tbl = d.emb_tbl; sa.frame_out = d.frame_out; sa.ldf = FS * D;
+                sa.emb_tbl = d.emb_tbl; sa.t2 = t2; sa.frame_out = d.frame_out; sa.ldf = FS * D;
                 sa.W2 = d.W2; sa.b2 = d.b2; sa.W3 = d.W3; sa.b3 = d.b3; sa.W4 = d.W4; sa.b4 = d.b4;
                 sa.logits = d.logits; sa.ws = d.persist_ws; sa.temperature = d.temperature; sa.seed = d.seed;
+                {
+                    static const int timing = getenv("PARROT_SR_TIMING") ? atoi(getenv("PARROT_SR_TIMING")) : 0;
+                    sa.pad = timing;
+                }
                 SR_TRY(srp_launch(sa, st));
                 continue;
             }
@@ -312,8 +383,10 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_EN
     SrPlan* p = new (std::nothrow) SrPlan();
     if (!p) return PARROT_ERR_BADARG;
     p->d = *desc;
+    p->make_tiled();
     p->persist = desc->persist_ws && srp_eligible(desc->B, desc->D, desc->Q, desc->FS) &&
-                 desc->persist_ws_floats >= srp_ws_floats(desc->D, desc->Q) && srp_prepare(desc->D) == 0;
+                 desc->persist_ws_floats >= srp_ws_floats(desc->D, desc->Q) && srp_prepare(desc->D) == 0 &&
+                 srp_init_ws(desc->persist_ws, desc->D, desc->Q) == 0 && p->make_t2() == 0;
     *plan = p;
     return 0;
 }

@@ -8,17 +8,19 @@ struct SrpArgs {
     int* samples; int len;             // [B][len] sample history (read: the FS samples before t0; written: t0 .. t0+nsteps-1)
     int B, D, Q, FS, nsteps;
     const float* emb_tbl;              // [FS][Q][D]  (Embedding folded with L1_PrevSamples)
+    const float* t2;                   // [Q][D] = emb_tbl[FS-1] . W2: the newest sample's share of the L2 pre-activation
     const float* frame_out; int ldf;   // [B][ldf]; step i adds columns [i*D, (i+1)*D)
     const float* W2; const float* b2; const float* W3; const float* b3;   // [D][D], [D]
     const float* W4; const float* b4;                                      // [D][Q], [Q]
     float* logits;                     // [B][Q]: logits of the launch's last step (or null)
-    float* ws;                         // srp_ws_floats() floats, zero-filled once by the caller
+    float* ws;                         // srp_ws_floats() floats, prepared once by srp_init_ws
     float temperature; int pad;
     unsigned long long seed;
 };
 
 bool srp_eligible(int B, int D, int Q, int FS);
 long long srp_ws_floats(int D, int Q);
+int srp_init_ws(float* ws, int D, int Q);  // once per plan: sync words zero, hand-off slots EMPTY
 int srp_prepare(int D);  // once per process and width, outside stream capture (raises the kernel's LDS limit)
 int srp_launch(const SrpArgs& a, hipStream_t stream);
 // 0 when no launch on this workspace has timed out / mis-teamed so far

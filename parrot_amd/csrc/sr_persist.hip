@@ -9,10 +9,11 @@
 //   * every CU owns D/32 output columns of L2 / L3 and Q/32 of the output layer and keeps those weight slices on chip
 //     for the whole launch -- L2's in LDS (128 KB at D = 1024), L3's and the output layer's in VGPRs (64 + 16 per
 //     thread): no weight traffic per sample;
-//   * a hand-off = 16-byte stores of the CU's [4 streams x columns] slice (write-through into the XCD's L2), one
-//     L2-executed atomic per workgroup on the team counter, polling with the same kind of atomic, then sc1 loads (TCP
-//     miss, L2 hit) of the team's 16 KB activation vector: 1.66 us measured (tools/xcd_probe.hip; the agent-scope
-//     fence protocol costs 45 us, buffer_inv 15 us);
+//   * a hand-off = 16-byte stores of the CU's [4 streams x columns] slice (write-through into the XCD's L2) and sc1
+//     loads (TCP miss, L2 hit) on the consumer side that re-read a slot until it is no longer EMPTY (a NaN payload):
+//     one store-to-load latency per link.  The counted variant (store, s_waitcnt, L2 atomic, poll, load) measured
+//     1.66 us in isolation (tools/xcd_probe.hip; agent-scope fences: 45 us, buffer_inv: 15 us) and 4 us per link inside
+//     this kernel, of which 2.4 us were the four serialised L2 round trips;
 //   * the 4 streams of a team ride in the 4 lanes of an f32x4, the products run on the vector ALUs (a 4-row tile wastes
 //     3/4 of an MFMA; v_pk_fma_f32 has the same f32 peak as the matrix pipe);
 //   * the pick (argmax with lowest-index ties, or the seeded inverse-CDF draw) is recomputed by every CU of the team from
@@ -54,32 +55,50 @@ __device__ __forceinline__ f32x4 srp_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
 }
 
+// Hand-off slots are 16 bytes = one value for each of the team's 4 streams.  An empty slot holds a NaN with a payload
+// arithmetic never produces; a 16-byte store replaces it atomically in the L2, so a consumer simply re-reads a slot
+// until it is full: no store acknowledgement, arrival counter or flag poll sits between producer and consumer.
+constexpr unsigned SRP_EMPTY = 0x7FC0DEADu;
+__device__ __forceinline__ f32x4 srp_empty() {
+    const float e = __uint_as_float(SRP_EMPTY);
+    return (f32x4){e, e, e, e};
+}
+__device__ __forceinline__ bool srp_is_empty(const f32x4& v) {
+    return __float_as_uint(v[0]) == SRP_EMPTY || __float_as_uint(v[3]) == SRP_EMPTY;
+}
+
+// 100 MHz wall clock (timing aid, PARROT_SR_TIMING=1: workgroup 0 of team 0 stamps the phase boundaries of every step
+// into sync words 600..)
+__device__ __forceinline__ unsigned long long srp_clock() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 struct SrpShared {
     int rank, ok, gen;
     int hist[SRP_ROWS][SRP_MAXHIST];
     float mx[SRP_ROWS];
 };
 
-// Team barrier.  All threads have issued their payload stores; target = arrivals expected on the team counter.
-__device__ __forceinline__ void srp_barrier(unsigned* arrive, unsigned target, unsigned* abort_, SrpShared* sh) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        srp_l2_add(arrive, 1u);
-        unsigned spins = 0;
-        while ((int)(srp_l2_add(arrive, 0u) - target) < 0) {
-            if ((++spins & 1023u) == 0u) {
-                if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh->ok = 0; break; }
-                if (spins > (1u << 22)) {  // ~ 1 s
-                    __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(abort_ + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh->ok = 0;
-                    break;
-                }
+// Load a hand-off slot, re-reading until it is full (bounded: ~1 s, then the abort word is raised).
+__device__ __forceinline__ f32x4 srp_take(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned* abort_, SrpShared* sh) {
+    f32x4 v = srp_ld(r, byte_off);
+    unsigned n = 0;
+    while (srp_is_empty(v)) {
+        if ((++n & 1023u) == 0u) {
+            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh->ok = 0; break; }
+            if (n > (1u << 21)) {
+                __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(abort_ + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->ok = 0;
+                break;
             }
         }
+        __builtin_amdgcn_s_sleep(1);
+        v = srp_ld(r, byte_off);
     }
-    __syncthreads();
+    return v;
 }
 
 // f32x4 += the same vector of the lane selected by a DPP control (all four components)
@@ -153,7 +172,6 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     unsigned* sync = reinterpret_cast<unsigned*>(a.ws);
     unsigned* abort_ = sync + 512;
     const int team = srp_xcc();
-    unsigned* arrive = sync + team * 32;
     if (tid == 0) {
         const unsigned old = srp_l2_add(sync + 256 + team * 32, 1u);
         sh->rank = (int)(old % SRP_TEAM);
@@ -162,8 +180,6 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     }
     __syncthreads();
     const int cu = sh->rank;
-    const unsigned bar_base = (unsigned)sh->gen * (unsigned)(4 * a.nsteps) * SRP_TEAM;
-    unsigned nbar = 0;
 
     // ---- weight slices: L2 -> LDS, L3 and Output -> registers
     const int g = (tid >> 3) % G, s = 8 * (tid / (8 * G)) + (tid & 7);
@@ -190,70 +206,115 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         const int b = min(team * SRP_ROWS + r, a.B - 1);
         sh->hist[r][pos] = a.samples[(size_t)b * a.len + t0 - a.FS + pos];
     }
-    // team exchange buffers: x0 (gather output), x1, x2 ([D] f32x4 each), logits ([Q] f32x4)
-    float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * (3 * D + Q) * 4;
+    // team exchange buffers ([D] f32x4 each, 4 streams per vector): xb[2] (embedding base of the even / odd steps), x1, x2,
+    // and the logits ([Q] f32x4)
+    float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * (4 * D + Q) * 4;
     const __amdgpu_buffer_rsrc_t xr = srp_rsrc(xbase);
-    f32x4* x0 = reinterpret_cast<f32x4*>(xbase);
-    f32x4* x1 = x0 + D;
+    f32x4* xb = reinterpret_cast<f32x4*>(xbase);
+    f32x4* x1 = xb + 2 * D;
     f32x4* x2 = x1 + D;
     f32x4* lb = x2 + D;
     __syncthreads();
 
-    for (int i = 0; i < a.nsteps; ++i) {
-        // ---- gather phase: o1 = frame_out[:, i] + sum_pos tbl[pos][sample[t - FS + pos]]   (this CU's DC columns)
+    // Slot life cycle.  All slots are EMPTY when a plan is created (srp_init_ws) and every launch leaves them EMPTY again,
+    // except the logits of its last step, which their new owners empty right here (nobody looks at the logits before
+    // having taken a complete x2, and the emptying threads publish part of x1 -- after s_waitcnt vmcnt(0) -- before that).
+    // During the launch a buffer is emptied by its owner as soon as the owner has taken the NEXT buffer of the chain from
+    // all 32 CUs (which proves that all of them are done with this one), always by threads that later publish, behind an
+    // s_waitcnt vmcnt(0), something the readers take before they look at the emptied buffer again.  No counted barrier.
+    if (tid < QC) lb[fin_q] = srp_empty();
+
+    // base_i = frame_out[:, i] + sum_{pos < FS-1} tbl[pos][sample[t - FS + pos]] for this CU's DC columns: everything of
+    // step i's embedding sum that is known one step early (the newest sample's row is added when it is known)
+    auto publish_base = [&](int i) {
         if (tid < SRP_ROWS * DC) {
             const int r = tid / DC, c = tid % DC, col = cu * DC + c;
             const int b = min(team * SRP_ROWS + r, a.B - 1);
             float acc = a.frame_out[(size_t)b * a.ldf + (size_t)i * D + col];
-            for (int pos = 0; pos < a.FS; ++pos) {
+            for (int pos = 0; pos < a.FS - 1; ++pos) {
                 const int q = sh->hist[r][i + pos];
                 acc += a.emb_tbl[((size_t)pos * Q + q) * D + col];
             }
             tmp[c * SRP_ROWS + r] = acc;
         }
         __syncthreads();
-        if (tid < DC) x0[cu * DC + tid] = reinterpret_cast<const f32x4*>(tmp)[tid];
-        srp_barrier(arrive, bar_base + (++nbar) * SRP_TEAM, abort_, sh);
-        if (!sh->ok) return;
+        if (tid < DC) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            xb[(i & 1) * D + fin_h] = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC];
+        }
+    };
+    publish_base(0);
 
-        // ---- L2, L3 (relu), Output
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sync + 600);
+    const bool timing = a.pad && team == 0 && cu == 0 && tid == 0;
+    auto stamp = [&](int i, int q) { if (timing && i < 10) stamps[i * 8 + q] = srp_clock(); };
+    for (int i = 0; i < a.nsteps; ++i) {
+        const bool more = i + 1 < a.nsteps;
+        stamp(i, 0);
+        // ---- L2 on base_i; the newest sample's share of the pre-activation, t2[sample] = (tbl[FS-1][sample]) . W2, is a
+        //      precomputed row whose gather (this CU's columns only) flies while the product runs: nothing between the
+        //      pick and the L2 product but the load of the base
         {
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_ld(xr, (unsigned)(k * 16));
+            float tq[SRP_ROWS] = {0.f, 0.f, 0.f, 0.f};
+            if (tid < DC) {
+#pragma unroll
+                for (int r = 0; r < SRP_ROWS; ++r) tq[r] = a.t2[(size_t)sh->hist[r][i + a.FS - 1] * D + fin_h];
+            }
+            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)(((i & 1) * D + k) * 16), abort_, sh);
             __syncthreads();
+            if (!sh->ok) return;
+            stamp(i, 1);
             f32x4 v;
             srp_layer<KP, G, true>(act, w3, w2l, red, v);
             if (tid < DC) {
                 v += bias2;
+                v += (f32x4){tq[0], tq[1], tq[2], tq[3]};
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 x1[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
-            srp_barrier(arrive, bar_base + (++nbar) * SRP_TEAM, abort_, sh);
-            if (!sh->ok) return;
+            stamp(i, 2);
+            stamp(i, 3);
         }
         {
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_ld(xr, (unsigned)((D + k) * 16));
+            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((2 * D + k) * 16), abort_, sh);
             __syncthreads();
+            if (!sh->ok) return;
+            stamp(i, 4);
+            // x1(i) complete => every CU is done with base_i and with the logits of step i-1
+            if (tid < DC) xb[(i & 1) * D + fin_h] = srp_empty();
+            if (i > 0 && tid < QC) lb[fin_q] = srp_empty();
             f32x4 v;
             srp_layer<KP, G, false>(act, w3, nullptr, red, v);
             if (tid < DC) {
                 v += bias3;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 x2[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
-            srp_barrier(arrive, bar_base + (++nbar) * SRP_TEAM, abort_, sh);
-            if (!sh->ok) return;
+            if (more) publish_base(i + 1);  // needs nothing from the other workgroups: runs while their x2 slices arrive
         }
         {
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_ld(xr, (unsigned)((2 * D + k) * 16));
+            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((3 * D + k) * 16), abort_, sh);
             __syncthreads();
+            if (!sh->ok) return;
+            stamp(i, 5);
+            if (tid < QC) {  // x2(i) complete => every CU is done with x1(i); emptied by the threads that publish lb
+#pragma unroll
+                for (int q = 0; q < DC / QC; ++q) x1[cu * DC + tid * (DC / QC) + q] = srp_empty();
+            }
             f32x4 v;
             srp_layer<KQ, GQ, false>(act, w4, nullptr, red, v);
-            if (tid < QC) lb[fin_q] = v + bias4;
-            srp_barrier(arrive, bar_base + (++nbar) * SRP_TEAM, abort_, sh);
-            if (!sh->ok) return;
+            if (tid < QC) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lb[fin_q] = v + bias4;
+            }
         }
 
         // ---- pick (every CU of the team, identical result): argmax with lowest-index ties, or the seeded draw
-        if (tid < Q) lg[tid] = srp_ld(xr, (unsigned)((3 * D + tid) * 16));
+        if (tid < Q) lg[tid] = srp_take(xr, (unsigned)((4 * D + tid) * 16), abort_, sh);
         __syncthreads();
+        if (!sh->ok) return;
+        stamp(i, 6);
+        if (tid < DC) x2[fin_h] = srp_empty();  // logits(i) complete => every CU is done with x2(i)
         const int t = t0 + i;
         if (wave < SRP_ROWS) {
             const int r = wave;
@@ -306,6 +367,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
             }
         }
         __syncthreads();
+        stamp(i, 7);
     }
 }
 
@@ -330,7 +392,15 @@ bool srp_eligible(int B, int D, int Q, int FS) {
     return D == 256 || D == 512 || D == 1024;
 }
 
-long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * (3 * D + Q) * 4; }
+long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * (4 * D + Q) * 4; }
+
+int srp_init_ws(float* ws, int D, int Q) {
+    // barrier / census / abort words zero, every hand-off slot EMPTY
+    PH_CHECK(hipMemset(ws, 0, SRP_SYNC_WORDS * sizeof(float)));
+    PH_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ws + SRP_SYNC_WORDS), (int)SRP_EMPTY,
+                          (size_t)SRP_NTEAMS * (4 * D + Q) * 4));
+    return (int)hipDeviceSynchronize();
+}
 
 int srp_status(const float* ws) {
     unsigned w[2] = {0, 0};
