@@ -48,9 +48,9 @@ long long parrot_profile_end(double* total_us, double* flops, double* bytes);
  * Dense projections (Blocks Linear / Fork applies, model.py:580-627, 739-755; lib.ops.Linear,
  * sampleRNN/lib/ops.py:32-128).  C[M,N] (+)= alpha * opA(A) * opB(B) + bias, f32 MFMA.
  *   transA = 0: A is [M,K] (lda), 1: A is stored [K,M] (lda)      (same for B / transB, [K,N])
- *   batched with element strides; split_k > 1 splits K over workgroups and combines the partial
- *   products with f32 atomics (C is cleared first unless accumulate); split_k = 0 picks a split
- *   automatically (long reductions with few output tiles, e.g. deferred weight gradients).
+ *   batched with element strides; split_k > 1 splits K over workgroups, the partial products are summed in
+ *   slice order by a second kernel (deterministic; inside a stream capture the product runs unsplit);
+ *   split_k = 0 picks a split automatically (long reductions with few output tiles, e.g. deferred weight gradients).
  * M <= 64 with transA = 0 dispatches to the weight-streaming recurrent-step kernel.
  * ------------------------------------------------------------------------------------------ */
 #define PARROT_PRECISION_F32 0

@@ -16,8 +16,8 @@ struct BgArgs {
     long long batchA, batchB, batchC;  // element strides between batch entries
     int nbatch;
     int splitk;      // >1: K is split over grid.y; the slices' partial tiles go to `ws` and are summed in slice
-                     // order by a second kernel (deterministic), or -- ws == null -- combined with f32 atomics
-    float* ws;       // [nbatch * splitk, M, N] partial sums or null
+                     // order by a second kernel (deterministic)
+    float* ws;       // [nbatch * splitk, M, N] partial sums (required when splitk > 1)
     int accumulate;  // C += result (C must hold valid data; with splitk>1 always accumulates)
     float alpha;
     int act;         // SkAct-compatible activation, only when splitk == 1

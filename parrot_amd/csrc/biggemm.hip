@@ -113,7 +113,6 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
     kchunk = (kchunk + BK - 1) / BK * BK;
     const int kbeg = ks * kchunk;
     const int kend = min(a.K, kbeg + kchunk);
-    if (kbeg >= kend && ks > 0 && !a.ws) return;  // (deterministic split-K: empty slices still write their zeros)
 
     const float* A = a.A + (long long)batch * a.batchA;
     const float* B = a.B + (long long)batch * a.batchB;
@@ -180,8 +179,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
                 float v = a.alpha * acc[i][j][q] + bias;
                 float* c = C + (long long)m * a.ldc + n;
                 if (a.splitk > 1) {
-                    if (a.ws) a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][j][q];  // bias added by the reducer
-                    else unsafeAtomicAdd(c, v);
+                    a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][j][q];  // bias added by the reducer
                 } else {
                     if (a.accumulate) v += *c;
                     if (a.act == 1) v = fmaxf(v, 0.f);
@@ -252,7 +250,6 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
     kchunk = (kchunk + BK - 1) / BK * BK;
     const int kbeg = ks * kchunk;
     const int kend = min(a.K, kbeg + kchunk);
-    if (kbeg >= kend && ks > 0 && !a.ws) return;  // (deterministic split-K: empty slices still write their zeros)
     const float* A = a.A + (long long)batch * a.batchA;
     const float* B = a.B + (long long)batch * a.batchB;
     float* C = a.C + (long long)batch * a.batchC;
@@ -307,8 +304,7 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
             float v = a.alpha * acc[i][q] + bias;
             float* c = C + (long long)m * a.ldc + n;
             if (a.splitk > 1) {
-                if (a.ws) a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][q];  // bias added by the reducer
-                else unsafeAtomicAdd(c, v);
+                a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][q];  // bias added by the reducer
             } else {
                 if (a.accumulate) v += *c;
                 if (a.act == 1) v = fmaxf(v, 0.f);
@@ -380,7 +376,6 @@ __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, 
     kchunk = (kchunk + BK16 - 1) / BK16 * BK16;
     const int kbeg = ks * kchunk;
     const int kend = min(a.K, kbeg + kchunk);
-    if (kbeg >= kend && ks > 0 && !a.ws) return;
     const float* A = a.A + (long long)batch * a.batchA;
     const float* B = a.B + (long long)batch * a.batchB;
     float* C = a.C + (long long)batch * a.batchC;
@@ -435,8 +430,7 @@ __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, 
             float v = a.alpha * acc[i][q] + bias;
             float* c = C + (long long)m * a.ldc + n;
             if (a.splitk > 1) {
-                if (a.ws) a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][q];  // bias added by the reducer
-                else unsafeAtomicAdd(c, v);
+                a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][q];  // bias added by the reducer
             } else {
                 if (a.accumulate) v += *c;
                 if (a.act == 1) v = fmaxf(v, 0.f);
@@ -476,7 +470,7 @@ int bg_reduce_launch(const BgArgs& a, hipStream_t stream) {
 }
 
 int bg_launch(const BgArgs& a, hipStream_t stream) {
-    if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch < 1 || a.splitk < 1) return PH_ERR_BADARG;
+    if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch < 1 || a.splitk < 1 || (a.splitk > 1 && !a.ws)) return PH_ERR_BADARG;
     const bool axc = (a.sam == 1), bxc = (a.sbn == 1);
     if (!axc && a.sak != 1) return PH_ERR_BADARG;
     if (!bxc && a.sbk != 1) return PH_ERR_BADARG;

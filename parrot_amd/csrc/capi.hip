@@ -89,47 +89,34 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     a.ws = nullptr;
     if (a.splitk > 1) {
         if (act != 0) return PARROT_ERR_BADARG;
-        // Deterministic split-K: the slices write partial tiles to a library-owned workspace and a second kernel
-        // adds them in slice order (results do not depend on scheduling; PARROT_GEMM_ATOMIC=1 restores the
-        // single-pass float-atomic combine).  The workspace grows on demand and is reused by later calls on the
-        // same stream order; calls are not captured into graphs (the scan plans use split_k = 1).
-        static int use_atomic = -1;
-        if (use_atomic < 0) {
-            const char* e = getenv("PARROT_GEMM_ATOMIC");
-            use_atomic = e ? atoi(e) : 0;
-        }
+        // Deterministic split-K: the slices write partial tiles to a library-owned workspace and a second kernel adds
+        // them in slice order (results do not depend on scheduling).  The workspace grows on demand and is reused by
+        // later calls in stream order.  Under stream capture (no allocation possible) or when the workspace cannot be
+        // had, the product runs unsplit instead: there is no float-atomic combine any more.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cs);
-        if (!use_atomic && cs == hipStreamCaptureStatusNone) {
-            static float* ws = nullptr;
-            static size_t ws_floats = 0;
-            const size_t need = (size_t)nbatch * a.splitk * M * N;
-            if (need > ws_floats) {
-                if (ws) {
-                    (void)hipDeviceSynchronize();
-                    (void)hipFree(ws);
-                    ws = nullptr;
-                    ws_floats = 0;
-                }
-                if (hipMalloc(&ws, need * sizeof(float)) == hipSuccess) ws_floats = need;
-                else ws = nullptr;
-            }
+        static float* ws = nullptr;
+        static size_t ws_floats = 0;
+        const size_t need = (size_t)nbatch * a.splitk * M * N;
+        if (cs == hipStreamCaptureStatusNone && need > ws_floats) {
             if (ws) {
-                a.ws = ws;
-                a.bias = nullptr;  // the reducer adds it
-                int rc = bg_launch(a, st);
-                if (rc) return rc;
-                a.bias = bias;
-                return bg_reduce_launch(a, st);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(ws);
+                ws = nullptr;
+                ws_floats = 0;
             }
+            if (hipMalloc(&ws, need * sizeof(float)) == hipSuccess) ws_floats = need;
+            else ws = nullptr;
         }
-        if (!accumulate) {  // atomics accumulate into C: clear it first
-            for (int b = 0; b < nbatch; ++b) {
-                hipError_t e = hipMemset2DAsync(C + (long long)b * strideC, sizeof(float) * (size_t)ldc, 0,
-                                                sizeof(float) * (size_t)N, (size_t)M, st);
-                if (e != hipSuccess) return (int)e;
-            }
+        if (ws && need <= ws_floats) {
+            a.ws = ws;
+            a.bias = nullptr;  // the reducer adds it
+            int rc = bg_launch(a, st);
+            if (rc) return rc;
+            a.bias = bias;
+            return bg_reduce_launch(a, st);
         }
+        a.splitk = 1;
     }
     return bg_launch(a, st);
 }

@@ -702,6 +702,244 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
     return n;
 }
 
+// ---- wide bf16 step kernel ("wk") ----------------------------------------------------------------------------
+// For the big bf16 launches (3 x LSTM-1536: 132 MB of weights per tick) sk_kernel's 32 x 32 tiles are bound by the
+// CU's L1 bandwidth: every tile re-reads its [32, K] f32 activation slab, 793 MB of L2 -> CU traffic per tick at 43 %
+// of the aggregate L1 peak.  Here a workgroup owns ALL (<= 64) rows of NC = 64 or 128 columns, the eight waves split N
+// (and, for NC = 64, the two row halves) instead of K, and the activation stage ([64, 64] f32 -> bf16) goes through
+// LDS once per workgroup: 342 MB per tick, no split-K reduction at all (every wave ends with complete sums and runs
+// its part of the fused epilogue).  Weights: one 1 KB fragment-major block per wave and 32-deep chunk, straight
+// into registers.  One __syncthreads per 64-deep stage, two LDS stage buffers, register rings for both operands.
+#ifndef WK_PA_DEPTH
+#define WK_PA_DEPTH 4
+#endif
+#ifndef WK_PB_DEPTH
+#define WK_PB_DEPTH 4
+#endif
+// K per stage; LDS row pitch in bytes; ring depths in stages (2/3, 4/4 and 8/8 measured the same at cfg4)
+enum { WK_STAGE = 64, WK_PITCH = 144, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH };
+
+struct WkLaunch {
+    SkJob job[SK_MAXJOB];
+    int njobs;
+    int wg_end[SK_MAXJOB];  // prefix of workgroups per job
+    int ncw[SK_MAXJOB];     // 16-column tiles per workgroup: 4 or 8
+};
+
+template <int NCW>
+__device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
+    constexpr int MB = NCW == 8 ? 4 : 2;  // row blocks per wave
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctl = NCW == 8 ? wave : (wave & 3), rh = NCW == 8 ? 0 : (wave >> 2);
+    const int M = job.M, N = job.N;
+    const int ntiles = job.epi == SK_EPI_LSTM ? (job.H >> 2) : ((N + 15) >> 4);
+    const int tile = min(wg * NCW + ctl, ntiles - 1);
+    const bool tile_ok = wg * NCW + ctl < ntiles;
+
+    // K stages over the concatenated segments.  The two operand streams run ahead of the MFMAs by different distances,
+    // so each has its own (wave-uniform) cursor into the segment list; past the end a cursor stays on the last stage.
+    int total = 0;
+    for (int q = 0; q < job.nseg; ++q) total += job.seg[q].K / WK_STAGE;
+    struct Cursor { const float* A; const float* B; int lda, ldb, left, seg, k; };
+    auto cursor_init = [&](Cursor& c) __attribute__((always_inline)) {
+        c.seg = 0; c.k = 0;
+        c.A = job.seg[0].A; c.B = job.seg[0].B; c.lda = job.seg[0].lda; c.ldb = job.seg[0].ldb;
+        c.left = job.seg[0].K / WK_STAGE;
+    };
+    auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
+        if (c.left > 1) { --c.left; c.k += WK_STAGE; return; }
+        if (c.seg + 1 < job.nseg) {
+            ++c.seg;
+            const SkSeg& sg = job.seg[c.seg];
+            c.A = sg.A; c.B = sg.B; c.lda = sg.lda; c.ldb = sg.ldb; c.left = sg.K / WK_STAGE; c.k = 0;
+        }
+    };
+
+    // staging role: rows r0 and r0 + 32, k = 4 * akq .. +3 of the stage: 16 lanes read one row's 256 contiguous bytes, a
+    // wave instruction 4 whole rows (8 full cache lines)
+    const int ar0 = min(tid >> 4, M - 1), ar1 = min((tid >> 4) + 32, M - 1), akq = tid & 15;
+    Cursor ca, cb;
+    cursor_init(ca);
+    cursor_init(cb);
+    auto loadA = [&](f32x4 (&a)[2]) __attribute__((always_inline)) {
+        a[0] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar0 * ca.lda + ca.k + 4 * akq);
+        a[1] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar1 * ca.lda + ca.k + 4 * akq);
+        cursor_next(ca);
+    };
+    auto loadB = [&](f32x4 (&b)[2]) __attribute__((always_inline)) {
+        const float* p = cb.B + (size_t)tile * cb.ldb + ((size_t)(cb.k >> 5) << 8) + (lane << 2);
+
+        // (non-temporal loads measured 51 us per launch instead of 35: at 64 columns the two row-half waves share a block)
+        b[0] = *reinterpret_cast<const f32x4*>(p);
+        b[1] = *reinterpret_cast<const f32x4*>(p + 256);
+        cursor_next(cb);
+    };
+
+    f32x4 acc[MB];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[WK_PA][2], rbv[WK_PB][2];
+#pragma unroll
+    for (int q = 0; q < WK_PA; ++q) loadA(ra[q]);
+#pragma unroll
+    for (int q = 0; q < WK_PB; ++q) loadB(rbv[q]);
+
+    const int kk = lane >> 4, i16 = lane & 15;
+    auto stage = [&](int st, f32x4 (&a)[2], f32x4 (&b)[2]) __attribute__((always_inline)) {
+        char* buf = smem + (st & 1) * (64 * WK_PITCH);
+        {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<bf16x4*>(buf + (tid >> 4) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[0], bf16x4);
+            *reinterpret_cast<bf16x4*>(buf + ((tid >> 4) + 32) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[1], bf16x4);
+        }
+        loadA(a);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(buf + (16 * (rh * MB + rb) + i16) * WK_PITCH + ks * 64 + 16 * kk);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rb], 0, 0, 0);
+            }
+        }
+        loadB(b);
+    };
+
+    // the rings are indexed with compile-time constants: unroll by WK_PB (a multiple of WK_PA)
+    static_assert(WK_PB % WK_PA == 0, "");
+    int st = 0;
+    for (; st + WK_PB <= total; st += WK_PB) {
+#pragma unroll
+        for (int q = 0; q < WK_PB; ++q) stage(st + q, ra[q % WK_PA], rbv[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < WK_PB - 1; ++q)
+        if (st + q < total) stage(st + q, ra[q % WK_PA], rbv[q]);
+    if (!tile_ok) return;
+
+    // fused epilogue, per wave (complete sums).  C layout: column = lane & 15, row = 4 * (lane >> 4) + reg.
+
+    const int g = lane >> 4, jj = lane & 15;
+    const int n = sk_col(job.epi, job.H, tile, jj);
+    const bool n_ok = n < N;
+    const float bias = (job.bias && n_ok) ? job.bias[n] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb) {
+        const int mb0 = 16 * (rh * MB + rb) + 4 * g;
+        if (job.epi == SK_EPI_LSTM) {
+            const int q = jj >> 2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb0 + r;
+                const bool ok = m < M && n_ok;
+                float pre = acc[rb][r] + bias;
+                if (job.add && ok) pre += job.add[(size_t)m * job.ld_add + n];
+                const float gate = (q == 3) ? tanhf(pre) : ph_sigmoid(pre);
+                if (job.o2 && ok) job.o2[(size_t)m * job.ldo2 + n] = gate;
+                const int src = lane & ~12;
+                const float gi = __shfl(gate, src | 0, 64);
+                const float gf = __shfl(gate, src | 4, 64);
+                const float go = __shfl(gate, src | 8, 64);
+                const float gg = __shfl(gate, src | 12, 64);
+                if (q == 0 && ok) {
+                    const float cp = job.e1[(size_t)m * job.lde1 + n];
+                    const float cn = cp * gf + gg * gi;
+                    job.o1[(size_t)m * job.ldo1 + n] = cn;
+                    job.out[(size_t)m * job.ldo + n] = tanhf(cn) * go;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb0 + r;
+                if (m >= M || !n_ok) continue;
+                float x = acc[rb][r] + bias;
+                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (job.act == SK_ACT_TANH) x = tanhf(x);
+                else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
+                float* o = job.out + (size_t)m * job.ldo + n;
+                if (job.accumulate) x += *o;
+                *o = x;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SK_THREADS) void wk_kernel(const WkLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) char wk_smem[];
+    int j = 0, bx = blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < SK_MAXJOB - 1; ++q)
+        if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
+    bx -= (j > 0 ? L.wg_end[j - 1] : 0);
+    const SkJob& job = L.job[j];
+    if (L.ncw[j] == 8) wk_body<8>(job, bx, wk_smem);
+    else wk_body<4>(job, bx, wk_smem);
+}
+
+// Takes the launch when every job is a bf16-operand LSTM / LINEAR job over <= 64 rows with 64-deep K segments.
+static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
+    const char* e = getenv("PARROT_WK");
+    const int enabled = e ? atoi(e) : 1;
+    if (!enabled) return false;
+    long long work = 0;
+    for (int q = 0; q < Lin.njobs; ++q) {
+        const SkJob& j = Lin.job[q];
+        if (j.seg[0].b_kcontig != 3 || !j.aligned || j.M > 64 || j.M < 1) return false;
+        if (j.epi != SK_EPI_LSTM && j.epi != SK_EPI_LINEAR) return false;
+        if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
+        for (int s = 0; s < j.nseg; ++s)
+            if (j.seg[s].K % WK_STAGE) return false;
+        work += (long long)j.N;
+    }
+    if (work < 4096 && enabled < 2) return false;
+    WkLaunch W;
+    memset(&W, 0, sizeof(W));
+    W.njobs = Lin.njobs;
+    int ksum[SK_MAXJOB], tiles[SK_MAXJOB];
+    int units = 0;
+    for (int q = 0; q < Lin.njobs; ++q) {
+        W.job[q] = Lin.job[q];
+        W.ncw[q] = 4;
+        ksum[q] = 0;
+        for (int s = 0; s < Lin.job[q].nseg; ++s) ksum[q] += Lin.job[q].seg[s].K;
+        tiles[q] = Lin.tile_end[q];
+        units += ceil_div(tiles[q], 4);
+    }
+
+    // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits
+    while (units > 256) {
+        int best = -1;
+        for (int q = 0; q < Lin.njobs; ++q)
+            if (W.ncw[q] == 4 && (best < 0 || ksum[q] < ksum[best])) best = q;
+        if (best < 0) break;
+        units -= ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8);
+        W.ncw[best] = 8;
+    }
+    int t = 0;
+    for (int q = 0; q < Lin.njobs; ++q) {
+        t += ceil_div(tiles[q], W.ncw[q]);
+        W.wg_end[q] = t;
+    }
+    const size_t lds = 2 * 64 * WK_PITCH;
+    if (g_prof.on) {
+        SkProfRec r;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        sk_account(Lin, r.flops, r.bytes);
+        hipExtLaunchKernelGGL(wk_kernel, dim3(t), dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, W);
+        g_prof.recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL(wk_kernel, dim3(t), dim3(SK_THREADS), lds, stream, W);
+    }
+    *rc = (int)hipGetLastError();
+    return true;
+}
+
+
 template <int MB, int NB>
 static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t stream) {
     if (g_prof.on) {
@@ -717,6 +955,10 @@ static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t st
 }
 
 int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
+    {
+        int rc = 0;
+        if (wk_try_launch(Lin, stream, &rc)) return rc;
+    }
     SkLaunch L = Lin;
     int maxM = 0, tiles = 0;
     bool nb2_ok = true;

@@ -154,3 +154,38 @@ def test_bf16_rejects_unsupported_shapes(dev):
         m.compute_cost(feat, torch.ones(4, 2, device=dev), torch.zeros(2, 5, dtype=torch.long, device=dev),
                        torch.ones(2, 5, device=dev), None, 1, 2)
     m.close()
+
+
+@pytest.mark.parametrize("B", [5, 37, 64])
+def test_wide_bf16_step_kernel_small(dev, B, monkeypatch):
+    """wk_kernel (all rows x 64/128 columns per workgroup, activation stage through LDS) forced onto small LSTM launches:
+    partial row blocks (B = 5, 37), several K segments, fwd (fused LSTM epilogue) and bwd (accumulating linear jobs)."""
+    monkeypatch.setenv("PARROT_WK", "2")
+    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=32, cell_type='lstm')
+    _bf16_check(dev, kw, T=5, B=B, U=9, seed=91 + B)
+
+
+def test_wide_and_tiled_bf16_kernels_agree(dev, monkeypatch):
+    """Same bf16 operands, different accumulation order: wk_kernel vs sk_kernel.  A 1e-7 difference in an f32 state can flip
+    the bf16 rounding of that element at the next step (4e-3 relative on it), so the two paths agree to bf16 noise, not to
+    f32 noise: 5e-3 norm-wise per gradient (the oracle tolerance of the mode is 5e-2), 1e-4 on the cost."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=2, rnn_h_dim=256, readouts_dim=256, encoder_type='bidirectional', encoder_dim=32, cell_type='lstm')
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=5, scale_by_fan_in=True)
+    feat, fm, lab, lm, spk = make_batch(cfg, 6, 48, 10, seed=6, ragged=True)
+    got = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("PARROT_WK", mode)
+        m = Parrot(device=dev, compute_dtype='bf16', **kw).allocate()
+        m.set_parameter_values(p)
+        m.zero_grad()
+        cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, 48)
+        cost.backward()
+        got[mode] = (float(cost), {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()})
+        m.close()
+    assert abs(got["0"][0] - got["2"][0]) <= 1e-4 * abs(got["0"][0])
+    for k, v in got["0"][1].items():
+        if float(v.abs().max()) > 1e-12:
+            assert rel_err(got["2"][1][k], v) < 5e-3, (k, rel_err(got["2"][1][k], v))
