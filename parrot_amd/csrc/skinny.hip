@@ -728,14 +728,10 @@ struct WkLaunch {
 
 template <int NCW>
 __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
-    // 128 columns: wave = column tile, all stages.  64 columns: wave = (column tile, K parity): the waves of parity kh
-    // consume the stages st = kh (mod 2) and the two partial sums meet in LDS at the end, so that every weight block is
-    // fetched by exactly one wave (with a row-half split both waves of a tile pulled the same block through the CU's
-    // address path, which is what bounds this kernel: ~45 GB/s per CU measured).
-    constexpr int MB = 4, KS = NCW == 8 ? 1 : 2;
+    constexpr int MB = NCW == 8 ? 4 : 2;  // row blocks per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ctl = NCW == 8 ? wave : (wave & 3), kh = NCW == 8 ? 0 : (wave >> 2);
+    const int ctl = NCW == 8 ? wave : (wave & 3), rh = NCW == 8 ? 0 : (wave >> 2);
     const int M = job.M, N = job.N;
     const int ntiles = job.epi == SK_EPI_LSTM ? (job.H >> 2) : ((N + 15) >> 4);
     const int tile = min(wg * NCW + ctl, ntiles - 1);
@@ -766,7 +762,6 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     Cursor ca, cb;
     cursor_init(ca);
     cursor_init(cb);
-    if (kh == 1) cursor_next(cb);
     auto loadA = [&](f32x4 (&a)[2]) __attribute__((always_inline)) {
         a[0] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar0 * ca.lda + ca.k + 4 * akq);
         a[1] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar1 * ca.lda + ca.k + 4 * akq);
@@ -775,10 +770,10 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     auto loadB = [&](f32x4 (&b)[2]) __attribute__((always_inline)) {
         const float* p = cb.B + (size_t)tile * cb.ldb + ((size_t)(cb.k >> 5) << 8) + (lane << 2);
 
+        // (non-temporal loads measured 51 us per launch instead of 35: at 64 columns the two row-half waves share a block)
         b[0] = *reinterpret_cast<const f32x4*>(p);
         b[1] = *reinterpret_cast<const f32x4*>(p + 256);
-#pragma unroll
-        for (int q = 0; q < KS; ++q) cursor_next(cb);
+        cursor_next(cb);
     };
 
     f32x4 acc[MB];
@@ -791,53 +786,51 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     for (int q = 0; q < WK_PB; ++q) loadB(rbv[q]);
 
     const int kk = lane >> 4, i16 = lane & 15;
-    auto stage = [&](int st, f32x4 (&a)[2], f32x4 (&b)[2], bool consume) __attribute__((always_inline)) {
+    // Stage st: the MFMA operands of stage st are read from the buffer the previous iteration filled, the NEXT stage is
+    // converted and written into the other buffer meanwhile, then the MFMAs run and one barrier closes the stage (it
+    // publishes stage st + 1 and retires the reads of stage st before that buffer is refilled).  With write -> barrier ->
+    // read -> MFMA in a row the LDS round trip and the barrier sat on every stage's critical path (measured: 875
+    // clocks per stage, independent of the prefetch depth; a variant that halved the waves working per stage doubled it).
+    auto fill = [&](int st, f32x4 (&a)[2]) __attribute__((always_inline)) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         char* buf = smem + (st & 1) * (64 * WK_PITCH);
-        {
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<bf16x4*>(buf + (tid >> 4) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[0], bf16x4);
-            *reinterpret_cast<bf16x4*>(buf + ((tid >> 4) + 32) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[1], bf16x4);
-        }
+        *reinterpret_cast<bf16x4*>(buf + (tid >> 4) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[0], bf16x4);
+        *reinterpret_cast<bf16x4*>(buf + ((tid >> 4) + 32) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[1], bf16x4);
         loadA(a);
-        __syncthreads();
-        if (consume) {
+    };
+    auto stage = [&](int st, f32x4 (&anext)[2], f32x4 (&b)[2]) __attribute__((always_inline)) {
+        const char* buf = smem + (st & 1) * (64 * WK_PITCH);
+        bf16x8 av[2][MB];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int rb = 0; rb < MB; ++rb) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(buf + (16 * rb + i16) * WK_PITCH + ks * 64 + 16 * kk);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rb], 0, 0, 0);
-                }
-            }
-            loadB(b);
+            for (int rb = 0; rb < MB; ++rb)
+                av[ks][rb] = *reinterpret_cast<const bf16x8*>(buf + (16 * (rh * MB + rb) + i16) * WK_PITCH + ks * 64 + 16 * kk);
+        if (st + 1 < total) fill(st + 1, anext);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
+#pragma unroll
+            for (int rb = 0; rb < MB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ks][rb], bv, acc[rb], 0, 0, 0);
         }
+        loadB(b);
+        __syncthreads();
     };
 
-    // the rings are indexed with compile-time constants: unroll by WK_PB * KS stages (a multiple of WK_PA); the launch
-    // starts at an even stage, so the parity of st + q is the parity of q
-    constexpr int UN = WK_PB * KS;
-    static_assert(UN % WK_PA == 0, "");
+    // the rings are indexed with compile-time constants: unroll by WK_PB (a multiple of WK_PA); stage st + 1 is filled
+    // from ring slot (st + 1) % WK_PA
+    static_assert(WK_PB % WK_PA == 0, "");
+    fill(0, ra[0]);
+    __syncthreads();
     int st = 0;
-    for (; st + UN <= total; st += UN) {
+    for (; st + WK_PB <= total; st += WK_PB) {
 #pragma unroll
-        for (int q = 0; q < UN; ++q) stage(st + q, ra[q % WK_PA], rbv[q / KS], KS == 1 || (q & 1) == kh);
+        for (int q = 0; q < WK_PB; ++q) stage(st + q, ra[(q + 1) % WK_PA], rbv[q]);
     }
 #pragma unroll
-    for (int q = 0; q < UN - 1; ++q)
-        if (st + q < total) stage(st + q, ra[q % WK_PA], rbv[q / KS], KS == 1 || (q & 1) == kh);
-    if (KS == 2) {  // the odd-stage waves hand their partial sums to the even-stage waves of the same column tile
-        __syncthreads();
-        f32x4* red = reinterpret_cast<f32x4*>(smem);
-        if (kh == 1) {
-#pragma unroll
-            for (int rb = 0; rb < MB; ++rb) red[(ctl * MB + rb) * 64 + lane] = acc[rb];
-        }
-        __syncthreads();
-        if (kh == 1) return;
-#pragma unroll
-        for (int rb = 0; rb < MB; ++rb) acc[rb] += red[(ctl * MB + rb) * 64 + lane];
-    }
+    for (int q = 0; q < WK_PB - 1; ++q)
+        if (st + q < total) stage(st + q, ra[(q + 1) % WK_PA], rbv[q]);
     if (!tile_ok) return;
 
     // fused epilogue, per wave (complete sums).  C layout: column = lane & 15, row = 4 * (lane >> 4) + reg.
@@ -848,7 +841,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     const float bias = (job.bias && n_ok) ? job.bias[n] : 0.f;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) {
-        const int mb0 = 16 * rb + 4 * g;
+        const int mb0 = 16 * (rh * MB + rb) + 4 * g;
         if (job.epi == SK_EPI_LSTM) {
             const int q = jj >> 2;
 #pragma unroll
@@ -945,7 +938,7 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
         t += ceil_div(tiles[q], W.ncw[q]);
         W.wg_end[q] = t;
     }
-    const size_t lds = 2 * 64 * WK_PITCH;  // two stage buffers (18 KB); the K-parity reduction reuses 16 KB of them
+    const size_t lds = 2 * 64 * WK_PITCH;
     if (g_prof.on) {
         SkProfRec r;
         (void)hipEventCreate(&r.e0);
