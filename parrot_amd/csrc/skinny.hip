@@ -717,7 +717,7 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
 #define WK_PB_DEPTH 4
 #endif
 // K per stage; LDS row pitch in bytes; ring depths in stages (2/3, 4/4 and 8/8 measured the same at cfg4)
-enum { WK_STAGE = 64, WK_PITCH = 144, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH, WK_MAXSTAGES = 256 };
+enum { WK_STAGE = 64, WK_PITCH = 144, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH };
 
 struct WkLaunch {
     SkJob job[SK_MAXJOB];
@@ -737,47 +737,43 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     const int tile = min(wg * NCW + ctl, ntiles - 1);
     const bool tile_ok = wg * NCW + ctl < ntiles;
 
-    // K stages over the concatenated segments.  Where stage s lives (segment base pointers advanced to its first K row,
-    // leading dimensions) is looked up in a small LDS table built once per workgroup: walking the segment list with
-    // scalar branches at every load made the kernel issue-bound (about 135 instructions per stage and wave around 4 MFMAs;
-    // halving either operand's bytes did not change its time, nor did the prefetch depth).
+    // K stages over the concatenated segments.  The two operand streams run ahead of the MFMAs by different distances,
+    // so each has its own (wave-uniform) cursor into the segment list; past the end a cursor stays on the last stage.
     int total = 0;
     for (int q = 0; q < job.nseg; ++q) total += job.seg[q].K / WK_STAGE;
-    struct StageEnt { const float* A; const float* B; int lda, ldb, pad0, pad1; };  // 32 bytes
-    StageEnt* tab = reinterpret_cast<StageEnt*>(smem + 2 * 64 * WK_PITCH);
-    if (tid < total) {
-        int acc_st = 0, sgi = 0, off = tid;
-        for (int q = 0; q < job.nseg; ++q) {
-            const int n = job.seg[q].K / WK_STAGE;
-            if (tid >= acc_st && tid < acc_st + n) { sgi = q; off = tid - acc_st; }
-            acc_st += n;
+    struct Cursor { const float* A; const float* B; int lda, ldb, left, seg, k; };
+    auto cursor_init = [&](Cursor& c) __attribute__((always_inline)) {
+        c.seg = 0; c.k = 0;
+        c.A = job.seg[0].A; c.B = job.seg[0].B; c.lda = job.seg[0].lda; c.ldb = job.seg[0].ldb;
+        c.left = job.seg[0].K / WK_STAGE;
+    };
+    auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
+        if (c.left > 1) { --c.left; c.k += WK_STAGE; return; }
+        if (c.seg + 1 < job.nseg) {
+            ++c.seg;
+            const SkSeg& sg = job.seg[c.seg];
+            c.A = sg.A; c.B = sg.B; c.lda = sg.lda; c.ldb = sg.ldb; c.left = sg.K / WK_STAGE; c.k = 0;
         }
-        const SkSeg sg = job.seg[sgi];
-        StageEnt e;
-        e.A = sg.A + (size_t)off * WK_STAGE;
-        e.B = sg.B + ((size_t)(off * 2) << 8);
-        e.lda = sg.lda; e.ldb = sg.ldb; e.pad0 = 0; e.pad1 = 0;
-        tab[tid] = e;
-    }
-    __syncthreads();
-    const int last = total - 1;
+    };
 
     // staging role: rows r0 and r0 + 32, k = 4 * akq .. +3 of the stage: 16 lanes read one row's 256 contiguous bytes, a
     // wave instruction 4 whole rows (8 full cache lines)
     const int ar0 = min(tid >> 4, M - 1), ar1 = min((tid >> 4) + 32, M - 1), akq = tid & 15;
-    int sa = 0, sb = 0;  // next stage each operand stream will request
+    Cursor ca, cb;
+    cursor_init(ca);
+    cursor_init(cb);
     auto loadA = [&](f32x4 (&a)[2]) __attribute__((always_inline)) {
-        const StageEnt e = tab[min(sa, last)];
-        ++sa;
-        a[0] = *reinterpret_cast<const f32x4*>(e.A + (size_t)ar0 * e.lda + 4 * akq);
-        a[1] = *reinterpret_cast<const f32x4*>(e.A + (size_t)ar1 * e.lda + 4 * akq);
+        a[0] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar0 * ca.lda + ca.k + 4 * akq);
+        a[1] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar1 * ca.lda + ca.k + 4 * akq);
+        cursor_next(ca);
     };
     auto loadB = [&](f32x4 (&b)[2]) __attribute__((always_inline)) {
-        const StageEnt e = tab[min(sb, last)];
-        ++sb;
-        const float* p = e.B + (size_t)tile * e.ldb + (lane << 2);
+        const float* p = cb.B + (size_t)tile * cb.ldb + ((size_t)(cb.k >> 5) << 8) + (lane << 2);
+
+        // (non-temporal loads measured 51 us per launch instead of 35: at 64 columns the two row-half waves share a block)
         b[0] = *reinterpret_cast<const f32x4*>(p);
         b[1] = *reinterpret_cast<const f32x4*>(p + 256);
+        cursor_next(cb);
     };
 
     f32x4 acc[MB];
@@ -909,12 +905,8 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
         if (j.seg[0].b_kcontig != 3 || !j.aligned || j.M > 64 || j.M < 1) return false;
         if (j.epi != SK_EPI_LSTM && j.epi != SK_EPI_LINEAR) return false;
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
-        int stages = 0;
-        for (int s = 0; s < j.nseg; ++s) {
+        for (int s = 0; s < j.nseg; ++s)
             if (j.seg[s].K % WK_STAGE) return false;
-            stages += j.seg[s].K / WK_STAGE;
-        }
-        if (stages > WK_MAXSTAGES) return false;
         work += (long long)j.N;
     }
     if (work < 4096 && enabled < 2) return false;
@@ -946,7 +938,7 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
         t += ceil_div(tiles[q], W.ncw[q]);
         W.wg_end[q] = t;
     }
-    const size_t lds = 2 * 64 * WK_PITCH + WK_MAXSTAGES * 32;  // two stage buffers + the stage table
+    const size_t lds = 2 * 64 * WK_PITCH;
     if (g_prof.on) {
         SkProfRec r;
         (void)hipEventCreate(&r.e0);
