@@ -3,7 +3,7 @@
 which any non-empty string is truthy.  Plotting / animation helpers (utils.py:30-170) are cosmetic
 and out of scope.
 
-Extra flags (not in the reference): --num_layers, --encoder_literal, --synthetic_examples, --max_steps,
+Extra flags (not in the reference): --num_layers, --cell_type, --compute_dtype, --encoder_literal, --synthetic_examples, --max_steps,
 --device, --use_graph.
 """
 from __future__ import annotations
@@ -21,6 +21,10 @@ def _results_dir():
 
 def _common_extras(parser):
     parser.add_argument('--num_layers', type=int, default=3, help='decoder GRU layers (reference: 3)')
+    parser.add_argument('--cell_type', type=str, default='gru', choices=('gru', 'lstm'),
+                        help="decoder layers: 'gru' (the reference's GatedRecurrent) or 'lstm' (BASELINE configs[3])")
+    parser.add_argument('--compute_dtype', type=str, default='float32', choices=('float32', 'bf16'),
+                        help='bf16: bf16 MFMA operands, f32 accumulation / states / master weights (DESIGN.md 3.7)')
     parser.add_argument('--encoder_literal', type=int, default=1,
                         help='1: scan the encoder over the batch axis like the reference does')
     parser.add_argument('--device', type=str, default='cuda')

@@ -55,7 +55,7 @@ def main(argv=None):
         attention_alignment=saved_args.attention_alignment, sampling_bias=args.sampling_bias,
         sharpening_coeff=args.sharpening_coeff, timing_coeff=args.timing_coeff,
         encoder_type=saved_args.encoder_type, raw_output=raw_output, name='parrot',
-        num_layers=getattr(saved_args, 'num_layers', 3),
+        num_layers=getattr(saved_args, 'num_layers', 3), cell_type=getattr(saved_args, 'cell_type', 'gru'),
         encoder_literal=bool(getattr(saved_args, 'encoder_literal', 1)), device=device)
     parrot.allocate()
     parrot.set_parameter_values(parameters)

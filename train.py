@@ -84,7 +84,7 @@ def main(argv=None):
         which_cost=args.which_cost, num_characters=args.num_characters, attention_type=args.attention_type,
         attention_alignment=args.attention_alignment, encoder_type=args.encoder_type,
         weights_init=IsotropicGaussian(0.01), biases_init=Constant(0.), raw_output=raw_output, name='parrot',
-        num_layers=args.num_layers, encoder_literal=bool(args.encoder_literal), device=device,
+        num_layers=args.num_layers, cell_type=args.cell_type, compute_dtype=args.compute_dtype, encoder_literal=bool(args.encoder_literal), device=device,
         use_graph=bool(args.use_graph))
     parrot.initialize()
     best_path = os.path.join(save_dir, 'pkl', 'best_' + exp_name + '.tar')
