@@ -25,12 +25,6 @@
 #ifndef ATT_PROJ_UNROLL
 #define ATT_PROJ_UNROLL 8
 #endif
-#ifndef ATT_FWD_WINDOW
-#define ATT_FWD_WINDOW 1  // speculative preload of the context rows the window is about to cover (att_fwd_kernel)
-#endif
-#ifndef ATT_WIN_BACK
-#define ATT_WIN_BACK 12   // rows below floor(min kappa_prev) where the speculative window starts
-#endif
 #ifndef ATT_FWD_PRELOAD
 #define ATT_FWD_PRELOAD 0  // measured: no gain in the forward kernel (the backward preloads pay)
 #endif
@@ -99,25 +93,6 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
             const int u = ug + q * G;
-            pre[q] = (u < U && e < e1) ? ctx[(size_t)u * E + e] : 0.f;
-        }
-    }
-    // Speculative window: the support of phi at this step starts a few positions below the smallest kappa of the
-    // previous step (the window only moves forward, model.py:672) and is a few dozen rows long.  The NPRE * G rows from
-    // there are requested now; if the support turns out to lie inside them, step 4 adds the same products in the same
-    // order without a second, dependent round trip to the context (rows outside the support carry phi == 0 exactly and
-    // add nothing); otherwise the dependent walk below takes over.  Bit-identical either way.
-    int w0 = 0, wfirst = 0;
-    const bool use_win = ATT_FWD_WINDOW && !use_pre && !g.dense && (EW <= CW);
-    if (use_win) {
-        float kmin = INFINITY;
-        for (int j = 0; j < A; ++j) kmin = fminf(kmin, g.kappa_prev[(size_t)b * A + j]);
-        w0 = max(0, min((int)floorf(kmin) - ATT_WIN_BACK, U - NPRE * G));
-        wfirst = w0 + ((ug - w0 % G + G) % G);  // first row >= w0 of this thread's group (u = ug mod G)
-        const int e = e0 + c;
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) {
-            const int u = wfirst + q * G;
             pre[q] = (u < U && e < e1) ? ctx[(size_t)u * E + e] : 0.f;
         }
     }
@@ -228,15 +203,6 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
                 const int u = ug + q * G;
                 if (u < U) acc += s_phi[u] * pre[q];
             }
-        } else if (use_win && u_lo >= w0 && u_lo <= u_hi) {
-            // rows of this thread inside the speculative window, ascending; then (rare) the rows beyond it
-            int u = wfirst;
-#pragma unroll
-            for (int q = 0; q < NPRE; ++q) {
-                if (u + q * G <= u_hi) acc = __builtin_fmaf(s_phi[u + q * G], pre[q], acc);
-            }
-            if (e < e1)
-                for (u = wfirst + NPRE * G; u <= u_hi; u += G) acc = __builtin_fmaf(s_phi[u], ctx[(size_t)u * E + e], acc);
         } else if (e < e1 && u_lo <= u_hi) {
             // rows of this thread: u = ug (mod G), as in the dense walk, starting at the first one >= u_lo
             int u = u_lo + ((ug - u_lo % G + G) % G);
