@@ -70,17 +70,24 @@ def init_params(c, seed=1234, dtype=torch.float64, perturb=0.0):
     _linear_params(p, g, 'BigFrameLevel.rnn_inp_fusion', [BFS, c['FEAT_DIM']], BD, init='he', weightnorm=wn)
     HM = c['H0_MULT']
     p['BigFrameLevel.h0'] = torch.zeros(c['N_RNN'], HM * BD, dtype=torch.float64)
+    skip = c['SKIP_CONN']
     for tier, dim in (('BigFrameLevel', BD), ('FrameLevel', D)):
         for layer in range(1, c['N_RNN'] + 1):
+            # with skip connections the layers above the first also see the stack's input (ops.py:663-680, 872-888)
+            in_dim = dim if (layer == 1 or not skip) else 2 * dim
+            tag = '+inpskip' if (skip and layer > 1) else ''
+            if skip:  # output skips: Linear(h_layer) summed into the stack's output; only the first carries a bias
+                nm = f'{tier}.GRU.outskip{layer}y' if c['RNN_TYPE'] == 'GRU' else f'{tier}.LSTM{layer}.outskip{layer}y'
+                _linear_params(p, g, nm, dim, dim, biases=(layer == 1), init='he', weightnorm=wn)
             if c['RNN_TYPE'] == 'GRU':
-                pre = f'{tier}.GRU{layer}.Step'
-                _linear_params(p, g, f'{pre}.Input', dim, 3 * dim, weightnorm=wn)
+                pre = f'{tier}.GRU{layer}{tag}.Step'
+                _linear_params(p, g, f'{pre}.Input', in_dim, 3 * dim, weightnorm=wn)
                 _linear_params(p, g, f'{pre}.Recurrent_Gates', dim, 2 * dim, biases=False, weightnorm=wn)
                 _linear_params(p, g, f'{pre}.Recurrent_Candidate', dim, dim, biases=False, init='orthogonal',
                                weightnorm=wn)
             else:  # ops.py:505-530
-                pre = f'{tier}.LSTM{layer}.Step'
-                _linear_params(p, g, f'{pre}.Input', dim, 4 * dim, biases=False, weightnorm=wn)
+                pre = f'{tier}.LSTM{layer}{tag}.Step'
+                _linear_params(p, g, f'{pre}.Input', in_dim, 4 * dim, biases=False, weightnorm=wn)
                 _linear_params(p, g, f'{pre}.Recurrent_Gates', dim, 4 * dim, biases=False, weightnorm=wn)
                 b = torch.zeros(4 * dim, dtype=torch.float64)
                 b[dim:2 * dim] = 3.0
@@ -140,23 +147,34 @@ def lstm_step(p, c, name, dim, x, hc):
 
 
 def stacked_gru(p, c, name, dim, inputs, h0):
-    """stackedGRU / stackedLSTM without skip connections (ops.py:612-777, 823-989): inputs [B,n,dim],
-    h0 [B,n_rnn,H0_MULT*dim].  `name` ends in '.GRU'; the LSTM parameters use '.LSTM' instead."""
-    assert not c['SKIP_CONN']
+    """stackedGRU / stackedLSTM (ops.py:612-777, 823-989): inputs [B,n,dim], h0 [B,n_rnn,H0_MULT*dim].  `name` ends in
+    '.GRU'; the LSTM parameters use '.LSTM' instead.  With SKIP_CONN (Graves' stacks, ops.py:650-695, 861-880) layer k > 1
+    reads [h_{k-1} ; inputs] (its parameters are named '<base>k+inpskip') and the stack's output is the sum of one Linear
+    per layer ('<GRU base>.outskipky' / '<LSTM base>k.outskipky'; only the first has a bias)."""
     lstm = c['RNN_TYPE'] == 'LSTM'
+    skip = c['SKIP_CONN']
+    assert not (skip and c['N_RNN'] == 1), "Single layer RNN cannot have skip connections"
     base = name[:-4] + ('.LSTM' if lstm else '.GRU')
     x = inputs
     lasts = []
+    out = None
     for layer in range(c['N_RNN']):
+        k = layer + 1
         h = h0[:, layer]
+        tag = '+inpskip' if (skip and k > 1) else ''
+        xin = torch.cat([x, inputs], -1) if (skip and k > 1) else x
         outs = []
-        for t in range(x.shape[1]):
-            h = (lstm_step if lstm else gru_step)(p, c, f'{base}{layer + 1}.Step', dim, x[:, t], h)
+        for t in range(xin.shape[1]):
+            h = (lstm_step if lstm else gru_step)(p, c, f'{base}{k}{tag}.Step', dim, xin[:, t], h)
             outs.append(h)
         full = torch.stack(outs, 1)
         lasts.append(full[:, -1])
         x = full[:, :, :dim]
-    return x, torch.stack(lasts, 1)
+        if skip:
+            nm = f'{base}{k}.outskip{k}y' if lstm else f'{base}.outskip{k}y'
+            y = linear(p, c, nm, x, biases=(k == 1))
+            out = y if out is None else out + y
+    return (out if skip else x), torch.stack(lasts, 1)
 
 
 def _frames_to_float(frames, c):

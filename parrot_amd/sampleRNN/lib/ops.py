@@ -137,19 +137,28 @@ def LowMemGRU(name, input_dim, hidden_dim, inputs, h0=None, mask=None, weightnor
 
 
 def stackedGRU(name, n_rnn, input_dim, hidden_dim, inputs, h0, weightnorm, skip_conn):
-    """ops.py:612-777; h0 [B, n_rnn, hidden_dim].  Returns (out [B,n,hidden], last_hiddens [B,n_rnn,hidden])."""
+    """ops.py:612-777; h0 [B, n_rnn, hidden_dim].  Returns (out [B,n,hidden], last_hiddens [B,n_rnn,hidden]).
+    skip_conn (ops.py:650-695): layer k > 1 reads [h_{k-1} ; inputs] and the output is the sum of one Linear per layer."""
     assert n_rnn in range(1, 6), "n_rnn should be in [1,2,3,4,5]"
     assert not (n_rnn == 1 and skip_conn), "Single layer RNN cannot have skip connections"
-    if skip_conn:
-        raise NotImplementedError("skip connections (ops.py:650-695) are off in the reference run "
-                                  "configuration (three_tier.py:145) and not built")
-    out = inputs
+    prev, out = inputs, None
     last = []
-    dim = input_dim
     for layer in range(n_rnn):
-        out = LowMemGRU(name + str(layer + 1), dim, hidden_dim, out, h0=h0[:, layer], weightnorm=weightnorm)
-        last.append(out[:, -1])
-        dim = hidden_dim
+        k = layer + 1
+        if layer == 0:
+            inp, dim, nm = inputs, input_dim, name + '1'
+        elif not skip_conn:
+            inp, dim, nm = prev, hidden_dim, name + str(k)
+        else:
+            inp, dim, nm = torch.cat([prev, inputs], dim=-1), hidden_dim + input_dim, name + str(k) + '+inpskip'
+        prev = LowMemGRU(nm, dim, hidden_dim, inp, h0=h0[:, layer], weightnorm=weightnorm)
+        last.append(prev[:, -1])
+        if skip_conn:  # among the output skips only the first carries a bias (ops.py:655-661)
+            y = Linear(name + '.outskip%dy' % k, hidden_dim, hidden_dim, prev, biases=(k == 1), initialization='he',
+                       weightnorm=weightnorm)
+            out = y if out is None else out + y
+        else:
+            out = prev
     return out, torch.stack(last, dim=1)
 
 
@@ -175,17 +184,27 @@ def LowMemLSTM(name, input_dim, hidden_dim, inputs, h0=None, mask=None, weightno
 
 
 def stackedLSTM(name, n_rnn, input_dim, hidden_dim, inputs, h0, weightnorm, skip_conn):
-    """ops.py:823-989; h0 [B, n_rnn, 2*hidden_dim].  Returns (out [B,n,hidden], last_hiddens [B,n_rnn,2*hidden])."""
+    """ops.py:823-989; h0 [B, n_rnn, 2*hidden_dim].  Returns (out [B,n,hidden], last_hiddens [B,n_rnn,2*hidden]).
+    skip_conn (ops.py:861-880) as in stackedGRU; the output skips are named '<name>k.outskipky' here."""
     assert n_rnn in range(1, 6), "n_rnn should be in [1,2,3,4,5]"
     assert not (n_rnn == 1 and skip_conn), "Single layer RNN cannot have skip connections"
-    if skip_conn:
-        raise NotImplementedError("skip connections (ops.py:861-880) are off in the reference run configuration")
-    out = inputs
+    prev, out = inputs, None
     last = []
-    dim = input_dim
     for layer in range(n_rnn):
-        full = LowMemLSTM(name + str(layer + 1), dim, hidden_dim, out, h0=h0[:, layer], weightnorm=weightnorm)
+        k = layer + 1
+        if layer == 0:
+            inp, dim, nm = inputs, input_dim, name + '1'
+        elif not skip_conn:
+            inp, dim, nm = prev, hidden_dim, name + str(k)
+        else:
+            inp, dim, nm = torch.cat([prev, inputs], dim=-1), hidden_dim + input_dim, name + str(k) + '+inpskip'
+        full = LowMemLSTM(nm, dim, hidden_dim, inp, h0=h0[:, layer], weightnorm=weightnorm)
         last.append(full[:, -1])
-        out = full[:, :, :hidden_dim]
-        dim = hidden_dim
+        prev = full[:, :, :hidden_dim]
+        if skip_conn:
+            y = Linear(name + '%d.outskip%dy' % (k, k), hidden_dim, hidden_dim, prev, biases=(k == 1),
+                       initialization='he', weightnorm=weightnorm)
+            out = y if out is None else out + y
+        else:
+            out = prev
     return out, torch.stack(last, dim=1)

@@ -189,8 +189,10 @@ class DeviceGenerator:
     """Device-resident generation loop (samplernn_generate_*, include/parrot_hip.h)."""
 
     def __init__(self, batch, n_frames, temperature=0.0, seed=234, use_graph=True):
-        """GRU or LSTM tiers, 1..5 stacked layers (three_tier.py:147-169); skip connections are not built."""
-        assert not SKIP_CONN
+        """GRU or LSTM tiers, 1..5 stacked layers (three_tier.py:147-169).  Stacks with skip connections run on the literal
+        three-function loop (generate_and_save_samples(..., use_device_loop=False) is chosen automatically)."""
+        if SKIP_CONN:
+            raise NotImplementedError("the device-resident generator does not take skip-connection stacks")
         self.B, self.T = batch, n_frames
         dev = lib.device()
         f = dict(device=dev, dtype=torch.float32)
@@ -328,7 +330,7 @@ def generate_and_save_samples(tag, path_to_save=None, features=None, features_le
         test_feats = numpy.asarray(features, dtype='float32')
     n_seqs, n_frames = test_feats.shape[1], test_feats.shape[0]
     LENGTH = n_frames * BIG_FRAME_SIZE
-    if use_device_loop:
+    if use_device_loop and not SKIP_CONN:  # (the device loop does not take the skip-connection stacks: literal loop)
         gen = DeviceGenerator(n_seqs, n_frames, temperature=temperature)
         samples = gen.generate(test_feats).cpu().numpy()
         gen.close()

@@ -38,6 +38,8 @@ PATH = os.path.join(HERE, 'ref_golden.npz')
 # ----------------------------------------------------------------------------- SampleRNN cases
 SR_DIM, SR_EMB = 32, 8
 SR_CASES = {'gru1': ('GRU', 1), 'lstm2': ('LSTM', 2), 'gru2': ('GRU', 2)}
+# stacks with Graves' skip connections (ops.py:650-695, 861-880; --skip_conn True, off in the reference's run string)
+SR_SKIP_CASES = {'gru2skip': ('GRU', 2), 'lstm3skip': ('LSTM', 3)}
 BIG_GRAD = 4096  # gradients with more elements are stored as 4 seeded random projections
 
 
@@ -54,9 +56,9 @@ def sr_inputs(rnn, n):
     return seq, feats, h0, bh0, mask
 
 
-def sr_params(rnn, n):
+def sr_params(rnn, n, skip=False):
     from oracle import samplernn_ref as S
-    c = S.config(DIM=SR_DIM, EMB_SIZE=SR_EMB, RNN_TYPE=rnn, N_RNN=n)
+    c = S.config(DIM=SR_DIM, EMB_SIZE=SR_EMB, RNN_TYPE=rnn, N_RNN=n, SKIP_CONN=skip)
     return c, S.init_params(c, seed=9, perturb=0.2)
 
 
@@ -141,12 +143,14 @@ def _gen_ops(blob, ops, lib, th):
 def _gen_sr(blob, lib, ops, tt, th):
     from oracle.refshim.loader import quiet_call as q
     V = lambda t: th.Var(t.clone())  # noqa: E731
-    for case, (rnn, n) in SR_CASES.items():
+    for case, (rnn, n) in list(SR_CASES.items()) + list(SR_SKIP_CASES.items()):
+        skip = case in SR_SKIP_CASES
         lib.clear_all_params()
         tt.DIM = tt.BIG_DIM = SR_DIM
         tt.EMB_SIZE, tt.RNN_TYPE, tt.N_RNN, tt.N_BIG_RNN = SR_EMB, rnn, n, n
         tt.H0_MULT = 2 if rnn == 'LSTM' else 1
-        c, p = sr_params(rnn, n)
+        tt.SKIP_CONN = skip
+        c, p = sr_params(rnn, n, skip)
         seq, feats, h0, bh0, mask = sr_inputs(rnn, n)
         for reset in (0, 1):
             args = lambda: (V(seq.int()), V(feats), V(h0), V(bh0), V(torch.tensor(float(reset))), V(mask))  # noqa: E731

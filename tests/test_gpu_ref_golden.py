@@ -63,16 +63,17 @@ def test_ops_level_hip_vs_reference_ops(dev, gold):
         lib.delete_all_params()
 
 
-@pytest.mark.parametrize("case", ["gru1", "lstm2", "gru2"])
+@pytest.mark.parametrize("case", ["gru1", "lstm2", "gru2", "gru2skip", "lstm3skip"])
 def test_three_tier_hip_vs_reference(dev, gold, mk, case):
     from parrot_amd.sampleRNN import lib
     from parrot_amd.sampleRNN.models.conditional import three_tier as tt
-    rnn, n = mk.SR_CASES[case]
+    skip = case in mk.SR_SKIP_CASES  # stacks with skip connections (ops.py:650-695, 861-880)
+    rnn, n = (mk.SR_SKIP_CASES if skip else mk.SR_CASES)[case]
     lib.delete_all_params()
     lib.set_device(dev)
-    tt.configure(DIM=mk.SR_DIM, EMB_SIZE=mk.SR_EMB, RNN_TYPE=rnn, N_RNN=n)
+    tt.configure(DIM=mk.SR_DIM, EMB_SIZE=mk.SR_EMB, RNN_TYPE=rnn, N_RNN=n, SKIP_CONN=skip)
     try:
-        c, p = mk.sr_params(rnn, n)
+        c, p = mk.sr_params(rnn, n, skip)
         lib.set_params(p)
         seq, feats, h0, bh0, mask = mk.sr_inputs(rnn, n)
         for reset in (0, 1):
@@ -103,7 +104,7 @@ def test_three_tier_hip_vs_reference(dev, gold, mk, case):
             assert np.array_equal(out, gold['sr:gru1|samples']), "greedy indices vs the reference's own sample loop"
     finally:
         lib.delete_all_params()
-        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1, SKIP_CONN=False)
 
 
 @pytest.mark.parametrize("case", ["base", "fb_spk", "softmax_ln", "gmm", "sharp"])

@@ -260,3 +260,33 @@ def test_persistent_sample_kernel_seeded_draws(dev):
     finally:
         lib.delete_all_params()
         tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+
+
+@pytest.mark.parametrize("rnn_type,n_rnn", [("GRU", 2), ("LSTM", 2)])
+def test_generation_with_skip_connection_stacks(dev, rnn_type, n_rnn):
+    """--skip_conn True (ops.py:650-695, 861-880): the tiers' stacks feed the stack input to every layer and sum per-layer
+    output projections.  Generation runs on the literal three-function loop (three_tier.py:809-832); greedy indices equal
+    the fp64 oracle's."""
+    from oracle import samplernn_ref as S
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=32, EMB_SIZE=8, RNN_TYPE=rnn_type, N_RNN=n_rnn, SKIP_CONN=True)
+    try:
+        c = S.config(DIM=32, EMB_SIZE=8, RNN_TYPE=rnn_type, N_RNN=n_rnn, SKIP_CONN=True)
+        p = S.init_params(c, seed=9, perturb=0.3)
+        lib.set_params(p)
+        g = torch.Generator().manual_seed(4)
+        T, B = 3, 2
+        feats = torch.randn(T, B, 63, generator=g, dtype=torch.float64)
+        with torch.no_grad():
+            ref = S.generate(p, c, feats).numpy()
+        fns = tt.getting_generation_functions()
+        out = tt.generate_and_save_samples("t", None, feats.float().numpy(), None, 0., *fns, temperature=0.0)
+        assert np.array_equal(out, ref), f"{(out != ref).sum()} of {out.size} greedy indices differ"
+        with pytest.raises(NotImplementedError):
+            tt.DeviceGenerator(B, T)
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1, SKIP_CONN=False)

@@ -73,11 +73,12 @@ def test_blocks_shim_gru_equals_reference_grustep(gold):
     _close(h, gold['ops|out:gru'], 'Blocks GatedRecurrent vs __GRUStep')
 
 
-@pytest.mark.parametrize("case", ["gru1", "lstm2", "gru2"])
+@pytest.mark.parametrize("case", ["gru1", "lstm2", "gru2", "gru2skip", "lstm3skip"])
 def test_three_tier_compute_cost_and_gradients(gold, mk, case):
     from oracle import samplernn_ref as S
-    rnn, n = mk.SR_CASES[case]
-    c, p = mk.sr_params(rnn, n)
+    skip = case in mk.SR_SKIP_CASES  # stacks with skip connections (ops.py:650-695, 861-880)
+    rnn, n = (mk.SR_SKIP_CASES if skip else mk.SR_CASES)[case]
+    c, p = mk.sr_params(rnn, n, skip)
     seq, feats, h0, bh0, mask = mk.sr_inputs(rnn, n)
     for reset in (0, 1):
         pre = f'sr:{case}:r{reset}|'
