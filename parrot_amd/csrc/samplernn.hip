@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "../../include/parrot_hip.h"
+#include "biggemm.h"
 #include "skinny.h"
 #include "sr_persist.h"
 
@@ -143,6 +144,7 @@ struct SrPlan {
     float* t2 = nullptr;  // [Q, D] = emb_tbl[FS-1] . W2 (persistent sample kernel)
     int make_t2() {
         if (hipMalloc(&t2, (size_t)d.Q * d.D * sizeof(float)) != hipSuccess) { t2 = nullptr; return 1; }
+        BgPrecisionScope f32_only(0);  // whatever the process-wide GEMM precision is: this table feeds an f32 path
         int rc = parrot_gemm(d.emb_tbl + (size_t)(d.FS - 1) * d.Q * d.D, d.D, 0, d.W2, d.D, 0, t2, d.D, d.Q, d.D, d.D, nullptr, 1.f,
                              0, 0, 1, 0, 0, 0, 1, nullptr);
         if (rc == 0) rc = (int)hipDeviceSynchronize();
