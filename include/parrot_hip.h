@@ -260,6 +260,9 @@ typedef struct ParrotDecoderDesc {
 long long parrot_decoder_persist_floats(const ParrotDecoderDesc* desc);
 /* 1 when the plan's forward scan runs on the persistent phase machine. */
 int parrot_decoder_is_persistent(void* plan);
+/* Waits for the device; 0, or non-zero when a persistent launch of this plan gave up (a workgroup waited ~1 s for a
+ * rendezvous or for an operand that never arrived): the results of that window are invalid.  0 on the launch schedules. */
+int parrot_decoder_status(void* plan);
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
 int parrot_decoder_seq_fwd(void* plan, void* stream);
@@ -347,6 +350,8 @@ typedef struct ParrotSampleDesc {
 
 long long parrot_sample_persist_floats(const ParrotSampleDesc* desc);
 int parrot_sample_is_persistent(void* plan);
+/* Like parrot_decoder_status, for a decode plan. */
+int parrot_sample_status(void* plan);
 
 int parrot_sample_create(const ParrotSampleDesc* desc, void** plan);
 int parrot_sample_run(void* plan, void* stream);

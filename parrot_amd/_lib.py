@@ -156,6 +156,8 @@ SIGNATURES = {
     "parrot_sample_create": (_i, [C.POINTER(SampleDesc), C.POINTER(C.c_void_p)]),
     "parrot_sample_persist_floats": (C.c_longlong, [C.POINTER(SampleDesc)]),
     "parrot_sample_is_persistent": (_i, [_vp]),
+    "parrot_sample_status": (_i, [_vp]),
+    "parrot_decoder_status": (_i, [_vp]),
     "parrot_sample_run": (_i, [_vp, _vp]),
     "parrot_sample_destroy": (_i, [_vp]),
     "parrot_plan_last_error": (_i, [_vp]),

@@ -18,7 +18,7 @@
 #include "common.h"
 
 enum { PM_MAXENT = 12,   // unit descriptors per workgroup: n_slots * maxu <= PM_MAXENT (training 3 x 3, decode 9 x 1)
-       PM_MAXSLOTS = 9, PM_THREADS = 512, PM_MAXINIT = 8, PM_MAXDST = 6, PM_MAXWDST = 8 };
+       PM_MAXSLOTS = 9, PM_THREADS = 512, PM_MAXINIT = 12, PM_MAXDST = 6, PM_MAXWDST = 8, PM_MAXFILL = 16 };
 enum { PM_NONE = 0, PM_GEMM = 1, PM_ATT = 2 };
 enum { PM_EPI_LINEAR = 0, PM_EPI_GATES = 1, PM_EPI_CAND = 2 };
 
@@ -85,8 +85,21 @@ struct PmInit {  // prologue: row-major [M,K] (ld) -> chunks [chunk, chunk + K/1
     int nch, chunk, ld, K, pad;
 };
 
+// Dataflow mode (PmProgram::dataflow): no grid barriers.  Every buffer a unit reads from another workgroup is write-once
+// per launch; pm_launch fills those buffers (PmFill) with PM_EMPTY, a NaN payload arithmetic never produces, producers
+// overwrite 16-byte slots with single write-through stores, and consumers re-read a slot until it is full.  A unit's
+// inputs always come from units at earlier (tick, slot) positions and every workgroup walks its units in (tick, slot)
+// order, so some unit can always run.  A hand-off then costs one store-to-load latency instead of store acknowledgement
+// + barrier + load.
+struct PmFill {
+    void* p;
+    long long bytes;
+};
+
 struct PmProgram {
     int T, n_ticks, nwg, MB, M, ninit, n_slots, maxu;  // a tick = n_slots phases of up to maxu units per workgroup
+    int dataflow, nfill;
+    PmFill fill[PM_MAXFILL];
     const PmUnit* units;  // device: [n_slots][nwg][maxu]
     unsigned* sync;       // device: PM_SYNC_WORDS + PM_DBG_WORDS unsigned, zeroed before every launch
     float* fm_base;       // start of the fragment-major slab region (all PmDst / a_off offsets are relative to it)
@@ -96,7 +109,10 @@ struct PmProgram {
 
 enum { PM_SYNC_WORDS = 1024, PM_DBG_WORDS = 256 * 24 * 2 };  // dbg: per workgroup 24 x u64: work[9], wait[9] per slot, 4 gemm stages (100 MHz ticks)
 // word offsets inside `sync` (128 B apart)
-enum { PM_S_XCNT = 0, PM_S_XGEN = 256, PM_S_TOP = 512, PM_S_CENSUS = 544, PM_S_TOTAL = 800, PM_S_ABORT = 832 };
+enum { PM_S_XCNT = 0, PM_S_XGEN = 256, PM_S_TOP = 512, PM_S_CENSUS = 544, PM_S_TOTAL = 800, PM_S_ABORT = 832,
+       PM_S_STICKY = 992 };  // words >= PM_S_STICKY survive pm_launch's clearing: [PM_S_STICKY] != 0 = some launch gave up
+#define PM_EMPTY 0x7FC0DEADu
 
 int pm_launch(const PmProgram& prog, hipStream_t stream);
+int pm_status(const PmProgram& prog);  // synchronises; 0, or non-zero when a launch on this program's workspace gave up
 int pm_max_workgroups();  // number of workgroups the machine runs with on this device (one per CU, <= 256)

@@ -112,6 +112,16 @@ __device__ __forceinline__ bool pm_barrier(unsigned* sync, const PmBar& c, unsig
     return *ok_sh != 0;
 }
 
+__device__ __forceinline__ bool pm_is_empty(const f32x4& v) {
+    return __float_as_uint(v[0]) == PM_EMPTY || __float_as_uint(v[3]) == PM_EMPTY;
+}
+// somebody waited ~1 s for a slot that never filled: everybody leaves, the host sees the sticky word
+__device__ __forceinline__ void pm_give_up(unsigned* sync) {
+    pm_st(sync + PM_S_ABORT, 1u);
+    pm_st(sync + PM_S_STICKY, 1u);
+}
+constexpr unsigned PM_POLL_LIMIT = 1u << 21;
+
 __device__ __forceinline__ f32x4 pm_rm_load(const PmRM& o, int t, int m, int n0) {
     // 16 B of row m at columns n0..n0+3 (sc1: written by another workgroup in an earlier phase)
     const float* p = o.p + (long long)t * o.st + (long long)m * o.ld + n0;
@@ -124,6 +134,21 @@ __device__ __forceinline__ f32x4 pm_rm_load(const PmRM& o, int t, int m, int n0)
     f32x4 v;
     v[0] = __uint_as_float((unsigned)x0); v[1] = __uint_as_float((unsigned)(x0 >> 32));
     v[2] = __uint_as_float((unsigned)x1); v[3] = __uint_as_float((unsigned)(x1 >> 32));
+    return v;
+}
+// dataflow mode: the same operand, re-read until its producer's 16-byte store has landed (a torn pair of 8-byte loads
+// shows EMPTY in one of the two checked words)
+__device__ __forceinline__ f32x4 pm_rm_take(const PmRM& o, int t, int m, int n0, unsigned* sync) {
+    f32x4 v = pm_rm_load(o, t, m, n0);
+    unsigned n = 0;
+    while (pm_is_empty(v)) {
+        if ((++n & 1023u) == 0u) {
+            if (pm_ld(sync + PM_S_ABORT)) break;
+            if (n > PM_POLL_LIMIT) { pm_give_up(sync); break; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = pm_rm_load(o, t, m, n0);
+    }
     return v;
 }
 // 16-byte row-major stores.  WT = true: write-through (sc1) for values another workgroup reads later in this launch
@@ -148,9 +173,9 @@ __device__ __forceinline__ f32x4 pm_sigmoid4(f32x4 x) {
 // 8 waves = MB row blocks x KS = 8/MB contiguous K ranges.  Wave (rb, ks) owns row block rb of the 16-column tile
 // over its K range: per 16-deep chunk one fragment-major A block (1 KB, sc1 global load) and one B block (1 KB from
 // LDS, shared by the MB waves of the same ks; or a global load when the slab is streamed) feed 4 MFMA 16x16x4.
-template <int MB>
+template <int MB, bool DF>
 __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds_w, float* lds_red,
-                                        const __amdgpu_buffer_rsrc_t fm, unsigned long long* stage) {
+                                        const __amdgpu_buffer_rsrc_t fm, unsigned long long* stage, unsigned* sync) {
     const unsigned long long ts0 = pm_clock();
     constexpr int KS = 8 / MB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -176,11 +201,13 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
           p_e1 = {0.f, 0.f, 0.f, 0.f};
     if (fin && row_ok) {
         if (u.bias) p_bias = *reinterpret_cast<const f32x4*>(u.bias + n0);
+        if (!DF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (u.add[q].p) p_add += pm_rm_load(u.add[q], t, m, n0);
-        if (u.e0.p) p_e0 = pm_rm_load(u.e0, t, m, n0);
-        if (u.e1.p) p_e1 = pm_rm_load(u.e1, t, m, n0);
+            for (int q = 0; q < 4; ++q)
+                if (u.add[q].p) p_add += pm_rm_load(u.add[q], t, m, n0);
+            if (u.e0.p) p_e0 = pm_rm_load(u.e0, t, m, n0);
+            if (u.e1.p) p_e1 = pm_rm_load(u.e1, t, m, n0);
+        }
     }
 
     const unsigned long long ts1 = pm_clock();
@@ -192,6 +219,20 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
     auto mma = [&](const f32x4& a, const f32x4& b, f32x4& acc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc, 0, 0, 0);
+    };
+    // dataflow: block c was requested earlier; while any lane still holds an EMPTY slot, ask again (wave-uniform loop)
+    auto takeA = [&](f32x4& a, int c) {
+        if (!DF) return;
+        unsigned n = 0;
+        // (lanes of padding rows are never waited for: the attention units only write the rows that exist)
+        while (__builtin_amdgcn_ballot_w64(row_ok && pm_is_empty(a)) != 0ull) {
+            if ((++n & 1023u) == 0u) {
+                if (pm_ld(sync + PM_S_ABORT)) break;
+                if (n > PM_POLL_LIMIT) { pm_give_up(sync); break; }
+            }
+            __builtin_amdgcn_s_sleep(1);
+            a = loadA(c);
+        }
     };
     // two copies of the K loop: weights from LDS (ds_read_b128) or streamed from global memory.  One loop with a
     // run-time pointer would turn both into flat loads (conservative waits on both counters).
@@ -214,6 +255,7 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
         for (; c + D <= c1; c += D) {
 #pragma unroll
             for (int d = 0; d < D; ++d) {
+                takeA(ra[d], c + d);
                 mma(ra[d], rbv[d % DB], (d & 1) ? acc1 : acc0);
                 ra[d] = loadA(min(c + D + d, last));
                 rbv[d % DB] = loadB(min(c + DB + d, last));
@@ -222,6 +264,7 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
 #pragma unroll
         for (int d = 0; d < D - 1; ++d)
             if (c + d < c1) {
+                takeA(ra[d], c + d);
                 mma(ra[d], rbv[d % DB], (d & 1) ? acc1 : acc0);
                 rbv[d % DB] = loadB(min(c + DB + d, last));
             }
@@ -231,6 +274,13 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
         else run(std::false_type{});
     }
     const f32x4 part = acc0 + acc1;
+    if (DF && fin && row_ok) {  // epilogue operands, produced by other workgroups at earlier positions: take them now
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (u.add[q].p) p_add += pm_rm_take(u.add[q], t, m, n0, sync);
+        if (u.e0.p) p_e0 = pm_rm_take(u.e0, t, m, n0, sync);
+        if (u.e1.p) p_e1 = pm_rm_take(u.e1, t, m, n0, sync);
+    }
     const unsigned long long ts2 = pm_clock();
 
     // split-K reduction through LDS: C layout (col = lane & 15, row = 4 (lane >> 4) + reg) -> [row][col] tiles, rows
@@ -294,7 +344,8 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
 // GMM-window attention of batch row b at step t (model.py:664-690) by the whole workgroup (512 threads):
 // projection h1 . Watt, window parameters, phi over the context, w = sum_u phi[u] ctx[b,u,:] over the support of the
 // window.  Same formulas as att_fwd_kernel (attention.hip); the summation order over u differs (two row groups).
-__device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* sm, float* fm_base) {
+template <bool DF>
+__device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* sm, float* fm_base, unsigned* sync) {
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_p = sm;                        // [3A]
     float* s_a = s_p + 3 * PM_ATT_MAXA;     // [A]
@@ -313,7 +364,18 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t hr = pm_rsrc(h);
         for (int k = 4 * lane; k < H; k += 256) {
-            const f32x4 hv = pm_ld16(hr, (unsigned)k << 2);
+            f32x4 hv = pm_ld16(hr, (unsigned)k << 2);
+            if (DF) {
+                unsigned n = 0;
+                while (pm_is_empty(hv)) {
+                    if ((++n & 1023u) == 0u) {
+                        if (pm_ld(sync + PM_S_ABORT)) break;
+                        if (n > PM_POLL_LIMIT) { pm_give_up(sync); break; }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    hv = pm_ld16(hr, (unsigned)k << 2);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = wave + 8 * q;
@@ -447,7 +509,7 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-template <int MB>
+template <int MB, bool DF>
 __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* lds_w = lds;
@@ -468,18 +530,21 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     // census of the workgroup -> XCC placement (not architecturally defined), then the first rendezvous
     PmBar bar;
     bar.xcc = pm_xcc_id();
-    if (tid == 0) {
-        pm_add(sync + PM_S_CENSUS + bar.xcc * 32, 1u);
-        pm_add(sync + PM_S_TOTAL, 1u);
-        const bool ok = pm_spin_ge(sync + PM_S_TOTAL, (unsigned)nwg, sync);
-        for (int x = 0; x < 8; ++x) cen[x] = pm_ld(sync + PM_S_CENSUS + x * 32);
-        ok_sh = ok ? 1 : 0;
+    bar.n_x = 0; bar.n_xcc = 0;
+    if (!DF) {
+        if (tid == 0) {
+            pm_add(sync + PM_S_CENSUS + bar.xcc * 32, 1u);
+            pm_add(sync + PM_S_TOTAL, 1u);
+            const bool ok = pm_spin_ge(sync + PM_S_TOTAL, (unsigned)nwg, sync);
+            for (int x = 0; x < 8; ++x) cen[x] = pm_ld(sync + PM_S_CENSUS + x * 32);
+            if (!ok) pm_st(sync + PM_S_STICKY, 1u);
+            ok_sh = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!ok_sh) return;
+        bar.n_x = cen[bar.xcc];
+        for (int x = 0; x < 8; ++x) bar.n_xcc += cen[x] ? 1u : 0u;
     }
-    __syncthreads();
-    if (!ok_sh) return;
-    bar.n_x = cen[bar.xcc];
-    bar.n_xcc = 0;
-    for (int x = 0; x < 8; ++x) bar.n_xcc += cen[x] ? 1u : 0u;
 
     {
         static_assert(sizeof(PmUnit) % 4 == 0, "");
@@ -522,7 +587,7 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
         }
     }
     unsigned epoch = 1;
-    if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
+    if (!DF && !pm_barrier(sync, bar, epoch++, &ok_sh)) return;
 
     // phase timers (work / barrier wait per slot, summed over the ticks): a handful of s_memrealtime reads per phase
     unsigned long long* t_work = reinterpret_cast<unsigned long long*>(lds_red + PM_LDS_RED + PM_LDS_UNITS + 20);
@@ -539,12 +604,21 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
                 if (kind == PM_NONE) continue;
                 const int t = tick - __builtin_amdgcn_readfirstlane(u.lag);
                 if (t < 0 || t >= P.T) continue;
-                if (kind == PM_GEMM) pm_gemm<MB>(u, t, lds_w, lds_red, fmr, stage);
-                else pm_att_row(P.att, u.row, t, lds_att, P.fm_base);
+                if (kind == PM_GEMM) pm_gemm<MB, DF>(u, t, lds_w, lds_red, fmr, stage, sync);
+                else pm_att_row<DF>(P.att, u.row, t, lds_att, P.fm_base, sync);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long tb = pm_clock();
-            if (!pm_barrier(sync, bar, epoch++, &ok_sh)) return;
+            if (DF) {  // no rendezvous: only look at the abort word now and then
+                if ((s == 0) && (tick & 7) == 0) {
+                    if (tid == 0) ok_sh = pm_ld(sync + PM_S_ABORT) ? 0 : 1;
+                    __syncthreads();
+                    if (!ok_sh) return;
+                }
+            } else if (!pm_barrier(sync, bar, epoch++, &ok_sh)) {
+                if (tid == 0) pm_st(sync + PM_S_STICKY, 1u);
+                return;
+            }
             if (tid == 0) {
                 t_work[s] += tb - ta;
                 t_wait[s] += pm_clock() - tb;
@@ -573,24 +647,45 @@ int pm_max_workgroups() {
     return n;
 }
 
+int pm_status(const PmProgram& P) {
+    PH_CHECK(hipDeviceSynchronize());
+    unsigned w = 0;
+    PH_CHECK(hipMemcpy(&w, P.sync + PM_S_STICKY, sizeof(w), hipMemcpyDeviceToHost));
+    return w ? PH_ERR_UNSUPPORTED + 100 : 0;
+}
+
 int pm_launch(const PmProgram& P, hipStream_t stream) {
     if (P.nwg < 1 || P.nwg > pm_max_workgroups() || !P.units || !P.sync || P.n_slots < 1 || P.n_slots > PM_MAXSLOTS ||
-        P.maxu < 1 || P.n_slots * P.maxu > PM_MAXENT)
+        P.maxu < 1 || P.n_slots * P.maxu > PM_MAXENT || P.nfill < 0 || P.nfill > PM_MAXFILL)
         return PH_ERR_BADARG;
     if (P.att.U > PM_ATT_MAXU || P.att.A > PM_ATT_MAXA) return PH_ERR_UNSUPPORTED;
-    PH_CHECK(hipMemsetAsync(P.sync, 0, (PM_SYNC_WORDS + PM_DBG_WORDS) * sizeof(unsigned), stream));
+    // barrier / census / abort words and the timers are cleared; the sticky words at the end of the sync area are not
+    PH_CHECK(hipMemsetAsync(P.sync, 0, PM_S_STICKY * sizeof(unsigned), stream));
+    PH_CHECK(hipMemsetAsync(P.sync + PM_SYNC_WORDS, 0, PM_DBG_WORDS * sizeof(unsigned), stream));
+    if (P.dataflow)
+        for (int q = 0; q < P.nfill; ++q)
+            PH_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.fill[q].p), (int)PM_EMPTY,
+                                       (size_t)(P.fill[q].bytes / 4), stream));
     const size_t lds = (size_t)PM_LDS_FLOATS * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int l = (int)lds;
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l));
+        PH_CHECK(hipFuncSetAttribute((const void*)pm_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l));
         attr_done = true;
     }
-    switch (P.MB) {
-        case 1: hipLaunchKernelGGL(pm_kernel<1>, dim3(P.nwg), dim3(PM_THREADS), lds, stream, P); break;
-        case 2: hipLaunchKernelGGL(pm_kernel<2>, dim3(P.nwg), dim3(PM_THREADS), lds, stream, P); break;
-        case 4: hipLaunchKernelGGL(pm_kernel<4>, dim3(P.nwg), dim3(PM_THREADS), lds, stream, P); break;
+    const dim3 grid(P.nwg), block(PM_THREADS);
+    switch (P.MB * 2 + (P.dataflow ? 1 : 0)) {
+        case 2: hipLaunchKernelGGL((pm_kernel<1, false>), grid, block, lds, stream, P); break;
+        case 3: hipLaunchKernelGGL((pm_kernel<1, true>), grid, block, lds, stream, P); break;
+        case 4: hipLaunchKernelGGL((pm_kernel<2, false>), grid, block, lds, stream, P); break;
+        case 5: hipLaunchKernelGGL((pm_kernel<2, true>), grid, block, lds, stream, P); break;
+        case 8: hipLaunchKernelGGL((pm_kernel<4, false>), grid, block, lds, stream, P); break;
+        case 9: hipLaunchKernelGGL((pm_kernel<4, true>), grid, block, lds, stream, P); break;
         default: return PH_ERR_BADARG;
     }
     return (int)hipGetLastError();

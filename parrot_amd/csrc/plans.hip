@@ -373,10 +373,12 @@ struct DecoderPlan : PlanBase {
         // no streamed unit is longer than a resident recurrent one.
         float* pre[PARROT_MAX_LAYERS][2][PERSIST_MAXPIECES];
         memset(pre, 0, sizeof(pre));
+        float* const pre_begin = ws;
         for (int l = 1; l < L; ++l)
             for (int g = 0; g < 2; ++g)
                 for (int q = 0; q < (l == 1 ? PERSIST_MAXPIECES / 2 : PERSIST_MAXPIECES); ++q)
                     pre[l][g][q] = take((long long)T * B * (g == 0 ? 2 * H : H));
+        float* const pre_end = ws;
         auto boff = [&](const float* p) { return (unsigned)((p - fm_base) * 4); };
         auto mkdst = [&](float* slab, long long step0, long long kslab, int chunk) {
             PmDst q;
@@ -518,9 +520,25 @@ struct DecoderPlan : PlanBase {
         add_init(d.w, E, E, XG[0], kx[0], H / 16);
         add_init(d.w, E, E, XC[0], kx[0], H / 16);
         P.ninit = ni;
+        // dataflow mode: everything a unit reads from another workgroup starts EMPTY (slot 0 of the histories is the
+        // caller's: the states entering the window)
+        {
+            const char* e = getenv("PARROT_PM_DATAFLOW");
+            P.dataflow = e ? atoi(e) : 0;
+        }
+        auto add_fill = [&](void* q, long long nfloats) {
+            if (nfloats > 0) { P.fill[P.nfill].p = q; P.fill[P.nfill].bytes = nfloats * 4; ++P.nfill; }
+        };
+        add_fill(fm_base, fm_bytes / 4);
+        add_fill(pre_begin, (long long)(pre_end - pre_begin));
+        for (int l = 0; l < L; ++l) {
+            add_fill(d.h[l] + BH, (long long)T * BH);
+            add_fill(d.z[l], (long long)T * BH);
+        }
         persist_ok = true;
         return 0;
     }
+    int persist_status() const { return persist_ok ? pm_status(pm_prog) : 0; }
 
     // ---- weight operands: plain packed matrices, or their fragment-major copies when the caller gave them
     bool tiled = false;
@@ -1434,6 +1452,7 @@ struct SamplePlan : PlanBase {
         float* XR = take(S * rows * kr);
         float* XO = take(S * rows * R);
         if ((long long)(ws - fm_base) * 4 >= 0xfff00000ll) return 0;
+        float* const fm_end = ws;
         float* zh[PARROT_MAX_LAYERS];
         for (int l = 0; l < L; ++l) hist_h[l] = take((S + 1) * BH);
         for (int l = 0; l < L; ++l) zh[l] = take(S * BH);
@@ -1562,10 +1581,31 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < L; ++l) add_init(d.h[l], H, H, XG[l], kx[l], 0);   // initial states (slot 0 of the ping-pong)
         add_init(d.w, E, E, XG[0], kx[0], H / 16);
         add_init(d.w, E, E, XC[0], kx[0], H / 16);
-        P.ninit = ni;   // x[0] = 0 (model.py:834-835): the x chunks of slot 0 stay at their zero fill
+        // x[0] = 0 (model.py:834-835): slot 0 of d.x, converted like the other entering states (the slabs start EMPTY in
+        // dataflow mode, so "stays at the zero fill" is not enough)
+        for (int l = 0; l < L; ++l) {
+            if (!fb_rows(d, l)) continue;
+            if (ni + 2 > PM_MAXINIT) return 0;
+            add_init(d.x, d.ldx, 64, XG[l], kx[l], (int)((kx[l] - 64) / 16));
+            add_init(d.x, d.ldx, 64, XC[l], kx[l], (int)((kx[l] - 64) / 16));
+        }
+        P.ninit = ni;
+        {
+            const char* e2 = getenv("PARROT_PM_DATAFLOW");
+            P.dataflow = e2 ? atoi(e2) : 0;
+        }
+        auto add_fill = [&](void* q, long long nfloats) {
+            if (nfloats > 0) { P.fill[P.nfill].p = q; P.fill[P.nfill].bytes = nfloats * 4; ++P.nfill; }
+        };
+        add_fill(fm_base, (long long)(fm_end - fm_base));
+        for (int l = 0; l < L; ++l) {
+            add_fill(hist_h[l] + BH, (long long)S * BH);
+            add_fill(zh[l], (long long)S * BH);
+        }
         persist_ok = true;
         return 0;
     }
+    int persist_status() const { return persist_ok ? pm_status(pm_prog) : 0; }
 
     int run_persist(hipStream_t st) {
         const size_t BH = (size_t)d.B * d.H;
@@ -1883,6 +1923,8 @@ long long parrot_sample_persist_floats(const ParrotSampleDesc* desc) { PH_ENTRY(
     return SamplePlan::persist_floats(*desc, pm_max_workgroups());
 }
 int parrot_sample_is_persistent(void* plan) { return static_cast<SamplePlan*>(plan)->persist_ok ? 1 : 0; }
+int parrot_sample_status(void* plan) { PH_ENTRY(); return plan ? static_cast<SamplePlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }
+int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<DecoderPlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }
 
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
 

@@ -728,6 +728,8 @@ class Parrot(Brick):
         self._tiled_weights(refresh=True)
 
         # --- the scan (model.py:651-737)
+        if 'persist_ws' in ws:  # opt-in persistent forward scan: did the previous window's launch give up? (synchronises)
+            _lib.call('parrot_decoder_status', ws['plan'])
         _lib.call('parrot_decoder_seq_fwd', ws['plan'], ops._stream())
 
         # --- readouts and output (model.py:739-755)
@@ -1117,6 +1119,8 @@ class Parrot(Brick):
         if 'pm' in ws:
             self._refresh_sample_machine_weights(ws)
         _lib.call('parrot_sample_run', ws['plan'], ops._stream())
+        if 'pm' in ws:  # persistent machine: a launch that gave up leaves invalid frames -- fail loudly (synchronises)
+            _lib.call('parrot_sample_status', ws['plan'])
         sx = ws['x'][1:, :, :O]
         pi = ws['pi_out'] if self.which_cost == 'GMM' else sx
         return [sx, ws['kappa'][1:], ws['w'][1:], pi, ws['phi'], ws['a']]
