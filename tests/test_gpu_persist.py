@@ -200,3 +200,36 @@ def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
         m.close()
     for a, b, n in zip(res["1"], res["0"], ("sample_x", "k", "w", "pi", "phi", "pi_att")):
         assert_close(a, b, 2e-5, f"machine vs launches: {n}")
+
+
+def test_dataflow_mode_matches_the_barrier_mode_bit_for_bit(dev, monkeypatch):
+    """PARROT_PM_DATAFLOW=1: no grid barriers, consumers re-read 16-byte slots until they stop being EMPTY (persist.h).
+    Same units, same arithmetic: the training forward (cost, frames) and the decode outputs equal the barrier mode's
+    bit for bit, with padding rows (B = 5, 37), three layers, feedback, and a second call on the same workspace."""
+    from oracle import parrot_ref as R
+    from parrot_amd import _lib
+    from parrot_amd.model import Parrot
+    monkeypatch.setenv("PARROT_SCHEDULE", "4")
+    for kw, T, B, U in ((dict(num_layers=3, weak_feedback=True), 9, 37, 11), (dict(num_layers=2), 8, 5, 9)):
+        full = dict(SMALL, **kw)
+        cfg = R.default_config(**full)
+        p = R.init_params(cfg, seed=4, scale_by_fan_in=True)
+        feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=5, ragged=True)
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PARROT_PM_DATAFLOW", mode)
+            m = Parrot(device=dev, **full).allocate()
+            m.set_parameter_values(p)
+            for rep in range(2):
+                m.zero_grad()
+                cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev),
+                                                None, 1, B)
+                cost.backward()
+            assert _is_persistent(m, T, B, U)
+            outs = m.sample_model_device(lab, lm.float(), None, B, 6)
+            ws = m._train_workspace(T, B, U)
+            _lib.call('parrot_decoder_status', ws['plan'])  # raises if a launch gave up
+            got[mode] = [cost.detach().clone(), av[0].clone(), av[2].clone()] + [o.clone() for o in outs[:3]]
+            m.close()
+        for a, b in zip(got["0"], got["1"]):
+            assert torch.equal(a, b)
