@@ -324,22 +324,36 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
 // 4 v_mfma_f32_32x32x16_bf16 per K-tile (32 cycles each) where the f32 kernel issues 32 v_mfma_f32_32x32x2_f32
 // (64 cycles each) for the same K range: the matrix pipe stops being the limit and the kernel becomes bound by
 // the L2 -> LDS operand traffic (32 KB of f32 per K-tile and workgroup).
-constexpr int BK16 = 32, PITCH16 = 40;
+constexpr int BK16 = 32, PITCH16 = 40, PITCHT = 144;  // row pitches in bf16: [x][k] image / [k][x] image
 
-// XC = true : x contiguous (element (x,k) at p[k*sk + x]): thread -> (x = t & 127, kg = t >> 7), 8 dword loads down k.
-// XC = false: k contiguous (element (x,k) at p[x*sx + k]): thread -> (x = t >> 2, kg = t & 3), two 16-byte loads.
+// k-contiguous operand (element (x,k) at p[x*sx + k]): thread -> (x = t >> 2, kg = t & 3), two 16-byte loads, one
+// ds_write_b128 into an [x][k] image; MFMA fragments are plain ds_read_b128.
+// x-contiguous operand (element (x,k) at p[k*sk + x], e.g. both operands of the weight gradients X^T . dG): thread ->
+// (xq = t & 31, k = t >> 5 and + 16): two 16-byte loads of 4 consecutive x (a wave instruction = two whole 512-byte
+// rows), one ds_write_b64 each into a [k][x] image (pitch 288 B).  The MFMA operand wants 8 consecutive k per lane:
+// ds_read_b64_tr_b16 (gfx950) hands lane i of a 16-lane group the i-th column of the 4 x 16 block the group's lanes
+// point at (measured mapping: tools/ notes in DESIGN.md 3.7), so two of them give k0 .. k0+7 of row x0 + i without any
+// transposition in registers.  The first version fetched these operands with eight 4-byte loads per thread.
 template <bool XC>
 __device__ __forceinline__ void bg_load16(const float* __restrict__ p, int x0, int X, int k0, int kend,
                                           long long sx, long long sk, bool vec, int t, f32x4 (&v)[2]) {
     v[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     v[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (XC) {
-        const int x = x0 + (t & 127), k = k0 + 8 * (t >> 7);
-        if (x < X) {
-            const float* q = p + (long long)k * sk + x;
+        const int x = x0 + 4 * (t & 31);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k + u < kend) v[u >> 2][u & 3] = q[(long long)u * sk];
+        for (int ps = 0; ps < 2; ++ps) {
+            const int k = k0 + (t >> 5) + 16 * ps;
+            if (k < kend) {
+                const float* q = p + (long long)k * sk + x;
+                if (vec && x + 3 < X) {
+                    v[ps] = *reinterpret_cast<const f32x4*>(q);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (x + u < X) v[ps][u] = q[u];
+                }
+            }
         }
     } else {
         const int x = x0 + (t >> 2), k = k0 + 8 * (t & 3);
@@ -359,14 +373,41 @@ __device__ __forceinline__ void bg_load16(const float* __restrict__ p, int x0, i
 
 template <bool XC>
 __device__ __forceinline__ void bg_store16(__bf16* __restrict__ s, int t, const f32x4 (&v)[2]) {
-    const int x = XC ? (t & 127) : (t >> 2), kg = XC ? (t >> 7) : (t & 3);
-    *reinterpret_cast<bf16x8*>(s + x * PITCH16 + 8 * kg) = ph_bf16x8(v[0], v[1]);
+    if (XC) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            *reinterpret_cast<bf16x4*>(s + ((t >> 5) + 16 * ps) * PITCHT + 4 * (t & 31)) = __builtin_convertvector(v[ps], bf16x4);
+    } else {
+        *reinterpret_cast<bf16x8*>(s + (t >> 2) * PITCH16 + 8 * (t & 3)) = ph_bf16x8(v[0], v[1]);
+    }
+}
+
+// MFMA 32x32x16 operand of lane (kk = lane >> 5, li = lane & 31): row xb + li, k = 16 s + 8 kk .. +7
+template <bool XC>
+__device__ __forceinline__ bf16x8 bg_frag16(const __bf16* __restrict__ img, int xb, int s, int lane) {
+    const int kk = lane >> 5, li = lane & 31;
+    if (XC) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds4;
+        // 16-lane group: rows (k) k0 + q, q = (li >> 2) & 3; 4 lanes per row, 4 columns (x) each
+        const int k0 = 16 * s + 8 * kk, q = (li >> 2) & 3, xg = xb + (li & 16) + 4 * (li & 3);
+        const __bf16* p = img + (k0 + q) * PITCHT + xg;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 4 * PITCHT));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        return *reinterpret_cast<const bf16x8*>(img + (xb + li) * PITCH16 + 16 * s + 8 * kk);
+    }
 }
 
 template <bool AXC, bool BXC>
 __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * PITCH16];
-    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * PITCH16];
+    constexpr int ASZ = AXC ? BK16 * PITCHT : BM * PITCH16, BSZ = BXC ? BK16 * PITCHT : BN * PITCH16;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][ASZ];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BSZ];
     int tm, tn;
     bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -402,13 +443,11 @@ __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, 
             bg_load16<AXC>(A, m0, a.M, kbeg + (kt + 1) * BK16, kend, a.sam, a.sak, vecA, t, ra);
             bg_load16<BXC>(B, n0, a.N, kbeg + (kt + 1) * BK16, kend, a.sbn, a.sbk, vecB, t, rb);
         }
-        const __bf16* as = As[cur] + (wm * 64 + li) * PITCH16 + 8 * kk;
-        const __bf16* bs = Bs[cur] + (wn * 32 + li) * PITCH16 + 8 * kk;
 #pragma unroll
         for (int s = 0; s < BK16 / 16; ++s) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(as + 16 * s);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(as + 32 * PITCH16 + 16 * s);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bs + 16 * s);
+            const bf16x8 a0 = bg_frag16<AXC>(As[cur], wm * 64, s, lane);
+            const bf16x8 a1 = bg_frag16<AXC>(As[cur], wm * 64 + 32, s, lane);
+            const bf16x8 b0 = bg_frag16<BXC>(Bs[cur], wn * 32, s, lane);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1], 0, 0, 0);
         }
