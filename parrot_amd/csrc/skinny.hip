@@ -711,13 +711,20 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
 // its part of the fused epilogue).  Weights: one 1 KB fragment-major block per wave and 32-deep chunk, straight
 // into registers.  One __syncthreads per 64-deep stage, two LDS stage buffers, register rings for both operands.
 #ifndef WK_PA_DEPTH
-#define WK_PA_DEPTH 4
+#define WK_PA_DEPTH 2
 #endif
 #ifndef WK_PB_DEPTH
-#define WK_PB_DEPTH 4
+#define WK_PB_DEPTH 2
 #endif
 // K per stage; LDS row pitch in bytes; ring depths in stages (2/3, 4/4 and 8/8 measured the same at cfg4)
-enum { WK_STAGE = 64, WK_PITCH = 144, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH };
+#ifndef WK_STAGE_K
+#define WK_STAGE_K 128
+#endif
+enum { WK_STAGE = WK_STAGE_K, WK_PITCH = 2 * WK_STAGE_K + 16, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH,
+       WK_TPR = WK_STAGE_K / 4,          // threads per activation row of a stage (4 k each)
+       WK_RPP = SK_THREADS / WK_TPR,     // rows per staging pass
+       WK_NP = 64 / WK_RPP,              // staging passes = 16-byte loads per thread and stage
+       WK_KS = WK_STAGE_K / 32 };        // MFMA k-steps = weight blocks per wave and stage
 
 struct WkLaunch {
     SkJob job[SK_MAXJOB];
@@ -756,30 +763,29 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
         }
     };
 
-    // staging role: rows r0 and r0 + 32, k = 4 * akq .. +3 of the stage: 16 lanes read one row's 256 contiguous bytes, a
-    // wave instruction 4 whole rows (8 full cache lines)
-    const int ar0 = min(tid >> 4, M - 1), ar1 = min((tid >> 4) + 32, M - 1), akq = tid & 15;
+    // staging role: rows r0 + p * WK_RPP (p < WK_NP), k = 4 * akq .. +3 of the stage: WK_TPR lanes read one row's
+    // contiguous 4 * WK_STAGE bytes
+    const int ar0 = tid / WK_TPR, akq = tid % WK_TPR;
     Cursor ca, cb;
     cursor_init(ca);
     cursor_init(cb);
-    auto loadA = [&](f32x4 (&a)[2]) __attribute__((always_inline)) {
-        a[0] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar0 * ca.lda + ca.k + 4 * akq);
-        a[1] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)ar1 * ca.lda + ca.k + 4 * akq);
+    auto loadA = [&](f32x4 (&a)[WK_NP]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < WK_NP; ++p)
+            a[p] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq);
         cursor_next(ca);
     };
-    auto loadB = [&](f32x4 (&b)[2]) __attribute__((always_inline)) {
+    auto loadB = [&](f32x4 (&b)[WK_KS]) __attribute__((always_inline)) {
         const float* p = cb.B + (size_t)tile * cb.ldb + ((size_t)(cb.k >> 5) << 8) + (lane << 2);
-
-        // (non-temporal loads measured 51 us per launch instead of 35: at 64 columns the two row-half waves share a block)
-        b[0] = *reinterpret_cast<const f32x4*>(p);
-        b[1] = *reinterpret_cast<const f32x4*>(p + 256);
+#pragma unroll
+        for (int q = 0; q < WK_KS; ++q) b[q] = *reinterpret_cast<const f32x4*>(p + 256 * q);
         cursor_next(cb);
     };
 
     f32x4 acc[MB];
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) acc[rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra[WK_PA][2], rbv[WK_PB][2];
+    f32x4 ra[WK_PA][WK_NP], rbv[WK_PB][WK_KS];
 #pragma unroll
     for (int q = 0; q < WK_PA; ++q) loadA(ra[q]);
 #pragma unroll
@@ -791,28 +797,25 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     // publishes stage st + 1 and retires the reads of stage st before that buffer is refilled).  With write -> barrier ->
     // read -> MFMA in a row the LDS round trip and the barrier sat on every stage's critical path (measured: 875
     // clocks per stage, independent of the prefetch depth; a variant that halved the waves working per stage doubled it).
-    auto fill = [&](int st, f32x4 (&a)[2]) __attribute__((always_inline)) {
+    auto fill = [&](int st, f32x4 (&a)[WK_NP]) __attribute__((always_inline)) {
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         char* buf = smem + (st & 1) * (64 * WK_PITCH);
-        *reinterpret_cast<bf16x4*>(buf + (tid >> 4) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[0], bf16x4);
-        *reinterpret_cast<bf16x4*>(buf + ((tid >> 4) + 32) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[1], bf16x4);
+#pragma unroll
+        for (int p = 0; p < WK_NP; ++p)
+            *reinterpret_cast<bf16x4*>(buf + (ar0 + p * WK_RPP) * WK_PITCH + 8 * akq) = __builtin_convertvector(a[p], bf16x4);
         loadA(a);
     };
-    auto stage = [&](int st, f32x4 (&anext)[2], f32x4 (&b)[2]) __attribute__((always_inline)) {
+    auto stage = [&](int st, f32x4 (&anext)[WK_NP], f32x4 (&b)[WK_KS]) __attribute__((always_inline)) {
         const char* buf = smem + (st & 1) * (64 * WK_PITCH);
-        bf16x8 av[2][MB];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int rb = 0; rb < MB; ++rb)
-                av[ks][rb] = *reinterpret_cast<const bf16x8*>(buf + (16 * (rh * MB + rb) + i16) * WK_PITCH + ks * 64 + 16 * kk);
         if (st + 1 < total) fill(st + 1, anext);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < WK_KS; ++ks) {
             const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
 #pragma unroll
-            for (int rb = 0; rb < MB; ++rb)
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ks][rb], bv, acc[rb], 0, 0, 0);
+            for (int rb = 0; rb < MB; ++rb) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(buf + (16 * (rh * MB + rb) + i16) * WK_PITCH + ks * 64 + 16 * kk);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rb], 0, 0, 0);
+            }
         }
         loadB(b);
         __syncthreads();
@@ -938,7 +941,7 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
         t += ceil_div(tiles[q], W.ncw[q]);
         W.wg_end[q] = t;
     }
-    const size_t lds = 2 * 64 * WK_PITCH;
+    const size_t lds = 2 * 64 * WK_PITCH;  // two stage buffers
     if (g_prof.on) {
         SkProfRec r;
         (void)hipEventCreate(&r.e0);

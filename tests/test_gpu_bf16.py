@@ -161,7 +161,7 @@ def test_wide_bf16_step_kernel_small(dev, B, monkeypatch):
     """wk_kernel (all rows x 64/128 columns per workgroup, activation stage through LDS) forced onto small LSTM launches:
     partial row blocks (B = 5, 37), several K segments, fwd (fused LSTM epilogue) and bwd (accumulating linear jobs)."""
     monkeypatch.setenv("PARROT_WK", "2")
-    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=32, cell_type='lstm')
+    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
     _bf16_check(dev, kw, T=5, B=B, U=9, seed=91 + B)
 
 
@@ -171,7 +171,7 @@ def test_wide_and_tiled_bf16_kernels_agree(dev, monkeypatch):
     f32 noise: 5e-3 norm-wise per gradient (the oracle tolerance of the mode is 5e-2), 1e-4 on the cost."""
     from oracle import parrot_ref as R
     from parrot_amd.model import Parrot
-    kw = dict(num_layers=2, rnn_h_dim=256, readouts_dim=256, encoder_type='bidirectional', encoder_dim=32, cell_type='lstm')
+    kw = dict(num_layers=2, rnn_h_dim=256, readouts_dim=256, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
     cfg = R.default_config(**kw)
     p = R.init_params(cfg, seed=5, scale_by_fan_in=True)
     feat, fm, lab, lm, spk = make_batch(cfg, 6, 48, 10, seed=6, ragged=True)
