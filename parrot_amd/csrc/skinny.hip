@@ -711,17 +711,14 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
 // its part of the fused epilogue).  Weights: one 1 KB fragment-major block per wave and 32-deep chunk, straight
 // into registers.  One __syncthreads per 64-deep stage, two LDS stage buffers, register rings for both operands.
 #ifndef WK_PA_DEPTH
-#define WK_PA_DEPTH 4
+#define WK_PA_DEPTH 2
 #endif
 #ifndef WK_PB_DEPTH
-#define WK_PB_DEPTH 4
+#define WK_PB_DEPTH 2
 #endif
 // K per stage; LDS row pitch in bytes; ring depths in stages (2/3, 4/4 and 8/8 measured the same at cfg4)
 #ifndef WK_STAGE_K
-#define WK_STAGE_K 64
-#endif
-#ifndef WK_ROT
-#define WK_ROT 5
+#define WK_STAGE_K 128
 #endif
 enum { WK_STAGE = WK_STAGE_K, WK_PITCH = 2 * WK_STAGE_K + 16, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH,
        WK_TPR = WK_STAGE_K / 4,          // threads per activation row of a stage (4 k each)
@@ -759,9 +756,11 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     };
     auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
         if (c.left > 1) { --c.left; c.k += WK_STAGE; return; }
-        c.seg = c.seg + 1 < job.nseg ? c.seg + 1 : 0;  // (wraps: workgroups start at different stages, see below)
-        const SkSeg& sg = job.seg[c.seg];
-        c.A = sg.A; c.B = sg.B; c.lda = sg.lda; c.ldb = sg.ldb; c.left = sg.K / WK_STAGE; c.k = 0;
+        if (c.seg + 1 < job.nseg) {
+            ++c.seg;
+            const SkSeg& sg = job.seg[c.seg];
+            c.A = sg.A; c.B = sg.B; c.lda = sg.lda; c.ldb = sg.ldb; c.left = sg.K / WK_STAGE; c.k = 0;
+        }
     };
 
     // staging role: rows r0 + p * WK_RPP (p < WK_NP), k = 4 * akq .. +3 of the stage: WK_TPR lanes read one row's
@@ -770,12 +769,6 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     Cursor ca, cb;
     cursor_init(ca);
     cursor_init(cb);
-    // Every workgroup of a job reads the SAME activation rows; started together at k = 0 they all ask the same L2
-    // channel for the same lines at the same time.  Workgroup w starts WK_ROT * w stages into the K range and wraps.
-    {
-        const int s0 = WK_ROT ? (wg * WK_ROT) % total : 0;
-        for (int q = 0; q < s0; ++q) { cursor_next(ca); cursor_next(cb); }
-    }
     auto loadA = [&](f32x4 (&a)[WK_NP]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < WK_NP; ++p)
