@@ -711,14 +711,16 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
 // its part of the fused epilogue).  Weights: one 1 KB fragment-major block per wave and 32-deep chunk, straight
 // into registers.  One __syncthreads per 64-deep stage, two LDS stage buffers, register rings for both operands.
 #ifndef WK_PA_DEPTH
-#define WK_PA_DEPTH 2
+#define WK_PA_DEPTH 4
 #endif
 #ifndef WK_PB_DEPTH
-#define WK_PB_DEPTH 2
+#define WK_PB_DEPTH 4
 #endif
-// K per stage; LDS row pitch in bytes; ring depths in stages (2/3, 4/4 and 8/8 measured the same at cfg4)
+// K per stage; LDS row pitch in bytes; ring depths in stages.  Measured the same at cfg4 (34.4-36.1 us per launch):
+// ring depths 2/3, 4/4 and 8/8, a stage of 128 instead of 64 K rows.  Measured worse: starting every workgroup at a
+// different stage of the K range (43 us: the lock-step walk is what makes the shared activation rows hit in L2).
 #ifndef WK_STAGE_K
-#define WK_STAGE_K 128
+#define WK_STAGE_K 64
 #endif
 enum { WK_STAGE = WK_STAGE_K, WK_PITCH = 2 * WK_STAGE_K + 16, WK_PA = WK_PA_DEPTH, WK_PB = WK_PB_DEPTH,
        WK_TPR = WK_STAGE_K / 4,          // threads per activation row of a stage (4 k each)
