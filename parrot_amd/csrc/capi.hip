@@ -9,6 +9,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 static int gemm_target_wgs() {
     static int v = -1;
     if (v < 0) {
@@ -18,7 +20,7 @@ static int gemm_target_wgs() {
     return v;
 }
 
-static int g_gemm_bf16 = 0;                 // parrot_set_gemm_precision
+static std::atomic<int> g_gemm_bf16{0};      // parrot_set_gemm_precision (process-wide; plans override per thread)
 static thread_local int t_gemm_bf16 = -1;   // BgPrecisionScope (-1: follow the process-wide mode)
 BgPrecisionScope::BgPrecisionScope(int bf16) : saved(t_gemm_bf16) { t_gemm_bf16 = bf16 ? 1 : 0; }
 BgPrecisionScope::~BgPrecisionScope() { t_gemm_bf16 = saved; }
@@ -27,11 +29,11 @@ extern "C" {
 
 int parrot_set_gemm_precision(int mode) { PH_ENTRY();
     if (mode != PARROT_PRECISION_F32 && mode != PARROT_PRECISION_BF16) return PARROT_ERR_BADARG;
-    g_gemm_bf16 = mode;
+    g_gemm_bf16.store(mode, std::memory_order_relaxed);
     return 0;
 }
 
-int parrot_get_gemm_precision(void) { PH_ENTRY(); return g_gemm_bf16; }
+int parrot_get_gemm_precision(void) { PH_ENTRY(); return g_gemm_bf16.load(std::memory_order_relaxed); }
 
 const char* parrot_hip_version(void) { PH_ENTRY(); return "parrot_hip 0.1.0 gfx950"; }
 
@@ -71,7 +73,7 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     a.batchA = strideA; a.batchB = strideB; a.batchC = strideC;
     a.nbatch = nbatch;
     a.accumulate = accumulate; a.alpha = alpha; a.act = act;
-    a.bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16;
+    a.bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16.load(std::memory_order_relaxed);
     int split = split_k;
     if (split <= 0) {
         // auto: few output tiles but a long reduction (deferred weight gradients: K = T*B rows)
