@@ -79,3 +79,31 @@ def test_workspace_cache_is_bounded_and_frees_evicted_entries():
     assert freed == [1, 2, 3, 4, 5, 6, 7]
     c.clear()
     assert len(c) == 0 and len(freed) == 10
+
+
+def test_learning_rate_schedule_matches_the_reference_class():
+    """tests/golden/schedule_golden.json: what the reference's own LearningRateSchedule.do (extensions.py:119-152, executed
+    by make_schedule_golden.py on stand-ins for its Blocks collaborators) did at every validation check of four seeded
+    trajectories -- learning rate, number of cuts, patience counter, best-parameter reload + buffer reset, finish."""
+    import json
+    import os
+    from parrot_amd.trainer import LearningRateSchedule
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_golden.json")))
+    assert len(gold) == 8
+    for key, case in gold.items():
+        _, p, c = key.split('|')
+        tr, reloads = _FakeTrainer(), []
+        tr.lr = 1e-4
+        s = LearningRateSchedule(tr, lambda: reloads.append(1), patience=int(p[1:]), num_cuts=int(c[1:]), cut_size=.5)
+        finished = False
+        for v, row in zip(case['values'], case['rows']):
+            assert not finished, key
+            n_rel, n_cut = len(reloads), tr.cuts
+            cut, fin = s.update(float('nan') if v is None else v)
+            finished = finished or fin
+            assert abs(tr.lr - row['lr']) <= 1e-12 * row['lr'], (key, tr.lr, row['lr'])
+            assert s.count_cuts == row['cuts'] and s.counter == row['counter'], (key, s.count_cuts, s.counter, row)
+            assert cut == row['reloaded'] == row['buffers_zeroed'], (key, cut, row)
+            assert (len(reloads) - n_rel == 1) == cut and (tr.cuts - n_cut == 1) == cut
+            assert finished == row['finish'], (key, finished, row)
+        assert finished == case['rows'][-1]['finish']
