@@ -71,3 +71,46 @@ def test_end_of_utterance_heuristic():
     assert end_of_utterance(phi, U, 100) == 24 + 40
     assert end_of_utterance(phi, U, 50) == 50
     assert end_of_utterance(phi[:10], U, 77) == 77  # never reaches the end
+
+
+def _datasets_golden():
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mk_ds", os.path.join(here, "golden", "make_datasets_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    return mk, np.load(os.path.join(here, "golden", "datasets_golden.npz"))
+
+
+def test_segment_sequence_matches_the_reference_class():
+    """tests/golden/datasets_golden.npz: the windows the reference's own SegmentSequence.get_data (datasets.py:109-138,
+    executed by make_datasets_golden.py) cut out of seeded padded batches -- two batches in a row per case, so the reset
+    between batches is covered -- for the training configuration and for overlap / return_last variants."""
+    mk, gold = _datasets_golden()
+    for case, (n, seq, share, ret_last, min_size) in mk.CASES.items():
+        batch = mk.batch_for(case)
+        seg = SegmentSequence([batch, batch], ('features', 'features_mask', 'labels'), seq_size=seq, share_value=share,
+                              return_last=ret_last, add_flag=True, min_size=min_size,
+                              which_sources=('features', 'features_mask'))
+        out = list(seg)
+        assert len(out) == int(gold[f'{case}|n']), case
+        for k, (f, fm, lab, flag) in enumerate(out):
+            assert np.array_equal(f, gold[f'{case}|{k}|features']), (case, k)
+            assert np.array_equal(fm, gold[f'{case}|{k}|features_mask']), (case, k)
+            assert np.array_equal(lab, gold[f'{case}|{k}|labels']), (case, k)
+            assert int(flag) == int(gold[f'{case}|{k}|flag']), (case, k)
+
+
+def test_raw_transformer_matches_the_reference_function():
+    """_chunk + get_raw_transformer (datasets.py:28-29, 187-196) as executed from the reference file on the reference's
+    quantize.py: same frames, same integer codes (the oracle quantiser stands in for the HIP kernel on CPU; the kernel is
+    bit-exact against the same module, the quantiser tests)."""
+    mk, gold = _datasets_golden()
+    chunked = _chunk(gold['raw|in'])
+    assert np.array_equal(chunked, gold['raw|chunked'])
+    for q_type in ('mu-law', 'linear'):
+        tf = get_raw_transformer(q_type, 256, quantizer=lambda x, ql, qt: Q.batch_quantize(x, ql, qt))
+        got = tf(chunked.copy())
+        assert got.shape == gold[f'raw|{q_type}'].shape
+        assert np.array_equal(got.astype(np.int64), gold[f'raw|{q_type}'].astype(np.int64)), q_type
