@@ -294,8 +294,10 @@ struct SrPlan {
         for (int f = 0; f < nfr; ++f) {
             // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
             const int toff = f * FS;
-            hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(D, 256), B), dim3(256), 0, st, d.samples, len, d.tbase, toff,
-                               FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
+            // (on the persistent path the previous frame's sample kernel has already left this frame's input in gru_in)
+            if (!persist || f == 0)
+                hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(D, 256), B), dim3(256), 0, st, d.samples, len, d.tbase,
+                                   toff, FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
             const float* ftop = nullptr;
             SR_TRY(stack_step(false, d.gru_in, &ftop, st));
             SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st,
@@ -308,6 +310,10 @@ struct SrPlan {
                 sa.emb_tbl = d.emb_tbl; sa.t2 = t2; sa.frame_out = d.frame_out; sa.ldf = FS * D;
                 sa.W2 = d.W2; sa.b2 = d.b2; sa.W3 = d.W3; sa.b3 = d.b3; sa.W4 = d.W4; sa.b4 = d.b4;
                 sa.logits = d.logits; sa.ws = d.persist_ws; sa.temperature = d.temperature; sa.seed = d.seed;
+                if (f + 1 < nfr) {  // the next frame of this period: its big-tier conditioning is already known
+                    sa.next_in = d.gru_in; sa.next_Win = d.frm_Win; sa.next_bias = d.frm_bin;
+                    sa.next_add = d.big_out + (size_t)(f + 1) * D; sa.next_ld_add = nfr * D;
+                }
                 {
                     static const int timing = getenv("PARROT_SR_TIMING") ? atoi(getenv("PARROT_SR_TIMING")) : 0;
                     sa.pad = timing;

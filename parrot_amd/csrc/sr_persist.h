@@ -13,6 +13,10 @@ struct SrpArgs {
     const float* W2; const float* b2; const float* W3; const float* b3;   // [D][D], [D]
     const float* W4; const float* b4;                                      // [D][Q], [Q]
     float* logits;                     // [B][Q]: logits of the launch's last step (or null)
+    // Optional: the frame tier's input for the NEXT frame (three_tier.py:398-411), computed by every team for its own
+    // streams from the samples it has just produced: next_in[b][d] = next_bias[d] + next_add[b][d] + sum_i xf_i * next_Win[i][d],
+    // xf_i = (sample / (Q/2) - 1) * 2 of the launch's last FS samples.  next_in == null: not computed.
+    float* next_in; const float* next_Win; const float* next_bias; const float* next_add; int next_ld_add, pad1;
     float* ws;                         // srp_ws_floats() floats, prepared once by srp_init_ws
     float temperature; int pad;
     unsigned long long seed;

@@ -369,6 +369,21 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         __syncthreads();
         stamp(i, 7);
     }
+    // ---- the next frame's frame-tier input for this team's streams (saves the launch that would compute it)
+    if (a.next_in) {
+        const float half_q = (float)(Q / 2);
+        for (int idx = tid; idx < SRP_ROWS * DC; idx += SRP_THREADS) {
+            const int r = idx / DC, col = cu * DC + idx % DC;
+            const int b = team * SRP_ROWS + r;
+            if (b >= a.B) continue;
+            float acc = 0.f;
+            for (int p = 0; p < a.FS; ++p) {
+                const float xf = ((float)sh->hist[r][a.nsteps + p] / half_q - 1.0f) * 2.0f;
+                acc = fmaf(xf, a.next_Win[(size_t)p * D + col], acc);
+            }
+            a.next_in[(size_t)b * D + col] = acc + a.next_bias[col] + a.next_add[(size_t)b * a.next_ld_add + col];
+        }
+    }
 }
 
 size_t srp_lds_bytes(int D) {
