@@ -114,3 +114,33 @@ def test_raw_transformer_matches_the_reference_function():
         got = tf(chunked.copy())
         assert got.shape == gold[f'raw|{q_type}'].shape
         assert np.array_equal(got.astype(np.int64), gold[f'raw|{q_type}'].astype(np.int64)), q_type
+
+
+def test_parrot_stream_matches_the_reference_pipeline():
+    """tests/golden/stream_golden.npz: every item the reference's own parrot_stream (datasets.py:199-298, executed from the
+    reference file by make_stream_golden.py on restated Fuel classes) yields over a 19-example synthetic validation set --
+    sort window 8, batches of 4 (the short last batch dropped), padding + masks, time-major transpose, 80-sample chunks
+    quantised per utterance, TBPTT windows of 21 frames with one frame of overlap, start flag, noise source."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mk_st", os.path.join(here, "golden", "make_stream_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = np.load(os.path.join(here, "golden", "stream_golden.npz"))
+    ds = mk.synthetic_examples()
+    for case, kw in mk.CASES.items():
+        s = parrot_stream('vctk', dataset=ds, num_examples=mk.N_EXAMPLES,
+                          quantizer=lambda x, ql, qt: Q.batch_quantize(x, ql, qt), **dict(mk.COMMON, **kw))
+        assert sorted(s.sources) == gold[f'{case}|sources'].tolist(), (case, s.sources)
+        items = list(s.get_epoch_iterator())
+        assert len(items) == int(gold[f'{case}|n']), (case, len(items))
+        for k, item in enumerate(items):
+            for name, val in zip(s.sources, item):
+                ref = gold[f'{case}|{k}|{name}']
+                got = np.asarray(val)
+                assert got.shape == ref.shape, (case, k, name, got.shape, ref.shape)
+                if name == 'raw_audio':
+                    assert np.array_equal(got.astype(np.int64), ref.astype(np.int64)), (case, k, name)
+                else:
+                    assert np.array_equal(got, ref), (case, k, name)
