@@ -332,7 +332,7 @@ constexpr int BK16 = 32, PITCH16 = 40, PITCHT = 144;  // row pitches in bf16: [x
 // (xq = t & 31, k = t >> 5 and + 16): two 16-byte loads of 4 consecutive x (a wave instruction = two whole 512-byte
 // rows), one ds_write_b64 each into a [k][x] image (pitch 288 B).  The MFMA operand wants 8 consecutive k per lane:
 // ds_read_b64_tr_b16 (gfx950) hands lane i of a 16-lane group the i-th column of the 4 x 16 block the group's lanes
-// point at (measured mapping: tools/ notes in DESIGN.md 3.7), so two of them give k0 .. k0+7 of row x0 + i without any
+// point at (mapping measured with tools/tr_probe.hip), so two of them give k0 .. k0+7 of row x0 + i without any
 // transposition in registers.  The first version fetched these operands with eight 4-byte loads per thread.
 template <bool XC>
 __device__ __forceinline__ void bg_load16(const float* __restrict__ p, int x0, int X, int k0, int kend,
