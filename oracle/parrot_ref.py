@@ -394,6 +394,51 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
     return cost, new_carry, attention_vars, extras
 
 
+def cost_and_grads_checkpointed(p, cfg, features, features_mask, labels, labels_mask, speaker=None, chunk=100):
+    """compute_cost(...) followed by cost.backward() for ONE window, with the memory of `chunk` steps: truncated
+    nothing, recomputed everything (backpropagation through time with checkpoints at the chunk boundaries).  Pass 1
+    walks the window chunk by chunk without a graph and keeps the carried state (h, kappa, w) entering each chunk;
+    pass 2 walks the chunks backwards, rebuilds each chunk's graph from its stored carry, and backpropagates the
+    chunk's share of the masked mean (model.py:784) plus <carried state out, gradient wrt it from the later chunks>.
+    Parameter gradients accumulate in p[*].grad exactly as in the one-piece call (tests/test_oracle_cpu.py checks
+    that at 1e-12); this exists so that the fp64 oracle fits the host memory at T_dec = 800 (model.py:726-737
+    saves every step).  Returns (cost, attention_vars) with the per-chunk outputs concatenated along time."""
+    T = features.shape[0] - 1
+    bounds = list(range(0, T, chunk)) + [T]
+    spans = list(zip(bounds[:-1], bounds[1:]))
+    den = features_mask[1:].sum() + 1e-5
+    carries, nums, avs = [None], [], []
+    with torch.no_grad():
+        carry = None
+        for i, (a, b) in enumerate(spans):
+            c, carry, av, _ = compute_cost(p, cfg, features[a:b + 1], features_mask[a:b + 1], labels, labels_mask,
+                                           speaker, 1 if i == 0 else 0, carry)
+            carries.append(carry)
+            nums.append(c * (features_mask[a + 1:b + 1].sum() + 1e-5))  # the chunk's masked sum
+            avs.append(av)
+    cost = sum(nums) / den
+    dcarry = None
+    for i in reversed(range(len(spans))):
+        a, b = spans[i]
+        cin = None
+        if i > 0:
+            src = carries[i]
+            cin = dict(h=[x.detach().clone().requires_grad_() for x in src['h']],
+                       k=src['k'].detach().clone().requires_grad_(), w=src['w'].detach().clone().requires_grad_())
+        c, cout, _, _ = compute_cost(p, cfg, features[a:b + 1], features_mask[a:b + 1], labels, labels_mask, speaker,
+                                     1 if i == 0 else 0, cin)
+        total = c * (features_mask[a + 1:b + 1].sum() + 1e-5) / den
+        if dcarry is not None:
+            for x, g in zip(cout['h'], dcarry['h']):
+                total = total + (x * g).sum()
+            total = total + (cout['k'] * dcarry['k']).sum() + (cout['w'] * dcarry['w']).sum()
+        total.backward()
+        if cin is not None:
+            dcarry = dict(h=[x.grad for x in cin['h']], k=cin['k'].grad, w=cin['w'].grad)
+    cat = [torch.cat([av[j] for av in avs], 0) for j in range(len(avs[0]))]
+    return cost, cat
+
+
 def sample_gmm(mu, sigma, weight, unif, noise):
     """sample_gmm (model.py:94-118) with the randomness made explicit: Theano's
     theano_rng.multinomial(pvals=weight) one-hot draw + argmax == first k with cumsum(weight) > u

@@ -26,6 +26,7 @@ struct BgArgs {
 
 int bg_launch(const BgArgs& a, hipStream_t stream);
 int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of the deterministic split-K
+void bg_set_lds_pad(int bytes);  // unused dynamic LDS per workgroup: limits co-residency (see biggemm.hip)
 
 // Operand precision of parrot_gemm's batched path: the process-wide mode (parrot_set_gemm_precision) unless a scan
 // plan running on this thread pins its own (a plan built for bf16 operands keeps them whatever the caller's mode is).

@@ -12,6 +12,8 @@
 // remapped so that each XCD (private 4 MiB L2) works on 8 x 8 blocks of tiles (bg_tile_of_block).
 #include "biggemm.h"
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -508,7 +510,14 @@ int bg_reduce_launch(const BgArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
+// Extra (unused) dynamic LDS per workgroup of the batched GEMM kernels: caps how many of them share a CU, so that a
+// product running BESIDE the latency-bound scan (the weight-gradient GEMMs) leaves wave slots and LDS
+// for the scan's workgroups.  0 = as many as fit (the stand-alone optimum).
+static std::atomic<int> g_bg_lds_pad{0};
+void bg_set_lds_pad(int bytes) { g_bg_lds_pad.store(bytes < 0 ? 0 : bytes, std::memory_order_relaxed); }
+
 int bg_launch(const BgArgs& a, hipStream_t stream) {
+    const size_t pad = (size_t)g_bg_lds_pad.load(std::memory_order_relaxed);
     if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch < 1 || a.splitk < 1 || (a.splitk > 1 && !a.ws)) return PH_ERR_BADARG;
     const bool axc = (a.sam == 1), bxc = (a.sbn == 1);
     if (!axc && a.sak != 1) return PH_ERR_BADARG;
@@ -525,10 +534,10 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     if (a.bf16) {
         dim3 b8(512);
         // vector loads of the k-contiguous layout take 8 consecutive k: both 16-byte halves must be aligned
-        if (axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<true, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-        else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel_bf16<true, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-        else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<false, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((bg_kernel_bf16<false, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        if (axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<true, true>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel_bf16<true, false>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<false, true>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((bg_kernel_bf16<false, false>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
         return (int)hipGetLastError();
     }
     static int w8 = -1;
@@ -538,15 +547,15 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     }
     if (w8) {
         dim3 b8(512);
-        if (axc && bxc) hipLaunchKernelGGL((bg_kernel8<true, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-        else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel8<true, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-        else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel8<false, true>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((bg_kernel8<false, false>), grid, b8, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+        if (axc && bxc) hipLaunchKernelGGL((bg_kernel8<true, true>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel8<true, false>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel8<false, true>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((bg_kernel8<false, false>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
         return (int)hipGetLastError();
     }
-    if (axc && bxc) hipLaunchKernelGGL((bg_kernel<true, true>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-    else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel<true, false>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-    else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel<false, true>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((bg_kernel<false, false>), grid, block, 0, stream, a, vecA, vecB, tiles_m, tiles_n);
+    if (axc && bxc) hipLaunchKernelGGL((bg_kernel<true, true>), grid, block, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+    else if (axc && !bxc) hipLaunchKernelGGL((bg_kernel<true, false>), grid, block, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+    else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel<false, true>), grid, block, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((bg_kernel<false, false>), grid, block, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
     return (int)hipGetLastError();
 }

@@ -10,6 +10,8 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
 
 static int gemm_target_wgs() {
     static int v = -1;
@@ -34,6 +36,29 @@ int parrot_set_gemm_precision(int mode) { PH_ENTRY();
 }
 
 int parrot_get_gemm_precision(void) { PH_ENTRY(); return g_gemm_bf16.load(std::memory_order_relaxed); }
+
+int parrot_set_gemm_lds_pad(int bytes) { PH_ENTRY();
+    if (bytes < 0 || bytes > 128 * 1024) return PARROT_ERR_BADARG;
+    bg_set_lds_pad(bytes);
+    return 0;
+}
+
+int parrot_stream_create(int priority, void** stream) { PH_ENTRY();
+    if (!stream) return PARROT_ERR_BADARG;
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return (int)e;
+    const int prio = priority < 0 ? greatest : (priority > 0 ? least : (least + greatest) / 2);
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
+    if (e != hipSuccess) return (int)e;
+    *stream = s;
+    return 0;
+}
+
+int parrot_stream_destroy(void* stream) { PH_ENTRY();
+    return stream ? (int)hipStreamDestroy((hipStream_t)stream) : PARROT_ERR_BADARG;
+}
 
 const char* parrot_hip_version(void) { PH_ENTRY(); return "parrot_hip 0.1.0 gfx950"; }
 
@@ -93,24 +118,34 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
         if (act != 0) return PARROT_ERR_BADARG;
         // Deterministic split-K: the slices write partial tiles to a library-owned workspace and a second kernel adds
         // them in slice order (results do not depend on scheduling).  The workspace grows on demand and is reused by
-        // later calls in stream order.  Under stream capture (no allocation possible) or when the workspace cannot be
-        // had, the product runs unsplit instead: there is no float-atomic combine any more.
+        // later calls in stream order.  Under stream capture or when the workspace cannot be had, the product runs
+        // unsplit instead: there is no float-atomic combine any more.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cs);
-        static float* ws = nullptr;
-        static size_t ws_floats = 0;
+        // One workspace per stream: products on different streams (the weight-gradient GEMMs that run beside the
+        // backward scan, model.py's _backward) never share partial tiles.  Under capture the product runs unsplit,
+        // so no graph ever holds a pointer into a workspace that a later, larger call may replace.
+        struct Ws { float* p; size_t floats; };
+        static std::mutex ws_mu;
+        static std::map<hipStream_t, Ws> ws_of;
         const size_t need = (size_t)nbatch * a.splitk * M * N;
-        if (cs == hipStreamCaptureStatusNone && need > ws_floats) {
-            if (ws) {
-                (void)hipDeviceSynchronize();
-                (void)hipFree(ws);
-                ws = nullptr;
-                ws_floats = 0;
+        float* ws = nullptr;
+        if (cs == hipStreamCaptureStatusNone) {
+            std::lock_guard<std::mutex> lock(ws_mu);
+            Ws& w = ws_of[st];
+            if (need > w.floats) {
+                if (w.p) {
+                    (void)hipStreamSynchronize(st);
+                    (void)hipFree(w.p);
+                    w.p = nullptr;
+                    w.floats = 0;
+                }
+                if (hipMalloc(&w.p, need * sizeof(float)) == hipSuccess) w.floats = need;
+                else w.p = nullptr;
             }
-            if (hipMalloc(&ws, need * sizeof(float)) == hipSuccess) ws_floats = need;
-            else ws = nullptr;
+            if (w.p && need <= w.floats) ws = w.p;
         }
-        if (ws && need <= ws_floats) {
+        if (ws) {
             a.ws = ws;
             a.bias = nullptr;  // the reducer adds it
             int rc = bg_launch(a, st);

@@ -69,10 +69,60 @@ struct PlanBase {
         if (rc__ != 0) return rc__; \
     } while (0)
 
-int launch_jobs(const SkJob* jobs, int n, hipStream_t s) {
+int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0) {
     SkLaunch L;
     PL_TRY(sk_make_launch(L, jobs, n));
+    L.full_wgs = full_wgs;
     return sk_launch(L, s);
+}
+
+// Batch rows [b0, b0 + nb) of a launch argument block: every per-row pointer moves down b0 rows, the row count
+// becomes nb.  The recurrence never mixes batch rows, so a window can be advanced as several independent row
+// ranges ("strands", see DecoderPlan) without touching any kernel.
+struct Strand { int b0, nb; };
+template <class P>
+static inline void shift(P*& p, long long rows, long long ld) { if (p) p += rows * ld; }
+void take_rows(SkJob& j, const Strand& s) {
+    if (s.b0 == 0 && s.nb == j.M) return;
+    for (int q = 0; q < j.nseg; ++q) shift(j.seg[q].A, s.b0, j.seg[q].lda);
+    shift(j.add, s.b0, j.ld_add); shift(j.out, s.b0, j.ldo);
+    shift(j.e0, s.b0, j.lde0); shift(j.e1, s.b0, j.lde1);
+    shift(j.o1, s.b0, j.ldo1); shift(j.o2, s.b0, j.ldo2);
+    shift(j.mask, s.b0, 1);
+    j.M = s.nb;
+}
+void take_rows(AttFwdArgs& g, const Strand& s) {
+    if (s.b0 == 0 && s.nb == g.B) return;
+    shift(g.h1, s.b0, g.ldh); shift(g.kappa_prev, s.b0, g.A); shift(g.ctx, s.b0, (long long)g.U * g.E);
+    shift(g.a_out, s.b0, g.A); shift(g.b_out, s.b0, g.A); shift(g.kappa_out, s.b0, g.A);
+    shift(g.phi_out, s.b0, g.U); shift(g.w_out, s.b0, g.ldw); shift(g.sup_out, s.b0, 2);
+    g.B = s.nb;
+}
+void take_rows(AttBwdArgs& g, const Strand& s) {
+    if (s.b0 == 0 && s.nb == g.B) return;
+    shift(g.dw, s.b0, g.lddw); shift(g.dw2, s.b0, g.lddw); shift(g.ctx, s.b0, (long long)g.U * g.E);
+    shift(g.a, s.b0, g.A); shift(g.b, s.b0, g.A); shift(g.kappa, s.b0, g.A); shift(g.kappa_prev, s.b0, g.A);
+    shift(g.dkappa, s.b0, g.A); shift(g.dp_out, s.b0, 3 * g.A); shift(g.dh1, s.b0, g.lddh); shift(g.sup, s.b0, 2);
+    g.B = s.nb;
+}
+void take_rows(GruStateBwdArgs& g, const Strand& s) {
+    if (s.b0 == 0 && s.nb == g.B) return;
+    for (int q = 0; q < g.nchain; ++q) {
+        GruStateBwdChain& c = g.chain[q];
+        shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.hprev, s.b0, g.H); shift(c.z, s.b0, g.H);
+        shift(c.c, s.b0, g.H); shift(c.mask, s.b0, 1); shift(c.dC, s.b0, g.H); shift(c.dG, s.b0, 2 * g.H);
+        shift(c.dhprev, s.b0, g.H);
+    }
+    g.B = s.nb;
+}
+void take_rows(LstmStateBwdArgs& g, const Strand& s) {
+    if (s.b0 == 0 && s.nb == g.B) return;
+    for (int q = 0; q < g.nchain; ++q) {
+        LstmStateBwdChain& c = g.chain[q];
+        shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.dc, s.b0, g.H); shift(c.gates, s.b0, 4 * g.H);
+        shift(c.c_prev, s.b0, g.H); shift(c.c_new, s.b0, g.H); shift(c.dP, s.b0, 4 * g.H);
+    }
+    g.B = s.nb;
 }
 
 // ----------------------------------------------------------------------------- GRU scan
@@ -270,6 +320,157 @@ struct DecoderPlan : PlanBase {
     // are the hoisted ones); layer_norm with L >= 2 therefore runs on 3.
     int schedule = 0, chunk = 50;
     bool try_persist = false;
+
+    // ---- strands and parts (schedule 0) -----------------------------------------------------------------------
+    // A step kernel of the scan is latency-bound: the matrix pipes idle while a launch waits for
+    // its first operands, reduces its partial tiles and drains.  Utterances never interact inside the scan
+    // (model.py:651-724 is row-wise), so the batch is cut into `nstrands` row ranges that advance as INDEPENDENT
+    // chains of launches, one hipStream each: while one strand sits in a launch boundary the other strands'
+    // workgroups own the CUs.  Every strand runs exactly the arithmetic of the single-chain scan on its rows (the
+    // split-K order inside a workgroup does not depend on the tile shape), so the results are bit-identical.
+    // The window is also cut along time into `parts` of `qpart` wavefront ticks, one hipGraph per (strand, part):
+    // the host can start strand 1 while strand 0's later parts are still being enqueued, and the caller can hang
+    // work that only needs the finished part (the deferred weight-gradient GEMMs) on another stream.
+    int nstrands = 1, qpart = 0, full_wgs = 0;
+    Strand cur = {0, 0};
+    std::vector<Strand> strands;
+    std::vector<hipStream_t> sside;         // streams of strands 1..n-1 (strand 0 runs on the caller's stream)
+    std::vector<hipEvent_t> ev_join;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipGraphExec_t> piece[2];   // [which][strand * nparts + part]
+
+    void free_strands() {
+        for (int w = 0; w < 2; ++w)
+            for (hipGraphExec_t e : piece[w])
+                if (e) (void)hipGraphExecDestroy(e);
+        for (hipStream_t s : sside) (void)hipStreamDestroy(s);
+        for (hipEvent_t e : ev_join) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+    }
+
+    int nparts() const { return qpart > 0 ? ceil_div(nticks(), qpart) : 1; }
+    void part_ticks(int part, int& q0, int& q1) const {
+        const int Q = nticks();
+        if (qpart <= 0) { q0 = 0; q1 = Q; return; }
+        q0 = part * qpart;
+        q1 = q0 + qpart < Q ? q0 + qpart : Q;
+    }
+    // Steps [t_lo, t_hi) that EVERY layer has finished once parts 0..part of direction `which` have run
+    // (forward: layer l lags l ticks; backward: layer l lags L-1-l ticks, walking down from T-1).
+    void part_steps(int which, int part, int& t_lo, int& t_hi) const {
+        int q0, q1;
+        part_ticks(part, q0, q1);
+        if (which == 0) {
+            t_lo = 0;
+            t_hi = q1 >= nticks() ? d.T : std::max(0, q1 - (d.L - 1));
+        } else {
+            t_hi = d.T;
+            t_lo = q1 >= nticks() ? 0 : std::min(d.T, d.T - q1 + (d.L - 1));
+        }
+    }
+
+    void setup_strands() {
+        strands.clear();
+        const char* e = getenv("PARROT_STRANDS");
+        int want = e ? atoi(e) : (d.reserved > 0 ? d.reserved : 1);
+        if (schedule != 0 || d.layer_norm || want < 1) want = 1;
+        const int blocks = ceil_div(d.B, 16);
+        if (want > blocks) want = blocks;
+        if (want > 8) want = 8;
+        const int per = ceil_div(blocks, want) * 16;
+        for (int b0 = 0; b0 < d.B; b0 += per) strands.push_back(Strand{b0, std::min(per, d.B - b0)});
+        nstrands = (int)strands.size();
+        cur = Strand{0, d.B};
+        const char* qp = getenv("PARROT_QPART");
+        qpart = qp ? atoi(qp) : (d.T >= 200 ? 100 : 0);
+        if (schedule != 0) qpart = 0;
+        const char* fw = getenv("PARROT_SK_FULL");
+        full_wgs = fw ? atoi(fw) : (nstrands > 1 ? std::max(64, 224 / nstrands) : 0);
+    }
+
+    int enqueue_piece(int which, int k, int part, hipStream_t s) {
+        BgPrecisionScope precision(d.bf16);
+        int q0, q1;
+        part_ticks(part, q0, q1);
+        cur = strands[k];
+        const int es = esplit;
+        esplit = att_default_esplit(cur.nb, d.E);
+        const int rc = which == 0 ? fwd(s, q0, q1) : bwd(s, q0, q1);
+        esplit = es;
+        cur = Strand{0, d.B};
+        return rc;
+    }
+
+    // One (strand, part) piece on stream s: a replay of its graph, or the launches themselves.
+    int run_piece(int which, int k, int part, hipStream_t s) {
+        if (!use_graph) return enqueue_piece(which, k, part, s);
+        const int np = nparts();
+        if (piece[which].empty()) piece[which].assign((size_t)nstrands * np, nullptr);
+        hipGraphExec_t& ex = piece[which][(size_t)k * np + part];
+        if (!ex) {
+            if (!cap_stream) {
+                hipError_t e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipError_t e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed);
+            if (e != hipSuccess) return (int)e;
+            const int rc = enqueue_piece(which, k, part, cap_stream);
+            hipGraph_t graph = nullptr;
+            e = hipStreamEndCapture(cap_stream, &graph);
+            if (rc != 0) {
+                if (graph) hipGraphDestroy(graph);
+                return rc;
+            }
+            if (e != hipSuccess) return (int)e;
+            e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                ex = nullptr;
+                return (int)e;
+            }
+        }
+        return (int)hipGraphLaunch(ex, s);
+    }
+
+    bool stranded(int which) const { return schedule == 0 && !(which == 0 && persist_ok) && (nstrands > 1 || qpart > 0); }
+
+    int ensure_strand_streams() {
+        if ((int)sside.size() >= nstrands - 1 && ev_fork) return 0;
+        if (!ev_fork) PL_TRY((int)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        while ((int)sside.size() < nstrands - 1) {
+            hipStream_t s = nullptr;
+            hipEvent_t e = nullptr;
+            int least = 0, greatest = 0;  // the scan is the critical path of a training step: highest priority
+            PL_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
+            PL_TRY((int)hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+            sside.push_back(s);
+            PL_TRY((int)hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev_join.push_back(e);
+        }
+        return 0;
+    }
+
+    // Parts [p0, p1) of direction `which` for all strands: the side streams fork from `s` and join it again.
+    int run_parts(int which, int p0, int p1, hipStream_t s) {
+        if (nstrands > 1) {
+            PL_TRY(ensure_strand_streams());
+            PL_TRY((int)hipEventRecord(ev_fork, s));
+            for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipStreamWaitEvent(sside[k - 1], ev_fork, 0));
+        }
+        for (int part = p0; part < p1; ++part)
+            for (int k = 0; k < nstrands; ++k) PL_TRY(run_piece(which, k, part, k == 0 ? s : sside[k - 1]));
+        for (int k = 1; k < nstrands; ++k) {
+            PL_TRY((int)hipEventRecord(ev_join[k - 1], sside[k - 1]));
+            PL_TRY((int)hipStreamWaitEvent(s, ev_join[k - 1], 0));
+        }
+        return 0;
+    }
+
+    int run_part(int which, int part, hipStream_t s) {
+        if (!stranded(which)) return part == 0 ? run(which, s) : note(PARROT_ERR_BADARG);
+        if (part < 0 || part >= nparts()) return note(PARROT_ERR_BADARG);
+        return note(run_parts(which, part, part + 1, s));
+    }
 
     int enqueue(int which, hipStream_t s) override {
         BgPrecisionScope precision(d.bf16);  // the hoisted projections follow the plan's operand mode
@@ -591,6 +792,7 @@ struct DecoderPlan : PlanBase {
         j.o1 = d.z[l] + t * BH; j.ldo1 = d.H;
         j.o2 = d.r[l] + t * BH; j.ldo2 = d.H;
         j.out = d.rh[l] + t * BH; j.ldo = d.H;
+        take_rows(j, cur);
     }
 
     void cand_job(SkJob& j, int l, int t) const {
@@ -604,6 +806,7 @@ struct DecoderPlan : PlanBase {
         j.e1 = d.z[l] + t * BH; j.lde1 = d.H;
         j.o1 = d.c[l] + t * BH; j.ldo1 = d.H;
         j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
+        take_rows(j, cur);
     }
 
     void lstm_job(SkJob& j, int l, int t) const {
@@ -617,6 +820,7 @@ struct DecoderPlan : PlanBase {
         j.o1 = d.cst[l] + (t + 1) * BH; j.ldo1 = d.H;
         j.o2 = d.gate4[l] + t * 4 * BH; j.ldo2 = 4 * d.H;
         j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
+        take_rows(j, cur);
     }
 
     int att_fwd_step(int t, hipStream_t st) const {
@@ -633,14 +837,17 @@ struct DecoderPlan : PlanBase {
         g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
         g.sharpening = d.sharpening; g.timing = d.timing;
         g.sup_out = d.att_sup ? d.att_sup + (size_t)t * d.B * 2 : nullptr;
+        take_rows(g, cur);
         return att_fwd_launch(g, st);
     }
 
     // Forward wavefront: at tick q layer l advances step t = q - l, so the gate GEMMs of all layers share
     // one launch, the candidate GEMMs a second one, and the attention of step q is the third.  Layer
     // l >= 1 needs h_j(t) (j < l) and w_t, both produced in earlier ticks; layer 0 needs w_{t-1}.
-    int fwd(hipStream_t st) {
-        for (int q = 0; q < d.T + d.L - 1; ++q) {
+    int nticks() const { return d.T + d.L - 1; }
+    int fwd(hipStream_t st) { return fwd(st, 0, nticks()); }
+    int fwd(hipStream_t st, int q0, int q1) {
+        for (int q = q0; q < q1; ++q) {
             SkJob jobs[PARROT_MAX_LAYERS];
             int n = 0;
             if (d.cell == 1) {  // LSTM layers: a single fused GEMM + cell update per layer-step
@@ -648,7 +855,7 @@ struct DecoderPlan : PlanBase {
                     const int t = q - l;
                     if (t >= 0 && t < d.T) lstm_job(jobs[n++], l, t);
                 }
-                PL_TRY(launch_jobs(jobs, n, st));
+                PL_TRY(launch_jobs(jobs, n, st, full_wgs));
                 if (q < d.T) PL_TRY(att_fwd_step(q, st));
                 continue;
             }
@@ -656,13 +863,13 @@ struct DecoderPlan : PlanBase {
                 const int t = q - l;
                 if (t >= 0 && t < d.T) gates_job(jobs[n++], l, t);
             }
-            PL_TRY(launch_jobs(jobs, n, st));
+            PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             n = 0;
             for (int l = 0; l < d.L; ++l) {
                 const int t = q - l;
                 if (t >= 0 && t < d.T) cand_job(jobs[n++], l, t);
             }
-            PL_TRY(launch_jobs(jobs, n, st));
+            PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             if (q < d.T) PL_TRY(att_fwd_step(q, st));
         }
         return 0;
@@ -674,10 +881,11 @@ struct DecoderPlan : PlanBase {
     // Gradient contributions that cross layers land in separate buffers (dhup[l] for the state, dw0
     // for layer 0's share of dw), so no two jobs of a launch update the same element: no atomics, and
     // the result is deterministic.  The consumers add the parts when they read.
-    int bwd(hipStream_t st) {
-        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
+    int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
+    int bwd(hipStream_t st, int q0, int q1) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
         const int H = d.H, E = d.E;
-        for (int q = 0; q < d.T + d.L - 1; ++q) {
+        for (int q = q0; q < q1; ++q) {
             int tl[PARROT_MAX_LAYERS];
             for (int l = 0; l < d.L; ++l) tl[l] = d.T - 1 - (q - (d.L - 1 - l));
             const int t0 = tl[0];
@@ -701,6 +909,7 @@ struct DecoderPlan : PlanBase {
                     c.c_new = d.cst[l] + (t + 1) * BH;
                     c.dP = d.dG[l] + (size_t)t * 4 * BH;
                 }
+                take_rows(la, cur);
                 if (la.nchain > 0) PL_TRY(att_state_bwd_launch(att_on ? &g : nullptr, la, att_on ? la.nchain - 1 : -1, st));
                 for (int l = d.L - 1; l >= 0; --l) {
                     const int t = tl[l];
@@ -731,7 +940,8 @@ struct DecoderPlan : PlanBase {
                         j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
                     }
                 }
-                if (nl > 0) PL_TRY(launch_jobs(jl, nl, st));
+                for (int q2 = 0; q2 < nl; ++q2) take_rows(jl[q2], cur);
+                if (nl > 0) PL_TRY(launch_jobs(jl, nl, st, full_wgs));
                 continue;
             }
             GruStateBwdArgs ga;
@@ -795,9 +1005,12 @@ struct DecoderPlan : PlanBase {
             }
             if (ga.nchain == 0) continue;
             // layer 0's chain (if active) is the last one added; attention + all state updates in one launch
+            take_rows(ga, cur);
+            for (int q2 = 0; q2 < nx; ++q2) take_rows(jx[q2], cur);
+            for (int q2 = 0; q2 < ny; ++q2) take_rows(jy[q2], cur);
             PL_TRY(att_state_bwd_launch(att_on ? &g : nullptr, ga, att_on ? ga.nchain - 1 : -1, st));
-            PL_TRY(launch_jobs(jx, nx, st));
-            PL_TRY(launch_jobs(jy, ny, st));
+            PL_TRY(launch_jobs(jx, nx, st, full_wgs));
+            PL_TRY(launch_jobs(jy, ny, st, full_wgs));
         }
         return 0;
     }
@@ -915,6 +1128,7 @@ struct DecoderPlan : PlanBase {
         g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
         g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = d.H;
         g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
+        take_rows(g, cur);
         return g;
     }
     int att_bwd_step(int t0, hipStream_t st) const { return att_bwd_launch(att_bwd_args(t0), st); }
@@ -1211,6 +1425,7 @@ struct DecoderPlan : PlanBase {
 
     int run(int which, hipStream_t s) override {
         BgPrecisionScope precision(d.bf16);
+        if (stranded(which)) return note(run_parts(which, 0, nparts(), s));
         if (schedule != 2) return PlanBase::run(which, s);
         return note(run_pipe(which, s));
     }
@@ -1230,6 +1445,7 @@ struct DecoderPlan : PlanBase {
     size_t ev_next = 0;
 
     ~DecoderPlan() override {
+        free_strands();
         for (int w = 0; w < 2; ++w)
             for (auto g : pieces[w])
                 if (g) hipGraphExecDestroy(g);
@@ -1897,6 +2113,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         }
     }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
+    p->setup_strands();
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule >= 2;
         for (int l = 1; l < desc->L && ok; ++l)
@@ -1930,6 +2147,26 @@ int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(
 
 int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_decoder_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
+int parrot_decoder_parts(void* plan, int* strands) { PH_ENTRY();
+    if (!plan) return 0;
+    DecoderPlan* p = static_cast<DecoderPlan*>(plan);
+    if (strands) *strands = p->nstrands;
+    return p->stranded(1) ? p->nparts() : 1;
+}
+int parrot_decoder_part_steps(void* plan, int which, int part, int* t_lo, int* t_hi) { PH_ENTRY();
+    if (!plan || !t_lo || !t_hi || which < 0 || which > 1) return PARROT_ERR_BADARG;
+    DecoderPlan* p = static_cast<DecoderPlan*>(plan);
+    if (!p->stranded(which)) { *t_lo = 0; *t_hi = p->d.T; return part == 0 ? 0 : PARROT_ERR_BADARG; }
+    if (part < 0 || part >= p->nparts()) return PARROT_ERR_BADARG;
+    p->part_steps(which, part, *t_lo, *t_hi);
+    return 0;
+}
+int parrot_decoder_seq_fwd_part(void* plan, int part, void* stream) { PH_ENTRY();
+    return plan ? static_cast<DecoderPlan*>(plan)->run_part(0, part, (hipStream_t)stream) : PARROT_ERR_BADARG;
+}
+int parrot_decoder_seq_bwd_part(void* plan, int part, void* stream) { PH_ENTRY();
+    return plan ? static_cast<DecoderPlan*>(plan)->run_part(1, part, (hipStream_t)stream) : PARROT_ERR_BADARG;
+}
 int parrot_decoder_destroy(void* plan) { PH_ENTRY();
     delete static_cast<PlanBase*>(plan);
     return 0;

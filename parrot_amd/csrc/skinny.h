@@ -53,6 +53,8 @@ struct SkLaunch {
     SkJob job[SK_MAXJOB];
     int njobs, zmode;  // zmode: grid.z = job index (all jobs have the same number of workgroups)
     int tile_end[SK_MAXJOB];  // 16-column tiles per job; sk_launch turns it into the prefix of workgroups
+    int full_wgs;  // host-side hint: workgroups at which the launch counts as filling its share of the chip
+                   // (0 = the whole chip, 224); plans that run several launches side by side pass less
 };
 
 // Enqueue one launch on `stream`. Returns hipError_t / PH_ERR_*.

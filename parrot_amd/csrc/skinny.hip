@@ -990,6 +990,7 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
     // is what limits this kernel, so prefer the shape with the fewest operand bytes per flop
     // (1/(16 mb) + 1/(16 nb)) among those that still give the chip >= 224 workgroups; if none does,
     // take the shape with the most workgroups.
+    const int full_thr = Lin.full_wgs > 0 ? Lin.full_wgs : 224;
     const int mbmax = maxM >= 49 ? 4 : (maxM + 15) / 16;
     int best_mb = 1, best_nb = 1, best_wg = -1;
     double best_cost = 1e30;
@@ -1008,7 +1009,7 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
             // fill the chip (cfg2 merged launches, and the 2300-workgroup launches of a 3 x LSTM-1536 decoder:
             // <2,2> 183 k frames/s vs <4,2> 154 k, <4,1> 162 k, <3,2> 152 k), so rows beyond 32 earn no credit
             const double cost = 1.0 / (mb > 2 ? 2 : mb) + 1.0 / nb + (mb > 2 ? 0.1 : 0.0);
-            const bool full = wg >= 224, best_full = best_wg >= 224;
+            const bool full = wg >= full_thr, best_full = best_wg >= full_thr;
             bool better;
             if (full != best_full) better = full;
             else if (full) better = cost < best_cost - 1e-9;

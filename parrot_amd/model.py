@@ -114,7 +114,7 @@ class Parrot(Brick):
             raw_output=False,
             # --- extensions (not in the reference) ---
             num_layers=3, encoder_literal=True, use_graph=True, seed=1234,
-            cell_type='gru', lstm_forget_bias=3.0, compute_dtype='float32',
+            cell_type='gru', lstm_forget_bias=3.0, compute_dtype='float32', strands=0,
             **kwargs):
         kwargs.setdefault('name', 'parrot')
         kwargs.setdefault('weights_init', IsotropicGaussian(0.01))  # train.py:30
@@ -146,6 +146,9 @@ class Parrot(Brick):
         self.num_speakers, self.speaker_dim = num_speakers, speaker_dim
         self.k_gmm, self.sampling_bias = k_gmm, sampling_bias
         self.num_layers, self.encoder_literal, self.use_graph = num_layers, encoder_literal, use_graph
+        # strands: independent batch-row ranges the training scan advances side by side (0: the library's default;
+        # see ParrotDecoderDesc.reserved).  Results do not depend on it.
+        self.strands = int(strands)
         # Pre-activation groups of a decoder layer: (key, width, Fork output suffix, packed matrix, name of the
         # recurrent block).  GRU (Blocks GatedRecurrent): gates 2H + candidate H.  LSTM (cell_type='lstm', the
         # BASELINE configs[3] generalisation; cell algebra of sampleRNN/lib/ops.py:505-553): one 4H group.
@@ -530,6 +533,7 @@ class Parrot(Brick):
         d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, L
         d.att_type = 1 if self.attention_type == 'softmax' else 0
         d.use_graph = int(self.use_graph)
+        d.reserved = self.strands
         d.eps, d.alignment, d.sharpening, d.timing = self.epsilon, self.attention_alignment, 1.0, 1.0
         st = self.store.storage
         for l in range(L):
@@ -852,10 +856,14 @@ class Parrot(Brick):
         dro = [dread] * L  # gradient wrt each h{l}_to_readout output
         if self.layer_norm:
             dro = [ops.simple_norm_bwd(dread, *save[('ln_ro', l)]) for l in range(L)]
+        # weight gradients of the readout stack: nothing in the backward scan needs them, so they are handed to
+        # _scan_bwd_and_weight_grads, which may run them beside the scan
+        def readout_weight_grads():
+            for l in range(L):
+                ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dro[l], out=gWr[l * H:(l + 1) * H], accumulate=True)
+            ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True)
         for l in range(L):
-            ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dro[l], out=gWr[l * H:(l + 1) * H], accumulate=True)
             self._g(f'/h{l + 1}_to_readout.b').add_(ops.colsum(dro[l]) if self.layer_norm else db)
-        ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True)
         self._g('/att_to_readout.b').add_(db)
         if self.use_speaker:
             dsum = dread.view(T, B, R).sum(0)
@@ -874,28 +882,18 @@ class Parrot(Brick):
             if t_ is not None:
                 t_.zero_()
 
-        _lib.call('parrot_decoder_seq_bwd', ws['plan'], ops._stream())
+        self._scan_bwd_and_weight_grads(ws, save, T, B, before=readout_weight_grads)
 
-        # deferred weight gradients of the scan: dW = X^T dPre over all (t, b) rows
+        # the rest of the deferred gradients of the scan (biases, per-step additive inputs)
         sg_, sc_ = self.store.storage_grad, self.store.storage
         for l in range(L):
             ll = l + 1
-            hprev = ws['h'][l][:T].view(T * B, H)
-            wsrc = (ws['w'][:T] if l == 0 else ws['w'][1:]).view(T * B, E)
             for key, wd, suf, mat, rec in self._groups:
                 dP = ws['d' + key.upper()][l].view(T * B, wd)
-                gW = sg_[f'{mat}{ll}']
-                # the candidate block of the GRU multiplies r*h_prev, every other block h_prev
-                rec_in = ws['rh'][l].view(T * B, H) if key == 'c' else hprev
-                ops.gemm(rec_in.t(), dP, out=gW[0:H], accumulate=True)
-                ops.gemm(wsrc.t(), dP, out=gW[H:H + E], accumulate=True)
-                for j in range(l):
-                    r0 = H + E + j * H
-                    dPj = dP
-                    if self.layer_norm:  # seq_bwd left the gradient wrt the pre-norm projection in ln_y
-                        dPj = ws['ln_y' + key][(l, j)].view(T * B, wd)
-                        self._g(f'/h{j + 1}_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(ops.colsum(dPj))
-                    ops.gemm(ws['h'][j][1:].view(T * B, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
+                if self.layer_norm:  # the normalised lower-layer Forks keep their own biases (model.py:703-722)
+                    for j in range(l):
+                        self._g(f'/h{j + 1}_to_h{ll}/fork_rnn{ll}_{suf}.b').add_(
+                            ops.colsum(ws['ln_y' + key][(l, j)].view(T * B, wd)))
                 db = ops.colsum(dP)
                 for n in self._layer_bias_names(ll, suf):
                     self._g(n).add_(db)
@@ -925,10 +923,8 @@ class Parrot(Brick):
         if save['start_flag']:
             ops.colsum(ws['dw'][0], out=self._g('.initial_w'), accumulate=True)
             ops.colsum(ws['dw0'][0], out=self._g('.initial_w'), accumulate=True)
-        # attention projection
-        dpj = ws['dp'].view(T * B, 3 * A)
-        ops.gemm(dpj.t(), ws['h'][0][1:].view(T * B, H), out=sg_['dec.WattT'], accumulate=True)
-        ops.colsum(dpj, out=sg_['dec.batt'], accumulate=True)
+        # attention projection bias (the weight gradient is part of _weight_grad_rows)
+        ops.colsum(ws['dp'].view(T * B, 3 * A), out=sg_['dec.batt'], accumulate=True)
         # encoder output: dctx[b] = phi[:, b, :]^T . dw_total[1:, b, :]   (batched over b)
         dctx = torch.empty(B, U, E, device=readouts.device, dtype=torch.float32)
         _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
@@ -937,6 +933,92 @@ class Parrot(Brick):
             self._scatter_rows_add(self._g('/lookuptable.W'), save['spk_idx'], demb_spk)
         self._encoder_backward(dctx, save)
         self._saved = None
+
+    def _weight_grad_rows(self, ws, save, T, B, t0, t1):
+        """Deferred weight gradients of the scan for the steps [t0, t1): dW += X[t0:t1]^T . dPre[t0:t1] over the
+        (t, b) rows (the Theano gradient of the Fork / GatedRecurrent weights inside model.py:651-724, summed over the
+        scan's steps).  Called once for the whole window, or part by part beside the backward scan."""
+        if t1 <= t0:
+            return
+        H, E, L = self.rnn_h_dim, self.encoded_input_dim, self.num_layers
+        sg_ = self.store.storage_grad
+        R = (t1 - t0) * B
+        for l in range(L):
+            ll = l + 1
+            hprev = ws['h'][l][t0:t1].view(R, H)
+            wsrc = (ws['w'][t0:t1] if l == 0 else ws['w'][t0 + 1:t1 + 1]).view(R, E)
+            for key, wd, suf, mat, rec in self._groups:
+                dP = ws['d' + key.upper()][l][t0:t1].view(R, wd)
+                gW = sg_[f'{mat}{ll}']
+                # the candidate block of the GRU multiplies r*h_prev, every other block h_prev
+                rec_in = ws['rh'][l][t0:t1].view(R, H) if key == 'c' else hprev
+                ops.gemm(rec_in.t(), dP, out=gW[0:H], accumulate=True)
+                ops.gemm(wsrc.t(), dP, out=gW[H:H + E], accumulate=True)
+                for j in range(l):
+                    r0 = H + E + j * H
+                    dPj = dP
+                    if self.layer_norm:  # seq_bwd left the gradient wrt the pre-norm projection in ln_y
+                        dPj = ws['ln_y' + key][(l, j)][t0:t1].view(R, wd)
+                    ops.gemm(ws['h'][j][t0 + 1:t1 + 1].view(R, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
+        # attention projection (h1_to_att Fork)
+        A = self.attention_size
+        ops.gemm(ws['dp'][t0:t1].view(R, 3 * A).t(), ws['h'][0][t0 + 1:t1 + 1].view(R, H),
+                 out=sg_['dec.WattT'], accumulate=True)
+
+    def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None):
+        """The backward scan and the weight-gradient GEMMs that only read what it leaves behind.  When the plan runs
+        the window in parts (parrot_decoder_parts > 1) the GEMMs of a finished part are enqueued on a second,
+        low-priority stream and run BESIDE the rest of the scan: the scan's step kernels are latency-bound and leave
+        most of the matrix pipes idle.  Same sums either way, taken in part order."""
+        plan = ws['plan']
+        lib = _lib.load()
+        nparts = int(lib.parrot_decoder_parts(plan, None))
+        overlap = nparts > 1 and os.environ.get('PARROT_DW_OVERLAP', '1') != '0'
+        if not overlap:
+            if before is not None:
+                before()
+            _lib.call('parrot_decoder_seq_bwd', plan, ops._stream())
+            self._weight_grad_rows(ws, save, T, B, 0, T)
+            return
+        main = torch.cuda.current_stream()
+        side = self._gemm_side_stream()
+        lo, hi = C.c_int(0), C.c_int(0)
+        done = T  # steps [done, T) have their weight-gradient GEMMs enqueued
+        pad = int(os.environ.get('PARROT_DW_LDS_PAD', '0'))
+        if before is not None:  # `before`: weight-gradient GEMMs whose operands are ready before the scan starts
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if pad:
+                    _lib.call('parrot_set_gemm_lds_pad', pad)
+                try:
+                    before()
+                finally:
+                    if pad:
+                        _lib.call('parrot_set_gemm_lds_pad', 0)
+        for p_ in range(nparts):
+            _lib.call('parrot_decoder_seq_bwd_part', plan, p_, main.cuda_stream)
+            _lib.call('parrot_decoder_part_steps', plan, 1, p_, C.byref(lo), C.byref(hi))
+            if lo.value < done:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    if pad:
+                        _lib.call('parrot_set_gemm_lds_pad', pad)
+                    try:
+                        self._weight_grad_rows(ws, save, T, B, lo.value, done)
+                    finally:
+                        if pad:
+                            _lib.call('parrot_set_gemm_lds_pad', 0)
+                done = lo.value
+        main.wait_stream(side)
+
+    def _gemm_side_stream(self):
+        st = getattr(self, '_side_stream', None)
+        if st is None:
+            h = C.c_void_p()
+            _lib.call('parrot_stream_create', int(os.environ.get('PARROT_DW_PRIORITY', '1')), C.byref(h))
+            self._side_stream_handle = h
+            st = self._side_stream = torch.cuda.ExternalStream(h.value, device=self._dev())
+        return st
 
     @staticmethod
     def _split(rows):

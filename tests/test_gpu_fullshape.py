@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, make_batch, rel_err
+from tests.util import assert_close, make_batch, rel_err, rel_err_elem
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,82 @@ def test_cfg4_width_lstm1536_cost_and_every_gradient(dev):
     """BASELINE configs[3] widths in fp32 (3 x LSTM-1536 + attention, 64 rows per GPU)."""
     kw = dict(num_layers=3, encoder_type='bidirectional', rnn_h_dim=1536, readouts_dim=1536, cell_type='lstm')
     _full_check(dev, kw, T=4, B=64, U=120, seed=23, kappa_bias=-1.0)
+
+
+def test_cfg2_benchmarked_window_T800_matches_oracle(dev, capsys):
+    """BASELINE configs[1] EXACTLY as bench.py runs it -- L=2 GRU, H=R=1024, B=64, T_enc=200, **T_dec=800**, the
+    train.py:30-31 initialisation with the kappa bias at -1.5, full masks -- against the fp64 oracle (checkpointed BPTT,
+    oracle/parrot_ref.cost_and_grads_checkpointed): cost, predicted frames, kappa, w, phi at 1e-4 (north star), every
+    parameter gradient at 1e-3 norm-wise.  kappa is an 800-term running sum of exp(.), h an 800-deep fp32 recurrence:
+    this is the test that says the benchmarked window itself is right, not only short ones.  Prints the norm-wise and
+    the element-wise relative errors."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=2, encoder_type='bidirectional', rnn_h_dim=1024, readouts_dim=1024)
+    T, B, U = 800, 64, 200
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=1234)  # N(0, 0.01) weights, zero biases: bench.py's model
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.5)
+    m = Parrot(device=dev, use_graph=True, **kw).allocate()
+    m.set_parameter_values(p)
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=77)
+    m.zero_grad()
+    cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+    cost.backward()
+    grads = m.get_gradient_dict()
+    for v in p.values():
+        v.requires_grad_()
+    rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=100)
+    report = [f"cost: hip {float(cost):.8f} oracle {float(rc):.8f} rel {abs(float(cost) - float(rc)) / abs(float(rc)):.2e}"]
+    assert float(rav[1][-1].min()) > 100.0, "kappa must have moved through the text for the window to mean anything"
+    for i, n in ((0, "predicted frames"), (1, "kappa"), (2, "w"), (4, "phi")):
+        e = assert_close(av[i], rav[i], 1e-4, n)
+        report.append(f"{n}: norm-wise {e:.2e}, element-wise {rel_err_elem(av[i], rav[i]):.2e}")
+    assert_close(cost, rc, 1e-4, "cost")
+    worst, n_checked = ("", 0.0), 0
+    for name, ref in p.items():
+        if ref.grad is None:
+            continue
+        scale = float(ref.grad.abs().max())
+        if scale < 1e-12:
+            assert float(grads[name].abs().max()) < 1e-6, name
+            continue
+        e = rel_err(grads[name], ref.grad)
+        assert e <= 1e-3, f"grad {name}: rel err {e:.3e} (element-wise {rel_err_elem(grads[name], ref.grad):.3e})"
+        if e > worst[1]:
+            worst = (name, e)
+        n_checked += 1
+    assert n_checked >= 10
+    report.append(f"{n_checked} parameter gradients within 1e-3; worst {worst[0]}: {worst[1]:.2e}")
+    with capsys.disabled():
+        print("\n[T800 parity] " + "\n[T800 parity] ".join(report))
+    m.close()
+
+
+def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):
+    """BASELINE configs[2] at its real length: decode, batch 16, H=1024, weak feedback, **1000 frames**, every output
+    of sample_model vs the fp64 oracle at 1e-4 (the 60-step test below cannot see a slow drift of the fed-back frame)."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=2, encoder_type='bidirectional', rnn_h_dim=1024, readouts_dim=1024, weak_feedback=True)
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=29, scale_by_fan_in=True)
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.9)  # ~0.15 positions per frame: still inside the text at frame 1000
+    m = Parrot(device=dev, use_graph=True, **kw).allocate()
+    m.set_parameter_values(p)
+    N, U, S = 16, 200, 1000
+    _, _, lab, lm, _ = make_batch(cfg, 2, N, U, seed=31)
+    with torch.no_grad():
+        ref = R.sample_model(p, cfg, lab, lm, None, S)
+    outs = m.sample_model(lab.numpy(), lm.float().numpy(), None, None, N, S)
+    report = []
+    for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+        assert o.shape == tuple(r.shape), n
+        e = assert_close(torch.from_numpy(o), r, 1e-4, n)
+        report.append(f"{n}: norm-wise {e:.2e}, element-wise {rel_err_elem(torch.from_numpy(o), r):.2e}")
+    with capsys.disabled():
+        print("\n[decode-1000 parity] " + "\n[decode-1000 parity] ".join(report))
+    m.close()
 
 
 def test_cfg3_decode_width(dev):

@@ -297,6 +297,24 @@ def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
                           use_graph=True)
 
 
+# ----------------------------------------------------------------------------- strands and parts
+@pytest.mark.parametrize("strands,qpart,overlap", [("2", "3", "1"), ("3", "0", "1"), ("4", "2", "0"), ("1", "4", "1")])
+@pytest.mark.parametrize("cell", ["gru", "lstm"])
+def test_strands_and_parts_agree_with_oracle(dev, monkeypatch, strands, qpart, overlap, cell):
+    """The training scan advanced as several independent batch-row ranges on their own streams (PARROT_STRANDS), cut
+    along time into graph parts (PARROT_QPART ticks) with the weight-gradient GEMMs of finished parts running beside
+    the rest of the backward scan (PARROT_DW_OVERLAP): the same arithmetic per row, so everything must match the
+    oracle -- ragged row ranges (B = 40 -> 32 + 8 / 16 + 16 + 8), a ragged last part, eager and graph."""
+    monkeypatch.setenv("PARROT_STRANDS", strands)
+    monkeypatch.setenv("PARROT_QPART", qpart)
+    monkeypatch.setenv("PARROT_DW_OVERLAP", overlap)
+    for use_graph in (False, True):
+        _check_cost_and_grads(dev, T=8, B=40, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
+                              use_speaker=True, cell_type=cell, use_graph=use_graph)
+    _check_cost_and_grads(dev, T=7, B=20, U=6, num_layers=2, encoder_type='bidirectional', cell_type=cell,
+                          use_graph=True, ragged=True)
+
+
 # ----------------------------------------------------------------------------- layer_norm=True (model.py:24-34)
 @pytest.mark.parametrize("kw", [
     dict(num_layers=3, full_feedback=True, use_speaker=True),
@@ -431,3 +449,43 @@ def test_full_size_cfg2_properties(dev, monkeypatch):
     assert_close(torch.cat([o2[0][1], o2[1][1]], 0), o1[0][1], 1e-5, "TBPTT carry at full size")
     _, g3 = run(False, upstream=2.0)
     assert_close(g3, 2.0 * g1, 1e-6, "backward linearity")
+
+
+def test_full_size_cfg2_strands_are_bit_identical(dev, monkeypatch):
+    """BASELINE configs[1] at its real sizes: the scan as 1, 2 and 4 strands gives bitwise the same cost, frames, kappa
+    and -- with the weight-gradient GEMMs taken over the whole window -- bitwise the same flat gradient; with the GEMMs
+    taken part by part beside the scan the gradient agrees to the rounding of the changed summation order."""
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=2, rnn_h_dim=1024, readouts_dim=1024, encoder_type='bidirectional')
+    T, B, U = 800, 64, 200
+    g = torch.Generator().manual_seed(4321)
+    feat = torch.randn(T + 1, B, 63, generator=g).to(dev)
+    fm = torch.ones(T + 1, B, device=dev)
+    lab = torch.randint(0, 43, (B, U), generator=g).to(dev)
+    lm = torch.ones(B, U, device=dev)
+
+    def run(strands, qpart, overlap):
+        monkeypatch.setenv("PARROT_STRANDS", str(strands))
+        monkeypatch.setenv("PARROT_QPART", str(qpart))
+        monkeypatch.setenv("PARROT_DW_OVERLAP", str(overlap))
+        m = Parrot(device=dev, use_graph=True, seed=5, **kw).initialize()
+        with torch.no_grad():
+            m.get_parameter_dict()['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.5)
+        m.zero_grad()
+        c, upd, av, _ = m.compute_cost(feat, fm, lab, lm, None, 1, B)
+        c.backward()
+        out = (c.detach().clone(), av[0].clone(), av[1].clone(), m.flat_gradients.clone())
+        m.close()
+        return out
+
+    base = run(1, 0, 0)
+    for strands, qpart, overlap in ((2, 0, 0), (4, 100, 0), (2, 100, 1), (4, 64, 1)):
+        o = run(strands, qpart, overlap)
+        what = f"strands={strands} qpart={qpart} overlap={overlap}"
+        assert torch.equal(o[0], base[0]), what + ": cost"
+        assert torch.equal(o[1], base[1]), what + ": frames"
+        assert torch.equal(o[2], base[2]), what + ": kappa"
+        if not overlap:
+            assert torch.equal(o[3], base[3]), what + ": gradient"
+        else:
+            assert_close(o[3], base[3], 1e-6, what + ": gradient")

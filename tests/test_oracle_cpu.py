@@ -60,6 +60,32 @@ def test_tbptt_carry_equivalence():
     assert torch.allclose(both, av[0], atol=1e-12)
 
 
+def test_checkpointed_bptt_equals_one_piece_backward():
+    """R.cost_and_grads_checkpointed (what the T_dec = 800 GPU parity test uses to fit the host memory) gives the cost,
+    the outputs and EVERY parameter gradient of the one-piece compute_cost(...).backward(): ragged masks, feedback,
+    speaker, 3 layers, a ragged last chunk."""
+    from tests.util import make_batch
+    for kw in (dict(num_layers=3, weak_feedback=True, use_speaker=True, num_speakers=4, speaker_dim=5),
+               dict(num_layers=2)):
+        cfg, p = _tiny(**kw)
+        T, B, U = 11, 3, 6
+        feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=5, ragged=True, speaker=cfg['use_speaker'])
+        for v in p.values():
+            v.requires_grad_()
+        c, _, av, _ = R.compute_cost(p, cfg, feat, fm, lab, lm, spk, 1)
+        c.backward()
+        ref = {k: v.grad.clone() for k, v in p.items() if v.grad is not None}
+        for v in p.values():
+            v.grad = None
+        c2, av2 = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, spk, chunk=4)
+        assert abs(float(c2) - float(c)) < 1e-12 * abs(float(c))
+        for x, y in zip(av, av2):
+            assert torch.allclose(x.detach(), y, atol=1e-12)
+        assert set(ref) == {k for k, v in p.items() if v.grad is not None}
+        for k, g in ref.items():
+            assert torch.allclose(p[k].grad, g, rtol=1e-10, atol=1e-13), k
+
+
 def test_sample_step_equals_train_step_under_teacher_forcing():
     """sample_step fed with the data equals the training step."""
     cfg, p = _tiny(num_layers=2)

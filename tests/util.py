@@ -14,9 +14,22 @@ def rel_err(a, b):
     return float((a - b).abs().max()) / denom
 
 
+def rel_err_elem(a, b, floor_frac=1e-3):
+    """Element-wise relative error max_i |a_i - b_i| / max(|b_i|, floor_frac * max|b|): every element is held to its
+    own magnitude, down to a floor of floor_frac of the largest one (below that an fp32 result has no relative
+    accuracy left to speak of).  Stricter than rel_err by up to 1 / floor_frac."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    top = float(b.abs().max())
+    if top == 0.0:
+        return float((a - b).abs().max())
+    return float(((a - b).abs() / b.abs().clamp_min(floor_frac * top)).max())
+
+
 def assert_close(a, b, tol, what=""):
     e = rel_err(a, b)
-    assert e <= tol, f"{what}: relative error {e:.3e} > {tol:.1e}"
+    assert e <= tol, f"{what}: relative error {e:.3e} (element-wise {rel_err_elem(a, b):.3e}) > {tol:.1e}"
     return e
 
 
