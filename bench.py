@@ -56,6 +56,12 @@ def parse():
                          "kappa advances ~1 per frame and leaves the text after ~210 frames, after which no context row "
                          "is read at all -- a favourable, unrealistic case)")
     ap.add_argument("--no-dense", action="store_true", help="skip the second timed run that reads all context rows")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` object (decode configs[2], SampleRNN configs[4], configs[3] bf16 step), "
+                         "measured after the headline region in child processes")
+    ap.add_argument("--no-parity", action="store_true", help="skip the `parity_check` object (HIP step vs fp64 oracle)")
+    ap.add_argument("--secondary-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--parity-only", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.config == "cfg4":
         a.L, a.H, a.cell = 3, 1536, "lstm"
@@ -218,6 +224,136 @@ def cpu_baseline_leg(a):
                       f"oracle/parrot_ref.py (torch-CPU fp32, autograd backward, clip+Adam), {nthreads} threads"}
 
 
+def parity_leg(a):
+    """The HIP training step against the fp64 oracle ON THE CPU-BASELINE LEG'S OWN BATCH (the cfg2 shapes at T_dec =
+    --cpu-T, seed 99, the same initialisation): relative errors of the cost, the predicted frames, kappa and the worst
+    parameter gradient.  The oracle is the checker here, never the thing timed or shipped."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    torch.set_num_threads(host_cores())
+    dev = torch.device("cuda", 0)
+    kw = model_kwargs(a)
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=1234)  # float64
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(a.kappa_bias)
+    g = torch.Generator().manual_seed(99)
+    lab = torch.randint(0, 43, (a.B, a.U), generator=g)
+    lm = torch.ones(a.B, a.U, dtype=torch.float64)
+    feat = torch.randn(a.cpu_T + 1, a.B, 63, generator=g).double()
+    fm = torch.ones(a.cpu_T + 1, a.B, dtype=torch.float64)
+    m = Parrot(device=dev, use_graph=True, compute_dtype='bf16' if a.dtype == 'bf16' else 'float32', **kw).allocate()
+    m.set_parameter_values(p)
+    m.zero_grad()
+    cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, a.B)
+    cost.backward()
+    grads = m.get_gradient_dict()
+    for v in p.values():
+        v.requires_grad_()
+    rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=50)
+
+    def rel(x, y):
+        x, y = torch.as_tensor(x).detach().double().cpu(), torch.as_tensor(y).detach().double().cpu()
+        return float((x - y).abs().max() / y.abs().max())
+    worst = ("", 0.0)
+    for name, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+            continue
+        e = rel(grads[name], ref.grad)
+        if e > worst[1]:
+            worst = (name, e)
+    m.close()
+    return {"against": "oracle/parrot_ref.py in float64 (checkpointed BPTT)", "T_dec": a.cpu_T, "batch": a.B,
+            "cost_hip": float(cost), "cost_oracle": float(rc),
+            "cost_rel_err": abs(float(cost) - float(rc)) / abs(float(rc)),
+            "frames_rel_err": rel(av[0], rav[0]), "kappa_rel_err": rel(av[1], rav[1]),
+            "grad_rel_err_max": worst[1], "grad_worst": worst[0],
+            "norm": "max|hip - oracle| / max|oracle| per tensor"}
+
+
+def secondary_leg(a):
+    """BASELINE configs[2] (decode latency) and configs[4] (SampleRNN sample loop) on the device, a few seconds each,
+    each against its own algorithmic-bytes roofline (58.5 MB of weights per decode step, 27.4 MB per
+    SampleRNN sample step; HBM peak 8 TB/s)."""
+    import numpy  # noqa: F401
+    dev = torch.device("cuda", 0)
+    out = {}
+    from parrot_amd.model import Parrot
+    m = Parrot(device=dev, num_layers=2, rnn_h_dim=1024, readouts_dim=1024, encoder_type='bidirectional',
+               weak_feedback=True, use_graph=True).initialize()
+    g = torch.Generator().manual_seed(0)
+    N, U, S = 16, 100, 1000
+    lab, lm = torch.randint(0, 43, (N, U), generator=g), torch.ones(N, U)
+    best = None
+    for rep in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.sample_model_device(lab, lm, None, N, S)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if rep > 0:
+            best = dt if best is None else min(best, dt)
+    m.close()
+    alg = 58.5e6
+    out["decode_cfg3"] = {"workload": "BASELINE configs[2]: greedy decode, batch 16, 1000 frames, 2-layer GRU h=1024, feedback on",
+                          "us_per_step": round(1e6 * best / S, 2), "frames_per_s": round(N * S / best, 1),
+                          "alg_bytes_per_step": int(alg), "alg_GBps": round(alg * S / best * 1e-9, 1),
+                          "frac": round(alg * S / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000}
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params(); lib.set_device(dev)
+    tt.configure(DIM=1024, EMB_SIZE=256)
+    B, T = 32, 26  # 25 generated big frames = 2000 samples per stream
+    seq = torch.randint(0, 256, (2, 160 + 80), generator=g).to(dev)
+    with torch.no_grad():  # registers all parameters with the reference initialisation
+        tt.compute_cost(seq, torch.randn(2, 2, 63, device=dev), torch.zeros(2, 1, 1024, device=dev),
+                        torch.zeros(2, 1, 1024, device=dev), 1, torch.ones(2, 240, device=dev))
+    gen = tt.DeviceGenerator(B, T, temperature=0.0)
+    feats = torch.randn(T, B, 63, generator=g).numpy()
+    best = None
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        gen.generate(feats)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if rep > 0:
+            best = dt if best is None else min(best, dt)
+    gen.close()
+    nsamp = (T - 1) * 80
+    alg = 27.4e6
+    out["samplernn_cfg5"] = {"workload": "BASELINE configs[4]: 3-tier GRU h=1024, batch 32, greedy, 2000 samples per stream",
+                             "us_per_sample_step": round(1e6 * best / nsamp, 2),
+                             "samples_per_s": round(B * nsamp / best, 1),
+                             "x_realtime_per_stream": round(nsamp / best / 16000.0, 3),
+                             "alg_bytes_per_sample_step": int(alg), "alg_GBps": round(alg * nsamp / best * 1e-9, 1),
+                             "frac": round(alg * nsamp / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000}
+    return out
+
+
+def child_json(a, flag, extra=(), timeout=420):
+    """Runs `bench.py <flag>` in a child process (own HIP context, hard wall-clock limit) and returns its JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), flag, "--T", str(a.T), "--B", str(a.B), "--U", str(a.U),
+           "--H", str(a.H), "--L", str(a.L), "--cell", a.cell, "--dtype", a.dtype, "--cpu-T", str(a.cpu_T),
+           "--kappa-bias", str(a.kappa_bias)] + list(extra)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"exceeded its {timeout} s limit"}
+
+
+def secondary_subprocess(a):
+    sec = child_json(a, "--secondary-only", timeout=300)
+    if a.config == "cfg2":  # BASELINE configs[3] per GPU (the 8-GPU line's workload), bf16 operands
+        d = child_json(a, "--no-secondary", ["--config", "cfg4", "--no-cpu-baseline", "--no-dense", "--no-parity",
+                                              "--steps", "3", "--warmup", "1", "--L", "3", "--H", "1536",
+                                              "--cell", "lstm", "--dtype", "bf16"], timeout=420)
+        sec["cfg4_bf16"] = ({"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"],
+                             "frames_per_s": d["value"], "roofline": d.get("roofline")}
+                            if "ms_per_step" in d else d)
+    return sec
+
+
 def cpu_baseline_subprocess(a):
     """Runs the CPU leg in a child process with a hard wall-clock limit so a mis-sized thread pool can
     never stall the GPU job."""
@@ -242,6 +378,12 @@ def main():
     torch.set_num_threads(host_cores())
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline_leg(a)), flush=True)
+        return
+    if a.secondary_only:
+        print(json.dumps(secondary_leg(a)), flush=True)
+        return
+    if a.parity_only:
+        print(json.dumps(parity_leg(a)), flush=True)
         return
     from parrot_amd import dist as pdist
     rank, local_rank, world = pdist.init_process_group()
@@ -285,13 +427,20 @@ def main():
         dense = {"value": round(world * a.B * a.T * a.steps / el_d, 1), "ms_per_step": round(1e3 * el_d / a.steps, 3)}
         model.close()
 
-    roof = cpu = None
+    roof = cpu = parity = secondary = None
     if rank == 0:
         if not a.no_roofline:
             roof = roofline_leg(a, dev, model.flat_parameters)
-        if world == 1 and not a.no_cpu_baseline:
-            cpu = cpu_baseline_subprocess(a)
     model.close()
+    if rank == 0 and world == 1:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline_subprocess(a)
+        if not a.no_parity:
+            parity = child_json(a, "--parity-only", timeout=300)
+        if not a.no_secondary:
+            secondary = secondary_subprocess(a)
     if world > 1:
         pdist.barrier()
     if rank == 0:
@@ -320,7 +469,7 @@ def main():
                        "scan_schedule": os.environ.get("PARROT_SCHEDULE", "0 (merged wavefront launches)")},
             "dense": dense,
             "final_cost": round(final_cost, 5),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity_check": parity, "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -78,6 +78,7 @@ __device__ __forceinline__ bool pm_spin_ge(unsigned* p, unsigned target, unsigne
             if (pm_ld(sync + PM_S_ABORT)) return false;
             if (wall_clock64() - t0 > 20000000ull) {
                 pm_st(sync + PM_S_ABORT, 1u);
+                pm_st(sync + PM_S_STICKY, 1u);  // the word pm_status reads: survives the next launch's clearing
                 return false;
             }
         }
@@ -587,7 +588,10 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
         }
     }
     unsigned epoch = 1;
-    if (!DF && !pm_barrier(sync, bar, epoch++, &ok_sh)) return;
+    if (!DF && !pm_barrier(sync, bar, epoch++, &ok_sh)) {
+        if (tid == 0) pm_st(sync + PM_S_STICKY, 1u);
+        return;
+    }
 
     // phase timers (work / barrier wait per slot, summed over the ticks): a handful of s_memrealtime reads per phase
     unsigned long long* t_work = reinterpret_cast<unsigned long long*>(lds_red + PM_LDS_RED + PM_LDS_UNITS + 20);

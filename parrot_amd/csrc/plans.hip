@@ -7,7 +7,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/parrot_hip.h"
@@ -340,6 +344,7 @@ struct DecoderPlan : PlanBase {
     std::vector<hipGraphExec_t> piece[2];   // [which][strand * nparts + part]
 
     void free_strands() {
+        stop_workers();
         for (int w = 0; w < 2; ++w)
             for (hipGraphExec_t e : piece[w])
                 if (e) (void)hipGraphExecDestroy(e);
@@ -384,6 +389,8 @@ struct DecoderPlan : PlanBase {
         const char* qp = getenv("PARROT_QPART");
         qpart = qp ? atoi(qp) : (d.T >= 200 ? 100 : 0);
         if (schedule != 0) qpart = 0;
+        const char* th = getenv("PARROT_STRAND_THREADS");
+        use_threads = th ? atoi(th) != 0 : true;
         const char* fw = getenv("PARROT_SK_FULL");
         full_wgs = fw ? atoi(fw) : (nstrands > 1 ? std::max(64, 224 / nstrands) : 0);
     }
@@ -392,44 +399,90 @@ struct DecoderPlan : PlanBase {
         BgPrecisionScope precision(d.bf16);
         int q0, q1;
         part_ticks(part, q0, q1);
-        cur = strands[k];
-        const int es = esplit;
-        esplit = att_default_esplit(cur.nb, d.E);
+        cur = strands[k];  // (the attention keeps the column split of the whole batch: its sums depend on it)
         const int rc = which == 0 ? fwd(s, q0, q1) : bwd(s, q0, q1);
-        esplit = es;
         cur = Strand{0, d.B};
         return rc;
     }
 
-    // One (strand, part) piece on stream s: a replay of its graph, or the launches themselves.
-    int run_piece(int which, int k, int part, hipStream_t s) {
-        if (!use_graph) return enqueue_piece(which, k, part, s);
+    // Graph of one (strand, part) piece; captured on first use, on the caller's thread.
+    int capture_piece(int which, int k, int part) {
         const int np = nparts();
         if (piece[which].empty()) piece[which].assign((size_t)nstrands * np, nullptr);
         hipGraphExec_t& ex = piece[which][(size_t)k * np + part];
-        if (!ex) {
-            if (!cap_stream) {
-                hipError_t e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
-                if (e != hipSuccess) return (int)e;
-            }
-            hipError_t e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed);
+        if (ex) return 0;
+        if (!cap_stream) {
+            hipError_t e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
             if (e != hipSuccess) return (int)e;
-            const int rc = enqueue_piece(which, k, part, cap_stream);
-            hipGraph_t graph = nullptr;
-            e = hipStreamEndCapture(cap_stream, &graph);
-            if (rc != 0) {
-                if (graph) hipGraphDestroy(graph);
-                return rc;
-            }
-            if (e != hipSuccess) return (int)e;
-            e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
-            if (e != hipSuccess) {
-                ex = nullptr;
-                return (int)e;
-            }
         }
-        return (int)hipGraphLaunch(ex, s);
+        hipError_t e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed);
+        if (e != hipSuccess) return (int)e;
+        const int rc = enqueue_piece(which, k, part, cap_stream);
+        hipGraph_t graph = nullptr;
+        e = hipStreamEndCapture(cap_stream, &graph);
+        if (rc != 0) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return (int)e;
+        e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            ex = nullptr;
+            return (int)e;
+        }
+        return 0;
+    }
+
+    // Parts [p0, p1) of strand k on stream s: replays of their graphs, or the launches themselves.
+    int run_strand(int which, int k, int p0, int p1, hipStream_t s) {
+        const int np = nparts();
+        for (int part = p0; part < p1; ++part) {
+            if (!use_graph) PL_TRY(enqueue_piece(which, k, part, s));
+            else PL_TRY((int)hipGraphLaunch(piece[which][(size_t)k * np + part], s));
+        }
+        return 0;
+    }
+
+    // A host thread per side strand: replaying a graph costs host time per kernel node, and one thread feeding
+    // several streams hands the device its strands one piece after the other (measured: the queues then alternate
+    // piece by piece instead of running side by side).  The workers only replay instantiated graphs.
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        int which = 0, p0 = 0, p1 = 0, rc = 0, device = 0;
+        bool pending = false, quit = false;
+    };
+    std::vector<std::unique_ptr<Worker>> workers;
+    bool use_threads = false;
+
+    void worker_main(int k) {
+        Worker& w = *workers[k - 1];
+        (void)hipSetDevice(w.device);
+        std::unique_lock<std::mutex> lock(w.mu);
+        for (;;) {
+            w.cv.wait(lock, [&] { return w.pending || w.quit; });
+            if (w.quit) return;
+            hipStream_t st = sside[k - 1];
+            int rc = (int)hipStreamWaitEvent(st, ev_fork, 0);
+            if (rc == 0) rc = run_strand(w.which, k, w.p0, w.p1, st);
+            if (rc == 0) rc = (int)hipEventRecord(ev_join[k - 1], st);
+            w.rc = rc;
+            w.pending = false;
+            w.cv.notify_all();
+        }
+    }
+    void stop_workers() {
+        for (auto& w : workers) {
+            {
+                std::lock_guard<std::mutex> lock(w->mu);
+                w->quit = true;
+            }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+        workers.clear();
     }
 
     bool stranded(int which) const { return schedule == 0 && !(which == 0 && persist_ok) && (nstrands > 1 || qpart > 0); }
@@ -440,9 +493,12 @@ struct DecoderPlan : PlanBase {
         while ((int)sside.size() < nstrands - 1) {
             hipStream_t s = nullptr;
             hipEvent_t e = nullptr;
-            int least = 0, greatest = 0;  // the scan is the critical path of a training step: highest priority
+            int least = 0, greatest = 0;
             PL_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
-            PL_TRY((int)hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+            const char* pe = getenv("PARROT_STRAND_PRIO");  // -1 highest, 0 default (default), 1 lowest
+            const int pr = pe ? atoi(pe) : 0;
+            PL_TRY((int)hipStreamCreateWithPriority(&s, hipStreamNonBlocking,
+                                                    pr < 0 ? greatest : (pr > 0 ? least : (least + greatest) / 2)));
             sside.push_back(s);
             PL_TRY((int)hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ev_join.push_back(e);
@@ -452,17 +508,46 @@ struct DecoderPlan : PlanBase {
 
     // Parts [p0, p1) of direction `which` for all strands: the side streams fork from `s` and join it again.
     int run_parts(int which, int p0, int p1, hipStream_t s) {
-        if (nstrands > 1) {
-            PL_TRY(ensure_strand_streams());
-            PL_TRY((int)hipEventRecord(ev_fork, s));
+        if (use_graph)  // all captures on this thread, before anything is handed to the workers
+            for (int part = p0; part < p1; ++part)
+                for (int k = 0; k < nstrands; ++k) PL_TRY(capture_piece(which, k, part));
+        if (nstrands == 1) return run_strand(which, 0, p0, p1, s);
+        PL_TRY(ensure_strand_streams());
+        PL_TRY((int)hipEventRecord(ev_fork, s));
+        const bool threaded = use_threads && use_graph;
+        if (threaded) {
+            if (workers.empty()) {
+                int dev = 0;
+                PL_TRY((int)hipGetDevice(&dev));
+                for (int k = 1; k < nstrands; ++k) {
+                    workers.emplace_back(new Worker());
+                    workers.back()->device = dev;
+                }
+                for (int k = 1; k < nstrands; ++k) workers[k - 1]->th = std::thread([this, k] { worker_main(k); });
+            }
+            for (int k = 1; k < nstrands; ++k) {
+                Worker& w = *workers[k - 1];
+                {
+                    std::lock_guard<std::mutex> lock(w.mu);
+                    w.which = which; w.p0 = p0; w.p1 = p1; w.pending = true;
+                }
+                w.cv.notify_all();
+            }
+            int rc = run_strand(which, 0, p0, p1, s);
+            for (int k = 1; k < nstrands; ++k) {  // the join events are recorded once the workers are through
+                Worker& w = *workers[k - 1];
+                std::unique_lock<std::mutex> lock(w.mu);
+                w.cv.wait(lock, [&] { return !w.pending; });
+                if (rc == 0) rc = w.rc;
+            }
+            PL_TRY(rc);
+        } else {
             for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipStreamWaitEvent(sside[k - 1], ev_fork, 0));
+            for (int part = p0; part < p1; ++part)
+                for (int k = 0; k < nstrands; ++k) PL_TRY(run_strand(which, k, part, part + 1, k == 0 ? s : sside[k - 1]));
+            for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipEventRecord(ev_join[k - 1], sside[k - 1]));
         }
-        for (int part = p0; part < p1; ++part)
-            for (int k = 0; k < nstrands; ++k) PL_TRY(run_piece(which, k, part, k == 0 ? s : sside[k - 1]));
-        for (int k = 1; k < nstrands; ++k) {
-            PL_TRY((int)hipEventRecord(ev_join[k - 1], sside[k - 1]));
-            PL_TRY((int)hipStreamWaitEvent(s, ev_join[k - 1], 0));
-        }
+        for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipStreamWaitEvent(s, ev_join[k - 1], 0));
         return 0;
     }
 

@@ -85,6 +85,12 @@ __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M,
 #ifndef SK_DEPTH
 #define SK_DEPTH 2
 #endif
+#ifndef SK_PIPE
+#define SK_PIPE 0
+#endif
+#ifndef SK_A_FRAG_PROBE
+#define SK_A_FRAG_PROBE 0
+#endif
 
 template <int MB>
 __device__ __forceinline__ void sk_mma(const f32x4 (&a)[MB], const f32x4& b, f32x4 (&acc)[MB]) {
@@ -105,7 +111,12 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
     const int k = kc + 4 * kk;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) {
-#if SK_A_PERMUTE
+#if SK_A_FRAG_PROBE
+        // TIMING PROBE ONLY (values are wrong): the load pattern of a fragment-major activation copy -- one contiguous
+        // 1 KB block per (16-row block, 16-deep chunk), lanes in MFMA operand order, no lane permutation afterwards
+        a[rb] = *reinterpret_cast<const f32x4*>(A + ((size_t)((mrow[rb] >> 4) * (lda >> 4) + (kc >> 4)) << 8) +
+                                                ((threadIdx.x & 63) << 2));
+#elif SK_A_PERMUTE
         // quad-contiguous mapping: lane l reads 16 B of row (l >> 2) at k-offset 4 * (l & 3), so every quad of
         // lanes covers one contiguous 64-B segment; sk_a_unpermute moves the quads to the MFMA lanes later.
         a[rb] = *reinterpret_cast<const f32x4*>(A + (size_t)mrow[rb] * lda + kc + 4 * (threadIdx.x & 3));
@@ -132,7 +143,7 @@ __device__ __forceinline__ void sk_fetch_fast(const float* __restrict__ A, int l
 // MFMA lane (kk, i) = kk * 16 + i takes the quad that lane 4 * i + kk loaded (see sk_fetch_fast).
 template <int MB>
 __device__ __forceinline__ void sk_a_unpermute(f32x4 (&a)[MB]) {
-#if SK_A_PERMUTE
+#if SK_A_PERMUTE && !SK_A_FRAG_PROBE
     const int lane = threadIdx.x & 63;
     const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;  // byte address of the source lane
 #pragma unroll
@@ -307,6 +318,41 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 }
                 sk_fetch_fast<MB, NB, BM>(A, lda, B, ldb, (g - beg) << 4, mrow, ncl, btile, kk, a, b);
             };
+#if SK_PIPE
+            // Three-stage software pipeline, stages kept apart with scheduling barriers: [loads of chunk i+SK_DEPTH-1]
+            // [lane permutation of chunk i+1 (ds_bpermute into its own registers)] [MFMAs of chunk i].  Left to itself
+            // the scheduler parks every ds_bpermute right in front of the MFMA pair that consumes it, so each pair
+            // waits out an LDS round trip (s_waitcnt lgkmcnt(0) eight times per chunk) and the matrix pipe starves;
+            // it also hoists later chunks' permutations upwards, which drags their vmcnt waits along and collapses
+            // the load prefetch distance.  Here the permutation of the next chunk flies while this chunk multiplies.
+            {
+                f32x4 ra[SK_DEPTH][MB], rb_[SK_DEPTH][NB], pa[2][MB];
+#pragma unroll
+                for (int dd = 0; dd < SK_DEPTH; ++dd) fetch(min(first + dd * STR, last), ra[dd], rb_[dd]);
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) pa[0][rb] = ra[0][rb];
+                sk_a_unpermute<MB>(pa[0]);
+                int g = first;
+                // one iteration = SK_DEPTH chunks (static slot indices); the tail runs with clamped fetches
+                const int ngroups = (mine + SK_DEPTH - 1) / SK_DEPTH;
+                for (int gr = 0; gr < ngroups; ++gr) {
+#pragma unroll
+                    for (int dd = 0; dd < SK_DEPTH; ++dd) {
+                        const int nx = (dd + 1) % SK_DEPTH;
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int rb = 0; rb < MB; ++rb) pa[(dd + 1) & 1][rb] = ra[nx][rb];
+                        sk_a_unpermute<MB>(pa[(dd + 1) & 1]);   // next chunk's lanes, consumed one stage later
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (g + dd * STR <= last) sk_mma2<MB, NB>(pa[dd & 1], rb_[dd], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fetch(min(g + (SK_DEPTH + dd) * STR, last), ra[dd], rb_[dd]);
+                    }
+                    g += SK_DEPTH * STR;
+                }
+                return;
+            }
+#endif
             // Ring of SK_DEPTH register buffers, SK_DEPTH chunks per iteration, each slot refilled right after
             // it has fed the MFMAs: no register copies, so nothing in the body waits for loads it has just
             // issued, and SK_DEPTH chunks stay in flight per wave.

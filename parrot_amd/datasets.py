@@ -233,25 +233,57 @@ class PinnedAsyncLoader:
         q: queue.Queue = queue.Queue(maxsize=self.depth)
         sentinel = object()
 
+        stop = threading.Event()
+        failure = []
+
+        def put(x):  # a consumer that left early (break / exception) must not leave the worker blocked forever
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def worker():
             try:
                 k = 0
                 for item in self.stream.get_epoch_iterator():
+                    if stop.is_set():
+                        return
                     slot = self._slots[k % len(self._slots)]
                     k += 1
                     if slot['event'] is not None:
                         slot['event'].synchronize()  # copies issued from this slot's buffers are done
                     staged = [self._stage(slot, i, x) if isinstance(x, numpy.ndarray) else x
                               for i, x in enumerate(item)]
-                    q.put((slot, staged))
+                    if not put((slot, staged)):
+                        return
+            except BaseException as e:  # re-raised in the consumer: an error is not an end of epoch
+                failure.append(e)
             finally:
-                q.put(sentinel)
+                put(sentinel)
 
         th = threading.Thread(target=worker, daemon=True)
         th.start()
+        try:
+            yield from self._consume(q, sentinel, failure)
+        finally:
+            stop.set()
+            while True:  # let a worker blocked in put() see the flag, then drop what it staged
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            th.join(timeout=5.0)
+
+    def _consume(self, q, sentinel, failure):
+        import torch
         while True:
             got = q.get()
             if got is sentinel:
+                if failure:
+                    raise failure[0]
                 break
             slot, staged = got
             out, ev = [], None

@@ -727,14 +727,15 @@ class Parrot(Brick):
             ws['kappa'][0].copy_(carry['k'])
 
         # --- encoder (model.py:645-646) and summed layer biases
-        ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, save))
+        with ops.gemm_precision(ops.PRECISION_F32):  # the encoder stays f32 in every operand mode
+            ws['ctx'].copy_(self._encoder_forward(labels, labels_mask, save))
         self._sum_layer_biases(ws)
         self._tiled_weights(refresh=True)
 
         # --- the scan (model.py:651-737)
-        if 'persist_ws' in ws:  # opt-in persistent forward scan: did the previous window's launch give up? (synchronises)
-            _lib.call('parrot_decoder_status', ws['plan'])
         _lib.call('parrot_decoder_seq_fwd', ws['plan'], ops._stream())
+        if 'persist_ws' in ws:  # opt-in persistent forward scan: fail before the cost or any gradient of a launch
+            _lib.call('parrot_decoder_status', ws['plan'])  # that gave up is consumed (synchronises)
 
         # --- readouts and output (model.py:739-755)
         readouts = ws['readouts']
@@ -927,11 +928,12 @@ class Parrot(Brick):
         ops.colsum(ws['dp'].view(T * B, 3 * A), out=sg_['dec.batt'], accumulate=True)
         # encoder output: dctx[b] = phi[:, b, :]^T . dw_total[1:, b, :]   (batched over b)
         dctx = torch.empty(B, U, E, device=readouts.device, dtype=torch.float32)
-        _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
-                  dctx.data_ptr(), E, U, E, T, None, 1.0, 0, 0, B, U, E, U * E, 1, ops._stream())
-        if self.use_speaker:
-            self._scatter_rows_add(self._g('/lookuptable.W'), save['spk_idx'], demb_spk)
-        self._encoder_backward(dctx, save)
+        with ops.gemm_precision(ops.PRECISION_F32):  # attention + encoder: f32 operands in every operand mode
+            _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
+                      dctx.data_ptr(), E, U, E, T, None, 1.0, 0, 0, B, U, E, U * E, 1, ops._stream())
+            if self.use_speaker:
+                self._scatter_rows_add(self._g('/lookuptable.W'), save['spk_idx'], demb_spk)
+            self._encoder_backward(dctx, save)
         self._saved = None
 
     def _weight_grad_rows(self, ws, save, T, B, t0, t1):
@@ -962,8 +964,9 @@ class Parrot(Brick):
                     ops.gemm(ws['h'][j][t0 + 1:t1 + 1].view(R, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
         # attention projection (h1_to_att Fork)
         A = self.attention_size
-        ops.gemm(ws['dp'][t0:t1].view(R, 3 * A).t(), ws['h'][0][t0 + 1:t1 + 1].view(R, H),
-                 out=sg_['dec.WattT'], accumulate=True)
+        with ops.gemm_precision(ops.PRECISION_F32):  # the attention window stays f32 in every operand mode
+            ops.gemm(ws['dp'][t0:t1].view(R, 3 * A).t(), ws['h'][0][t0 + 1:t1 + 1].view(R, H),
+                     out=sg_['dec.WattT'], accumulate=True)
 
     def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None):
         """The backward scan and the weight-gradient GEMMs that only read what it leaves behind.  When the plan runs

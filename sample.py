@@ -56,10 +56,16 @@ def main(argv=None):
         sharpening_coeff=args.sharpening_coeff, timing_coeff=args.timing_coeff,
         encoder_type=saved_args.encoder_type, raw_output=raw_output, name='parrot',
         num_layers=getattr(saved_args, 'num_layers', 3), cell_type=getattr(saved_args, 'cell_type', 'gru'),
-        encoder_literal=bool(getattr(saved_args, 'encoder_literal', 1)), device=device)
+        encoder_literal=bool(getattr(saved_args, 'encoder_literal', 1)),
+        compute_dtype=getattr(saved_args, 'compute_dtype', 'float32'), device=device)
+    print("Operand precision of the decoder: %s" % getattr(saved_args, 'compute_dtype', 'float32'))
     parrot.allocate()
     parrot.set_parameter_values(parameters)
-    if raw_output and srn_parameters:
+    if raw_output:
+        if not srn_parameters:
+            raise ValueError("the experiment was trained with --raw_output but its checkpoint holds no "
+                             "'/parrot/samplernn/*' parameters: the SampleRNN head would sample from its random "
+                             "initialisation (noise)")
         from parrot_amd.sampleRNN import lib as srn_lib
         srn_lib.set_params(srn_parameters)
     print("Successfully loaded the parameters.")

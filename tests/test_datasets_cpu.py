@@ -144,3 +144,43 @@ def test_parrot_stream_matches_the_reference_pipeline():
                     assert np.array_equal(got.astype(np.int64), ref.astype(np.int64)), (case, k, name)
                 else:
                     assert np.array_equal(got, ref), (case, k, name)
+
+
+def test_async_loader_propagates_worker_errors_and_stops_when_the_consumer_leaves():
+    """PinnedAsyncLoader (the replacement of Fuel's server/iterator pair, datasets.py:199-298): an exception raised
+    while a batch is produced reaches the consumer (it is not an end of epoch), and a consumer that breaks out early
+    leaves no producer thread blocked on the queue."""
+    import threading
+
+    import numpy as np
+    import pytest
+
+    from parrot_amd.datasets import PinnedAsyncLoader
+
+    class Stream:
+        sources = ('x',)
+
+        def __init__(self, n, fail_at=None):
+            self.n, self.fail_at = n, fail_at
+
+        def get_epoch_iterator(self):
+            for i in range(self.n):
+                if i == self.fail_at:
+                    raise ValueError("quantiser blew up")
+                yield (np.full((2, 3), i, dtype=np.float32),)
+
+    got = [int(b['x'][0, 0]) for b in PinnedAsyncLoader(Stream(5), 'cpu')]
+    assert got == [0, 1, 2, 3, 4]
+    with pytest.raises(ValueError, match="quantiser"):
+        for _ in PinnedAsyncLoader(Stream(5, fail_at=2), 'cpu'):
+            pass
+    before = threading.active_count()
+    for i, _ in enumerate(PinnedAsyncLoader(Stream(1000), 'cpu', depth=2)):
+        if i == 1:
+            break
+    import time
+    for _ in range(50):
+        if threading.active_count() <= before:
+            break
+        time.sleep(0.1)
+    assert threading.active_count() <= before, "the producer thread is still alive after the consumer left"
