@@ -272,6 +272,10 @@ typedef struct ParrotDecoderDesc {
 long long parrot_decoder_persist_floats(const ParrotDecoderDesc* desc);
 /* 1 when the plan's forward scan runs on the persistent phase machine. */
 int parrot_decoder_is_persistent(void* plan);
+/* The launch schedule the plan's scan runs on (PARROT_SCHEDULE, after the fall-backs for configurations a schedule does
+ * not cover): 0 merged wavefront, 2 / 3 chunked pipelines, 5 balanced wavefront (attention beside the upper layers'
+ * input projections), 6 two launches per tick (attention inside the gate launch). */
+int parrot_decoder_schedule(void* plan);
 /* Waits for the device; 0, or non-zero when a persistent launch of this plan gave up (a workgroup waited ~1 s for a
  * rendezvous or for an operand that never arrived): the results of that window are invalid.  0 on the launch schedules. */
 int parrot_decoder_status(void* plan);

@@ -1,0 +1,212 @@
+// Forward step of the GMM-window attention for ONE (batch row, column slice) pair, run by the first ATT_THREADS
+// threads of a workgroup (reference model.py:664-690).  Shared by att_fwd_kernel (attention.hip) and by the
+// heterogeneous step launch of skinny.hip, whose spare workgroups carry the attention of the tick beside the
+// upper layers' input projections (plans.hip, schedule 5).  Everything that calls __syncthreads() here is reached by
+// exactly the threads t < ATT_THREADS of the workgroup: callers with larger workgroups retire the other waves first
+// (s_barrier only waits for the waves of a workgroup that are still alive).
+#pragma once
+#include "attention.h"
+
+#ifndef ATT_PROJ_UNROLL
+#define ATT_PROJ_UNROLL 8
+#endif
+#ifndef ATT_FWD_PRELOAD
+#define ATT_FWD_PRELOAD 0  // measured: no gain in the forward kernel (the backward preloads pay)
+#endif
+
+constexpr int ATT_THREADS = 256;
+constexpr int ATT_MAXA = 32;  // attention_size limit (reference default 10)
+
+static inline size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + 2 * ATT_THREADS); }
+
+template <int PROJ_UNROLL>
+__device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, const int es, float* sm) {
+    const int A = g.A, U = g.U, E = g.E, H = g.H;
+    float* s_p = sm;                 // [3A] projection
+    float* s_a = s_p + 3 * ATT_MAXA; // [A]
+    float* s_b = s_a + ATT_MAXA;
+    float* s_k = s_b + ATT_MAXA;
+    float* s_red = s_k + ATT_MAXA;   // [8]
+    float* s_phi = s_red + 8;        // [U]
+    float* s_acc = s_phi + ((U + 3) & ~3);  // [ATT_THREADS] (+ column loop reuse)
+    float* s_out = s_acc + ATT_THREADS;     // [ATT_THREADS] finished w values of one column pass (published hand-off)
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const float* h = g.h1 + (size_t)b * g.ldh;
+
+    // Geometry of step 4 (w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E), fixed up front so
+    // that the context values can be requested before anything else: they do not depend on phi, and their
+    // latency then hides behind the projection / window phases instead of following them.
+    const int EW = (E + g.esplit - 1) / g.esplit;
+    const int e0 = es * EW, e1 = min(E, e0 + EW);
+    int CW = 1;
+    while (CW < EW && CW < ATT_THREADS) CW <<= 1;  // columns handled per pass (power of two)
+    const int G = ATT_THREADS / CW;                // u-groups
+    const int c = t % CW, ug = t / CW;
+    const float* ctx = g.ctx + (size_t)b * U * E;
+    constexpr int NPRE = 32;
+    const bool use_pre = ATT_FWD_PRELOAD && (EW <= CW) && ((U + G - 1) / G <= NPRE);
+    float pre[NPRE];
+    if (use_pre) {
+        const int e = e0 + c;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int u = ug + q * G;
+            pre[q] = (u < U && e < e1) ? ctx[(size_t)u * E + e] : 0.f;
+        }
+    }
+
+    // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
+    // Wave w owns outputs j = w, w+4, ... (up to 8 per pass); the loads of all its outputs for one k-slab
+    // are issued together (8 rows + h in flight), instead of one output after the other.
+    for (int jb = wave; jb < 3 * A; jb += 32) {
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll PROJ_UNROLL
+        for (int k = lane; k < H; k += 64) {
+            const float hv = h[k];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = jb + 4 * q;
+                const float wv = (j < 3 * A) ? g.WattT[(size_t)j * H + k] : 0.f;
+                acc[q] += hv * wv;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float r = wave_sum(acc[q]);
+            const int j = jb + 4 * q;
+            if (lane == 0 && j < 3 * A) s_p[j] = r + (g.batt ? g.batt[j] : 0.f);
+        }
+    }
+    __syncthreads();
+
+    // 2) window parameters
+    if (g.att_type == 1) {
+        if (t == 0) {
+            float mx = -INFINITY;
+            for (int j = 0; j < A; ++j) mx = fmaxf(mx, s_p[j]);
+            float s = 0.f;
+            for (int j = 0; j < A; ++j) s += expf(s_p[j] - mx);
+            s_red[4] = mx;
+            s_red[5] = s;
+        }
+        __syncthreads();
+    }
+    if (t < A) {
+        float av;
+        if (g.att_type == 1) av = expf(s_p[t] - s_red[4]) / s_red[5] + g.eps;
+        else av = expf(s_p[t]) + g.eps;
+        const float bv = expf(s_p[A + t]) * g.sharpening + g.eps;
+        const float kv = g.kappa_prev[(size_t)b * A + t] + g.alignment * expf(s_p[2 * A + t]) / g.timing;
+        s_a[t] = av;
+        s_b[t] = bv;
+        s_k[t] = kv;
+        if (t == 0) {  // support of the window: [lo, hi] = positions whose phi is not exactly zero
+            reinterpret_cast<int*>(s_red)[6] = U;
+            reinterpret_cast<int*>(s_red)[7] = -1;
+        }
+        if (es == 0) {
+            g.a_out[(size_t)b * A + t] = av;
+            g.b_out[(size_t)b * A + t] = bv;
+            g.kappa_out[(size_t)b * A + t] = kv;
+        }
+    }
+    __syncthreads();
+
+    // 3) phi[u]
+    for (int u = t; u < U; u += ATT_THREADS) {
+        float ph = 0.f;
+        const float uf = (float)u;
+        if (g.att_type == 1) {
+            for (int j = 0; j < A; ++j) {
+                const float d = s_k[j] - uf;
+                ph += s_a[j] * sqrtf(s_b[j]) * expf(-0.5f * s_b[j] * d * d);
+            }
+            ph *= 0.3989422917366028f;
+        } else {
+            for (int j = 0; j < A; ++j) {
+                const float d = s_k[j] - uf;
+                ph += s_a[j] * expf(-s_b[j] * d * d);
+            }
+        }
+        s_phi[u] = ph;
+        if (ph != 0.f) {
+            atomicMin(&reinterpret_cast<int*>(s_red)[6], u);
+            atomicMax(&reinterpret_cast<int*>(s_red)[7], u);
+        }
+        if (es == 0) g.phi_out[(size_t)b * U + u] = ph;
+    }
+    __syncthreads();
+    // The Gaussian window underflows to exactly 0.0f a few positions away from kappa (exp(-b d^2), fp32), and a
+    // zero weight adds exactly nothing to w: rows outside [lo, hi] are not read.  Same sums, same order, minus
+    // the +0 terms -- bit-identical to reading all U rows (PARROT_ATT_DENSE=1 reads them all).
+    int u_lo = 0, u_hi = U - 1;
+    if (!g.dense) {
+        u_lo = reinterpret_cast<int*>(s_red)[6];
+        u_hi = reinterpret_cast<int*>(s_red)[7];
+    }
+    if (g.sup_out && es == 0 && t == 0) {  // saved for the backward step (dense mode saves the full range)
+        g.sup_out[2 * b] = u_lo;
+        g.sup_out[2 * b + 1] = u_hi;
+    }
+
+    // (hand-off mode) whole 16-byte groups: every slice starts and ends on a multiple of 4 columns of aligned rows
+    const bool wide = g.flag && !(EW & 3) && !(E & 3) && !(g.ldw & 3) && !((size_t)g.w_out & 15) && CW >= 4;
+    // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
+    for (int eb = e0; eb < e1; eb += CW) {
+        const int e = eb + c;
+        float acc = 0.f;
+        if (use_pre) {
+#pragma unroll
+            for (int q = 0; q < NPRE; ++q) {
+                const int u = ug + q * G;
+                if (u < U) acc += s_phi[u] * pre[q];
+            }
+        } else if (e < e1 && u_lo <= u_hi) {
+            // rows of this thread: u = ug (mod G), as in the dense walk, starting at the first one >= u_lo
+            int u = u_lo + ((ug - u_lo % G + G) % G);
+            for (; u + 7 * G <= u_hi; u += 8 * G) {  // 8 independent row reads in flight
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
+            }
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (u + q * G <= u_hi) ? ctx[(size_t)(u + q * G) * E + e] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (u + q * G <= u_hi) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);  // same rounding as above
+        }
+        __syncthreads();
+        s_acc[t] = acc;
+        __syncthreads();
+        if (ug == 0 && e < e1) {
+            float s = 0.f;
+            for (int q = 0; q < G; ++q) s += s_acc[q * CW + c];
+            if (!g.flag) g.w_out[(size_t)b * g.ldw + e] = s;
+            else if (wide) s_out[c] = s;
+            else  // consumed inside this launch: write-through, visible to every XCD once vmcnt drains
+                __hip_atomic_store(reinterpret_cast<unsigned*>(g.w_out + (size_t)b * g.ldw + e), __float_as_uint(s),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (g.flag && wide) {  // 16-byte write-through stores (a 4-byte sc1 store is one fabric write each)
+            __syncthreads();
+            if (4 * t < CW && eb + 4 * t < e1) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(s_out + 4 * t);
+                float* p = g.w_out + (size_t)b * g.ldw + eb + 4 * t;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+            }
+        }
+    }
+    if (g.flag) {  // publish: every wave drains its stores, then one lane arrives (protocol of persist.hip's barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) (void)__hip_atomic_fetch_add(g.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+

@@ -15,6 +15,8 @@ struct AttFwdArgs {
     float eps, alignment, sharpening, timing;
     int* sup_out;  // [B,2] or null: first / last context position with phi != 0 (saved for the backward step)
     int dense;  // set by att_fwd_launch (PARROT_ATT_DENSE=1): read all U context rows, also those with phi == 0
+    unsigned* flag;  // null, or an arrival counter: w_out is stored write-through (sc1) and every workgroup adds 1 once
+                     // its slice is out, so that workgroups of the SAME launch can consume w (skinny.hip, SkJob::wait_flag)
 };
 
 struct AttBwdArgs {
@@ -32,6 +34,8 @@ struct AttBwdArgs {
 };
 
 int att_fwd_launch(const AttFwdArgs& g, hipStream_t stream);
+// Validates the arguments and sets `dense` from PARROT_ATT_DENSE (what att_fwd_launch does before it launches).
+int att_fwd_check(AttFwdArgs& g);
 int att_bwd_launch(const AttBwdArgs& g, hipStream_t stream);
 struct GruStateBwdArgs;
 // att (or null) + the GRU state backward of all chains in one launch; l0_chain = index of layer 0's chain or -1.

@@ -17,23 +17,15 @@
 // row-segment reads; the tiny projection and the window are recomputed per slice (L2-resident
 // inputs).  Reductions over A happen in-lane, reductions over U / H use wave shuffles + LDS.
 #include "attention.h"
+#include "att_fwd_body.h"
 #include "elementwise.h"
 
 #include <stdlib.h>
 #include <string.h>
 
-#ifndef ATT_PROJ_UNROLL
-#define ATT_PROJ_UNROLL 8
-#endif
-#ifndef ATT_FWD_PRELOAD
-#define ATT_FWD_PRELOAD 0  // measured: no gain in the forward kernel (the backward preloads pay)
-#endif
-
 namespace {
 
-constexpr int ATT_THREADS = 256;
 constexpr int ATTB_THREADS = 1024;  // backward: one workgroup per batch row, 16 waves
-constexpr int ATT_MAXA = 32;  // attention_size limit (reference default 10)
 
 // Block-wide sum of `n` per-thread partial vectors (n <= 3*ATT_MAXA); result in out[0..n).
 // part: per-thread array in registers is awkward for runtime n, so partials are staged in LDS:
@@ -62,173 +54,7 @@ __device__ __forceinline__ float block_sum8(float v, float* red) {  // backward 
 
 __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int A = g.A, U = g.U, E = g.E, H = g.H;
-    float* s_p = sm;                 // [3A] projection
-    float* s_a = s_p + 3 * ATT_MAXA; // [A]
-    float* s_b = s_a + ATT_MAXA;
-    float* s_k = s_b + ATT_MAXA;
-    float* s_red = s_k + ATT_MAXA;   // [8]
-    float* s_phi = s_red + 8;        // [U]
-    float* s_acc = s_phi + ((U + 3) & ~3);  // [ATT_THREADS] (+ column loop reuse)
-
-    const int b = blockIdx.x, es = blockIdx.y, t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const float* h = g.h1 + (size_t)b * g.ldh;
-
-    // Geometry of step 4 (w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E), fixed up front so
-    // that the context values can be requested before anything else: they do not depend on phi, and their
-    // latency then hides behind the projection / window phases instead of following them.
-    const int EW = (E + g.esplit - 1) / g.esplit;
-    const int e0 = es * EW, e1 = min(E, e0 + EW);
-    int CW = 1;
-    while (CW < EW && CW < ATT_THREADS) CW <<= 1;  // columns handled per pass (power of two)
-    const int G = ATT_THREADS / CW;                // u-groups
-    const int c = t % CW, ug = t / CW;
-    const float* ctx = g.ctx + (size_t)b * U * E;
-    constexpr int NPRE = 32;
-    const bool use_pre = ATT_FWD_PRELOAD && (EW <= CW) && ((U + G - 1) / G <= NPRE);
-    float pre[NPRE];
-    if (use_pre) {
-        const int e = e0 + c;
-#pragma unroll
-        for (int q = 0; q < NPRE; ++q) {
-            const int u = ug + q * G;
-            pre[q] = (u < U && e < e1) ? ctx[(size_t)u * E + e] : 0.f;
-        }
-    }
-
-    // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
-    // Wave w owns outputs j = w, w+4, ... (up to 8 per pass); the loads of all its outputs for one k-slab
-    // are issued together (8 rows + h in flight), instead of one output after the other.
-    for (int jb = wave; jb < 3 * A; jb += 32) {
-        float acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-#pragma unroll ATT_PROJ_UNROLL
-        for (int k = lane; k < H; k += 64) {
-            const float hv = h[k];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = jb + 4 * q;
-                const float wv = (j < 3 * A) ? g.WattT[(size_t)j * H + k] : 0.f;
-                acc[q] += hv * wv;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float r = wave_sum(acc[q]);
-            const int j = jb + 4 * q;
-            if (lane == 0 && j < 3 * A) s_p[j] = r + (g.batt ? g.batt[j] : 0.f);
-        }
-    }
-    __syncthreads();
-
-    // 2) window parameters
-    if (g.att_type == 1) {
-        if (t == 0) {
-            float mx = -INFINITY;
-            for (int j = 0; j < A; ++j) mx = fmaxf(mx, s_p[j]);
-            float s = 0.f;
-            for (int j = 0; j < A; ++j) s += expf(s_p[j] - mx);
-            s_red[4] = mx;
-            s_red[5] = s;
-        }
-        __syncthreads();
-    }
-    if (t < A) {
-        float av;
-        if (g.att_type == 1) av = expf(s_p[t] - s_red[4]) / s_red[5] + g.eps;
-        else av = expf(s_p[t]) + g.eps;
-        const float bv = expf(s_p[A + t]) * g.sharpening + g.eps;
-        const float kv = g.kappa_prev[(size_t)b * A + t] + g.alignment * expf(s_p[2 * A + t]) / g.timing;
-        s_a[t] = av;
-        s_b[t] = bv;
-        s_k[t] = kv;
-        if (t == 0) {  // support of the window: [lo, hi] = positions whose phi is not exactly zero
-            reinterpret_cast<int*>(s_red)[6] = U;
-            reinterpret_cast<int*>(s_red)[7] = -1;
-        }
-        if (es == 0) {
-            g.a_out[(size_t)b * A + t] = av;
-            g.b_out[(size_t)b * A + t] = bv;
-            g.kappa_out[(size_t)b * A + t] = kv;
-        }
-    }
-    __syncthreads();
-
-    // 3) phi[u]
-    for (int u = t; u < U; u += ATT_THREADS) {
-        float ph = 0.f;
-        const float uf = (float)u;
-        if (g.att_type == 1) {
-            for (int j = 0; j < A; ++j) {
-                const float d = s_k[j] - uf;
-                ph += s_a[j] * sqrtf(s_b[j]) * expf(-0.5f * s_b[j] * d * d);
-            }
-            ph *= 0.3989422917366028f;
-        } else {
-            for (int j = 0; j < A; ++j) {
-                const float d = s_k[j] - uf;
-                ph += s_a[j] * expf(-s_b[j] * d * d);
-            }
-        }
-        s_phi[u] = ph;
-        if (ph != 0.f) {
-            atomicMin(&reinterpret_cast<int*>(s_red)[6], u);
-            atomicMax(&reinterpret_cast<int*>(s_red)[7], u);
-        }
-        if (es == 0) g.phi_out[(size_t)b * U + u] = ph;
-    }
-    __syncthreads();
-    // The Gaussian window underflows to exactly 0.0f a few positions away from kappa (exp(-b d^2), fp32), and a
-    // zero weight adds exactly nothing to w: rows outside [lo, hi] are not read.  Same sums, same order, minus
-    // the +0 terms -- bit-identical to reading all U rows (PARROT_ATT_DENSE=1 reads them all).
-    int u_lo = 0, u_hi = U - 1;
-    if (!g.dense) {
-        u_lo = reinterpret_cast<int*>(s_red)[6];
-        u_hi = reinterpret_cast<int*>(s_red)[7];
-    }
-    if (g.sup_out && es == 0 && t == 0) {  // saved for the backward step (dense mode saves the full range)
-        g.sup_out[2 * b] = u_lo;
-        g.sup_out[2 * b + 1] = u_hi;
-    }
-
-    // 4) w[e] = sum_u phi[u] ctx[b,u,e] for this workgroup's slice of E.
-    for (int eb = e0; eb < e1; eb += CW) {
-        const int e = eb + c;
-        float acc = 0.f;
-        if (use_pre) {
-#pragma unroll
-            for (int q = 0; q < NPRE; ++q) {
-                const int u = ug + q * G;
-                if (u < U) acc += s_phi[u] * pre[q];
-            }
-        } else if (e < e1 && u_lo <= u_hi) {
-            // rows of this thread: u = ug (mod G), as in the dense walk, starting at the first one >= u_lo
-            int u = u_lo + ((ug - u_lo % G + G) % G);
-            for (; u + 7 * G <= u_hi; u += 8 * G) {  // 8 independent row reads in flight
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
-            }
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (u + q * G <= u_hi) ? ctx[(size_t)(u + q * G) * E + e] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (u + q * G <= u_hi) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);  // same rounding as above
-        }
-        __syncthreads();
-        s_acc[t] = acc;
-        __syncthreads();
-        if (ug == 0 && e < e1) {
-            float s = 0.f;
-            for (int q = 0; q < G; ++q) s += s_acc[q * CW + c];
-            g.w_out[(size_t)b * g.ldw + e] = s;
-        }
-    }
+    att_fwd_block<ATT_PROJ_UNROLL>(g, blockIdx.x, blockIdx.y, sm);
 }
 
 // Backward of one step for batch row b (one workgroup per row).
@@ -454,21 +280,26 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_state_bwd_kernel(const AttBw
 
 }  // namespace
 
-static size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + ATT_THREADS); }
 static size_t att_bwd_lds(int U, int E) {
     const int dwsz = ((E + 3) & ~3) > 16 * 3 * ATT_MAXA ? ((E + 3) & ~3) : 16 * 3 * ATT_MAXA;  // also holds s_part
     return sizeof(float) * (6 * ATT_MAXA + 24 + dwsz + ((U + 3) & ~3));
 }
 
-int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
-    AttFwdArgs g = gin;
+int att_fwd_check(AttFwdArgs& g) {
     {   // read per launch (launches happen once, at graph capture): tests toggle it between two plans
         const char* e = getenv("PARROT_ATT_DENSE");
         g.dense = e ? atoi(e) : 0;
     }
     if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.esplit < 1) return PH_ERR_BADARG;
+    if (att_fwd_lds(g.U) > 160 * 1024) return PH_ERR_UNSUPPORTED;
+    return 0;
+}
+
+int att_fwd_launch(const AttFwdArgs& gin, hipStream_t stream) {
+    AttFwdArgs g = gin;
+    const int rc = att_fwd_check(g);
+    if (rc != 0) return rc;
     const size_t lds = att_fwd_lds(g.U);
-    if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(att_fwd_kernel, dim3(g.B, g.esplit), dim3(ATT_THREADS), lds, stream, g);
     return (int)hipGetLastError();
 }

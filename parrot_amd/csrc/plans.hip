@@ -73,11 +73,21 @@ struct PlanBase {
         if (rc__ != 0) return rc__; \
     } while (0)
 
-int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0) {
+int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0, int force_tile = 0) {
     SkLaunch L;
     PL_TRY(sk_make_launch(L, jobs, n));
     L.full_wgs = full_wgs;
+    L.force_tile = force_tile;
     return sk_launch(L, s);
+}
+
+// The attention forward step and n step-GEMM jobs in one heterogeneous launch (skinny.hip: ska_kernel).
+int launch_jobs_att(const SkJob* jobs, int n, const AttFwdArgs& att, hipStream_t s, int full_wgs = 0) {
+    if (n < 1) return att_fwd_launch(att, s);
+    SkLaunch L;
+    PL_TRY(sk_make_launch(L, jobs, n));
+    L.full_wgs = full_wgs;
+    return sk_launch_att(L, att, s);
 }
 
 // Batch rows [b0, b0 + nb) of a launch argument block: every per-row pointer moves down b0 rows, the row count
@@ -345,6 +355,8 @@ struct DecoderPlan : PlanBase {
 
     void free_strands() {
         stop_workers();
+        if (att_flags) (void)hipFree(att_flags);
+        att_flags = nullptr;
         for (int w = 0; w < 2; ++w)
             for (hipGraphExec_t e : piece[w])
                 if (e) (void)hipGraphExecDestroy(e);
@@ -562,6 +574,8 @@ struct DecoderPlan : PlanBase {
         if (which == 0 && persist_ok) return pm_launch(pm_prog, s);  // schedule 4: the persistent phase machine
         if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
+        if (schedule == 5) return which == 0 ? fwd5(s) : bwd(s);
+        if (schedule == 6) return which == 0 ? fwd6(s) : bwd(s);
         return which == 0 ? fwd(s) : bwd(s);
     }
 
@@ -576,10 +590,17 @@ struct DecoderPlan : PlanBase {
         // scan, LSTM layers, layer_norm, B > 64 -- runs on the launch schedules chosen below)
         const bool want_persist = want == 4;  // opt-in: measured at cfg2 it only matches the launch schedules
         if (want_persist) want = -1;
-        if (want < 0) want = 0;
+        if (want < 0) {
+            // default: the balanced wavefront (5) where it applies -- f32 GRU layers, L >= 2 -- unless the caller asked
+            // for independent row strands (a schedule-0 feature); measured at cfg2: forward scan 29.2 -> 25.2 ms
+            const char* se = getenv("PARROT_STRANDS");
+            const int strands_wanted = se ? atoi(se) : d.reserved;
+            want = (pipe_ok && d.cell == 0 && !d.layer_norm && !d.bf16 && strands_wanted <= 1) ? 5 : 0;
+        }
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
-        if (want >= 2 && !pipe_ok) want = 0;
+        if (want >= 2 && !pipe_ok && !(want == 6 && d.L == 1)) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
+        if (want >= 5 && (d.cell != 0 || d.layer_norm || d.bf16)) want = 0;  // balanced wavefronts: f32 GRU layers
         schedule = want;
         try_persist = want_persist && d.cell == 0 && !d.layer_norm && !d.bf16;
         const char* c = getenv("PARROT_CHUNK");
@@ -908,7 +929,7 @@ struct DecoderPlan : PlanBase {
         take_rows(j, cur);
     }
 
-    int att_fwd_step(int t, hipStream_t st) const {
+    AttFwdArgs att_fwd_args(int t) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
         AttFwdArgs g{};
         g.h1 = d.h[0] + (t + 1) * BH; g.ldh = d.H;
@@ -923,8 +944,9 @@ struct DecoderPlan : PlanBase {
         g.sharpening = d.sharpening; g.timing = d.timing;
         g.sup_out = d.att_sup ? d.att_sup + (size_t)t * d.B * 2 : nullptr;
         take_rows(g, cur);
-        return att_fwd_launch(g, st);
+        return g;
     }
+    int att_fwd_step(int t, hipStream_t st) const { return att_fwd_launch(att_fwd_args(t), st); }
 
     // Forward wavefront: at tick q layer l advances step t = q - l, so the gate GEMMs of all layers share
     // one launch, the candidate GEMMs a second one, and the attention of step q is the third.  Layer
@@ -956,6 +978,155 @@ struct DecoderPlan : PlanBase {
             }
             PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             if (q < d.T) PL_TRY(att_fwd_step(q, st));
+        }
+        return 0;
+    }
+
+    // ---- schedule 5: balanced wavefront (GRU layers, L >= 2) --------------------------------------------------------
+    // A step launch costs ~4.7 us + ~4.8 us per 1024 of the LONGEST K among its workgroups (tools/skbench4.hip,
+    // profiles/r03_launch_cost_model.txt): in schedule 0 the upper layers' workgroups (K = 2H + E and more) set the
+    // pace of both GEMM launches while layer 0's finish early, and the attention launch leaves the chip idle.  Here
+    // the products of layer l >= 1 are cut in two: the INPUT projection [w_t ; h_0 .. h_{l-1}] . W[H:, :] (everything
+    // that comes from below, ready one tick before it is needed) is a separate linear job that writes the layer's
+    // additive-input buffer seq_g / seq_c and rides in the launch of the ATTENTION step (heterogeneous launch,
+    // skinny.hip ska_kernel); the gate / candidate launches keep only the recurrent K = H of the upper layers next to
+    // layer 0's K = H + E.  Layer l >= 1 lags l + 1 ticks.  Per tick q:
+    //   A: gates(l0, q), gates_rec(l, q - l - 1)     B: cand(l0, q), cand_rec(l, q - l - 1)
+    //   C: attention(q) + input projections of layer l for step q - l (all l >= 1)
+    // The pre-activation of an upper layer is now (recurrent sum) + (input sum) instead of one running sum over the
+    // concatenated K: same terms, other rounding (not bit-identical to schedule 0; the oracle tests cover both).
+    int esplit5 = 1;
+    int lag5(int l) const { return l == 0 ? 0 : l + 1; }
+    int nticks5() const { return d.T + lag5(d.L - 1); }
+    void input_job(SkJob& j, int l, int t, int g) const {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        const int wd = g == 0 ? 2 * d.H : d.H;
+        sk_job_init(j);
+        int n = 0;
+        j.seg[n++] = fseg(d.w + (size_t)(t + 1) * BE, d.E, l, g, d.H, d.E, wd);
+        for (int q = 0; q < l; ++q)
+            j.seg[n++] = fseg(d.h[q] + (size_t)(t + 1) * BH, d.H, l, g, d.H + d.E + q * d.H, d.H, wd);
+        j.nseg = n;
+        j.M = d.B; j.N = wd; j.H = d.H; j.epi = SK_EPI_LINEAR;
+        float* sq = (g == 0 ? d.seq_g[l] : d.seq_c[l]) + (size_t)t * d.B * wd;
+        j.out = sq; j.ldo = wd;
+        j.accumulate = (d.seq_init >> l) & 1;  // caller data (feedback / speaker terms) already in the buffer
+        take_rows(j, cur);
+    }
+    int fwd5(hipStream_t st) {
+        const int Q = nticks5();
+        const char* fe = getenv("PARROT_S5_FULL");
+        const int cfull = fe ? atoi(fe) : 160;
+        for (int q = 0; q < Q; ++q) {
+            SkJob jobs[SK_MAXJOB];
+            int n = 0;
+            for (int l = 0; l < d.L; ++l) {
+                const int t = q - lag5(l);
+                if (t < 0 || t >= d.T) continue;
+                SkJob& j = jobs[n++];
+                gates_job(j, l, t);
+                if (l > 0) j.nseg = 1;  // recurrent block only; the rest arrives through seq_g (has_seq)
+            }
+            if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
+            n = 0;
+            for (int l = 0; l < d.L; ++l) {
+                const int t = q - lag5(l);
+                if (t < 0 || t >= d.T) continue;
+                SkJob& j = jobs[n++];
+                cand_job(j, l, t);
+                if (l > 0) j.nseg = 1;
+            }
+            if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
+            n = 0;
+            for (int l = 1; l < d.L; ++l) {
+                const int t = q - lag5(l) + 1;
+                if (t < 0 || t >= d.T) continue;
+                input_job(jobs[n++], l, t, 0);
+                input_job(jobs[n++], l, t, 1);
+            }
+            if (q < d.T) {
+                AttFwdArgs ag = att_fwd_args(q);
+                if (n > 0) ag.esplit = esplit5;  // beside GEMM workgroups: one attention workgroup per batch row (measured)
+                PL_TRY(launch_jobs_att(jobs, n, ag, st, cfull));
+            } else if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
+        }
+        return 0;
+    }
+
+    // ---- schedule 6: two launches per tick (GRU layers, fragment-major weights) --------------------------------------
+    // The dependent chain of a decoder step is cand(t) -> h_t -> attention -> w_t -> gates(t+1) -> r -> cand(t+1): three
+    // launches per step in schedules 0 and 5, each with ~4.7 us of fixed cost.  But only the LAST K = E rows of layer 0's
+    // gate product depend on the attention; its first K = H rows need h_t alone.  So the attention of step q-1 and the
+    // gate product of step q share ONE heterogeneous launch (skinny.hip ska_kernel): the attention workgroups are
+    // dispatched first and publish w_q write-through plus an arrival count; layer 0's gate workgroups multiply their
+    // h rows meanwhile, wait for the count, and finish with the w rows (SkJob::wait_flag).  The launch also carries the
+    // upper layers' recurrent gate products and input projections (independent work for the CUs the wait leaves idle):
+    //   A'(q): attention(q-1) || gates(l0, q) [waits], gates_rec(l, q - lag_l), input(l, q - lag_l + 1)   (l >= 1)
+    //   B'(q): cand(l0, q), cand_rec(l, q - lag_l)                                                      lag_l = 2l + 1
+    // Same arithmetic per output element as schedule 5 (layer 0: as schedule 0, bit for bit).
+    unsigned* att_flags = nullptr;  // [T + 2] arrival counters, one per tick (plan-owned, zeroed at the head of the scan)
+    int esplit6 = 0;
+    // s6_ib: the input projections ride in B' instead of A' (then lag_l = 2l): A' keeps one workgroup per CU
+    bool s6_ib = true;
+    int s6_btile = 0;
+    int lag6(int l) const { return l == 0 ? 0 : (s6_ib ? 2 * l : 2 * l + 1); }
+    int nticks6() const { return d.T + std::max(1, lag6(d.L - 1)); }
+    int fwd6(hipStream_t st) {
+        if (!att_flags) return PARROT_ERR_BADARG;  // (allocated by parrot_decoder_create, outside any stream capture)
+        PL_TRY((int)hipMemsetAsync(att_flags, 0, sizeof(unsigned) * (size_t)(d.T + 2), st));
+        const int Q = nticks6();
+        const char* fe = getenv("PARROT_S5_FULL");
+        const int cfull = fe ? atoi(fe) : 160;
+        for (int q = 0; q < Q; ++q) {
+            SkJob jobs[SK_MAXJOB];
+            int n = 0;
+            const bool att_on = q >= 1 && q - 1 < d.T;
+            AttFwdArgs ag{};
+            if (att_on) {
+                ag = att_fwd_args(q - 1);
+                ag.esplit = esplit6;
+            }
+            if (q < d.T) {
+                SkJob& j = jobs[n++];
+                gates_job(j, 0, q);
+                if (att_on) {  // w_q arrives inside this launch
+                    j.wait_flag = att_flags + q;
+                    j.wait_target = (unsigned)(ag.B * ag.esplit);
+                    ag.flag = att_flags + q;
+                }
+            }
+            for (int l = 1; l < d.L; ++l) {
+                const int t = q - lag6(l);
+                if (t < 0 || t >= d.T) continue;
+                SkJob& j = jobs[n++];
+                gates_job(j, l, t);
+                j.nseg = 1;  // recurrent block; the rest arrives through seq_g (has_seq)
+            }
+            if (!s6_ib)
+                for (int l = 1; l < d.L; ++l) {
+                    const int t = q - lag6(l) + 1;
+                    if (t < 0 || t >= d.T) continue;
+                    input_job(jobs[n++], l, t, 0);
+                    input_job(jobs[n++], l, t, 1);
+                }
+            if (att_on) PL_TRY(launch_jobs_att(jobs, n, ag, st, cfull));
+            else if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
+            n = 0;
+            for (int l = 0; l < d.L; ++l) {
+                const int t = q - lag6(l);
+                if (t < 0 || t >= d.T) continue;
+                SkJob& j = jobs[n++];
+                cand_job(j, l, t);
+                if (l > 0) j.nseg = 1;
+            }
+            if (s6_ib)
+                for (int l = 1; l < d.L; ++l) {
+                    const int t = q - lag6(l) + 1;
+                    if (t < 0 || t >= d.T) continue;
+                    input_job(jobs[n++], l, t, 0);
+                    input_job(jobs[n++], l, t, 1);
+                }
+            if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs, s6_btile));
         }
         return 0;
     }
@@ -2197,6 +2368,24 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             p->tiled = true;
         }
     }
+    if (p->schedule == 6 && !p->tiled) p->schedule = 5;  // the in-launch hand-off reads fragment-major weights
+    if (p->schedule == 5 && desc->L < 2) p->schedule = 0;
+    if (p->schedule == 5) {
+        const char* e = getenv("PARROT_S5_ESPLIT");
+        p->esplit5 = e && atoi(e) > 0 ? atoi(e) : 1;
+    }
+    if (p->schedule == 6) {
+        if (hipMalloc(&p->att_flags, sizeof(unsigned) * (size_t)(desc->T + 2)) != hipSuccess) {
+            delete p;
+            return PARROT_ERR_BADARG;
+        }
+        const char* e = getenv("PARROT_S6_ESPLIT");
+        p->esplit6 = e && atoi(e) > 0 ? atoi(e) : 1;
+        e = getenv("PARROT_S6_IB");
+        p->s6_ib = e ? atoi(e) != 0 : true;
+        e = getenv("PARROT_S6_BTILE");
+        p->s6_btile = e ? atoi(e) : 0;
+    }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     p->setup_strands();
     if (desc->layer_norm && desc->L >= 2) {
@@ -2229,6 +2418,7 @@ int parrot_sample_status(void* plan) { PH_ENTRY(); return plan ? static_cast<Sam
 int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<DecoderPlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }
 
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
+int parrot_decoder_schedule(void* plan) { return plan ? static_cast<DecoderPlan*>(plan)->schedule : -1; }
 
 int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_decoder_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }

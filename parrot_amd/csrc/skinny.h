@@ -47,18 +47,32 @@ struct SkJob {
     float* o2;
     const float* mask;  // [M] optional step mask (GRU_CAND): h' = m*h' + (1-m)*h_prev
     int ld_add, ldo, lde0, lde1, ldo1, ldo2, pad0, pad1;
+    // Optional in-launch dependency: the A operand of the LAST segment is produced by other workgroups of the same
+    // launch (the attention step of a heterogeneous launch, ska_kernel).  The workgroup multiplies all other segments
+    // first, then waits until *wait_flag >= wait_target and takes the last segment with sc1 (L1-bypassing) loads.
+    // Fragment-major weights only; the producers must be dispatched BEFORE the waiting workgroups (sk_launch_att
+    // puts them first), the wait is bounded (~1 s, then the kernel traps).
+    const unsigned* wait_flag;
+    unsigned wait_target;
+    int pad2;
 };
 
 struct SkLaunch {
     SkJob job[SK_MAXJOB];
     int njobs, zmode;  // zmode: grid.z = job index (all jobs have the same number of workgroups)
     int tile_end[SK_MAXJOB];  // 16-column tiles per job; sk_launch turns it into the prefix of workgroups
+    int force_tile;  // host-side hint: 10 * MB + NB to use where legal (0 = the heuristic of sk_prepare)
     int full_wgs;  // host-side hint: workgroups at which the launch counts as filling its share of the chip
                    // (0 = the whole chip, 224); plans that run several launches side by side pass less
 };
 
 // Enqueue one launch on `stream`. Returns hipError_t / PH_ERR_*.
 int sk_launch(const SkLaunch& L, hipStream_t stream);
+// Tile shape, grid, dynamic LDS bytes and the finished descriptor of a launch (mbnb = 10 * MB + NB).
+void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid, size_t& lds, int& mbnb);
+struct AttFwdArgs;
+// The attention forward step and the jobs of L in ONE launch (attention workgroups first, see ska_kernel).
+int sk_launch_att(const SkLaunch& L, const AttFwdArgs& att, hipStream_t stream);
 void sk_profile_begin();
 long long sk_profile_end(double* total_us, double* flops, double* bytes);
 

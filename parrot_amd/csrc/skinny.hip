@@ -21,6 +21,7 @@
 //     sigmoid / tanh / state blend of the GRU (Blocks GatedRecurrent; twin in
 //     sampleRNN/lib/ops.py:364-393), its backward counterpart, or the LSTM cell (ops.py:505-553).
 #include "skinny.h"
+#include "att_fwd_body.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -206,6 +207,27 @@ __device__ __forceinline__ void sk_mma_bf16(const f32x4 (&a)[MB][2], const f32x4
             acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb], __builtin_bit_cast(bf16x8, b[nb]), acc[rb][nb], 0, 0, 0);
 }
 
+// Wait (one lane) until *p >= target; relaxed agent-scope polls with a back-off.  Bounded: a
+// producer that never arrives (it can only mean the dispatch order assumption of sk_launch_att broke) ends the kernel
+// with a trap, which the host sees as a launch failure -- loud, never a silent wrong result.
+__device__ __forceinline__ void sk_wait_flag(const unsigned* p, unsigned target) {
+    unsigned it = 0;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++it & 1023u) == 0 && wall_clock64() - t0 > 100000000ull) __builtin_trap();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (compiler ordering: the tail loads stay behind the poll)
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const void* p) {  // raw buffer over [p, p + 2 GB), p uniform
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
+}
+
 // One workgroup: (16*MB rows) x (16*NB columns) output tile, K split over the SK_NW waves.
 template <int MB, int NB, bool FAST>
 __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red) {
@@ -275,9 +297,11 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         const float* sB[SK_MAXSEG];
         int total = 0;
         const int csh = job.seg[0].b_kcontig == 3 ? 5 : 4;  // K rows per chunk: 32 (bf16 operands) or 16
+        const bool flagged = job.wait_flag != nullptr;       // (uniform) the last segment waits for its producers
+        const int nsm = flagged ? job.nseg - 1 : job.nseg;   // segments of the main ring
 #pragma unroll
         for (int s = 0; s < SK_MAXSEG; ++s) {
-            const bool on = s < job.nseg;
+            const bool on = s < nsm;
             const int ss = on ? s : 0;
             if (on) total += job.seg[ss].K >> csh;
             cend[s] = total;
@@ -414,6 +438,31 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             else if (job.seg[0].b_kcontig == 2) run(std::integral_constant<int, 2>{});
             else if (job.seg[0].b_kcontig == 1) run(std::integral_constant<int, 1>{});
             else run(std::integral_constant<int, 0>{});
+        }
+        if (flagged) {
+            // Tail segment (fragment-major weights, quad-contiguous activation loads as in sk_fetch_fast): its chunks are
+            // dealt round-robin like the main ring's, so with a main ring of a multiple of SK_NW chunks every wave adds
+            // exactly the terms, in exactly the order, of the unflagged kernel.
+            // ONE poller per workgroup (a thousand waves polling one word saturate its memory channel and slow the
+            // producers down: measured 36 ms instead of 26 ms per forward scan), behind a workgroup barrier
+            __syncthreads();
+            if (tid == 0) sk_wait_flag(job.wait_flag, job.wait_target);
+            __syncthreads();
+            const SkSeg& sg = job.seg[job.nseg - 1];
+            const int ntail = sg.K >> 4;
+            const __amdgpu_buffer_rsrc_t rs = sk_rsrc(sg.A);
+            for (int c = wave; c < ntail; c += SK_NW) {
+                f32x4 a[MB], b[NB];
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb)
+                    a[rb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        rs, (unsigned)((mrow[rb] * sg.lda + (c << 4) + 4 * (lane & 3)) * 4), 0, 16 /* sc1 */));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    b[nb] = *reinterpret_cast<const f32x4*>(sg.B + (size_t)btile[nb] * sg.ldb + ((size_t)c << 8) + (lane << 2));
+                sk_a_unpermute<MB>(a);
+                sk_mma2<MB, NB>(a, b, acc);
+            }
         }
     } else {
         // Generic path (NB == 1): per-element masks for K tails / unaligned operands (e.g. the 63-wide
@@ -569,6 +618,43 @@ __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
     else sk_body<MB, 1, false>(job, tile0, red);
 }
 
+// Heterogeneous step launch: the first natt_x workgroups of every grid row carry the attention forward step
+// (att_fwd_body.h; one (batch row, column slice) pair each, on their first ATT_THREADS threads), the others are
+// step-GEMM workgroups as in sk_kernel (jobs found through the workgroup prefix table).  The attention of a tick is a
+// chain of dependent round trips that leaves the chip idle; here independent GEMM jobs (the upper layers' input
+// projections, plans.hip schedule 5) run in its shadow.
+#ifndef SKA_PROJ_UNROLL
+#define SKA_PROJ_UNROLL 4  // 8 (the stand-alone kernel's) would cost the GEMM side its second workgroup per CU
+#endif
+template <int MB, int NB>
+__global__ __launch_bounds__(SK_THREADS, 4) void ska_kernel(const SkLaunch L, const AttFwdArgs g, const int natt_x,
+                                                         const int att_last) {
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    int bx = blockIdx.x;
+    if (att_last) {  // GEMM workgroups (the long ones) are dispatched first, the attention fills in behind them
+        const int ngemm = (int)gridDim.x - natt_x;
+        bx = bx >= ngemm ? bx - ngemm : bx + natt_x;
+    }
+    if (bx < natt_x) {
+        if (threadIdx.x >= ATT_THREADS) return;  // wave-uniform: the attention step runs on the first four waves
+        const int id = blockIdx.y * natt_x + bx;
+        if (id >= g.B * g.esplit) return;
+        att_fwd_block<SKA_PROJ_UNROLL>(g, id / g.esplit, id % g.esplit, reinterpret_cast<float*>(sk_smem));
+        return;
+    }
+    bx -= natt_x;
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < SK_MAXJOB - 1; ++q)
+        if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
+    bx -= (j > 0 ? L.tile_end[j - 1] : 0);
+    const SkJob& job = L.job[j];
+    const int tile0 = bx * NB;
+    if (NB > 1 || job.aligned) sk_body<MB, NB, true>(job, tile0, red);
+    else sk_body<MB, 1, false>(job, tile0, red);
+}
+
 void sk_job_init(SkJob& j) { memset(&j, 0, sizeof(j)); }
 
 void sk_finalize_job(SkJob& j) {
@@ -582,6 +668,7 @@ void sk_finalize_job(SkJob& j) {
         if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
+    if (j.wait_flag && (!al || j.nseg < 2 || j.seg[0].b_kcontig != 2 || !SK_A_PERMUTE)) j.aligned = -1;  // rejected by sk_make_launch
 }
 
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
@@ -592,7 +679,7 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
         L.job[q] = jobs[q];
         sk_finalize_job(L.job[q]);
         const SkJob& j = L.job[q];
-        if (j.nseg < 1 || j.nseg > SK_MAXSEG || j.M < 1 || j.N < 1) return PH_ERR_BADARG;
+        if (j.nseg < 1 || j.nseg > SK_MAXSEG || j.M < 1 || j.N < 1 || j.aligned < 0) return PH_ERR_BADARG;
         if (j.seg[0].b_kcontig >= 2 && !j.aligned) return PH_ERR_BADARG;  // tiled weights: fast path only
         int tiles;
         if (j.epi == SK_EPI_LSTM) {
@@ -1019,12 +1106,9 @@ static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t st
     }
 }
 
-int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
-    {
-        int rc = 0;
-        if (wk_try_launch(Lin, stream, &rc)) return rc;
-    }
-    SkLaunch L = Lin;
+// Tile shape, grid and finished descriptor (workgroup prefix, z-mode) of a launch.
+void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid_out, size_t& lds_out, int& mbnb_out) {
+    L = Lin;
     int maxM = 0, tiles = 0;
     bool nb2_ok = true;
     for (int q = 0; q < L.njobs; ++q) {
@@ -1074,6 +1158,12 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
         16 * (force_mb - 1) < maxM) {
         best_mb = force_mb; best_nb = force_nb;
     }
+    if (Lin.force_tile > 0) {  // the plan's choice for this launch
+        const int fmb = Lin.force_tile / 10, fnb = Lin.force_tile % 10;
+        if (fmb >= 1 && fmb <= 4 && (fnb == 1 || (fnb == 2 && nb2_ok)) && 16 * (fmb - 1) < maxM) {
+            best_mb = fmb; best_nb = fnb;
+        }
+    }
     const int mb = best_mb, nb = best_nb;
     int t = 0, wmax = 0;
     bool equal = true;
@@ -1085,9 +1175,30 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
         L.tile_end[q] = t;  // prefix of workgroups (used when !zmode)
     }
     L.zmode = equal ? 1 : 0;
-    dim3 grid(equal ? wmax : t, ceil_div(maxM, 16 * mb), equal ? L.njobs : 1);
-    const size_t lds = (size_t)SK_NW * mb * nb * 64 * sizeof(f32x4);
-    switch (mb * 10 + nb) {
+    grid_out = dim3(equal ? wmax : t, ceil_div(maxM, 16 * mb), equal ? L.njobs : 1);
+    // development knob: PARROT_SK_LDS_PAD=bytes of extra dynamic LDS per workgroup (caps the workgroups per CU)
+    static long long lds_pad = -1;
+    if (lds_pad < 0) {
+        const char* e = getenv("PARROT_SK_LDS_PAD");
+        lds_pad = e ? atoll(e) : 0;
+    }
+    lds_out = (size_t)SK_NW * mb * nb * 64 * sizeof(f32x4) + (size_t)lds_pad;
+    mbnb_out = mb * 10 + nb;
+}
+
+int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
+    for (int q = 0; q < Lin.njobs; ++q)
+        if (Lin.job[q].wait_flag) return PH_ERR_BADARG;  // a flag needs its producers in the launch: sk_launch_att
+    {
+        int rc = 0;
+        if (wk_try_launch(Lin, stream, &rc)) return rc;
+    }
+    SkLaunch L;
+    dim3 grid;
+    size_t lds;
+    int mbnb;
+    sk_prepare(Lin, L, grid, lds, mbnb);
+    switch (mbnb) {
         case 11: sk_dispatch<1, 1>(L, grid, lds, stream); break;
         case 12: sk_dispatch<1, 2>(L, grid, lds, stream); break;
         case 21: sk_dispatch<2, 1>(L, grid, lds, stream); break;
@@ -1096,6 +1207,91 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
         case 32: sk_dispatch<3, 2>(L, grid, lds, stream); break;
         case 41: sk_dispatch<4, 1>(L, grid, lds, stream); break;
         default: sk_dispatch<4, 2>(L, grid, lds, stream); break;
+    }
+    return (int)hipGetLastError();
+}
+
+template <int MB, int NB>
+static void ska_allow_lds() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)ska_kernel<MB, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+}
+
+template <int MB, int NB>
+static void ska_dispatch(const SkLaunch& L, const AttFwdArgs& g, int natt_x, dim3 grid, size_t lds, hipStream_t stream) {
+    // Order of the two kinds of workgroups in the grid.  Without in-launch dependencies the GEMM workgroups (the long
+    // ones) go first and the attention fills in behind them (measured: forward scan 28.0 -> 25.3 ms at cfg2); a job that
+    // waits for the attention needs its producers dispatched first.
+    static int att_last_env = -1;
+    if (att_last_env < 0) {
+        const char* e = getenv("PARROT_SKA_ATT_LAST");
+        att_last_env = e ? atoi(e) : 1;
+    }
+    ska_allow_lds<MB, NB>();
+    int att_last = att_last_env;
+    for (int q = 0; q < L.njobs; ++q)
+        if (L.job[q].wait_flag) att_last = 0;
+    if (g_prof.on) {
+        SkProfRec r;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        sk_account(L, r.flops, r.bytes);
+        hipExtLaunchKernelGGL((ska_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, L, g, natt_x,
+                              att_last);
+        g_prof.recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL((ska_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, L, g, natt_x, att_last);
+    }
+}
+
+// One launch for the attention step `att` and the step-GEMM jobs of L (njobs may be 0: attention alone).
+int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream) {
+    AttFwdArgs g = att;
+    {
+        const int rc = att_fwd_check(g);
+        if (rc != 0) return rc;
+    }
+    if (Lin.njobs < 1) return att_fwd_launch(att, stream);
+    for (int q = 0; q < Lin.njobs; ++q)
+        if (Lin.job[q].seg[0].b_kcontig == 3) return PH_ERR_UNSUPPORTED;  // (the bf16 launches have their own wide kernel)
+    SkLaunch L;
+    dim3 grid;
+    size_t lds;
+    int mbnb;
+    sk_prepare(Lin, L, grid, lds, mbnb);
+    // sk_prepare may have chosen the z-grid; this kernel always walks the prefix table
+    if (L.zmode) {
+        const int per = (int)grid.x;
+        for (int q = 0; q < L.njobs; ++q) L.tile_end[q] = per * (q + 1);
+        grid.x = (unsigned)(per * L.njobs);
+        grid.z = 1;
+        L.zmode = 0;
+    }
+    const int natt = g.B * g.esplit;
+    const int natt_x = ceil_div(natt, (int)grid.y);
+    grid.x += (unsigned)natt_x;
+    const size_t alds = att_fwd_lds(g.U);
+    if (alds > lds) lds = alds;
+    {   // development knob: extra dynamic LDS per workgroup of the heterogeneous launches (caps the workgroups per CU)
+        static long long pad = -1;
+        if (pad < 0) {
+            const char* e = getenv("PARROT_SKA_LDS_PAD");
+            pad = e ? atoll(e) : 0;
+        }
+        lds += (size_t)pad;
+    }
+    switch (mbnb) {
+        case 11: ska_dispatch<1, 1>(L, g, natt_x, grid, lds, stream); break;
+        case 12: ska_dispatch<1, 2>(L, g, natt_x, grid, lds, stream); break;
+        case 21: ska_dispatch<2, 1>(L, g, natt_x, grid, lds, stream); break;
+        case 22: ska_dispatch<2, 2>(L, g, natt_x, grid, lds, stream); break;
+        case 31: ska_dispatch<3, 1>(L, g, natt_x, grid, lds, stream); break;
+        case 32: ska_dispatch<3, 2>(L, g, natt_x, grid, lds, stream); break;
+        case 41: ska_dispatch<4, 1>(L, g, natt_x, grid, lds, stream); break;
+        default: ska_dispatch<4, 2>(L, g, natt_x, grid, lds, stream); break;
     }
     return (int)hipGetLastError();
 }

@@ -26,7 +26,7 @@ def _build(dev, use_graph=False, **kw):
     return cfg, p, m
 
 
-def _check_cost_and_grads(dev, T, B, U, ragged=False, tol_out=1e-4, tol_grad=1e-3, **kw):
+def _check_cost_and_grads(dev, T, B, U, ragged=False, tol_out=1e-4, tol_grad=1e-3, expect_schedule=None, **kw):
     from oracle import parrot_ref as R
     cfg, p, m = _build(dev, **kw)
     feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=3, ragged=ragged, speaker=cfg['use_speaker'])
@@ -57,6 +57,10 @@ def _check_cost_and_grads(dev, T, B, U, ragged=False, tol_out=1e-4, tol_grad=1e-
             continue
         assert e <= tol_grad, f"grad {name}: rel err {e:.3e}"
         worst = max(worst, e)
+    if expect_schedule is not None:  # the plan really ran the schedule under test (no silent fall-back)
+        from parrot_amd import _lib
+        ws = next(iter(m._train_ws.values()))
+        assert int(_lib.load().parrot_decoder_schedule(ws['plan'])) == expect_schedule
     m.close()
     return worst
 
@@ -282,7 +286,7 @@ def test_lstm_decoder_sample_model_parity(dev, kw):
 
 
 # ----------------------------------------------------------------------------- scan schedules
-@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("2", "3"), ("2", "50"), ("3", "3"), ("3", "50")])
+@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("2", "3"), ("2", "50"), ("3", "3"), ("3", "50"), ("5", "50"), ("6", "50")])
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
 def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
     """The merged-wavefront schedule (0), the chunked layer pipeline (2) and the chunk-skewed wavefront with hoisted
@@ -297,6 +301,27 @@ def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
                           use_graph=True)
 
 
+@pytest.mark.parametrize("sched", [5, 6])
+def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
+    """Schedules 5 (attention in one heterogeneous launch with the upper layers' input projections) and 6 (attention
+    inside the gate launch: layer 0's gate workgroups wait for the attention workgroups of the same launch) on the
+    shapes the other schedules are tested on, plus the cases that stress the in-launch hand-off: one layer (the
+    launch holds nothing but the attention and the waiting gate product), more rows than one row tile, the softmax
+    window, ragged masks, a window of one step, eager and graph."""
+    monkeypatch.setenv("PARROT_SCHEDULE", str(sched))
+    for use_graph in (False, True):
+        _check_cost_and_grads(dev, T=9, B=40, U=9, num_layers=2, encoder_type='bidirectional', use_graph=use_graph,
+                              expect_schedule=sched)
+    _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
+                          use_speaker=True, ragged=True, use_graph=True, expect_schedule=sched)
+    _check_cost_and_grads(dev, T=6, B=4, U=9, num_layers=1, encoder_type='bidirectional', use_graph=True,
+                          expect_schedule=sched if sched == 6 else 0)
+    _check_cost_and_grads(dev, T=5, B=3, U=8, num_layers=2, encoder_type='bidirectional', attention_type='softmax',
+                          use_graph=True, expect_schedule=sched)
+    _check_cost_and_grads(dev, T=1, B=4, U=6, num_layers=2, encoder_type='bidirectional', use_graph=True,
+                          expect_schedule=sched)
+
+
 # ----------------------------------------------------------------------------- strands and parts
 @pytest.mark.parametrize("strands,qpart,overlap", [("2", "3", "1"), ("3", "0", "1"), ("4", "2", "0"), ("1", "4", "1")])
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
@@ -305,6 +330,7 @@ def test_strands_and_parts_agree_with_oracle(dev, monkeypatch, strands, qpart, o
     along time into graph parts (PARROT_QPART ticks) with the weight-gradient GEMMs of finished parts running beside
     the rest of the backward scan (PARROT_DW_OVERLAP): the same arithmetic per row, so everything must match the
     oracle -- ragged row ranges (B = 40 -> 32 + 8 / 16 + 16 + 8), a ragged last part, eager and graph."""
+    monkeypatch.setenv("PARROT_SCHEDULE", "0")  # strands and parts are features of the merged wavefront
     monkeypatch.setenv("PARROT_STRANDS", strands)
     monkeypatch.setenv("PARROT_QPART", qpart)
     monkeypatch.setenv("PARROT_DW_OVERLAP", overlap)
@@ -465,6 +491,7 @@ def test_full_size_cfg2_strands_are_bit_identical(dev, monkeypatch):
     lm = torch.ones(B, U, device=dev)
 
     def run(strands, qpart, overlap):
+        monkeypatch.setenv("PARROT_SCHEDULE", "0")
         monkeypatch.setenv("PARROT_STRANDS", str(strands))
         monkeypatch.setenv("PARROT_QPART", str(qpart))
         monkeypatch.setenv("PARROT_DW_OVERLAP", str(overlap))
