@@ -149,14 +149,23 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
     peak = 157.3  # f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass
     # with the timed run); the number is the committed measurement of the session named next to it, not of this run
+    # A figure is only reported while the kernel sources it was measured on are unchanged (digest stored by
+    # tools/pmc_traffic.py); otherwise `traffic` is null and `traffic_source` says which file went stale.
     traffic, traffic_src = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    import hashlib
+    hd = hashlib.sha256()
+    for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
+        hd.update(open(os.path.join(ROOT, "parrot_amd", "csrc", name), "rb").read())
+    for name in ("r03_pmc_traffic.json",):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             try:
                 blob = json.load(open(tpath))
-                traffic = blob.get("hbm_bytes_per_launch")
-                traffic_src = f"profiles/{name} ({blob.get('session', 'round-1 session r01e')}; tools/pmc_traffic.py)"
+                if blob.get("source_digest") == hd.hexdigest():
+                    traffic = blob.get("hbm_bytes_per_launch")
+                    traffic_src = f"profiles/{name} ({blob.get('session', '?')}; tools/pmc_traffic.py; separate --pmc passes)"
+                else:
+                    traffic_src = f"profiles/{name} is stale: the kernel sources changed after it was measured"
                 break
             except Exception:
                 traffic = None
@@ -416,6 +425,14 @@ def main():
 
     el, cost = timed(a.steps, a.warmup)
     final_cost = float(cost)
+    try:  # the launch schedule the plan actually ran (after the library's fall-backs)
+        from parrot_amd import _lib
+        sched_id = int(_lib.load().parrot_decoder_schedule(next(iter(model._train_ws.values()))['plan']))
+    except Exception:
+        sched_id = None
+    sched_names = {0: "0 (merged wavefront launches)", 2: "2 (chunked layer pipeline)", 3: "3 (chunk-skewed wavefront)",
+                   5: "5 (balanced wavefront: attention + upper layers' input projections in one heterogeneous launch)",
+                   6: "6 (attention inside the gate launch, in-launch hand-off)"}
     kappa_end = float(model._carry[a.B]['k'].mean()) if a.B in model._carry else None
     # second timed run, outside the headline region: the attention kernels read ALL context rows (no window support)
     dense = None
@@ -466,7 +483,7 @@ def main():
                                           if os.environ.get("PARROT_ATT_DENSE", "0") not in ("", "0") else
                                           "support: rows whose window weight phi is exactly 0.0f are not read "
                                           "(bit-identical results); `dense` = the same step reading all rows"),
-                       "scan_schedule": os.environ.get("PARROT_SCHEDULE", "0 (merged wavefront launches)")},
+                       "scan_schedule": sched_names.get(sched_id, str(sched_id))},
             "dense": dense,
             "final_cost": round(final_cost, 5),
             "roofline": roof, "cpu_baseline": cpu, "parity_check": parity, "secondary": secondary,

@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))

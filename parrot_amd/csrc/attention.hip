@@ -21,6 +21,7 @@
 #include "elementwise.h"
 
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g
 }
 
 // Backward of one step for batch row b (one workgroup per row).
-__device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* sm) {
+// dh_io (optional, used when every thread owns one column of dh1, H <= ATTB_THREADS): on entry the caller's prefetched
+// dh1[b][t], on exit the updated value; returns whether that path was taken (else dh1 was updated in memory only).
+__device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* sm, float* dh_io = nullptr) {
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_a = sm;                  // [A]
     float* s_b = s_a + ATT_MAXA;
@@ -233,9 +236,15 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
 #pragma unroll
             for (int j = 0; j < WPRE; ++j)
                 if (j < 3 * A) acc += s_dp[j] * wpre[j];
-            dh[t] += acc;
+            if (dh_io) {
+                const float v = *dh_io + acc;
+                dh[t] = v;
+                *dh_io = v;
+            } else {
+                dh[t] += acc;
+            }
         }
-        return;
+        return true;
     }
     for (int k = t; k < H; k += ATTB_THREADS) {
         float acc = 0.f;
@@ -243,6 +252,7 @@ __device__ __forceinline__ void att_bwd_row(const AttBwdArgs& g, int b, float* s
         for (int j = 0; j < 3 * A; ++j) acc += s_dp[j] * g.WattT[(size_t)j * H + k];
         dh[k] += acc;
     }
+    return false;
 }
 
 __global__ __launch_bounds__(ATTB_THREADS) void att_bwd_kernel(const AttBwdArgs g) {
@@ -267,6 +277,37 @@ __global__ __launch_bounds__(ATTB_THREADS) void att_state_bwd_kernel(const AttBw
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int bx = blockIdx.x;
     if (bx < att_rows) {
+        if constexpr (std::is_same<SA, GruStateBwdArgs>::value) {
+            // Layer 0's state backward needs nothing from the attention backward except dh1 itself: its operands (and
+            // the old dh1 the attention adds to) are requested up front, so that after the attention's chain of
+            // dependent phases only arithmetic and three stores remain (two memory round trips less per tick).
+            const int t = threadIdx.x, H = sa.H;
+            if (l0_chain >= 0 && H <= ATTB_THREADS && 3 * g.A <= 32) {
+                const GruStateBwdChain& c = sa.chain[l0_chain];
+                const size_t i = (size_t)bx * H + t;
+                float dh = 0.f, dh2 = 0.f, hp = 0.f, z = 0.f, cc = 0.f, dhp = 0.f, mk = 1.f;
+                if (t < H) {
+                    dh = c.dh[i];  // (= g.dh1[b][t]: the attention backward's accumulation target)
+                    if (c.dh2) dh2 = c.dh2[i];
+                    hp = c.hprev[i]; z = c.z[i]; cc = c.c[i]; dhp = c.dhprev[i];
+                    if (c.mask) mk = c.mask[bx];
+                }
+                const bool got = att_bwd_row(g, bx, sm, &dh);
+                if (got) {
+                    if (t < H) {
+                        dh += dh2;  // same order as gru_state_bwd_row: (dh1 + attention share) + share from above
+                        float dhp_direct = 0.f;
+                        if (c.mask) { dhp_direct = dh * (1.f - mk); dh *= mk; }
+                        c.dC[i] = dh * z * (1.f - cc * cc);
+                        c.dG[(size_t)bx * 2 * H + t] = dh * (cc - hp) * z * (1.f - z);
+                        c.dhprev[i] = dhp + (dh * (1.f - z) + dhp_direct);
+                    }
+                    return;
+                }
+                state_bwd_row(c, bx, H, t, ATTB_THREADS);
+                return;
+            }
+        }
         att_bwd_row(g, bx, sm);
         if (l0_chain >= 0) state_bwd_row(sa.chain[l0_chain], bx, sa.H, threadIdx.x, ATTB_THREADS);
         return;

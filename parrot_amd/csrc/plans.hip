@@ -1137,6 +1137,7 @@ struct DecoderPlan : PlanBase {
     // Gradient contributions that cross layers land in separate buffers (dhup[l] for the state, dw0
     // for layer 0's share of dw), so no two jobs of a launch update the same element: no atomics, and
     // the result is deterministic.  The consumers add the parts when they read.
+    bool bwd_split = true;  // PARROT_BWD_SPLIT=0: the dC products stay in the Y launch (K = 3H jobs), as before round 3
     int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
     int bwd(hipStream_t st, int q0, int q1) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -1202,7 +1203,7 @@ struct DecoderPlan : PlanBase {
             }
             GruStateBwdArgs ga;
             ga.nchain = 0; ga.B = d.B; ga.H = H;
-            SkJob jx[PARROT_MAX_LAYERS], jy[SK_MAXJOB];
+            SkJob jx[SK_MAXJOB], jy[SK_MAXJOB];
             int nx = 0, ny = 0;
             for (int l = d.L - 1; l >= 0; --l) {
                 const int t = tl[l];
@@ -1240,23 +1241,43 @@ struct DecoderPlan : PlanBase {
                     j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dh[l] + t * BH; j.ldo = H;
                 }
+                // The products with dC (K = H) do not need the X launch's dG_r: with bwd_split they ride in the X launch
+                // and the Y launch keeps the dG products (K = 2H) only, so no workgroup of a tick walks K = 3H any more
+                // (a launch costs ~4.7 us + ~4.8 us per 1024 of its LONGEST K: 12.0 + 7.9 + 19.9 -> 12.0 + 9.5 + 14.3 us).
                 {   // attention context
+                    float* out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE);
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
-                    j.nseg = 2;
+                    j.nseg = bwd_split ? 1 : 2;
                     j.seg[0] = rseg(dG, l, 0, H, 2 * H);
                     j.seg[1] = rseg(dC, l, 1, H, H);
                     j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                    j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
+                    j.out = out; j.ldo = E;
+                    if (bwd_split) {
+                        SkJob& k = jx[nx++];
+                        sk_job_init(k);
+                        k.nseg = 1;
+                        k.seg[0] = rseg(dC, l, 1, H, H);
+                        k.M = d.B; k.N = E; k.H = H; k.epi = SK_EPI_LINEAR; k.accumulate = 1;
+                        k.out = out; k.ldo = E;
+                    }
                 }
                 for (int p = 0; p < l; ++p) {  // lower layers' states of the same step
                     SkJob& j = jy[ny++];
                     sk_job_init(j);
-                    j.nseg = 2;
+                    j.nseg = bwd_split ? 1 : 2;
                     j.seg[0] = rseg(dG, l, 0, H + E + p * H, 2 * H);
                     j.seg[1] = rseg(dC, l, 1, H + E + p * H, H);
                     j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                     j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;  // separate buffer: no two jobs share a tile
+                    if (bwd_split) {
+                        SkJob& k = jx[nx++];
+                        sk_job_init(k);
+                        k.nseg = 1;
+                        k.seg[0] = rseg(dC, l, 1, H + E + p * H, H);
+                        k.M = d.B; k.N = H; k.H = H; k.epi = SK_EPI_LINEAR; k.accumulate = 1;
+                        k.out = d.dhup[p] + (t + 1) * BH; k.ldo = H;
+                    }
                 }
             }
             if (ga.nchain == 0) continue;
@@ -2370,6 +2391,10 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     }
     if (p->schedule == 6 && !p->tiled) p->schedule = 5;  // the in-launch hand-off reads fragment-major weights
     if (p->schedule == 5 && desc->L < 2) p->schedule = 0;
+    {
+        const char* e = getenv("PARROT_BWD_SPLIT");
+        p->bwd_split = e ? atoi(e) != 0 : true;
+    }
     if (p->schedule == 5) {
         const char* e = getenv("PARROT_S5_ESPLIT");
         p->esplit5 = e && atoi(e) > 0 ? atoi(e) : 1;
