@@ -1,8 +1,8 @@
-// Forward step of the GMM-window attention for ONE (batch row, column slice) pair, run by the first ATT_THREADS
+// Forward step of the GMM-window attention for ONE (batch row, column slice) pair, run by the first NT
 // threads of a workgroup (reference model.py:664-690).  Shared by att_fwd_kernel (attention.hip) and by the
 // heterogeneous step launch of skinny.hip, whose spare workgroups carry the attention of the tick beside the
 // upper layers' input projections (plans.hip, schedule 5).  Everything that calls __syncthreads() here is reached by
-// exactly the threads t < ATT_THREADS of the workgroup: callers with larger workgroups retire the other waves first
+// exactly the threads t < NT of the workgroup: callers with larger workgroups retire the other waves first
 // (s_barrier only waits for the waves of a workgroup that are still alive).
 #pragma once
 #include "attention.h"
@@ -17,9 +17,10 @@
 constexpr int ATT_THREADS = 256;
 constexpr int ATT_MAXA = 32;  // attention_size limit (reference default 10)
 
-static inline size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + 2 * ATT_THREADS); }
+constexpr int ATT_THREADS_MAX = 512;  // the heterogeneous step launch runs the block on all eight waves of its workgroups
+static inline size_t att_fwd_lds(int U) { return sizeof(float) * (6 * ATT_MAXA + 8 + ((U + 3) & ~3) + 2 * ATT_THREADS_MAX); }
 
-template <int PROJ_UNROLL>
+template <int NT, int PROJ_UNROLL>
 __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, const int es, float* sm) {
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_p = sm;                 // [3A] projection
@@ -28,8 +29,9 @@ __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, 
     float* s_k = s_b + ATT_MAXA;
     float* s_red = s_k + ATT_MAXA;   // [8]
     float* s_phi = s_red + 8;        // [U]
-    float* s_acc = s_phi + ((U + 3) & ~3);  // [ATT_THREADS] (+ column loop reuse)
-    float* s_out = s_acc + ATT_THREADS;     // [ATT_THREADS] finished w values of one column pass (published hand-off)
+    float* s_acc = s_phi + ((U + 3) & ~3);  // [NT] (+ column loop reuse)
+    float* s_out = s_acc + NT;              // [NT] finished w values of one column pass (published hand-off)
+    constexpr int NW = NT / 64;             // waves running the block
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -41,8 +43,8 @@ __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, 
     const int EW = (E + g.esplit - 1) / g.esplit;
     const int e0 = es * EW, e1 = min(E, e0 + EW);
     int CW = 1;
-    while (CW < EW && CW < ATT_THREADS) CW <<= 1;  // columns handled per pass (power of two)
-    const int G = ATT_THREADS / CW;                // u-groups
+    while (CW < EW && CW < NT) CW <<= 1;  // columns handled per pass (power of two)
+    const int G = NT / CW;                // u-groups
     const int c = t % CW, ug = t / CW;
     const float* ctx = g.ctx + (size_t)b * U * E;
     constexpr int NPRE = 32;
@@ -57,10 +59,10 @@ __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, 
         }
     }
 
-    // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+4, ...
-    // Wave w owns outputs j = w, w+4, ... (up to 8 per pass); the loads of all its outputs for one k-slab
+    // 1) projection p[j] = sum_k h[k] * Watt[k][j] + batt[j]; wave w handles j = w, w+NW, ...
+    // Wave w owns outputs j = w, w+NW, ... (up to 8 per pass); the loads of all its outputs for one k-slab
     // are issued together (8 rows + h in flight), instead of one output after the other.
-    for (int jb = wave; jb < 3 * A; jb += 32) {
+    for (int jb = wave; jb < 3 * A; jb += NW * 8) {
         float acc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
@@ -69,7 +71,7 @@ __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, 
             const float hv = h[k];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int j = jb + 4 * q;
+                const int j = jb + NW * q;
                 const float wv = (j < 3 * A) ? g.WattT[(size_t)j * H + k] : 0.f;
                 acc[q] += hv * wv;
             }
@@ -77,7 +79,7 @@ __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float r = wave_sum(acc[q]);
-            const int j = jb + 4 * q;
+            const int j = jb + NW * q;
             if (lane == 0 && j < 3 * A) s_p[j] = r + (g.batt ? g.batt[j] : 0.f);
         }
     }
@@ -117,7 +119,7 @@ __device__ __forceinline__ void att_fwd_block(const AttFwdArgs& g, const int b, 
     __syncthreads();
 
     // 3) phi[u]
-    for (int u = t; u < U; u += ATT_THREADS) {
+    for (int u = t; u < U; u += NT) {
         float ph = 0.f;
         const float uf = (float)u;
         if (g.att_type == 1) {

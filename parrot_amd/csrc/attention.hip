@@ -55,7 +55,7 @@ __device__ __forceinline__ float block_sum8(float v, float* red) {  // backward 
 
 __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    att_fwd_block<ATT_PROJ_UNROLL>(g, blockIdx.x, blockIdx.y, sm);
+    att_fwd_block<ATT_THREADS, ATT_PROJ_UNROLL>(g, blockIdx.x, blockIdx.y, sm);
 }
 
 // Backward of one step for batch row b (one workgroup per row).

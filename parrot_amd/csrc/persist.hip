@@ -1,6 +1,7 @@
 // Persistent phase machine for the decoder scan (see persist.h).  gfx950 only.
 #include "persist.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -79,6 +80,7 @@ __device__ __forceinline__ bool pm_spin_ge(unsigned* p, unsigned target, unsigne
             if (wall_clock64() - t0 > 20000000ull) {
                 pm_st(sync + PM_S_ABORT, 1u);
                 pm_st(sync + PM_S_STICKY, 1u);  // the word pm_status reads: survives the next launch's clearing
+                                                // (value = the site that gave up: 1 spin, 2 census, 3 first / 4 phase barrier, 5 slot poll)
                 return false;
             }
         }
@@ -119,7 +121,7 @@ __device__ __forceinline__ bool pm_is_empty(const f32x4& v) {
 // somebody waited ~1 s for a slot that never filled: everybody leaves, the host sees the sticky word
 __device__ __forceinline__ void pm_give_up(unsigned* sync) {
     pm_st(sync + PM_S_ABORT, 1u);
-    pm_st(sync + PM_S_STICKY, 1u);
+    pm_st(sync + PM_S_STICKY, 5u);
 }
 constexpr unsigned PM_POLL_LIMIT = 1u << 21;
 
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
             pm_add(sync + PM_S_TOTAL, 1u);
             const bool ok = pm_spin_ge(sync + PM_S_TOTAL, (unsigned)nwg, sync);
             for (int x = 0; x < 8; ++x) cen[x] = pm_ld(sync + PM_S_CENSUS + x * 32);
-            if (!ok) pm_st(sync + PM_S_STICKY, 1u);
+            if (!ok) pm_st(sync + PM_S_STICKY, 2u);
             ok_sh = ok ? 1 : 0;
         }
         __syncthreads();
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     }
     unsigned epoch = 1;
     if (!DF && !pm_barrier(sync, bar, epoch++, &ok_sh)) {
-        if (tid == 0) pm_st(sync + PM_S_STICKY, 1u);
+        if (tid == 0) pm_st(sync + PM_S_STICKY, 3u);
         return;
     }
 
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
                     if (!ok_sh) return;
                 }
             } else if (!pm_barrier(sync, bar, epoch++, &ok_sh)) {
-                if (tid == 0) pm_st(sync + PM_S_STICKY, 1u);
+                if (tid == 0) pm_st(sync + PM_S_STICKY, 4u + ((unsigned)tick << 8) + ((unsigned)s << 4));
                 return;
             }
             if (tid == 0) {
@@ -636,6 +638,26 @@ __global__ __launch_bounds__(PM_THREADS) void pm_kernel(const PmProgram P) {
     }
 }
 
+}  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void pm_fill_kernel(unsigned* p, long long n, unsigned v) {
+    const long long head = (16 - ((unsigned long long)p & 15)) % 16 / 4;  // words up to the first 16-byte boundary
+    const long long step = (long long)gridDim.x * 256, i0 = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (long long i = i0; i < (head < n ? head : n); i += step) p[i] = v;
+    if (n > head) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* q = reinterpret_cast<u32x4*>(p + head);
+        const long long n4 = (n - head) / 4;
+        const u32x4 vv = {v, v, v, v};
+        for (long long i = i0; i < n4; i += step) q[i] = vv;
+        for (long long i = head + 4 * n4 + i0; i < n; i += step) p[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void pm_clear_kernel(unsigned* a, int na, unsigned* b, int nb) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) a[i] = 0u;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nb; i += gridDim.x * 256) b[i] = 0u;
+}
 }  // namespace
 
 int pm_max_workgroups() {
@@ -655,6 +677,19 @@ int pm_status(const PmProgram& P) {
     PH_CHECK(hipDeviceSynchronize());
     unsigned w = 0;
     PH_CHECK(hipMemcpy(&w, P.sync + PM_S_STICKY, sizeof(w), hipMemcpyDeviceToHost));
+    if (w) {
+        fprintf(stderr, "[parrot_amd] persistent launch gave up: sticky word 0x%x (site %u)\n", w, w & 15u);
+        if (getenv("PARROT_PM_DUMP")) {  // development aid: the barrier words of the launch that gave up
+            unsigned h[PM_SYNC_WORDS];
+            if (hipMemcpy(h, P.sync, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "  nwg %d n_ticks %d n_slots %d  TOP %u TOTAL %u ABORT %u\n", P.nwg, P.n_ticks, P.n_slots, h[PM_S_TOP],
+                        h[PM_S_TOTAL], h[PM_S_ABORT]);
+                for (int x = 0; x < 8; ++x)
+                    fprintf(stderr, "  xcc %d: census %u arrivals %u generation %u\n", x, h[PM_S_CENSUS + 32 * x], h[PM_S_XCNT + 32 * x],
+                            h[PM_S_XGEN + 32 * x]);
+            }
+        }
+    }
     return w ? PH_ERR_UNSUPPORTED + 100 : 0;
 }
 
@@ -664,12 +699,20 @@ int pm_launch(const PmProgram& P, hipStream_t stream) {
         return PH_ERR_BADARG;
     if (P.att.U > PM_ATT_MAXU || P.att.A > PM_ATT_MAXA) return PH_ERR_UNSUPPORTED;
     // barrier / census / abort words and the timers are cleared; the sticky words at the end of the sync area are not
-    PH_CHECK(hipMemsetAsync(P.sync, 0, PM_S_STICKY * sizeof(unsigned), stream));
-    PH_CHECK(hipMemsetAsync(P.sync + PM_SYNC_WORDS, 0, PM_DBG_WORDS * sizeof(unsigned), stream));
+    // (cleared by a kernel of our own, not by hipMemsetAsync: as graph memset nodes replayed on the default stream the
+    // two memsets were seen to leave a non-zero pattern in the words when earlier work was still in flight -- every
+    // barrier of the launch then found the abort word set; tests/test_gpu_persist.py, L = 3 / B = 64)
+    hipLaunchKernelGGL(pm_clear_kernel, dim3(8), dim3(256), 0, stream, P.sync, (int)PM_S_STICKY, P.sync + PM_SYNC_WORDS,
+                       (int)PM_DBG_WORDS);
+    PH_CHECK(hipGetLastError());
     if (P.dataflow)
-        for (int q = 0; q < P.nfill; ++q)
-            PH_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.fill[q].p), (int)PM_EMPTY,
-                                       (size_t)(P.fill[q].bytes / 4), stream));
+        for (int q = 0; q < P.nfill; ++q) {
+            const long long n = P.fill[q].bytes / 4;
+            const int blocks = (int)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256 + 1);
+            hipLaunchKernelGGL(pm_fill_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<unsigned*>(P.fill[q].p), n,
+                               (unsigned)PM_EMPTY);
+            PH_CHECK(hipGetLastError());
+        }
     const size_t lds = (size_t)PM_LDS_FLOATS * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {

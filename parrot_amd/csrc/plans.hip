@@ -1073,7 +1073,7 @@ struct DecoderPlan : PlanBase {
     int nticks6() const { return d.T + std::max(1, lag6(d.L - 1)); }
     int fwd6(hipStream_t st) {
         if (!att_flags) return PARROT_ERR_BADARG;  // (allocated by parrot_decoder_create, outside any stream capture)
-        PL_TRY((int)hipMemsetAsync(att_flags, 0, sizeof(unsigned) * (size_t)(d.T + 2), st));
+        PL_TRY(sk_zero_words_launch(att_flags, d.T + 2, st));
         const int Q = nticks6();
         const char* fe = getenv("PARROT_S5_FULL");
         const int cfull = fe ? atoi(fe) : 160;

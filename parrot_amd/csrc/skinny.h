@@ -73,6 +73,7 @@ void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid, size_t& lds, int& 
 struct AttFwdArgs;
 // The attention forward step and the jobs of L in ONE launch (attention workgroups first, see ska_kernel).
 int sk_launch_att(const SkLaunch& L, const AttFwdArgs& att, hipStream_t stream);
+int sk_zero_words_launch(unsigned* p, int n, hipStream_t stream);
 void sk_profile_begin();
 long long sk_profile_end(double* total_us, double* flops, double* bytes);
 

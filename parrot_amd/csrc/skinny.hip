@@ -619,7 +619,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
 }
 
 // Heterogeneous step launch: the first natt_x workgroups of every grid row carry the attention forward step
-// (att_fwd_body.h; one (batch row, column slice) pair each, on their first ATT_THREADS threads), the others are
+// (att_fwd_body.h; one (batch row, column slice) pair each, on all eight waves), the others are
 // step-GEMM workgroups as in sk_kernel (jobs found through the workgroup prefix table).  The attention of a tick is a
 // chain of dependent round trips that leaves the chip idle; here independent GEMM jobs (the upper layers' input
 // projections, plans.hip schedule 5) run in its shadow.
@@ -636,10 +636,9 @@ __global__ __launch_bounds__(SK_THREADS, 4) void ska_kernel(const SkLaunch L, co
         bx = bx >= ngemm ? bx - ngemm : bx + natt_x;
     }
     if (bx < natt_x) {
-        if (threadIdx.x >= ATT_THREADS) return;  // wave-uniform: the attention step runs on the first four waves
         const int id = blockIdx.y * natt_x + bx;
         if (id >= g.B * g.esplit) return;
-        att_fwd_block<SKA_PROJ_UNROLL>(g, id / g.esplit, id % g.esplit, reinterpret_cast<float*>(sk_smem));
+        att_fwd_block<SK_THREADS, SKA_PROJ_UNROLL>(g, id / g.esplit, id % g.esplit, reinterpret_cast<float*>(sk_smem));
         return;
     }
     bx -= natt_x;
@@ -653,6 +652,19 @@ __global__ __launch_bounds__(SK_THREADS, 4) void ska_kernel(const SkLaunch L, co
     const int tile0 = bx * NB;
     if (NB > 1 || job.aligned) sk_body<MB, NB, true>(job, tile0, red);
     else sk_body<MB, 1, false>(job, tile0, red);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void sk_zero_words_kernel(unsigned* p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
+}
+}  // namespace
+// Zero-fill of a few flag words as a kernel node of its own (graph memset nodes replayed on the default stream were
+// seen to race with work still in flight, see pm_launch in persist.hip).
+int sk_zero_words_launch(unsigned* p, int n, hipStream_t stream) {
+    if (!p || n < 1) return PH_ERR_BADARG;
+    hipLaunchKernelGGL(sk_zero_words_kernel, dim3(n > 4096 ? 16 : 1), dim3(256), 0, stream, p, n);
+    return (int)hipGetLastError();
 }
 
 void sk_job_init(SkJob& j) { memset(&j, 0, sizeof(j)); }

@@ -132,25 +132,52 @@ def test_cfg2_benchmarked_window_T800_matches_oracle(dev, capsys):
 
 def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):
     """BASELINE configs[2] at its real length: decode, batch 16, H=1024, weak feedback, **1000 frames**, every output
-    of sample_model vs the fp64 oracle at 1e-4 (the 60-step test below cannot see a slow drift of the fed-back frame)."""
+    of sample_model vs the fp64 oracle (the 60-step test below cannot see a slow drift of the fed-back frame).
+
+    The decode loop feeds its own output back, and with these weights the map is expansive: measured on the MI355X
+    (tools/decode_drift.py, profiles/r03_decode_drift.txt) the distance to the fp64 trajectory grows smoothly by about
+    2 x per 70 frames -- 5e-7 after 10 frames, 2e-5 after 300, 6e-5 after 500 -- for the persistent machine AND for the
+    launch path, which end 1e-2 apart from EACH OTHER after 1000 frames although both are exact fp32 products.  No fp32
+    implementation can hold 1e-4 over 1000 free-running frames of this map, so the criterion is split:
+      * frames 0..299 at the north star's 1e-4 (measured 1.6e-5);
+      * the whole 1000 frames no worse than what fp32 arithmetic itself costs: at most 30 x the distance of the SAME
+        oracle run in float32 (torch-CPU) from its float64 run, at every horizon (a real defect -- a wrong carry, a
+        stale operand -- shows up as orders of magnitude, at once, not as this slow common drift);
+      * the teacher-forced 800-frame training window (test_cfg2_benchmarked_window_T800_matches_oracle) covers the long horizon without
+        the feedback amplification."""
     from oracle import parrot_ref as R
     from parrot_amd.model import Parrot
     kw = dict(num_layers=2, encoder_type='bidirectional', rnn_h_dim=1024, readouts_dim=1024, weak_feedback=True)
     cfg = R.default_config(**kw)
     p = R.init_params(cfg, seed=29, scale_by_fan_in=True)
-    p['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.9)  # ~0.15 positions per frame: still inside the text at frame 1000
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(-2.3)  # ~0.13 positions per frame: inside the 200-character text at frame 1000
     m = Parrot(device=dev, use_graph=True, **kw).allocate()
     m.set_parameter_values(p)
     N, U, S = 16, 200, 1000
     _, _, lab, lm, _ = make_batch(cfg, 2, N, U, seed=31)
     with torch.no_grad():
         ref = R.sample_model(p, cfg, lab, lm, None, S)
+        ref32 = R.sample_model({k: v.float() for k, v in p.items()}, cfg, lab, lm.float(), None, S)
+    assert float(ref[1][-1].mean()) < U - 5, "the windows must (on average) stay inside the text for the test to mean anything"
     outs = m.sample_model(lab.numpy(), lm.float().numpy(), None, None, N, S)
     report = []
-    for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+    for o, r, r32, n in zip(outs, ref, ref32, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
         assert o.shape == tuple(r.shape), n
-        e = assert_close(torch.from_numpy(o), r, 1e-4, n)
-        report.append(f"{n}: norm-wise {e:.2e}, element-wise {rel_err_elem(torch.from_numpy(o), r):.2e}")
+        o = torch.from_numpy(o).double()
+        r, r32 = r.double(), r32.double()
+        if o.shape[0] != S:  # (outputs without a time axis)
+            assert_close(o, r, 1e-4, n)
+            continue
+        line = []
+        for hz in (100, 300, 500, 700, 1000):
+            scale = float(r[:hz].abs().max())
+            e = float((o[:hz] - r[:hz]).abs().max()) / scale
+            e32 = float((r32[:hz] - r[:hz]).abs().max()) / scale
+            line.append(f"t<{hz}: {e:.1e} (oracle-f32 {e32:.1e})")
+            if hz <= 300:
+                assert e <= 1e-4, f"{n}: {e:.2e} over the first {hz} frames"
+            assert e <= max(1e-4, 30.0 * e32), f"{n}: {e:.2e} over {hz} frames, float32 oracle {e32:.2e}"
+        report.append(f"{n}: " + "  ".join(line))
     with capsys.disabled():
         print("\n[decode-1000 parity] " + "\n[decode-1000 parity] ".join(report))
     m.close()
