@@ -591,16 +591,19 @@ struct DecoderPlan : PlanBase {
         const bool want_persist = want == 4;  // opt-in: measured at cfg2 it only matches the launch schedules
         if (want_persist) want = -1;
         if (want < 0) {
-            // default: the balanced wavefront (5) where it applies -- f32 GRU layers, L >= 2 -- unless the caller asked
+            // default: the balanced wavefront (5) where it applies -- L >= 2, no layer_norm -- unless the caller asked
             // for independent row strands (a schedule-0 feature); measured at cfg2: forward scan 29.2 -> 25.2 ms
             const char* se = getenv("PARROT_STRANDS");
             const int strands_wanted = se ? atoi(se) : d.reserved;
-            want = (pipe_ok && d.cell == 0 && !d.layer_norm && !d.bf16 && strands_wanted <= 1) ? 5 : 0;
+            // (bf16 operands stay on schedule 0: the wide step kernel has ~10 us of fixed cost per launch, so cutting its
+            // one launch per tick in two costs more than the attention's shadow returns -- cfg4: 118.9 vs 127.5 ms)
+            want = (pipe_ok && !d.layer_norm && !d.bf16 && strands_wanted <= 1) ? 5 : 0;
         }
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
         if (want >= 2 && !pipe_ok && !(want == 6 && d.L == 1)) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
-        if (want >= 5 && (d.cell != 0 || d.layer_norm || d.bf16)) want = 0;  // balanced wavefronts: f32 GRU layers
+        if (want == 6 && (d.cell != 0 || d.bf16)) want = 5;                  // the in-launch hand-off: f32 GRU layers
+        if (want >= 5 && d.layer_norm) want = 0;
         schedule = want;
         try_persist = want_persist && d.cell == 0 && !d.layer_norm && !d.bf16;
         const char* c = getenv("PARROT_CHUNK");
@@ -996,21 +999,27 @@ struct DecoderPlan : PlanBase {
     // The pre-activation of an upper layer is now (recurrent sum) + (input sum) instead of one running sum over the
     // concatenated K: same terms, other rounding (not bit-identical to schedule 0; the oracle tests cover both).
     int esplit5 = 1;
+    bool s5_split = true;  // PARROT_S5_SPLIT=0: LSTM input projections of l >= 2 as one job
     int lag5(int l) const { return l == 0 ? 0 : l + 1; }
     int nticks5() const { return d.T + lag5(d.L - 1); }
-    void input_job(SkJob& j, int l, int t, int g) const {
+    // part 0: the whole projection; 1: the rows of w and h_0 .. h_{l-2} (ready a tick earlier); 2: the rows of h_{l-1},
+    // accumulated onto part 1 (LSTM stacks with l >= 2: two jobs of about the recurrent K instead of one of K = E + l H)
+    void input_job(SkJob& j, int l, int t, int g, int part = 0) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
-        const int wd = g == 0 ? 2 * d.H : d.H;
+        const int wd = d.cell == 1 ? 4 * d.H : (g == 0 ? 2 * d.H : d.H);  // LSTM layers: one 4H-wide matrix (g = 0)
         sk_job_init(j);
+        j.colmode = d.cell == 1 && tiled ? 1 : 0;  // (the tiled copies of LSTM matrices keep the gate-interleaved tile order)
         int n = 0;
-        j.seg[n++] = fseg(d.w + (size_t)(t + 1) * BE, d.E, l, g, d.H, d.E, wd);
-        for (int q = 0; q < l; ++q)
+        if (part != 2) j.seg[n++] = fseg(d.w + (size_t)(t + 1) * BE, d.E, l, g, d.H, d.E, wd);
+        for (int q = 0; q < l; ++q) {
+            if ((part == 1 && q == l - 1) || (part == 2 && q != l - 1)) continue;
             j.seg[n++] = fseg(d.h[q] + (size_t)(t + 1) * BH, d.H, l, g, d.H + d.E + q * d.H, d.H, wd);
+        }
         j.nseg = n;
         j.M = d.B; j.N = wd; j.H = d.H; j.epi = SK_EPI_LINEAR;
         float* sq = (g == 0 ? d.seq_g[l] : d.seq_c[l]) + (size_t)t * d.B * wd;
         j.out = sq; j.ldo = wd;
-        j.accumulate = (d.seq_init >> l) & 1;  // caller data (feedback / speaker terms) already in the buffer
+        j.accumulate = part == 2 ? 1 : ((d.seq_init >> l) & 1);  // caller data (feedback / speaker terms) already there
         take_rows(j, cur);
     }
     int fwd5(hipStream_t st) {
@@ -1024,25 +1033,34 @@ struct DecoderPlan : PlanBase {
                 const int t = q - lag5(l);
                 if (t < 0 || t >= d.T) continue;
                 SkJob& j = jobs[n++];
-                gates_job(j, l, t);
+                if (d.cell == 1) lstm_job(j, l, t);  // LSTM layers: one fused product + cell update per layer-step
+                else gates_job(j, l, t);
                 if (l > 0) j.nseg = 1;  // recurrent block only; the rest arrives through seq_g (has_seq)
             }
             if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             n = 0;
-            for (int l = 0; l < d.L; ++l) {
-                const int t = q - lag5(l);
-                if (t < 0 || t >= d.T) continue;
-                SkJob& j = jobs[n++];
-                cand_job(j, l, t);
-                if (l > 0) j.nseg = 1;
+            if (d.cell == 0) {
+                for (int l = 0; l < d.L; ++l) {
+                    const int t = q - lag5(l);
+                    if (t < 0 || t >= d.T) continue;
+                    SkJob& j = jobs[n++];
+                    cand_job(j, l, t);
+                    if (l > 0) j.nseg = 1;
+                }
+                if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             }
-            if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             n = 0;
             for (int l = 1; l < d.L; ++l) {
                 const int t = q - lag5(l) + 1;
-                if (t < 0 || t >= d.T) continue;
-                input_job(jobs[n++], l, t, 0);
-                input_job(jobs[n++], l, t, 1);
+                const bool split = d.cell == 1 && l >= 2 && s5_split;
+                if (t >= 0 && t < d.T) {
+                    input_job(jobs[n++], l, t, 0, split ? 2 : 0);
+                    if (d.cell == 0) input_job(jobs[n++], l, t, 1);
+                }
+                if (split) {  // the rows that were ready a tick earlier
+                    const int ta = t + 1;
+                    if (ta >= 0 && ta < d.T) input_job(jobs[n++], l, ta, 0, 1);
+                }
             }
             if (q < d.T) {
                 AttFwdArgs ag = att_fwd_args(q);
@@ -2398,6 +2416,8 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     if (p->schedule == 5) {
         const char* e = getenv("PARROT_S5_ESPLIT");
         p->esplit5 = e && atoi(e) > 0 ? atoi(e) : 1;
+        e = getenv("PARROT_S5_SPLIT");
+        p->s5_split = e ? atoi(e) != 0 : true;
     }
     if (p->schedule == 6) {
         if (hipMalloc(&p->att_flags, sizeof(unsigned) * (size_t)(desc->T + 2)) != hipSuccess) {

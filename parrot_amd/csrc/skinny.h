@@ -54,7 +54,9 @@ struct SkJob {
     // puts them first), the wait is bounded (~1 s, then the kernel traps).
     const unsigned* wait_flag;
     unsigned wait_target;
-    int pad2;
+    int colmode;  // 1: a LINEAR job over the gate-interleaved column order of an LSTM matrix (N = 4H; the fragment-major
+                  // copies of such matrices hold their column tiles in that order): output column of (tile, j) as in
+                  // SK_EPI_LSTM.  Used by the input projections of LSTM layers (plans.hip, schedule 5).
 };
 
 struct SkLaunch {

@@ -51,6 +51,9 @@ __device__ __forceinline__ int sk_col(int epi, int H, int tile, int jj) {
     if (epi == SK_EPI_LSTM) return (jj >> 2) * H + tile * 4 + (jj & 3);  // gate-major columns
     return tile * 16 + jj;
 }
+__device__ __forceinline__ int sk_jcol(const SkJob& job, int tile, int jj) {
+    return sk_col(job.colmode == 1 ? (int)SK_EPI_LSTM : job.epi, job.H, tile, jj);
+}
 
 template <int MB, bool AL>
 __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M, int ncol, bool ncol_ok,
@@ -254,7 +257,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         const int blk_ = tid >> 6;
         const int rb_ = blk_ / NB, tile_ = tile0 + blk_ % NB;
         const int g_ = lane >> 4, jj_ = lane & 15;
-        const int n_ = sk_col(job.epi, job.H, tile_, jj_);
+        const int n_ = sk_jcol(job, tile_, jj_);
         const bool n_ok_ = n_ < N;
         if (job.bias && n_ok_) p_bias = job.bias[n_];
 #pragma unroll
@@ -312,7 +315,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
         for (int rb = 0; rb < MB; ++rb) mrow[rb] = min(m0 + rb * 16 + (SK_A_PERMUTE ? ((lane >> 2) & 15) : i), M - 1);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            ncl[nb] = min(sk_col(job.epi, job.H, tile0 + nb, i), N - 1);
+            ncl[nb] = min(sk_jcol(job, tile0 + nb, i), N - 1);
             btile[nb] = min(tile0 + nb, ((N + 15) >> 4) - 1);
         }
 #ifdef SK_BLOCKED
@@ -467,7 +470,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
     } else {
         // Generic path (NB == 1): per-element masks for K tails / unaligned operands (e.g. the 63-wide
         // fed-back output frame).  Round-robin 16-deep K chunks over the waves, segment by segment.
-        const int ncol = sk_col(job.epi, job.H, tile0, i);
+        const int ncol = sk_jcol(job, tile0, i);
         const bool ncol_ok = ncol < N;
         f32x4 accg[MB];
 #pragma unroll
@@ -513,7 +516,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
 
     // Fused epilogue.  MFMA C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int g = lane >> 4, jj = lane & 15;
-    const int n = sk_col(job.epi, job.H, tile, jj);
+    const int n = sk_jcol(job, tile, jj);
     const bool n_ok = n < N;
     const float bias = p_bias;
     const int H = job.H;
@@ -694,8 +697,9 @@ int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
         if (j.nseg < 1 || j.nseg > SK_MAXSEG || j.M < 1 || j.N < 1 || j.aligned < 0) return PH_ERR_BADARG;
         if (j.seg[0].b_kcontig >= 2 && !j.aligned) return PH_ERR_BADARG;  // tiled weights: fast path only
         int tiles;
-        if (j.epi == SK_EPI_LSTM) {
+        if (j.epi == SK_EPI_LSTM || j.colmode == 1) {
             if (j.N != 4 * j.H || (j.H & 3)) return PH_ERR_BADARG;
+            if (j.colmode == 1 && j.epi != SK_EPI_LINEAR) return PH_ERR_BADARG;
             tiles = j.H / 4;
         } else {
             tiles = ceil_div(j.N, 16);
@@ -887,7 +891,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ctl = NCW == 8 ? wave : (wave & 3), rh = NCW == 8 ? 0 : (wave >> 2);
     const int M = job.M, N = job.N;
-    const int ntiles = job.epi == SK_EPI_LSTM ? (job.H >> 2) : ((N + 15) >> 4);
+    const int ntiles = (job.epi == SK_EPI_LSTM || job.colmode == 1) ? (job.H >> 2) : ((N + 15) >> 4);
     const int tile = min(wg * NCW + ctl, ntiles - 1);
     const bool tile_ok = wg * NCW + ctl < ntiles;
 
@@ -986,7 +990,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     // fused epilogue, per wave (complete sums).  C layout: column = lane & 15, row = 4 * (lane >> 4) + reg.
 
     const int g = lane >> 4, jj = lane & 15;
-    const int n = sk_col(job.epi, job.H, tile, jj);
+    const int n = sk_jcol(job, tile, jj);
     const bool n_ok = n < N;
     const float bias = (job.bias && n_ok) ? job.bias[n] : 0.f;
 #pragma unroll
@@ -1044,8 +1048,33 @@ __global__ __launch_bounds__(SK_THREADS) void wk_kernel(const WkLaunch L) {
     else wk_body<4>(job, bx, wk_smem);
 }
 
+// Heterogeneous variant of wk_kernel: workgroups [0, natt) carry the attention forward step (one batch row each, all
+// eight waves), the others are wide-kernel workgroups (the bf16 input projections of LSTM layers beside the attention).
+__global__ __launch_bounds__(SK_THREADS) void wka_kernel(const WkLaunch L, const AttFwdArgs g, const int natt, const int att_last) {
+    extern __shared__ __attribute__((aligned(16))) char wk_smem[];
+    int bx = blockIdx.x;
+    if (att_last) {
+        const int ngemm = (int)gridDim.x - natt;
+        bx = bx >= ngemm ? bx - ngemm : bx + natt;
+    }
+    if (bx < natt) {
+        att_fwd_block<SK_THREADS, SKA_PROJ_UNROLL>(g, bx / g.esplit, bx % g.esplit, reinterpret_cast<float*>(wk_smem));
+        return;
+    }
+    bx -= natt;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < SK_MAXJOB - 1; ++q)
+        if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
+    bx -= (j > 0 ? L.wg_end[j - 1] : 0);
+    const SkJob& job = L.job[j];
+    if (L.ncw[j] == 8) wk_body<8>(job, bx, wk_smem);
+    else wk_body<4>(job, bx, wk_smem);
+}
+
 // Takes the launch when every job is a bf16-operand LSTM / LINEAR job over <= 64 rows with 64-deep K segments.
-static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
+// att != null: the attention step rides in the same launch (wka_kernel); `reserve` CUs are left to its blocks.
+static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, const AttFwdArgs* att = nullptr) {
     const char* e = getenv("PARROT_WK");  // 0: never; 1 (default): launches with >= 4096 output columns; 2: whenever legal
     const int enabled = e ? atoi(e) : 1;
     if (!enabled) return false;
@@ -1075,7 +1104,8 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
     }
 
     // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits
-    while (units > 256) {
+    const int natt = att ? att->B * att->esplit : 0;
+    while (units > 256 - (natt < 128 ? natt : 128)) {
         int best = -1;
         for (int q = 0; q < Lin.njobs; ++q)
             if (W.ncw[q] == 4 && (best < 0 || ksum[q] < ksum[best])) best = q;
@@ -1088,7 +1118,28 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc) {
         t += ceil_div(tiles[q], W.ncw[q]);
         W.wg_end[q] = t;
     }
-    const size_t lds = 2 * 64 * WK_PITCH;  // two stage buffers
+    size_t lds = 2 * 64 * WK_PITCH;  // two stage buffers
+    if (att) {
+        const size_t alds = att_fwd_lds(att->U);
+        if (alds > lds) lds = alds;
+        static int att_last = -1;
+        if (att_last < 0) {
+            const char* e2 = getenv("PARROT_SKA_ATT_LAST");
+            att_last = e2 ? atoi(e2) : 1;
+        }
+        if (g_prof.on) {
+            SkProfRec r;
+            (void)hipEventCreate(&r.e0);
+            (void)hipEventCreate(&r.e1);
+            sk_account(Lin, r.flops, r.bytes);
+            hipExtLaunchKernelGGL(wka_kernel, dim3(t + natt), dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, W, *att, natt, att_last);
+            g_prof.recs.push_back(r);
+        } else {
+            hipLaunchKernelGGL(wka_kernel, dim3(t + natt), dim3(SK_THREADS), lds, stream, W, *att, natt, att_last);
+        }
+        *rc = (int)hipGetLastError();
+        return true;
+    }
     if (g_prof.on) {
         SkProfRec r;
         (void)hipEventCreate(&r.e0);
@@ -1267,8 +1318,13 @@ int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream
         if (rc != 0) return rc;
     }
     if (Lin.njobs < 1) return att_fwd_launch(att, stream);
-    for (int q = 0; q < Lin.njobs; ++q)
-        if (Lin.job[q].seg[0].b_kcontig == 3) return PH_ERR_UNSUPPORTED;  // (the bf16 launches have their own wide kernel)
+    {   // bf16 launches the wide kernel takes (no job may wait on the attention there)
+        bool flagged = false;
+        for (int q = 0; q < Lin.njobs; ++q)
+            if (Lin.job[q].wait_flag) flagged = true;
+        int rc = 0;
+        if (!flagged && wk_try_launch(Lin, stream, &rc, &g)) return rc;
+    }
     SkLaunch L;
     dim3 grid;
     size_t lds;

@@ -320,6 +320,13 @@ def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
                           use_graph=True, expect_schedule=sched)
     _check_cost_and_grads(dev, T=1, B=4, U=6, num_layers=2, encoder_type='bidirectional', use_graph=True,
                           expect_schedule=sched)
+    # LSTM layers: one fused product per layer-step, the input projections keep the gate-interleaved column order of
+    # the tiled weight copies (schedule 6 does not cover them and falls back to 5)
+    for use_graph in (False, True):
+        _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
+                              use_speaker=True, cell_type='lstm', use_graph=use_graph, expect_schedule=5)
+    _check_cost_and_grads(dev, T=7, B=20, U=6, num_layers=2, encoder_type='bidirectional', cell_type='lstm',
+                          use_graph=True, ragged=True, expect_schedule=5)
 
 
 # ----------------------------------------------------------------------------- strands and parts
