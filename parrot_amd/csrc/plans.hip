@@ -19,6 +19,7 @@
 #include "biggemm.h"
 #include "elementwise.h"
 #include "persist.h"
+#include "rowgru.h"
 #include "skinny.h"
 
 namespace {
@@ -143,7 +144,59 @@ void take_rows(LstmStateBwdArgs& g, const Strand& s) {
 struct GruSeqPlan : PlanBase {
     ParrotGruSeqDesc d;
 
-    int enqueue(int which, hipStream_t s) override { return which == 0 ? fwd(s) : bwd(s); }
+    // Narrow layers (H <= 256: the encoder) run the whole sequence as ONE launch per direction on the row-owning
+    // kernels of rowgru.hip (PARROT_GRU_ROWWISE=0: the per-step launches below).  The plan owns the fragment-major
+    // weight copies and refreshes them at the head of every forward scan (the weights change between steps).
+    bool rowwise = false;
+    float* tiled = nullptr;  // per chain: Wg_f, Wc_f, Wg_r, Wc_r
+    ~GruSeqPlan() override {
+        if (tiled) (void)hipFree(tiled);
+    }
+    int setup_rowwise() {
+        const char* e = getenv("PARROT_GRU_ROWWISE");
+        rowwise = rowgru_supported(d.T, d.B, d.H, d.nchain) && !(e && atoi(e) == 0);
+        for (int ch = 0; ch < d.nchain && rowwise; ++ch)  // (the tiling kernel wants 16-byte aligned matrices)
+            if (!d.Wg[ch] || !d.Wc[ch] || ((uintptr_t)d.Wg[ch] & 15) || ((uintptr_t)d.Wc[ch] & 15)) rowwise = false;
+        if (!rowwise) return 0;
+        const size_t per = (size_t)6 * d.H * d.H;  // 2 x (H x 2H + H x H) floats
+        if (hipMalloc(&tiled, sizeof(float) * per * d.nchain) != hipSuccess) {
+            tiled = nullptr;
+            rowwise = false;
+        }
+        return 0;
+    }
+    RowGruArgs row_args() const {
+        RowGruArgs g;
+        memset(&g, 0, sizeof(g));
+        const size_t HH = (size_t)d.H * d.H;
+        for (int ch = 0; ch < d.nchain; ++ch) {
+            RowGruChain& c = g.chain[ch];
+            float* base = tiled + (size_t)ch * 6 * HH;
+            c.Wg_f = base; c.Wc_f = base + 2 * HH; c.Wg_r = base + 3 * HH; c.Wc_r = base + 5 * HH;
+            c.inputs = d.inputs[ch]; c.gate_inputs = d.gate_inputs[ch];
+            c.h = d.h[ch]; c.z = d.z[ch]; c.r = d.r[ch]; c.rh = d.rh[ch]; c.c = d.c[ch];
+            c.dh = d.dh[ch]; c.dG = d.dG[ch]; c.dC = d.dC[ch];
+            c.reverse = d.reverse[ch];
+        }
+        g.mask = d.mask; g.T = d.T; g.B = d.B; g.H = d.H; g.nchain = d.nchain;
+        return g;
+    }
+    int fwd_rowwise(hipStream_t st) {
+        const RowGruArgs g = row_args();
+        for (int ch = 0; ch < d.nchain; ++ch) {
+            const RowGruChain& c = g.chain[ch];
+            PL_TRY(sk_tile_weights_launch(d.Wg[ch], d.H, 2 * d.H, 2 * d.H, const_cast<float*>(c.Wg_f), 0, 0, st));
+            PL_TRY(sk_tile_weights_launch(d.Wc[ch], d.H, d.H, d.H, const_cast<float*>(c.Wc_f), 0, 0, st));
+            PL_TRY(sk_tile_weights_launch(d.Wg[ch], d.H, 2 * d.H, 2 * d.H, const_cast<float*>(c.Wg_r), 1, 0, st));
+            PL_TRY(sk_tile_weights_launch(d.Wc[ch], d.H, d.H, d.H, const_cast<float*>(c.Wc_r), 1, 0, st));
+        }
+        return rowgru_fwd_launch(g, st);
+    }
+
+    int enqueue(int which, hipStream_t s) override {
+        if (rowwise) return which == 0 ? fwd_rowwise(s) : rowgru_bwd_launch(row_args(), s);
+        return which == 0 ? fwd(s) : bwd(s);
+    }
 
     int fwd(hipStream_t st) {
         const size_t BH = (size_t)d.B * d.H;
@@ -591,13 +644,15 @@ struct DecoderPlan : PlanBase {
         const bool want_persist = want == 4;  // opt-in: measured at cfg2 it only matches the launch schedules
         if (want_persist) want = -1;
         if (want < 0) {
-            // default: the balanced wavefront (5) where it applies -- L >= 2, no layer_norm -- unless the caller asked
+            // default: the balanced wavefront (5) where it pays -- GRU layers, L >= 2, no layer_norm -- unless the caller asked
             // for independent row strands (a schedule-0 feature); measured at cfg2: forward scan 29.2 -> 25.2 ms
             const char* se = getenv("PARROT_STRANDS");
             const int strands_wanted = se ? atoi(se) : d.reserved;
-            // (bf16 operands stay on schedule 0: the wide step kernel has ~10 us of fixed cost per launch, so cutting its
-            // one launch per tick in two costs more than the attention's shadow returns -- cfg4: 118.9 vs 127.5 ms)
-            want = (pipe_ok && !d.layer_norm && !d.bf16 && strands_wanted <= 1) ? 5 : 0;
+            // GRU stacks, f32 or bf16 operands (cfg2: 82.7 -> 74.6 ms f32, 59.8 -> 54.0 ms bf16; 3 layers 122.5 -> 115.0).
+            // LSTM stacks stay on schedule 0 (5 covers them, opt-in): their tick is ONE fused launch of > 1000 workgroups,
+            // bound by total work rather than by its longest K, and cutting it in two only adds fixed cost -- cfg4 bf16
+            // 118.9 vs 127.5 ms (the wide kernel has ~10 us of fixed cost per launch), cfg4 f32 256.5 vs 265.4 ms.
+            want = (pipe_ok && d.cell == 0 && !d.layer_norm && strands_wanted <= 1) ? 5 : 0;
         }
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
         if (want >= 2 && !pipe_ok && !(want == 6 && d.L == 1)) want = 0;
@@ -2357,6 +2412,7 @@ int parrot_gru_seq_create(const ParrotGruSeqDesc* desc, void** plan) { PH_ENTRY(
     if (!p) return PARROT_ERR_BADARG;
     p->d = *desc;
     p->use_graph = desc->use_graph;
+    p->setup_rowwise();
     *plan = p;
     return 0;
 }

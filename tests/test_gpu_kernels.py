@@ -138,6 +138,42 @@ def test_gru_seq_fwd_bwd(dev, reverse, use_mask):
         assert_close(t.grad, r.grad, 1e-4, n)
 
 
+@pytest.mark.parametrize("T,B,H,reverse,use_mask", [(6, 37, 128, False, True), (5, 20, 256, True, False),
+                                                   (64, 200, 128, True, True), (7, 16, 16, False, False)])
+def test_gru_seq_rowwise_vs_step_launches(dev, monkeypatch, T, B, H, reverse, use_mask):
+    """The row-owning scan kernels (rowgru.hip: one launch per direction for the whole sequence, H <= 256) against the
+    fp64 oracle and against the per-step launch path (PARROT_GRU_ROWWISE=0) -- the encoder's own shape (64 steps over
+    200 rows, H = 128), ragged row blocks, both directions, step masks, the widest and the narrowest layer it takes."""
+    from oracle import parrot_ref as R
+    from parrot_amd import ops
+    inp = _rand((T, B, H), dev, 1)
+    gin = _rand((T, B, 2 * H), dev, 2)
+    h0 = _rand((B, H), dev, 3)
+    Wc = _rand((H, H), dev, 4, 1 / math.sqrt(H))
+    Wg = _rand((H, 2 * H), dev, 5, 1 / math.sqrt(H))
+    mask = (torch.rand(T, B, generator=torch.Generator().manual_seed(6)) > 0.3).float().to(dev) if use_mask else None
+    gout = _rand((T, B, H), dev, 7)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PARROT_GRU_ROWWISE", mode)
+        ts = [t.clone().requires_grad_() for t in (inp, gin, h0, Wc, Wg)]
+        hs = ops.gru_seq(*ts, mask, reverse)
+        (hs * gout).sum().backward()
+        got[mode] = [hs.detach().clone()] + [t.grad.clone() for t in ts]
+    rs = [t.detach().double().cpu().requires_grad_() for t in (inp, gin, h0, Wc, Wg)]
+    mr = None if mask is None else mask.double().cpu()
+    if reverse:
+        ref = R.gru_scan(rs[0].flip(0), rs[1].flip(0), rs[2], rs[3], rs[4], None if mr is None else mr.flip(0)).flip(0)
+    else:
+        ref = R.gru_scan(rs[0], rs[1], rs[2], rs[3], rs[4], mr)
+    (ref * gout.double().cpu()).sum().backward()
+    names = ("h", "d_inputs", "d_gate_inputs", "dh0", "dWc", "dWg")
+    for a, r, n in zip(got["1"], [ref] + [x.grad for x in rs], names):
+        assert_close(a, r, 2e-5 if n == "h" else 1e-4, "row-wise vs oracle: " + n)
+    for a, b, n in zip(got["1"], got["0"], names):
+        assert_close(a, b, 2e-5, "row-wise vs step launches: " + n)
+
+
 @pytest.mark.parametrize("T,B,H", [(5, 3, 16), (7, 37, 64)])
 def test_lstm_seq_fwd_bwd(dev, T, B, H):
     """LSTM scan (ops.py:461-553 arithmetic) vs an fp64 torch loop, values and all gradients."""
