@@ -1,7 +1,7 @@
 // skbench3 + (a) the launch descriptor read through a device pointer instead of the kernarg segment (SKB_PTR=1),
 // (b) a K sweep of a single N = 4096 job on 256 workgroups (intercept = fixed cost of a launch, slope = cost per K),
 // (c) SKB_NSETS = operand sets rotated through (1: weights stay cache-resident), (d) PARROT_SK_LDS_PAD.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/skbench4.hip -o tools/probe_bin/skbench4
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSK_A_FRAG_PROBE=1] tools/skbench4.hip parrot_amd/csrc/attention.hip -o tools/probe_bin/skbench4
 #include "../parrot_amd/csrc/skinny.hip"
 
 #include <stdio.h>
