@@ -12,7 +12,10 @@ from parrot_amd import _lib, ops
 from parrot_amd.model import Parrot
 
 dev = torch.device("cuda:0")
-T, B, U = 800, 64, 200
+# PROBE_T=100 PROBE_STEPS=1 PROBE_SCANS=0: the short variant for `rocprofv3 --pmc` passes (counter collection costs
+# ~30 ms per launch: the full probe's ~20 000 launches do not finish in ten minutes; per-launch traffic does not depend on T)
+T, B, U = int(os.environ.get("PROBE_T", "800")), 64, 200
+STEPS, SCANS = int(os.environ.get("PROBE_STEPS", "2")), int(os.environ.get("PROBE_SCANS", "3"))
 m = Parrot(device=dev, num_layers=2, rnn_h_dim=1024, readouts_dim=1024, encoder_type='bidirectional',
            use_graph=True).initialize()
 with torch.no_grad():
@@ -22,7 +25,7 @@ feat = torch.randn(T + 1, B, 63, generator=g).to(dev)
 fm = torch.ones(T + 1, B, device=dev)
 lab = torch.randint(0, 43, (B, U), generator=g).to(dev)
 lm = torch.ones(B, U, device=dev)
-for _ in range(2):
+for _ in range(STEPS):
     m.zero_grad()
     c, _, _, _ = m.compute_cost(feat, fm, lab, lm, None, 1, B)
     c.backward()
@@ -30,7 +33,7 @@ torch.cuda.synchronize()
 ws = next(iter(m._train_ws.values()))
 plan = ws['plan']
 for which, name in ((0, 'parrot_decoder_seq_fwd'), (1, 'parrot_decoder_seq_bwd')):
-    for rep in range(3):
+    for rep in range(SCANS):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         _lib.call(name, plan, ops._stream())
