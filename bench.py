@@ -106,6 +106,36 @@ def build_model(a, dev, use_graph=True):
     return m
 
 
+def kernel_source_digest(root=ROOT):
+    """sha256 over the sources of the step kernels and their schedules: what a PMC traffic figure is valid for."""
+    import hashlib
+    hd = hashlib.sha256()
+    for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
+        hd.update(open(os.path.join(root, "parrot_amd", "csrc", name), "rb").read())
+    return hd.hexdigest()
+
+
+def pmc_traffic_figure(root=ROOT, names=("r03_pmc_traffic.json",)):
+    """(bytes per launch | None, source note).  HBM-side bytes per step-kernel launch come from separate rocprofv3 --pmc
+    passes (FETCH_SIZE / WRITE_SIZE cannot share a pass with the timed run), so the number is a committed measurement,
+    not one of this run -- and it is only reported while the kernel sources it was measured on are unchanged (digest
+    stored by tools/pmc_traffic.py); otherwise `traffic` is null and the note says which file went stale."""
+    for name in names:
+        tpath = os.path.join(root, "profiles", name)
+        if not os.path.exists(tpath):
+            continue
+        try:
+            blob = json.load(open(tpath))
+        except Exception:
+            return None, f"profiles/{name} is unreadable"
+        if blob.get("source_digest") == kernel_source_digest(root):
+            return blob.get("hbm_bytes_per_launch"), (f"profiles/{name} ({blob.get('session', '?')}; tools/pmc_traffic.py; "
+                                                      "separate --pmc passes)")
+        return None, f"profiles/{name} is stale: the kernel sources changed after it was measured"
+    return None, None
+
+
+
 def roofline_leg(a, dev, flat_params):
     """One extra, untimed training step with eager launches, every recurrent-step dispatch timed."""
     from parrot_amd import _lib, ops
@@ -149,26 +179,7 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
     peak = 157.3  # f32-input MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass
     # with the timed run); the number is the committed measurement of the session named next to it, not of this run
-    # A figure is only reported while the kernel sources it was measured on are unchanged (digest stored by
-    # tools/pmc_traffic.py); otherwise `traffic` is null and `traffic_source` says which file went stale.
-    traffic, traffic_src = None, None
-    import hashlib
-    hd = hashlib.sha256()
-    for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
-        hd.update(open(os.path.join(ROOT, "parrot_amd", "csrc", name), "rb").read())
-    for name in ("r03_pmc_traffic.json",):
-        tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath):
-            try:
-                blob = json.load(open(tpath))
-                if blob.get("source_digest") == hd.hexdigest():
-                    traffic = blob.get("hbm_bytes_per_launch")
-                    traffic_src = f"profiles/{name} ({blob.get('session', '?')}; tools/pmc_traffic.py; separate --pmc passes)"
-                else:
-                    traffic_src = f"profiles/{name} is stale: the kernel sources changed after it was measured"
-                break
-            except Exception:
-                traffic = None
+    traffic, traffic_src = pmc_traffic_figure()
     return {
         "kernel": "sk_kernel (fused GRU gate/candidate step GEMM, fwd + bwd)",
         "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",

@@ -1,0 +1,49 @@
+"""bench.py host logic that needs no GPU: the PMC `traffic` figure is only reported while the kernel sources it was
+measured on are unchanged."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _fake_tree(tmp_path):
+    csrc = tmp_path / "parrot_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
+        (csrc / name).write_text("// " + name + "\n")
+    (tmp_path / "profiles").mkdir()
+    return str(tmp_path)
+
+
+def test_traffic_figure_fresh_stale_absent(tmp_path):
+    import bench
+    root = _fake_tree(tmp_path)
+    assert bench.pmc_traffic_figure(root) == (None, None)  # nothing measured: null, no note
+    blob = {"hbm_bytes_per_launch": 12345678, "session": "unit test", "source_digest": bench.kernel_source_digest(root)}
+    path = os.path.join(root, "profiles", "r03_pmc_traffic.json")
+    json.dump(blob, open(path, "w"))
+    value, note = bench.pmc_traffic_figure(root)
+    assert value == 12345678 and "unit test" in note and "r03_pmc_traffic.json" in note
+    # a kernel source changes -> the figure is refused and the note says why
+    with open(os.path.join(root, "parrot_amd", "csrc", "plans.hip"), "a") as f:
+        f.write("// edited\n")
+    value, note = bench.pmc_traffic_figure(root)
+    assert value is None and "stale" in note
+    # an unreadable file never yields a number
+    open(path, "w").write("{not json")
+    value, note = bench.pmc_traffic_figure(root)
+    assert value is None and "unreadable" in note
+
+
+def test_repo_has_no_stale_traffic_figure():
+    """Whatever profiles/ holds for this tree: bench.py either reports a figure whose digest matches, or null."""
+    import bench
+    value, note = bench.pmc_traffic_figure()
+    if value is not None:
+        blob = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        assert blob["source_digest"] == bench.kernel_source_digest()
+    else:
+        assert note is None or "stale" in note or "unreadable" in note

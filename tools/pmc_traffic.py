@@ -38,12 +38,11 @@ for k in sorted(ft, key=lambda k: -ft[k]):
         sk_n += n
 out["hbm_bytes_per_launch"] = round(sk_bytes / sk_n) if sk_n else None
 # digest of the kernel sources the passes ran on: bench.py refuses the figure once they have changed
-import hashlib, os
+import os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-h = hashlib.sha256()
-for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
-    h.update(open(os.path.join(root, "parrot_amd", "csrc", name), "rb").read())
-out["source_digest"] = h.hexdigest()
+sys.path.insert(0, root)
+from bench import kernel_source_digest  # noqa: E402  (one definition of what the figure is valid for)
+out["source_digest"] = kernel_source_digest(root)
 if len(sys.argv) > 4:
     out["session"] = sys.argv[4]
 out["sk_launches"] = sk_n
