@@ -276,6 +276,14 @@ int parrot_decoder_is_persistent(void* plan);
  * not cover): 0 merged wavefront, 2 / 3 chunked pipelines, 5 balanced wavefront (attention beside the upper layers'
  * input projections), 6 two launches per tick (attention inside the gate launch). */
 int parrot_decoder_schedule(void* plan);
+/* Schedule tracing (test infrastructure of the library itself; runs without a GPU): instead of launching, the plan
+ * records for every launch of direction `which` (0 forward, 1 backward) and every job in it the byte ranges of the
+ * descriptor's buffers the job reads / writes.  Records are 5 x int64: launch index, job id (0..8 step-GEMM jobs, 100 the
+ * attention (+ the state backward fused behind it), 200 + c state-backward chain c), kind (0 read, 1 write, 2 read +
+ * write, 3 read behind an in-launch flag), lo, hi (byte addresses).  Returns the number of records (fills min(n, cap)
+ * of them into `out`), or -(error code); launch schedules 0, 5 and 6 only.  PARROT_TRACE_ONLY=1 lets schedule 6 be
+ * created on a box without a GPU. */
+long long parrot_decoder_trace(void* plan, int which, long long* out, long long cap);
 /* Waits for the device; 0, or non-zero when a persistent launch of this plan gave up (a workgroup waited ~1 s for a
  * rendezvous or for an operand that never arrived): the results of that window are invalid.  0 on the launch schedules. */
 int parrot_decoder_status(void* plan);

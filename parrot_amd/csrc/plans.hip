@@ -74,21 +74,126 @@ struct PlanBase {
         if (rc__ != 0) return rc__; \
     } while (0)
 
+// ---- schedule tracing (parrot_decoder_trace) ---------------------------------------------------------------------
+// With a tracer installed the launch helpers below do not launch anything: they record, per launch and per job, the
+// byte ranges the job reads, writes, reads-and-writes, or reads behind an in-launch flag.  tests/test_schedule_cpu.py
+// runs every launch schedule through it on fake device addresses (no GPU) and checks the orderings a schedule must keep:
+// no job of a launch touches what another job of the same launch writes, write-once buffers are read only after their
+// writer's launch, accumulators are not written after their consumer has read them.
+struct TraceRec { long long launch, job, kind, lo, hi; };  // kind: 0 read, 1 write, 2 read+write, 3 read behind a flag
+struct Tracer {
+    std::vector<TraceRec> recs;
+    long long launch = -1;
+    void begin() { ++launch; }
+    void mat(const void* p, long long rows, long long cols, long long ld, int kind, int job, int elt = 4) {
+        if (!p || rows < 1 || cols < 1) return;
+        const long long base = (long long)(uintptr_t)p;
+        if (ld == cols) { recs.push_back({launch, job, kind, base, base + rows * cols * elt}); return; }
+        for (long long r = 0; r < rows; ++r) recs.push_back({launch, job, kind, base + r * ld * elt, base + (r * ld + cols) * elt});
+    }
+    void sk_job(const SkJob& j, int id) {
+        for (int q = 0; q < j.nseg; ++q)
+            mat(j.seg[q].A, j.M, j.seg[q].K, j.seg[q].lda, (j.wait_flag && q == j.nseg - 1) ? 3 : 0, id);
+        mat(j.add, j.M, j.N, j.ld_add, 0, id);
+        const int H = j.H;
+        switch (j.epi) {
+            case SK_EPI_LINEAR: mat(j.out, j.M, j.N, j.ldo, j.accumulate ? 2 : 1, id); break;
+            case SK_EPI_GRU_GATES:
+                mat(j.e0, j.M, H, j.lde0, 0, id); mat(j.o1, j.M, H, j.ldo1, 1, id); mat(j.o2, j.M, H, j.ldo2, 1, id);
+                mat(j.out, j.M, H, j.ldo, 1, id);
+                break;
+            case SK_EPI_GRU_CAND:
+                mat(j.e0, j.M, H, j.lde0, 0, id); mat(j.e1, j.M, H, j.lde1, 0, id); mat(j.mask, j.M, 1, 1, 0, id);
+                mat(j.o1, j.M, H, j.ldo1, 1, id); mat(j.out, j.M, H, j.ldo, 1, id);
+                break;
+            case SK_EPI_BWD_RH:
+                mat(j.e0, j.M, H, j.lde0, 0, id); mat(j.e1, j.M, H, j.lde1, 0, id); mat(j.out, j.M, H, j.ldo, 1, id);
+                mat(j.o1, j.M, H, j.ldo1, 2, id);
+                break;
+            case SK_EPI_LSTM:
+                mat(j.e1, j.M, H, j.lde1, 0, id); mat(j.o1, j.M, H, j.ldo1, 1, id); mat(j.o2, j.M, 4 * H, j.ldo2, 1, id);
+                mat(j.out, j.M, H, j.ldo, 1, id);
+                break;
+            default: break;
+        }
+    }
+    void att_fwd(const AttFwdArgs& g, int id) {
+        mat(g.h1, g.B, g.H, g.ldh, 0, id); mat(g.kappa_prev, g.B, g.A, g.A, 0, id);
+        mat(g.a_out, g.B, g.A, g.A, 1, id); mat(g.b_out, g.B, g.A, g.A, 1, id); mat(g.kappa_out, g.B, g.A, g.A, 1, id);
+        mat(g.phi_out, g.B, g.U, g.U, 1, id); mat(g.w_out, g.B, g.E, g.ldw, 1, id); mat(g.sup_out, g.B, 2, 2, 1, id);
+    }
+    void att_bwd(const AttBwdArgs& g, int id) {
+        mat(g.dw, g.B, g.E, g.lddw, g.dw2 ? 2 : 0, id); mat(g.dw2, g.B, g.E, g.lddw, 0, id);
+        mat(g.a, g.B, g.A, g.A, 0, id); mat(g.b, g.B, g.A, g.A, 0, id); mat(g.kappa, g.B, g.A, g.A, 0, id);
+        mat(g.kappa_prev, g.B, g.A, g.A, 0, id); mat(g.sup, g.B, 2, 2, 0, id);
+        mat(g.dkappa, g.B, g.A, g.A, 2, id); mat(g.dp_out, g.B, 3 * g.A, 3 * g.A, 1, id); mat(g.dh1, g.B, g.H, g.lddh, 2, id);
+    }
+    void chain(const GruStateBwdChain& c, int B, int H, int id) {
+        mat(c.dh, B, H, H, 0, id); mat(c.dh2, B, H, H, 0, id); mat(c.hprev, B, H, H, 0, id); mat(c.z, B, H, H, 0, id);
+        mat(c.c, B, H, H, 0, id); mat(c.mask, B, 1, 1, 0, id);
+        mat(c.dC, B, H, H, 1, id); mat(c.dG, B, H, 2 * H, 1, id); mat(c.dhprev, B, H, H, 2, id);
+    }
+    void chain(const LstmStateBwdChain& c, int B, int H, int id) {
+        mat(c.dh, B, H, H, 0, id); mat(c.dh2, B, H, H, 0, id); mat(c.gates, B, 4 * H, 4 * H, 0, id);
+        mat(c.c_prev, B, H, H, 0, id); mat(c.c_new, B, H, H, 0, id);
+        mat(c.dc, B, H, H, 2, id); mat(c.dP, B, 4 * H, 4 * H, 1, id);
+    }
+};
+thread_local Tracer* g_tracer = nullptr;
+enum { TRACE_JOB_ATT = 100, TRACE_JOB_CHAIN = 200 };
+
 int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0, int force_tile = 0) {
     SkLaunch L;
     PL_TRY(sk_make_launch(L, jobs, n));
+    if (g_tracer) {
+        g_tracer->begin();
+        for (int q = 0; q < n; ++q) {
+            if (jobs[q].wait_flag) return PARROT_ERR_BADARG;  // (a flag needs its producers in the launch)
+            g_tracer->sk_job(jobs[q], q);
+        }
+        return 0;
+    }
     L.full_wgs = full_wgs;
     L.force_tile = force_tile;
     return sk_launch(L, s);
 }
 
+int traced_att_fwd_launch(const AttFwdArgs& att, hipStream_t s) {
+    if (g_tracer) {
+        g_tracer->begin();
+        g_tracer->att_fwd(att, TRACE_JOB_ATT);
+        return 0;
+    }
+    return att_fwd_launch(att, s);
+}
+
 // The attention forward step and n step-GEMM jobs in one heterogeneous launch (skinny.hip: ska_kernel).
 int launch_jobs_att(const SkJob* jobs, int n, const AttFwdArgs& att, hipStream_t s, int full_wgs = 0) {
-    if (n < 1) return att_fwd_launch(att, s);
+    if (n < 1) return traced_att_fwd_launch(att, s);
     SkLaunch L;
     PL_TRY(sk_make_launch(L, jobs, n));
+    if (g_tracer) {
+        g_tracer->begin();
+        g_tracer->att_fwd(att, TRACE_JOB_ATT);
+        for (int q = 0; q < n; ++q) g_tracer->sk_job(jobs[q], q);
+        return 0;
+    }
     L.full_wgs = full_wgs;
     return sk_launch_att(L, att, s);
+}
+
+// attention backward (or null) + the state backward of all chains in one launch; layer 0's chain is fused behind the
+// attention in the same workgroups (one job as far as ordering goes)
+template <class SA>
+int traced_att_state_bwd_launch(const AttBwdArgs* g, const SA& sa, int l0_chain, hipStream_t s) {
+    if (g_tracer) {
+        g_tracer->begin();
+        if (g) g_tracer->att_bwd(*g, TRACE_JOB_ATT);
+        for (int q = 0; q < sa.nchain; ++q)
+            g_tracer->chain(sa.chain[q], sa.B, sa.H, (g && q == l0_chain) ? (int)TRACE_JOB_ATT : TRACE_JOB_CHAIN + q);
+        return 0;
+    }
+    return att_state_bwd_launch(g, sa, l0_chain, s);
 }
 
 // Batch rows [b0, b0 + nb) of a launch argument block: every per-row pointer moves down b0 rows, the row count
@@ -408,7 +513,7 @@ struct DecoderPlan : PlanBase {
 
     void free_strands() {
         stop_workers();
-        if (att_flags) (void)hipFree(att_flags);
+        if (att_flags && !flags_fake) (void)hipFree(att_flags);
         att_flags = nullptr;
         for (int w = 0; w < 2; ++w)
             for (hipGraphExec_t e : piece[w])
@@ -620,6 +725,20 @@ struct DecoderPlan : PlanBase {
         if (!stranded(which)) return part == 0 ? run(which, s) : note(PARROT_ERR_BADARG);
         if (part < 0 || part >= nparts()) return note(PARROT_ERR_BADARG);
         return note(run_parts(which, part, part + 1, s));
+    }
+
+    // Records what the plan's launches of direction `which` read and write (see Tracer); schedules 0, 5 and 6 only.
+    int trace(int which, std::vector<TraceRec>& out) {
+        if (persist_ok || (schedule != 0 && schedule != 5 && schedule != 6) || d.layer_norm) return PARROT_ERR_UNSUPPORTED;
+        Tracer tr;
+        g_tracer = &tr;
+        const Strand keep = cur;
+        cur = Strand{0, d.B};
+        const int rc = enqueue(which, nullptr);
+        cur = keep;
+        g_tracer = nullptr;
+        out.swap(tr.recs);
+        return rc;
     }
 
     int enqueue(int which, hipStream_t s) override {
@@ -1004,7 +1123,7 @@ struct DecoderPlan : PlanBase {
         take_rows(g, cur);
         return g;
     }
-    int att_fwd_step(int t, hipStream_t st) const { return att_fwd_launch(att_fwd_args(t), st); }
+    int att_fwd_step(int t, hipStream_t st) const { return traced_att_fwd_launch(att_fwd_args(t), st); }
 
     // Forward wavefront: at tick q layer l advances step t = q - l, so the gate GEMMs of all layers share
     // one launch, the candidate GEMMs a second one, and the attention of step q is the third.  Layer
@@ -1138,6 +1257,7 @@ struct DecoderPlan : PlanBase {
     //   B'(q): cand(l0, q), cand_rec(l, q - lag_l)                                                      lag_l = 2l + 1
     // Same arithmetic per output element as schedule 5 (layer 0: as schedule 0, bit for bit).
     unsigned* att_flags = nullptr;  // [T + 2] arrival counters, one per tick (plan-owned, zeroed at the head of the scan)
+    bool flags_fake = false;        // (placeholder for CPU-only schedule tracing: never dereferenced, never freed)
     int esplit6 = 0;
     // s6_ib: the input projections ride in B' instead of A' (then lag_l = 2l): A' keeps one workgroup per CU
     bool s6_ib = true;
@@ -1146,7 +1266,7 @@ struct DecoderPlan : PlanBase {
     int nticks6() const { return d.T + std::max(1, lag6(d.L - 1)); }
     int fwd6(hipStream_t st) {
         if (!att_flags) return PARROT_ERR_BADARG;  // (allocated by parrot_decoder_create, outside any stream capture)
-        PL_TRY(sk_zero_words_launch(att_flags, d.T + 2, st));
+        if (!g_tracer) PL_TRY(sk_zero_words_launch(att_flags, d.T + 2, st));
         const int Q = nticks6();
         const char* fe = getenv("PARROT_S5_FULL");
         const int cfull = fe ? atoi(fe) : 160;
@@ -1240,7 +1360,7 @@ struct DecoderPlan : PlanBase {
                     c.dP = d.dG[l] + (size_t)t * 4 * BH;
                 }
                 take_rows(la, cur);
-                if (la.nchain > 0) PL_TRY(att_state_bwd_launch(att_on ? &g : nullptr, la, att_on ? la.nchain - 1 : -1, st));
+                if (la.nchain > 0) PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, la, att_on ? la.nchain - 1 : -1, st));
                 for (int l = d.L - 1; l >= 0; --l) {
                     const int t = tl[l];
                     if (t < 0 || t >= d.T) continue;
@@ -1358,7 +1478,7 @@ struct DecoderPlan : PlanBase {
             take_rows(ga, cur);
             for (int q2 = 0; q2 < nx; ++q2) take_rows(jx[q2], cur);
             for (int q2 = 0; q2 < ny; ++q2) take_rows(jy[q2], cur);
-            PL_TRY(att_state_bwd_launch(att_on ? &g : nullptr, ga, att_on ? ga.nchain - 1 : -1, st));
+            PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, ga, att_on ? ga.nchain - 1 : -1, st));
             PL_TRY(launch_jobs(jx, nx, st, full_wgs));
             PL_TRY(launch_jobs(jy, ny, st, full_wgs));
         }
@@ -2477,8 +2597,13 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     }
     if (p->schedule == 6) {
         if (hipMalloc(&p->att_flags, sizeof(unsigned) * (size_t)(desc->T + 2)) != hipSuccess) {
-            delete p;
-            return PARROT_ERR_BADARG;
+            if (!getenv("PARROT_TRACE_ONLY")) {  // (schedule tracing on a box without a GPU: a placeholder address)
+                delete p;
+                return PARROT_ERR_BADARG;
+            }
+            (void)hipGetLastError();
+            p->att_flags = reinterpret_cast<unsigned*>((uintptr_t)0x1000);
+            p->flags_fake = true;
         }
         const char* e = getenv("PARROT_S6_ESPLIT");
         p->esplit6 = e && atoi(e) > 0 ? atoi(e) : 1;
@@ -2520,6 +2645,19 @@ int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<De
 
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
 int parrot_decoder_schedule(void* plan) { return plan ? static_cast<DecoderPlan*>(plan)->schedule : -1; }
+long long parrot_decoder_trace(void* plan, int which, long long* out, long long cap) { PH_ENTRY();
+    if (!plan || which < 0 || which > 1) return -PARROT_ERR_BADARG;
+    std::vector<TraceRec> recs;
+    const int rc = static_cast<DecoderPlan*>(plan)->trace(which, recs);
+    if (rc != 0) return -(long long)rc;
+    const long long n = (long long)recs.size();
+    if (out)
+        for (long long i = 0; i < n && i < cap; ++i) {
+            out[5 * i] = recs[i].launch; out[5 * i + 1] = recs[i].job; out[5 * i + 2] = recs[i].kind;
+            out[5 * i + 3] = recs[i].lo; out[5 * i + 4] = recs[i].hi;
+        }
+    return n;
+}
 
 int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_decoder_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }

@@ -1,0 +1,252 @@
+"""Launch schedules of the training scan, checked WITHOUT a GPU: parrot_decoder_trace makes a plan record, for every
+launch and every job in it, the byte ranges it reads and writes (on fake device addresses; nothing is launched).  The
+orderings a schedule has to keep follow from the scan of model.py:651-737 and its gradient:
+
+  * no job of a launch touches a range another job of the same launch writes (the jobs of a launch run concurrently) --
+    except a read the job takes behind the in-launch flag of schedule 6, whose writer must then be the attention job;
+  * a write-once buffer (states, gates, window parameters, saved activations, pre-activation scratch; in the backward the
+    pre-activation gradients) is written exactly once per element and read only by LATER launches;
+  * an accumulator (dh, dw, dw0, dhup) is never written again after a job has taken it as a plain input (the state /
+    attention backward consuming the total).
+
+Run for schedules 0, 5 and 6, GRU and LSTM layers, 1-3 layers, with and without caller data in the per-step input
+buffers, forward and backward."""
+import ctypes as C
+import os
+
+import pytest
+
+
+def _lib():
+    from parrot_amd import _lib as L
+    try:
+        return L, L.load()
+    except L.HipLibraryMissing:
+        pytest.skip("libparrot_hip.so not built")
+
+
+class _Arena:
+    """Fake device address space: distinct, 4 KB aligned ranges; name -> (lo, hi)."""
+
+    def __init__(self):
+        self.top = 0x10000000
+        self.ranges = {}
+
+    def take(self, name, nbytes):
+        lo = self.top
+        self.top = (lo + max(nbytes, 16) + 4095) // 4096 * 4096 + 4096
+        self.ranges[name] = (lo, lo + nbytes)
+        return lo
+
+
+def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, E=16, A=4, U=7):
+    monkeypatch.setenv("PARROT_SCHEDULE", str(sched))
+    monkeypatch.setenv("PARROT_TRACE_ONLY", "1")
+    ar = _Arena()
+    d = L.DecoderDesc()
+    d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, nl
+    d.cell, d.use_graph, d.seq_init = cell, 0, seq_init
+    d.eps, d.alignment, d.sharpening, d.timing = 1e-5, 1.0, 1.0, 1.0
+    f = 4
+    gw = 4 * H if cell == 1 else 2 * H
+    for l in range(nl):
+        K = H + E + l * H
+        d.Wg[l] = ar.take(f"Wg{l}", K * gw * f)
+        d.bg[l] = ar.take(f"bg{l}", gw * f)
+        d.Wg_f[l] = ar.take(f"Wg_f{l}", K * gw * f)
+        d.Wg_r[l] = ar.take(f"Wg_r{l}", K * gw * f)
+        d.h[l] = ar.take(f"h{l}", (T + 1) * B * H * f)
+        d.dh[l] = ar.take(f"dh{l}", (T + 1) * B * H * f)
+        d.dG[l] = ar.take(f"dG{l}", T * B * gw * f)
+        if l < nl - 1:
+            d.dhup[l] = ar.take(f"dhup{l}", (T + 1) * B * H * f)
+        if l >= 1 or (seq_init >> l) & 1:
+            d.seq_g[l] = ar.take(f"seq_g{l}", T * B * gw * f)
+        if cell == 0:
+            d.Wc[l] = ar.take(f"Wc{l}", K * H * f)
+            d.bc[l] = ar.take(f"bc{l}", H * f)
+            d.Wc_f[l] = ar.take(f"Wc_f{l}", K * H * f)
+            d.Wc_r[l] = ar.take(f"Wc_r{l}", K * H * f)
+            for n in ("z", "r", "rh", "c"):
+                getattr(d, n)[l] = ar.take(f"{n}{l}", T * B * H * f)
+            d.dC[l] = ar.take(f"dC{l}", T * B * H * f)
+            if l >= 1 or (seq_init >> l) & 1:
+                d.seq_c[l] = ar.take(f"seq_c{l}", T * B * H * f)
+        else:
+            d.cst[l] = ar.take(f"cst{l}", (T + 1) * B * H * f)
+            d.gate4[l] = ar.take(f"gate4{l}", T * B * 4 * H * f)
+            d.dcell[l] = ar.take(f"dcell{l}", B * H * f)
+    d.WattT = ar.take("WattT", 3 * A * H * f)
+    d.batt = ar.take("batt", 3 * A * f)
+    d.ctx = ar.take("ctx", B * U * E * f)
+    d.w = ar.take("w", (T + 1) * B * E * f)
+    d.kappa = ar.take("kappa", (T + 1) * B * A * f)
+    d.a = ar.take("a", T * B * A * f)
+    d.b = ar.take("b", T * B * A * f)
+    d.phi = ar.take("phi", T * B * U * f)
+    d.dw = ar.take("dw", (T + 1) * B * E * f)
+    d.dw0 = ar.take("dw0", (T + 1) * B * E * f)
+    d.dkappa = ar.take("dkappa", B * A * f)
+    d.dp = ar.take("dp", T * B * 3 * A * f)
+    d.att_sup = ar.take("att_sup", T * B * 2 * 4)
+    plan = C.c_void_p()
+    rc = lib.parrot_decoder_create(C.byref(d), C.byref(plan))
+    assert rc == 0, rc
+    return plan, ar, d
+
+
+def _trace(lib, plan, which):
+    n = lib.parrot_decoder_trace(plan, which, None, 0)
+    assert n > 0, n
+    buf = (C.c_longlong * (5 * n))()
+    assert lib.parrot_decoder_trace(plan, which, buf, n) == n
+    recs = [tuple(buf[5 * i:5 * i + 5]) for i in range(n)]  # (launch, job, kind, lo, hi)
+    return recs
+
+
+def _owner(ar, lo):
+    for name, (a, b) in ar.ranges.items():
+        if a <= lo < b:
+            return name
+    return None
+
+
+def _overlap(a, b):
+    return a[0] < b[1] and b[0] < a[1]
+
+
+def _check(recs, ar, write_once, accumulators, T, slot_bytes):
+    by_launch = {}
+    for launch, job, kind, lo, hi in recs:
+        assert hi > lo
+        assert _owner(ar, lo) is not None and _owner(ar, lo) == _owner(ar, hi - 1), "range outside any buffer"
+        by_launch.setdefault(launch, []).append((job, kind, lo, hi))
+    # ---- 1. jobs of one launch do not interfere
+    for launch, rs in by_launch.items():
+        writes = [(job, lo, hi) for job, kind, lo, hi in rs if kind in (1, 2)]
+        for job, kind, lo, hi in rs:
+            for wjob, wlo, whi in writes:
+                if wjob == job or not _overlap((lo, hi), (wlo, whi)):
+                    continue
+                if kind == 3:
+                    assert wjob == 100, f"launch {launch}: flagged read of {_owner(ar, lo)} written by job {wjob}"
+                    continue
+                raise AssertionError(f"launch {launch}: job {job} ({'rwx?'[kind]}) and job {wjob} (w) overlap in "
+                                     f"{_owner(ar, lo)} [{lo:#x}, {hi:#x})")
+        flagged = [(lo, hi) for job, kind, lo, hi in rs if kind == 3]
+        for lo, hi in flagged:  # a flag without its producer in the launch would wait for ever
+            assert any(wjob == 100 and _overlap((lo, hi), (wlo, whi)) for wjob, wlo, whi in writes), launch
+    # ---- 2. write-once buffers: one writer per byte, readers strictly later (or behind the flag in the same launch)
+    first_write, last_write = {}, {}  # (name, granule) -> launch
+    G = 4  # bytes (one float)
+    def granules(lo, hi):
+        return range(lo // G, (hi + G - 1) // G)
+    for launch in sorted(by_launch):
+        for job, kind, lo, hi in by_launch[launch]:
+            name = _owner(ar, lo)
+            if name not in write_once or kind not in (1, 2):
+                continue
+            assert kind == 1 or name.startswith("seq_"), f"{name} is write-once but launch {launch} updates it in place"
+            for g in granules(lo, hi):
+                if kind == 1:
+                    assert (name, g) not in first_write, f"{name} written twice (launches {first_write.get((name, g))}, {launch})"
+                first_write.setdefault((name, g), launch)
+                last_write[(name, g)] = launch
+    for launch in sorted(by_launch):
+        for job, kind, lo, hi in by_launch[launch]:
+            name = _owner(ar, lo)
+            if name not in write_once or kind not in (0, 3):
+                continue
+            for g in granules(lo, hi):
+                w = first_write.get((name, g))
+                if w is None:
+                    # slot 0 of the histories = the state entering the window (caller's); everything else must be written
+                    a0 = ar.ranges[name][0]
+                    assert name in slot_bytes and g * G < a0 + slot_bytes[name], f"{name} read at launch {launch} but never written"
+                    continue
+                if kind == 3:
+                    assert w == launch
+                else:  # (after ALL writes: the two-part input projections of LSTM stacks update their scratch in place)
+                    assert last_write[(name, g)] < launch, f"{name}: read in launch {launch}, written in launch {last_write[(name, g)]}"
+    # ---- 3. accumulators: no write after a plain read
+    last_plain_read = {}
+    for launch in sorted(by_launch):
+        for job, kind, lo, hi in by_launch[launch]:
+            name = _owner(ar, lo)
+            if name not in accumulators:
+                continue
+            for g in granules(lo, hi):
+                if kind in (1, 2):
+                    r = last_plain_read.get((name, g))
+                    assert r is None or r[0] > launch or (r[0] == launch and r[1] == job), \
+                        f"{name}: written in launch {launch} after launch {r[0]} had consumed it"
+                if kind == 0:
+                    last_plain_read[(name, g)] = (launch, job)
+    return len(by_launch)
+
+
+@pytest.mark.parametrize("sched", [0, 5, 6])
+@pytest.mark.parametrize("cell,nl,seq_init", [(0, 1, 0), (0, 2, 0), (0, 3, 0), (0, 3, 0b101), (1, 2, 0), (1, 3, 0b010)])
+def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_init):
+    L, lib = _lib()
+    T, B, H, E, A, U = 5, 20, 32, 16, 4, 7
+    plan, ar, d = _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T, B, H, E, A, U)
+    try:
+        got = lib.parrot_decoder_schedule(plan)
+        want = sched
+        if sched == 6 and cell == 1:
+            want = 5        # the in-launch hand-off covers GRU layers only
+        if sched == 5 and nl == 1:
+            want = 0
+        assert got == want, (got, want)
+        f = 4
+        slot = {"w": B * E * f, "kappa": B * A * f}
+        fwd_once = {"w", "kappa", "a", "b", "phi", "att_sup"}
+        for l in range(nl):
+            slot[f"h{l}"] = B * H * f
+            fwd_once |= {f"h{l}"}
+            if cell == 0:
+                fwd_once |= {f"z{l}", f"r{l}", f"rh{l}", f"c{l}"}
+            else:
+                slot[f"cst{l}"] = B * H * f
+                fwd_once |= {f"cst{l}", f"gate4{l}"}
+            if l >= 1 and got >= 5:  # the input projections' scratch (caller data is accumulated onto, never rewritten)
+                fwd_once |= {f"seq_g{l}"} | ({f"seq_c{l}"} if cell == 0 else set())
+        recs = _trace(lib, plan, 0)
+        if got >= 5:  # buffers with caller data are read-modify-write targets of the input projections: whole buffer = "slot"
+            for l in range(1, nl):
+                if (seq_init >> l) & 1:
+                    gw = 4 * H if cell == 1 else 2 * H
+                    slot[f"seq_g{l}"] = T * B * gw * f
+                    if cell == 0:
+                        slot[f"seq_c{l}"] = T * B * H * f
+        n_fwd = _check(recs, ar, fwd_once, set(), T, slot)
+        ticks = {0: T + nl - 1, 5: T + nl, 6: T + max(1, 2 * (nl - 1))}[got]
+        per_tick = 2 if cell == 1 else {0: 3, 5: 3, 6: 2}[got]
+        assert n_fwd <= ticks * per_tick and n_fwd >= T * per_tick - 2, (n_fwd, ticks, per_tick)
+        # backward
+        bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)} | ({f"dC{l}" for l in range(nl)} if cell == 0 else set())
+        acc = {"dw", "dw0"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
+        recs = _trace(lib, plan, 1)
+        _check(recs, ar, bwd_once, acc, T, {})
+    finally:
+        lib.parrot_decoder_destroy(plan)
+
+
+def test_tracer_sees_a_broken_order(monkeypatch):
+    """The checker is not vacuous: the same trace with two consecutive launches swapped fails it."""
+    L, lib = _lib()
+    T, B, H, E, A, U = 4, 20, 32, 16, 4, 7
+    plan, ar, d = _make_plan(L, lib, 5, 0, 2, 0, monkeypatch, T, B, H, E, A, U)
+    try:
+        recs = _trace(lib, plan, 0)
+        f = 4
+        slot = {"w": B * E * f, "kappa": B * A * f, "h0": B * H * f, "h1": B * H * f}
+        once = {"w", "kappa", "a", "b", "phi", "att_sup", "h0", "h1", "z0", "r0", "rh0", "c0", "z1", "r1", "rh1", "c1",
+                "seq_g1", "seq_c1"}
+        _check(recs, ar, once, set(), T, slot)
+        swapped = [((1 if r[0] == 0 else 0 if r[0] == 1 else r[0]),) + r[1:] for r in recs]  # candidate before gates
+        with pytest.raises(AssertionError):
+            _check(swapped, ar, once, set(), T, slot)
+    finally:
+        lib.parrot_decoder_destroy(plan)
