@@ -284,6 +284,10 @@ int parrot_decoder_schedule(void* plan);
  * of them into `out`), or -(error code); launch schedules 0, 5 and 6 only.  PARROT_TRACE_ONLY=1 lets schedule 6 be
  * created on a box without a GPU. */
 long long parrot_decoder_trace(void* plan, int which, long long* out, long long cap);
+/* The same dry run, one record per job: 6 x int64 = launch index, job id, M (rows), N (output columns), K (sum over the
+ * job's segments), epilogue code (SkEpi; -1 attention forward, -2 attention backward: then M, N, K = B, E, H).  What
+ * tools/tick_model.py prices with the measured launch cost model. */
+long long parrot_decoder_trace_jobs(void* plan, int which, long long* out, long long cap);
 /* Waits for the device; 0, or non-zero when a persistent launch of this plan gave up (a workgroup waited ~1 s for a
  * rendezvous or for an operand that never arrived): the results of that window are invalid.  0 on the launch schedules. */
 int parrot_decoder_status(void* plan);

@@ -152,6 +152,7 @@ SIGNATURES = {
     "parrot_decoder_is_persistent": (_i, [_vp]),
     "parrot_decoder_schedule": (_i, [_vp]),
     "parrot_decoder_trace": (C.c_longlong, [_vp, _i, C.POINTER(C.c_longlong), C.c_longlong]),
+    "parrot_decoder_trace_jobs": (C.c_longlong, [_vp, _i, C.POINTER(C.c_longlong), C.c_longlong]),
     "parrot_decoder_seq_fwd": (_i, [_vp, _vp]),
     "parrot_decoder_seq_bwd": (_i, [_vp, _vp]),
     "parrot_decoder_destroy": (_i, [_vp]),

@@ -81,8 +81,10 @@ struct PlanBase {
 // no job of a launch touches what another job of the same launch writes, write-once buffers are read only after their
 // writer's launch, accumulators are not written after their consumer has read them.
 struct TraceRec { long long launch, job, kind, lo, hi; };  // kind: 0 read, 1 write, 2 read+write, 3 read behind a flag
+struct TraceJob { long long launch, job, M, N, Kmax_seg_sum, epi; };  // shape of a step-GEMM job (job 100: the attention)
 struct Tracer {
     std::vector<TraceRec> recs;
+    std::vector<TraceJob> jobs;
     long long launch = -1;
     void begin() { ++launch; }
     void mat(const void* p, long long rows, long long cols, long long ld, int kind, int job, int elt = 4) {
@@ -92,6 +94,9 @@ struct Tracer {
         for (long long r = 0; r < rows; ++r) recs.push_back({launch, job, kind, base + r * ld * elt, base + (r * ld + cols) * elt});
     }
     void sk_job(const SkJob& j, int id) {
+        long long ks = 0;
+        for (int q = 0; q < j.nseg; ++q) ks += j.seg[q].K;
+        jobs.push_back({launch, id, j.M, j.N, ks, j.epi});
         for (int q = 0; q < j.nseg; ++q)
             mat(j.seg[q].A, j.M, j.seg[q].K, j.seg[q].lda, (j.wait_flag && q == j.nseg - 1) ? 3 : 0, id);
         mat(j.add, j.M, j.N, j.ld_add, 0, id);
@@ -118,11 +123,13 @@ struct Tracer {
         }
     }
     void att_fwd(const AttFwdArgs& g, int id) {
+        jobs.push_back({launch, id, g.B, g.E, g.H, -1});
         mat(g.h1, g.B, g.H, g.ldh, 0, id); mat(g.kappa_prev, g.B, g.A, g.A, 0, id);
         mat(g.a_out, g.B, g.A, g.A, 1, id); mat(g.b_out, g.B, g.A, g.A, 1, id); mat(g.kappa_out, g.B, g.A, g.A, 1, id);
         mat(g.phi_out, g.B, g.U, g.U, 1, id); mat(g.w_out, g.B, g.E, g.ldw, 1, id); mat(g.sup_out, g.B, 2, 2, 1, id);
     }
     void att_bwd(const AttBwdArgs& g, int id) {
+        jobs.push_back({launch, id, g.B, g.E, g.H, -2});
         mat(g.dw, g.B, g.E, g.lddw, g.dw2 ? 2 : 0, id); mat(g.dw2, g.B, g.E, g.lddw, 0, id);
         mat(g.a, g.B, g.A, g.A, 0, id); mat(g.b, g.B, g.A, g.A, 0, id); mat(g.kappa, g.B, g.A, g.A, 0, id);
         mat(g.kappa_prev, g.B, g.A, g.A, 0, id); mat(g.sup, g.B, 2, 2, 0, id);
@@ -728,7 +735,7 @@ struct DecoderPlan : PlanBase {
     }
 
     // Records what the plan's launches of direction `which` read and write (see Tracer); schedules 0, 5 and 6 only.
-    int trace(int which, std::vector<TraceRec>& out) {
+    int trace(int which, std::vector<TraceRec>& out, std::vector<TraceJob>* jobs_out = nullptr) {
         if (persist_ok || (schedule != 0 && schedule != 5 && schedule != 6) || d.layer_norm) return PARROT_ERR_UNSUPPORTED;
         Tracer tr;
         g_tracer = &tr;
@@ -738,6 +745,7 @@ struct DecoderPlan : PlanBase {
         cur = keep;
         g_tracer = nullptr;
         out.swap(tr.recs);
+        if (jobs_out) jobs_out->swap(tr.jobs);
         return rc;
     }
 
@@ -2645,6 +2653,20 @@ int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<De
 
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
 int parrot_decoder_schedule(void* plan) { return plan ? static_cast<DecoderPlan*>(plan)->schedule : -1; }
+long long parrot_decoder_trace_jobs(void* plan, int which, long long* out, long long cap) { PH_ENTRY();
+    if (!plan || which < 0 || which > 1) return -PARROT_ERR_BADARG;
+    std::vector<TraceRec> recs;
+    std::vector<TraceJob> jobs;
+    const int rc = static_cast<DecoderPlan*>(plan)->trace(which, recs, &jobs);
+    if (rc != 0) return -(long long)rc;
+    const long long n = (long long)jobs.size();
+    if (out)
+        for (long long i = 0; i < n && i < cap; ++i) {
+            out[6 * i] = jobs[i].launch; out[6 * i + 1] = jobs[i].job; out[6 * i + 2] = jobs[i].M;
+            out[6 * i + 3] = jobs[i].N; out[6 * i + 4] = jobs[i].Kmax_seg_sum; out[6 * i + 5] = jobs[i].epi;
+        }
+    return n;
+}
 long long parrot_decoder_trace(void* plan, int which, long long* out, long long cap) { PH_ENTRY();
     if (!plan || which < 0 || which > 1) return -PARROT_ERR_BADARG;
     std::vector<TraceRec> recs;
