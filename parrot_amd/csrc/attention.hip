@@ -28,31 +28,6 @@ namespace {
 
 constexpr int ATTB_THREADS = 1024;  // backward: one workgroup per batch row, 16 waves
 
-// Block-wide sum of `n` per-thread partial vectors (n <= 3*ATT_MAXA); result in out[0..n).
-// part: per-thread array in registers is awkward for runtime n, so partials are staged in LDS:
-// scratch[t * n + j].  Simple tree over threads per j done by the first n threads.
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    // red: >= 4 floats
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
-
-__device__ __forceinline__ float block_sum8(float v, float* red) {  // backward variant, red >= 16 floats
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < ATTB_THREADS / 64; ++w) s += red[w];
-    return s;
-}
-
 __global__ __launch_bounds__(ATT_THREADS) void att_fwd_kernel(const AttFwdArgs g) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     att_fwd_block<ATT_THREADS, ATT_PROJ_UNROLL>(g, blockIdx.x, blockIdx.y, sm);

@@ -1172,11 +1172,10 @@ static void sk_dispatch(const SkLaunch& L, dim3 grid, size_t lds, hipStream_t st
 // Tile shape, grid and finished descriptor (workgroup prefix, z-mode) of a launch.
 void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid_out, size_t& lds_out, int& mbnb_out) {
     L = Lin;
-    int maxM = 0, tiles = 0;
+    int maxM = 0;
     bool nb2_ok = true;
     for (int q = 0; q < L.njobs; ++q) {
         maxM = L.job[q].M > maxM ? L.job[q].M : maxM;
-        tiles += L.tile_end[q];
         if (!L.job[q].aligned) nb2_ok = false;
     }
     // Tile shape per workgroup: (16*mb rows) x (16*nb columns).  Per-CU load bandwidth (~50 GB/s measured)
