@@ -250,3 +250,24 @@ def test_tracer_sees_a_broken_order(monkeypatch):
             _check(swapped, ar, once, set(), T, slot)
     finally:
         lib.parrot_decoder_destroy(plan)
+
+
+def test_tick_model_prices_the_headline_plan(monkeypatch, capsys):
+    """tools/tick_model.py (launch cost model of DESIGN.md 3.2 applied to a dry-run plan) runs without a GPU and lands on
+    the measured scan times of BASELINE configs[1]: forward 24.8 ms, backward 28.7 ms on schedule 5 (within 10 %)."""
+    import importlib.util
+    import re
+    import sys
+    _lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("tick_model", os.path.join(root, "tools", "tick_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["tick_model.py", "--schedule", "5"])
+    monkeypatch.setenv("PARROT_SCHEDULE", "5")  # (tick_model sets it itself; monkeypatch restores the environment)
+    monkeypatch.setenv("PARROT_TRACE_ONLY", "1")
+    mod.main()
+    out = capsys.readouterr().out
+    fwd = float(re.search(r"forward: \d+ launches, predicted ([0-9.]+) ms", out).group(1))
+    bwd = float(re.search(r"backward: \d+ launches, predicted ([0-9.]+) ms", out).group(1))
+    assert abs(fwd - 24.8) / 24.8 < 0.10 and abs(bwd - 28.7) / 28.7 < 0.10, out
