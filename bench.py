@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity_check` object (HIP step vs fp64 oracle)")
     ap.add_argument("--secondary-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--parity-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="N > 1 launch + collectives only (no GPU step, value null): what the CPU/gloo test of the "
+                         "self-launch path runs")
     a = ap.parse_args()
     if a.config == "cfg4":
         a.L, a.H, a.cell = 3, 1536, "lstm"
@@ -115,7 +118,7 @@ def kernel_source_digest(root=ROOT):
     return hd.hexdigest()
 
 
-def pmc_traffic_figure(root=ROOT, names=("r03_pmc_traffic.json",)):
+def pmc_traffic_figure(root=ROOT, names=("r04_pmc_traffic.json",)):
     """(bytes per launch | None, source note).  HBM-side bytes per step-kernel launch come from separate rocprofv3 --pmc
     passes (FETCH_SIZE / WRITE_SIZE cannot share a pass with the timed run), so the number is a committed measurement,
     not one of this run -- and it is only reported while the kernel sources it was measured on are unchanged (digest
@@ -167,10 +170,11 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
         # bf16 operands: 16 x the f32 matrix rate, half the weight bytes -- the step GEMMs (M = 64 rows per weight
         # element) are bound by how fast the weights and the f32 activations arrive, so the roof is HBM / L2 bandwidth
         gbps = by.value / us.value * 1e-3
+        traffic4, traffic4_src = pmc_traffic_figure(names=("r04_pmc_traffic_cfg4.json",))
         return {
             "kernel": "sk_kernel (fused LSTM/GRU step GEMM, bf16 operands, fwd + bwd)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000, "unit": "GB/s", "frac": round(gbps / 8000, 4),
-            "traffic": None, "traffic_source": None,
+            "traffic": traffic4, "traffic_source": traffic4_src,
             "launches_per_step": int(n), "avg_launch_us": round(us.value / n, 3),
             "alg_flops_per_launch": round(fl.value / n), "alg_bytes_per_launch": round(by.value / n),
             "alg_TFLOPs": round(ach, 2), "bf16_mfma_peak_TFLOPs": 2516.6,
@@ -393,9 +397,81 @@ def cpu_baseline_subprocess(a):
                 "sample": "cpu leg exceeded its 300 s limit"}
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: start the N ranks ourselves (one process per GPU, the
+    same command line under torch.distributed.run on 127.0.0.1) and hand back their exit code.  Rank 0's JSON line goes
+    to our stdout unchanged."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // a.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def ranks_seen(dev):
+    """All-reduce of ones: how many ranks the collective really spans (1 outside a process group)."""
+    from parrot_amd import dist as pdist
+    t = torch.ones(1, device=dev, dtype=torch.float32)
+    if pdist.is_distributed():
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+    return int(round(float(t)))
+
+
+def allreduce_ms(flat_groups, dev, reps=5):
+    """The gradient exchange alone: median wall time of the sum-all-reduce of the flat gradient bucket(s), as
+    Trainer.step issues it (blocking, on the compute stream), bracketed by barrier + synchronize; max over ranks."""
+    from parrot_amd import dist as pdist
+    if not pdist.is_distributed():
+        return None
+    times = []
+    for rep in range(reps + 1):
+        pdist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for g_ in flat_groups:
+            pdist.allreduce_flat_(g_)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        if rep > 0:
+            times.append(float(t))
+    times.sort()
+    return round(1e3 * times[len(times) // 2], 3)
+
+
+def plumbing_only(a):
+    """The N > 1 control flow without a GPU step: process group, ranks_seen, the timed bucket all-reduce, one line."""
+    from parrot_amd import dist as pdist
+    rank, local_rank, world = pdist.init_process_group()
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cpu")
+    seen = ranks_seen(dev)
+    bucket = torch.full((1 << 16,), float(rank + 1), dtype=torch.float32)
+    ar = allreduce_ms([bucket], dev, reps=2)
+    pdist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only (no GPU step)", "value": None, "n_gpus": world, "ranks_seen": seen,
+                          "allreduce_ms": ar, "steps": a.steps, "warmup": a.warmup, "plumbing_only": True}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     a = parse()
     torch.set_num_threads(host_cores())
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    if a.plumbing_only:
+        plumbing_only(a)
+        return
     if a.cpu_baseline_only:
         print(json.dumps(cpu_baseline_leg(a)), flush=True)
         return
@@ -407,7 +483,7 @@ def main():
         return
     from parrot_amd import dist as pdist
     rank, local_rank, world = pdist.init_process_group()
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # (ranks wrap around the visible devices only in the gloo plumbing test, PARROT_DIST_BACKEND=gloo)
     dev = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
@@ -436,6 +512,8 @@ def main():
 
     el, cost = timed(a.steps, a.warmup)
     final_cost = float(cost)
+    seen = ranks_seen(dev)
+    ar_ms = allreduce_ms([g_ for _, g_ in trainer.groups], dev)
     try:  # the launch schedule the plan actually ran (after the library's fall-backs)
         from parrot_amd import _lib
         sched_id = int(_lib.load().parrot_decoder_schedule(next(iter(model._train_ws.values()))['plan']))
@@ -475,7 +553,9 @@ def main():
         frames = world * a.B * a.T * a.steps
         out = {
             "metric": "acoustic feature frames/sec (train fwd+bwd+allreduce+clip/Adam)",
-            "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "ranks_seen": seen,
+            "allreduce_ms": ar_ms, "allreduce_bytes": int(sum(g_.numel() * 4 for _, g_ in trainer.groups)),
+            "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3] per GPU: 3-layer attention-LSTM decoder, h=1536, batch=64 per GPU "

@@ -564,7 +564,7 @@ struct DecoderPlan : PlanBase {
         nstrands = (int)strands.size();
         cur = Strand{0, d.B};
         const char* qp = getenv("PARROT_QPART");
-        qpart = qp ? atoi(qp) : (d.T >= 200 ? 100 : 0);
+        qpart = qp ? atoi(qp) : (nstrands > 1 && d.T >= 200 ? 100 : 0);  // parts only where strands asked for them
         if (schedule != 0) qpart = 0;
         const char* th = getenv("PARROT_STRAND_THREADS");
         use_threads = th ? atoi(th) != 0 : true;
@@ -1208,6 +1208,8 @@ struct DecoderPlan : PlanBase {
         const int Q = nticks5();
         const char* fe = getenv("PARROT_S5_FULL");
         const int cfull = fe ? atoi(fe) : 160;
+        // launches of a tick: <= L gate jobs, <= L candidate jobs, <= 3 input-projection jobs per upper layer
+        static_assert(3 * (PARROT_MAX_LAYERS - 1) <= SK_MAXJOB && PARROT_MAX_LAYERS <= SK_MAXJOB, "fwd5: jobs[] too short");
         for (int q = 0; q < Q; ++q) {
             SkJob jobs[SK_MAXJOB];
             int n = 0;
@@ -1278,6 +1280,8 @@ struct DecoderPlan : PlanBase {
         const int Q = nticks6();
         const char* fe = getenv("PARROT_S5_FULL");
         const int cfull = fe ? atoi(fe) : 160;
+        // A'(q): 1 gate job of layer 0 + (1 recurrent gate job + 2 input jobs) per upper layer
+        static_assert(1 + 3 * (PARROT_MAX_LAYERS - 1) <= SK_MAXJOB, "fwd6: jobs[] too short");
         for (int q = 0; q < Q; ++q) {
             SkJob jobs[SK_MAXJOB];
             int n = 0;
@@ -1404,6 +1408,9 @@ struct DecoderPlan : PlanBase {
             }
             GruStateBwdArgs ga;
             ga.nchain = 0; ga.B = d.B; ga.H = H;
+            // the split backward tick carries 1 + 1 + l jobs per layer in each of the X and Y launches
+            static_assert(PARROT_MAX_LAYERS * (PARROT_MAX_LAYERS + 3) / 2 <= SK_MAXJOB,
+                          "backward tick: jx / jy cannot hold every layer's jobs");
             SkJob jx[SK_MAXJOB], jy[SK_MAXJOB];
             int nx = 0, ny = 0;
             for (int l = d.L - 1; l >= 0; --l) {

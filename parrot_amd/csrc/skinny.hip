@@ -634,12 +634,14 @@ __global__ __launch_bounds__(SK_THREADS, 4) void ska_kernel(const SkLaunch L, co
                                                          const int att_last) {
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     int bx = blockIdx.x;
-    if (att_last) {  // GEMM workgroups (the long ones) are dispatched first, the attention fills in behind them
+    if (att_last == 1) {  // GEMM workgroups (the long ones) are dispatched first, the attention fills in behind them
         const int ngemm = (int)gridDim.x - natt_x;
         bx = bx >= ngemm ? bx - ngemm : bx + natt_x;
     }
     if (bx < natt_x) {
-        const int id = blockIdx.y * natt_x + bx;
+        // att_last == 2 (a job of this launch waits for the attention): all attention workgroups lead grid row 0
+        if (att_last == 2 && blockIdx.y != 0) return;
+        const int id = att_last == 2 ? bx : blockIdx.y * natt_x + bx;
         if (id >= g.B * g.esplit) return;
         att_fwd_block<SK_THREADS, SKA_PROJ_UNROLL>(g, id / g.esplit, id % g.esplit, reinterpret_cast<float*>(sk_smem));
         return;
@@ -1295,7 +1297,7 @@ static void ska_dispatch(const SkLaunch& L, const AttFwdArgs& g, int natt_x, dim
     ska_allow_lds<MB, NB>();
     int att_last = att_last_env;
     for (int q = 0; q < L.njobs; ++q)
-        if (L.job[q].wait_flag) att_last = 0;
+        if (L.job[q].wait_flag) att_last = 2;  // producers first, and all of them in grid row 0
     if (g_prof.on) {
         SkProfRec r;
         (void)hipEventCreate(&r.e0);
@@ -1338,7 +1340,14 @@ int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream
         L.zmode = 0;
     }
     const int natt = g.B * g.esplit;
-    const int natt_x = ceil_div(natt, (int)grid.y);
+    bool flagged = false;
+    for (int q = 0; q < L.njobs; ++q)
+        if (L.job[q].wait_flag) flagged = true;
+    // A job that waits for the attention inside the launch needs every producer dispatched BEFORE any waiter.
+    // Workgroups are dispatched row by row (blockIdx.x fastest), so with several grid rows the producers must all sit
+    // at the head of row 0 (ska_kernel, att_last == 2; rows y > 0 return at once there): spread over the rows they
+    // would queue behind all of row 0's waiters, and a chip full of waiters would spin until the 1 s trap.
+    const int natt_x = flagged ? natt : ceil_div(natt, (int)grid.y);
     grid.x += (unsigned)natt_x;
     const size_t alds = att_fwd_lds(g.U);
     if (alds > lds) lds = alds;

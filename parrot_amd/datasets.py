@@ -245,13 +245,15 @@ class PinnedAsyncLoader:
                     continue
             return False
 
+        slots = self._slots  # this iteration's ring: a straggling worker of an earlier iteration keeps ITS ring
+
         def worker():
             try:
                 k = 0
                 for item in self.stream.get_epoch_iterator():
                     if stop.is_set():
                         return
-                    slot = self._slots[k % len(self._slots)]
+                    slot = slots[k % len(slots)]
                     k += 1
                     if slot['event'] is not None:
                         slot['event'].synchronize()  # copies issued from this slot's buffers are done
@@ -276,6 +278,8 @@ class PinnedAsyncLoader:
                 except queue.Empty:
                     break
             th.join(timeout=5.0)
+            if th.is_alive():  # still inside an event wait or a slow source: the next iteration gets a ring of its own
+                self._slots = [dict(bufs={}, event=None) for _ in range(len(slots))]
 
     def _consume(self, q, sentinel, failure):
         import torch

@@ -976,7 +976,7 @@ class Parrot(Brick):
         plan = ws['plan']
         lib = _lib.load()
         nparts = int(lib.parrot_decoder_parts(plan, None))
-        overlap = nparts > 1 and os.environ.get('PARROT_DW_OVERLAP', '1') != '0'
+        overlap = nparts > 1 and os.environ.get('PARROT_DW_OVERLAP', '0') != '0'  # opt-in: measured slower
         if not overlap:
             if before is not None:
                 before()
@@ -1265,6 +1265,11 @@ class Parrot(Brick):
     def close(self):
         self._train_ws.clear()
         self._sample_ws.clear()
+        h = getattr(self, '_side_stream_handle', None)
+        if h is not None:  # the opt-in weight-gradient side stream (PARROT_DW_OVERLAP=1)
+            self._side_stream.synchronize()
+            _lib.call('parrot_stream_destroy', h)
+            self._side_stream = self._side_stream_handle = None
 
 
 class SampleRnn(Brick):
