@@ -423,18 +423,23 @@ def cost_and_grads_checkpointed(p, cfg, features, features_mask, labels, labels_
         cin = None
         if i > 0:
             src = carries[i]
-            cin = dict(h=[x.detach().clone().requires_grad_() for x in src['h']],
-                       k=src['k'].detach().clone().requires_grad_(), w=src['w'].detach().clone().requires_grad_())
+            fresh = lambda x: x.detach().clone().requires_grad_()
+            # (LSTM layers carry (state, cells) pairs, sampleRNN/lib/ops.py:505-553)
+            cin = dict(h=[tuple(fresh(y) for y in x) if isinstance(x, tuple) else fresh(x) for x in src['h']],
+                       k=fresh(src['k']), w=fresh(src['w']))
         c, cout, _, _ = compute_cost(p, cfg, features[a:b + 1], features_mask[a:b + 1], labels, labels_mask, speaker,
                                      1 if i == 0 else 0, cin)
         total = c * (features_mask[a + 1:b + 1].sum() + 1e-5) / den
         if dcarry is not None:
             for x, g in zip(cout['h'], dcarry['h']):
-                total = total + (x * g).sum()
+                for x_, g_ in (zip(x, g) if isinstance(x, tuple) else ((x, g),)):
+                    if g_ is not None:
+                        total = total + (x_ * g_).sum()
             total = total + (cout['k'] * dcarry['k']).sum() + (cout['w'] * dcarry['w']).sum()
         total.backward()
         if cin is not None:
-            dcarry = dict(h=[x.grad for x in cin['h']], k=cin['k'].grad, w=cin['w'].grad)
+            dcarry = dict(h=[tuple(y.grad for y in x) if isinstance(x, tuple) else x.grad for x in cin['h']],
+                          k=cin['k'].grad, w=cin['w'].grad)
     cat = [torch.cat([av[j] for av in avs], 0) for j in range(len(avs[0]))]
     return cost, cat
 

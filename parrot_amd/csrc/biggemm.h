@@ -25,6 +25,7 @@ struct BgArgs {
 };
 
 int bg_launch(const BgArgs& a, hipStream_t stream);
+void bg_tile_shape(int bf16, int& bm, int& bn);  // macro tile bg_launch will use (split-K heuristics)
 int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of the deterministic split-K
 void bg_set_lds_pad(int bytes);  // unused dynamic LDS per workgroup: limits co-residency (see biggemm.hip)
 

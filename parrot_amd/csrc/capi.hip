@@ -103,7 +103,9 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     if (split <= 0) {
         // auto: few output tiles but a long reduction (deferred weight gradients: K = T*B rows)
         // -> spread K over enough workgroups to fill 256 CUs.
-        const long long tiles = (long long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
+        int bm, bn;
+        bg_tile_shape(a.bf16, bm, bn);
+        const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn) * nbatch;
         split = 1;
         if (act == 0 && tiles < 512 && K >= 512) {
             split = (int)((gemm_target_wgs() + tiles - 1) / tiles);

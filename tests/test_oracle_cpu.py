@@ -63,10 +63,10 @@ def test_tbptt_carry_equivalence():
 def test_checkpointed_bptt_equals_one_piece_backward():
     """R.cost_and_grads_checkpointed (what the T_dec = 800 GPU parity test uses to fit the host memory) gives the cost,
     the outputs and EVERY parameter gradient of the one-piece compute_cost(...).backward(): ragged masks, feedback,
-    speaker, 3 layers, a ragged last chunk."""
+    speaker, 3 layers, LSTM layers (the cfg4 T_dec = 800 test), a ragged last chunk."""
     from tests.util import make_batch
     for kw in (dict(num_layers=3, weak_feedback=True, use_speaker=True, num_speakers=4, speaker_dim=5),
-               dict(num_layers=2)):
+               dict(num_layers=2), dict(num_layers=3, cell_type='lstm')):  # LSTM layers carry (state, cells) pairs
         cfg, p = _tiny(**kw)
         T, B, U = 11, 3, 6
         feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=5, ragged=True, speaker=cfg['use_speaker'])
