@@ -347,6 +347,43 @@ def secondary_leg(a):
                              "x_realtime_per_stream": round(nsamp / best / 16000.0, 3),
                              "alg_bytes_per_sample_step": int(alg), "alg_GBps": round(alg * nsamp / best * 1e-9, 1),
                              "frac": round(alg * nsamp / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000}
+    # ---- SampleRNN TRAINING (three_tier.py:534-636): one truncated-BPTT window, forward + backward of cost + ip_cost
+    try:
+        S = 4000
+        gs = torch.Generator().manual_seed(1)
+        seq = torch.randint(0, 256, (B, S + 80), generator=gs).to(dev)
+        feats_t = torch.randn(B, S // 80, 63, generator=gs).to(dev)
+        h0 = torch.zeros(B, 1, 1024, device=dev)
+        mask = torch.ones(B, S + 80, device=dev)
+
+        def train_step():
+            cost, ip_cost, params = tt.compute_cost(seq, feats_t, h0, h0, 1, mask)[:3]
+            for p_ in params:
+                p_.grad = None
+            (cost + ip_cost).backward()
+            return float(cost)
+        best = None
+        for rep in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            c_ = train_step()
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            if rep > 0:
+                best = dt if best is None else min(best, dt)
+        rows = B * S
+        mlp = 2.0 * rows * (2560 * 1024 + 2 * 1024 * 1024 + 1024 * 256)  # sample-level MLP, forward (three_tier.py:452-515)
+        ip = 2.0 * B * (S // 80) * 1024 * (256 * 80)                      # IndependentPreds projection
+        out["samplernn_train"] = {"workload": "configs[4] training window: 3-tier GRU h=1024, batch 32, SEQ_LEN 4000, "
+                                              "cost + ip_cost forward + backward (no optimiser)",
+                                  "ms_per_window": round(1e3 * best, 2), "samples_per_s": round(rows / best, 1),
+                                  "cost_bits": round(c_, 4),
+                                  "mlp_fwd_TFLOP": round(mlp * 1e-12, 3),
+                                  "alg_TFLOPs": round(3.0 * (mlp + ip) / best * 1e-12, 1),
+                                  "note": "alg_TFLOPs = 3 x (sample-MLP + IndependentPreds forward flops) / time: the "
+                                          "batched GEMMs' share of the f32 MFMA roof (157.3) if nothing else took time",
+                                  "frac": round(3.0 * (mlp + ip) / best * 1e-12 / 157.3, 4), "bound": "mfma",
+                                  "peak_TFLOPs": 157.3}
+    except Exception as e:  # a secondary figure must never take the headline line down with it
+        out["samplernn_train"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -156,7 +156,7 @@ def variant_batch(cfg, T, B, U, ragged, seed):
     return feat, fm, lab, lm
 
 
-def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, capsys, tag):
+def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, capsys, tag, yardstick=True):
     """One training window of VARIANTS[which] on the HIP path vs the fp64 oracle (checkpointed BPTT), and -- as the
     yardstick for what ANY float32 evaluation of this map can meet -- the oracle in float32 vs itself in float64."""
     from oracle import parrot_ref as R
@@ -179,7 +179,12 @@ def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, cap
     for v in p.values():
         v.requires_grad_()
     rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=100)
-    c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
+    if yardstick:
+        c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
+    else:  # (the tolerances of the bf16 operand mode are 100 x the oracle's float32 drift: tools/oracle_f32_drift.py cfg4)
+        c32, av32 = rc, rav
+        for k in p32:
+            p32[k].grad = p[k].grad
     rep = [f"{which} T_dec={T} B={B} U={U} ragged={ragged} operands={compute_dtype}",
            f"cost: hip {cost:.8f} oracle {float(rc):.8f} rel {abs(cost - float(rc)) / abs(float(rc)):.2e} "
            f"(oracle-f32 {abs(float(c32) - float(rc)) / abs(float(rc)):.2e})"]
@@ -227,7 +232,7 @@ def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
     """BASELINE configs[3] per GPU EXACTLY as `bench.py --config cfg4` runs it -- 3 x LSTM-1536, B = 64, T_enc = 200,
     **T_dec = 800**, bf16 MFMA operands / f32 accumulation -- vs the fp64 oracle.  Tolerances of the bf16 operand mode
     (tests/test_gpu_bf16.py, unchanged): 5e-3 cost, 2e-2 frames / kappa / w / phi, 5e-2 norm-wise per gradient."""
-    _window_check(dev, "cfg4", 800, 'bf16', 2e-2, 5e-3, 5e-2, capsys, "cfg4 bf16 T800 parity")
+    _window_check(dev, "cfg4", 800, 'bf16', 2e-2, 5e-3, 5e-2, capsys, "cfg4 bf16 T800 parity", yardstick=False)
 
 
 def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):
