@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -376,7 +377,7 @@ struct BgxSlab {
 };
 
 template <int BMT, int BNT, int BKT, int WR, int WC, bool AXC, bool BXC>
-__global__ __launch_bounds__(512) void bgx_kernel(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void bgx_body(const BgArgs& a, int vecA, int vecB, int tiles_m, int tiles_n, int bid, int z) {
     static_assert(WR * WC == 8, "eight waves");
     constexpr int WTM = BMT / WR, WTN = BNT / WC, MI = WTM / 32, NI = WTN / 32;
     using SA = BgxSlab<BMT, BKT, AXC>;
@@ -386,9 +387,8 @@ __global__ __launch_bounds__(512) void bgx_kernel(const BgArgs a, int vecA, int 
     float* As = bgx_smem;            // [2][ASZ]
     float* Bs = bgx_smem + 2 * ASZ;  // [2][BSZ]
     int tm, tn;
-    bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    bg_tile_of_block(bid, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BMT, n0 = tn * BNT;
-    const int z = blockIdx.y;
     const int batch = z / a.splitk, ks = z % a.splitk;
     int kchunk = (a.K + a.splitk - 1) / a.splitk;
     kchunk = (kchunk + BKT - 1) / BKT * BKT;
@@ -467,6 +467,41 @@ __global__ __launch_bounds__(512) void bgx_kernel(const BgArgs a, int vecA, int 
                 }
             }
         }
+}
+
+template <int BMT, int BNT, int BKT, int WR, int WC, bool AXC, bool BXC>
+__global__ __launch_bounds__(512) void bgx_kernel(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
+    bgx_body<BMT, BNT, BKT, WR, WC, AXC, BXC>(a, vecA, vecB, tiles_m, tiles_n, blockIdx.x, blockIdx.y);
+}
+
+// Grouped launch: the tiles of up to BG_MAXGROUP independent TN products (the deferred weight gradients of one window:
+// 10 products at cfg2) in ONE grid, so the chip drains once per window instead of once per product.  Workgroup ->
+// (job, K slice, tile) through a prefix table in the kernel arguments; within a job the slices are the slow index, so
+// the workgroups resident at any time share operand panels as in the single-product launch.
+template <int BMT, int BNT, int BKT, int WR, int WC>
+__global__ __launch_bounds__(512) void bgx_group_kernel(const BgGroup g) {
+    int j = 0, bx = blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < BG_MAXGROUP - 1; ++q)
+        if (q < g.njobs - 1 && bx >= g.wg_end[q]) j = q + 1;
+    bx -= (j > 0 ? g.wg_end[j - 1] : 0);
+    const BgArgs& a = g.job[j];
+    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = (a.N + BNT - 1) / BNT;
+    const int tiles = tiles_m * tiles_n;
+    bgx_body<BMT, BNT, BKT, WR, WC, true, true>(a, g.vec[j] & 1, (g.vec[j] >> 1) & 1, tiles_m, tiles_n, bx % tiles, bx / tiles);
+}
+
+template <int BMT, int BNT, int BKT, int WR, int WC>
+static int bgx_group_dispatch(const BgGroup& g, int total, size_t pad, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)BKT * ((BMT + 4) + (BNT + 4)) * sizeof(float) + pad;
+    static bool allowed = false;
+    if (!allowed) {
+        (void)hipFuncSetAttribute((const void*)bgx_group_kernel<BMT, BNT, BKT, WR, WC>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allowed = true;
+    }
+    hipLaunchKernelGGL((bgx_group_kernel<BMT, BNT, BKT, WR, WC>), dim3(total), dim3(512), lds, stream, g);
+    return (int)hipGetLastError();
 }
 
 template <int BMT, int BNT, int BKT, int WR, int WC>
@@ -658,6 +693,140 @@ __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, 
     }
 }
 
+// ---- bf16-IN variant (BgArgs::bf16 == 2, round 4): both operands ARE bf16 in HBM, x-contiguous (TN products) ----------
+// The deferred weight gradients of a bf16-operand decoder (X^T . dG over K = T*B rows, 6.8 TFLOP per cfg4 window) ran
+// at ~11 % of the bf16 MFMA peak on bg_kernel_bf16: f32 operands (4 B per element through L2 and the staging
+// registers), a 64 x 32 wave tile (1.5 KB of LDS fragment reads per MFMA: LDS-bound at twice the MFMA time).  Here the
+// operands are bf16 copies written once per window (parrot_to_bf16; half the bytes, no conversion in the loop), the
+// macro tile is 256 x 256 x BKT and a wave owns 128 x 64 (6 fragment reads per 8 MFMAs: 0.75 KB each).  LDS images
+// are [k][x] with a row pitch of 272 bf16 (544 B = 32 B mod 256: the four k rows of a ds_read_b64_tr_b16 group fall
+// on disjoint bank octets), written with one ds_write_b128 per 8 elements; fragments as in bg_frag16<true>.
+constexpr int HBMT = 256, HBNT = 256, HPITCH = 272;
+
+template <int BKT>
+__global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, int tiles_n) {
+    constexpr int NV = BKT / 16;         // 16-byte vectors per thread, operand and K-tile
+    constexpr int SZ = BKT * HPITCH;     // bf16 per image
+    extern __shared__ __attribute__((aligned(16))) __bf16 bgh_smem[];
+    __bf16* As = bgh_smem;            // [2][SZ]
+    __bf16* Bs = bgh_smem + 2 * SZ;   // [2][SZ]
+    int tm, tn;
+    bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * HBMT, n0 = tn * HBNT;
+    const int z = blockIdx.y;
+    const int batch = z / a.splitk, ks = z % a.splitk;
+    int kchunk = (a.K + a.splitk - 1) / a.splitk;
+    kchunk = (kchunk + BKT - 1) / BKT * BKT;
+    const int kbeg = ks * kchunk;
+    const int kend = min(a.K, kbeg + kchunk);
+    const __bf16* A = reinterpret_cast<const __bf16*>(a.A) + (long long)batch * a.batchA;
+    const __bf16* B = reinterpret_cast<const __bf16*>(a.B) + (long long)batch * a.batchB;
+    float* C = a.C + (long long)batch * a.batchC;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kk = lane >> 5, li = lane & 31;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    // staging role: vector id = t + 512 i -> k row id / 32, x = 8 * (id % 32): a wave reads two whole 512-byte rows
+    const int sk = t >> 5, sx = 8 * (t & 31);
+    auto load = [&](const __bf16* __restrict__ p, long long ld, int x0, int X, int k0, bf16x8 (&v)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int k = k0 + sk + 16 * i, x = x0 + sx;
+            bf16x8 r;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = (__bf16)0.f;
+            if (k < kend && x < X) r = *reinterpret_cast<const bf16x8*>(p + (long long)k * ld + x);  // (X % 8 == 0)
+            v[i] = r;
+        }
+    };
+    auto store = [&](__bf16* __restrict__ s, const bf16x8 (&v)[NV]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) *reinterpret_cast<bf16x8*>(s + (sk + 16 * i) * HPITCH + sx) = v[i];
+    };
+    // MFMA 32x32x16 operand of lane (kk, li): row xb + li, k = 16 s + 8 kk .. +7, from a [k][x] image
+    auto frag = [&](const __bf16* __restrict__ img, int xb, int s_) __attribute__((always_inline)) -> bf16x8 {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(3))) s16x4* lds4;
+        const int k0 = 16 * s_ + 8 * kk, q = (li >> 2) & 3, xg = xb + (li & 16) + 4 * (li & 3);
+        const __bf16* p = img + (k0 + q) * HPITCH + xg;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 4 * HPITCH));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    bf16x8 ra[NV], rb[NV];
+    const int nk = (kend - kbeg + BKT - 1) / BKT;
+    if (nk > 0) {
+        load(A, a.sak, m0, a.M, kbeg, ra);
+        load(B, a.sbk, n0, a.N, kbeg, rb);
+        store(As, ra);
+        store(Bs, rb);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load(A, a.sak, m0, a.M, kbeg + (kt + 1) * BKT, ra);
+            load(B, a.sbk, n0, a.N, kbeg + (kt + 1) * BKT, rb);
+        }
+        const __bf16* as = As + cur * SZ;
+        const __bf16* bs = Bs + cur * SZ;
+#pragma unroll
+        for (int s_ = 0; s_ < BKT / 16; ++s_) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = frag(bs, wn * 64 + 32 * j, s_);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag(as, wm * 128 + 32 * i, s_);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store(As + (cur ^ 1) * SZ, ra);
+            store(Bs + (cur ^ 1) * SZ, rb);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+                if (m >= a.M) continue;
+                const float v = a.alpha * acc[i][j][q];
+                if (a.splitk > 1) {
+                    a.ws[((long long)z * a.M + m) * a.N + n] = v;  // summed in slice order by the reducer
+                } else {
+                    float* c = C + (long long)m * a.ldc + n;
+                    *c = a.accumulate ? *c + v : v;
+                }
+            }
+        }
+}
+
+// f32 -> bf16 (round to nearest even), 8 elements per thread: the operand copies bgh_kernel reads.
+__global__ __launch_bounds__(256) void bg_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(x + 8 * i);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(x + 8 * i + 4);
+        *reinterpret_cast<bf16x8*>(y + 8 * i) = ph_bf16x8(lo, hi);
+    }
+}
+
 // C[b][m][n] (+)= bias[n] + sum over the K slices, in slice order (deterministic split-K).
 __global__ __launch_bounds__(256) void bg_reduce_kernel(const BgArgs a) {
     const long long mn = (long long)a.M * a.N;
@@ -702,6 +871,7 @@ int bg_f32_variant() {
 }
 void bg_tile_shape(int bf16, int& bm, int& bn) {
     bm = bn = 128;
+    if (bf16 == 2) { bm = HBMT; bn = HBNT; return; }
     if (bf16) return;
     switch (bg_f32_variant()) {
         case 2: case 3: bm = 256; break;
@@ -709,6 +879,56 @@ void bg_tile_shape(int bf16, int& bm, int& bn) {
         case 6: bm = bn = 256; break;
         default: break;
     }
+}
+
+bool bg_group_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PARROT_GEMM_GROUP");
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+void bg_group_tile_shape(int& bm, int& bn) { bg_tile_shape(0, bm, bn); }
+
+int bg_group_launch(const BgArgs* jobs, int njobs, hipStream_t stream) {
+    if (njobs < 1 || njobs > BG_MAXGROUP) return PH_ERR_BADARG;
+    const size_t pad = (size_t)g_bg_lds_pad.load(std::memory_order_relaxed);
+    BgGroup g;
+    memset(&g, 0, sizeof(g));
+    g.njobs = njobs;
+    int bm, bn;
+    bg_group_tile_shape(bm, bn);
+    int total = 0;
+    for (int q = 0; q < njobs; ++q) {
+        const BgArgs& a = jobs[q];
+        if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch != 1 || a.splitk < 1 || (a.splitk > 1 && !a.ws)) return PH_ERR_BADARG;
+        if (a.sam != 1 || a.sbn != 1 || a.bias || a.act || a.bf16) return PH_ERR_UNSUPPORTED;
+        auto al = [](const float* p, long long stride) { return (((uintptr_t)p & 15) == 0) && (stride % 4 == 0); };
+        g.job[q] = a;
+        g.vec[q] = (al(a.A, a.sak) ? 1 : 0) | (al(a.B, a.sbk) ? 2 : 0);
+        total += ceil_div(a.M, bm) * ceil_div(a.N, bn) * a.splitk;
+        g.wg_end[q] = total;
+    }
+    switch (bg_f32_variant()) {
+        case 1: return bgx_group_dispatch<128, 128, 32, 2, 4>(g, total, pad, stream);
+        case 2: return bgx_group_dispatch<256, 128, 16, 4, 2>(g, total, pad, stream);
+        case 3: return bgx_group_dispatch<256, 128, 32, 4, 2>(g, total, pad, stream);
+        case 4: return bgx_group_dispatch<128, 256, 16, 2, 4>(g, total, pad, stream);
+        case 5: return bgx_group_dispatch<128, 256, 32, 2, 4>(g, total, pad, stream);
+        case 6: return bgx_group_dispatch<256, 256, 16, 4, 2>(g, total, pad, stream);
+        default: return bgx_group_dispatch<128, 128, 16, 2, 4>(g, total, pad, stream);
+    }
+}
+
+int bg_to_bf16_launch(const float* x, void* y, long long n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if ((n & 7) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return PH_ERR_BADARG;
+    const long long n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bg_to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, x, reinterpret_cast<__bf16*>(y), n8);
+    return (int)hipGetLastError();
 }
 
 int bg_launch(const BgArgs& a, hipStream_t stream) {
@@ -726,6 +946,23 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
     dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
     dim3 block(256);
+    if (a.bf16 == 2) {  // operands are bf16 in memory, both x-contiguous (TN): bgh_kernel
+        if (!axc || !bxc || a.bias || a.act || (a.M & 7) || (a.N & 7) || (a.sak & 7) || (a.sbk & 7) ||
+            ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || (a.batchA & 7) || (a.batchB & 7))
+            return PH_ERR_UNSUPPORTED;
+        const int tm = ceil_div(a.M, HBMT), tn = ceil_div(a.N, HBNT);
+        static int bkt = -1;
+        if (bkt < 0) {
+            const char* e = getenv("PARROT_GEMM_BF16IN_BK");
+            bkt = e ? atoi(e) : 32;
+            (void)hipFuncSetAttribute((const void*)bgh_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)bgh_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        const dim3 g2(tm * tn, a.nbatch * a.splitk), b8(512);
+        if (bkt == 64) hipLaunchKernelGGL((bgh_kernel<64>), g2, b8, (size_t)4 * 64 * HPITCH * 2 + pad, stream, a, tm, tn);
+        else hipLaunchKernelGGL((bgh_kernel<32>), g2, b8, (size_t)4 * 32 * HPITCH * 2 + pad, stream, a, tm, tn);
+        return (int)hipGetLastError();
+    }
     if (a.bf16) {
         dim3 b8(512);
         // vector loads of the k-contiguous layout take 8 consecutive k: both 16-byte halves must be aligned

@@ -71,6 +71,84 @@ long long parrot_profile_end(double* total_us, double* flops, double* bytes) { P
     return sk_profile_end(total_us, flops, bytes);
 }
 
+// Split-K workspace, one per stream: products on different streams (the weight-gradient GEMMs that run beside the
+// backward scan, model.py's _backward) never share partial tiles.  Grows on demand, reused by later calls in stream
+// order.  Under stream capture (or when the memory cannot be had) there is none and the product runs unsplit, so no
+// graph ever holds a pointer into a workspace that a later, larger call may replace.
+static float* bg_workspace(hipStream_t st, size_t need) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    struct Ws { float* p; size_t floats; };
+    static std::mutex ws_mu;
+    static std::map<hipStream_t, Ws> ws_of;
+    std::lock_guard<std::mutex> lock(ws_mu);
+    Ws& w = ws_of[st];
+    if (need > w.floats) {
+        if (w.p) {
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(w.p);
+            w.p = nullptr;
+            w.floats = 0;
+        }
+        if (hipMalloc(&w.p, need * sizeof(float)) == hipSuccess) w.floats = need;
+        else w.p = nullptr;
+    }
+    return (w.p && need <= w.floats) ? w.p : nullptr;
+}
+
+// Auto split-K, the deterministic split-K workspace and the launch of one batched product (shared by parrot_gemm and
+// parrot_gemm_bf16in).
+static int bg_run(BgArgs a, int split_k, hipStream_t st) {
+    const int M = a.M, N = a.N, K = a.K, nbatch = a.nbatch, act = a.act;
+    const float* bias = a.bias;
+    int split = split_k;
+    if (split <= 0) {
+        // auto: few output tiles but a long reduction (deferred weight gradients: K = T*B rows)
+        // -> spread K over enough workgroups to fill 256 CUs.
+        int bm, bn;
+        bg_tile_shape(a.bf16, bm, bn);
+        const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn) * nbatch;
+        split = 1;
+        if (a.bf16 == 2 && K >= 512) {
+            // 256 x 256 tiles, one workgroup per CU: the slice count whose workgroups fill whole rounds of 256 best
+            // (at least two rounds, at most 16 slices, at least 1024 K rows per slice)
+            double best = -1.0;
+            for (int sp = 1; sp <= 16 && K / sp >= 1024; ++sp) {
+                const long long wgs = tiles * sp;
+                const double eff = (double)wgs / (double)((wgs + 255) / 256 * 256);
+                const double score = eff - (wgs < 512 ? 0.25 : 0.0) - 0.002 * sp;
+                if (score > best) { best = score; split = sp; }
+            }
+        } else if (act == 0 && tiles < 512 && K >= 512) {
+            split = (int)((gemm_target_wgs() + tiles - 1) / tiles);
+            const int maxs = K / 256 > 0 ? K / 256 : 1;
+            if (split > maxs) split = maxs;
+            if (split > 64) split = 64;
+        }
+    }
+    a.splitk = split;
+    a.ws = nullptr;
+    if (a.splitk > 1) {
+        if (act != 0) return PARROT_ERR_BADARG;
+        // Deterministic split-K: the slices write partial tiles to a library-owned workspace and a second kernel adds
+        // them in slice order (results do not depend on scheduling).  The workspace grows on demand and is reused by
+        // later calls in stream order.  Under stream capture or when the workspace cannot be had, the product runs
+        // unsplit instead: there is no float-atomic combine any more.
+        float* ws = bg_workspace(st, (size_t)nbatch * a.splitk * M * N);
+        if (ws) {
+            a.ws = ws;
+            a.bias = nullptr;  // the reducer adds it
+            int rc = bg_launch(a, st);
+            if (rc) return rc;
+            a.bias = bias;
+            return bg_reduce_launch(a, st);
+        }
+        a.splitk = 1;
+    }
+    return bg_launch(a, st);
+}
+
 int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
                 int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
                 long long strideA, long long strideB, long long strideC, int split_k, void* stream) { PH_ENTRY();
@@ -99,65 +177,93 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     a.nbatch = nbatch;
     a.accumulate = accumulate; a.alpha = alpha; a.act = act;
     a.bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16.load(std::memory_order_relaxed);
-    int split = split_k;
-    if (split <= 0) {
-        // auto: few output tiles but a long reduction (deferred weight gradients: K = T*B rows)
-        // -> spread K over enough workgroups to fill 256 CUs.
-        int bm, bn;
-        bg_tile_shape(a.bf16, bm, bn);
-        const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn) * nbatch;
-        split = 1;
-        if (act == 0 && tiles < 512 && K >= 512) {
-            split = (int)((gemm_target_wgs() + tiles - 1) / tiles);
-            const int maxs = K / 256 > 0 ? K / 256 : 1;
-            if (split > maxs) split = maxs;
-            if (split > 64) split = 64;
-        }
-    }
-    a.splitk = split;
-    a.ws = nullptr;
-    if (a.splitk > 1) {
-        if (act != 0) return PARROT_ERR_BADARG;
-        // Deterministic split-K: the slices write partial tiles to a library-owned workspace and a second kernel adds
-        // them in slice order (results do not depend on scheduling).  The workspace grows on demand and is reused by
-        // later calls in stream order.  Under stream capture or when the workspace cannot be had, the product runs
-        // unsplit instead: there is no float-atomic combine any more.
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cs);
-        // One workspace per stream: products on different streams (the weight-gradient GEMMs that run beside the
-        // backward scan, model.py's _backward) never share partial tiles.  Under capture the product runs unsplit,
-        // so no graph ever holds a pointer into a workspace that a later, larger call may replace.
-        struct Ws { float* p; size_t floats; };
-        static std::mutex ws_mu;
-        static std::map<hipStream_t, Ws> ws_of;
-        const size_t need = (size_t)nbatch * a.splitk * M * N;
-        float* ws = nullptr;
-        if (cs == hipStreamCaptureStatusNone) {
-            std::lock_guard<std::mutex> lock(ws_mu);
-            Ws& w = ws_of[st];
-            if (need > w.floats) {
-                if (w.p) {
-                    (void)hipStreamSynchronize(st);
-                    (void)hipFree(w.p);
-                    w.p = nullptr;
-                    w.floats = 0;
-                }
-                if (hipMalloc(&w.p, need * sizeof(float)) == hipSuccess) w.floats = need;
-                else w.p = nullptr;
-            }
-            if (w.p && need <= w.floats) ws = w.p;
-        }
-        if (ws) {
-            a.ws = ws;
-            a.bias = nullptr;  // the reducer adds it
-            int rc = bg_launch(a, st);
+    return bg_run(a, split_k, st);
+}
+
+int parrot_gemm_grouped_tn(const ParrotGemmTN* jobs, int njobs, void* stream) { PH_ENTRY();
+    if (!jobs || njobs < 1) return PARROT_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16.load(std::memory_order_relaxed);
+    auto fill = [&](const ParrotGemmTN& j, BgArgs& a) {
+        a.A = j.A; a.B = j.B; a.C = j.C; a.bias = nullptr;
+        a.M = j.M; a.N = j.N; a.K = j.K;
+        a.sam = 1; a.sak = j.lda; a.sbk = j.ldb; a.sbn = 1;
+        a.ldc = j.ldc;
+        a.batchA = a.batchB = a.batchC = 0;
+        a.nbatch = 1;
+        a.accumulate = j.accumulate; a.alpha = 1.0f; a.act = 0;
+        a.bf16 = bf16;
+        a.splitk = 1; a.ws = nullptr;
+    };
+    for (int q = 0; q < njobs; ++q)
+        if (!jobs[q].A || !jobs[q].B || !jobs[q].C || jobs[q].M < 1 || jobs[q].N < 1 || jobs[q].K < 1) return PARROT_ERR_BADARG;
+    // one grid for the whole group: f32 operands, at most BG_MAXGROUP products; otherwise product by product
+    if (bf16 || njobs > BG_MAXGROUP || !bg_group_enabled()) {
+        for (int q = 0; q < njobs; ++q) {
+            BgArgs a;
+            fill(jobs[q], a);
+            const int rc = bg_run(a, 0, st);
             if (rc) return rc;
-            a.bias = bias;
-            return bg_reduce_launch(a, st);
         }
-        a.splitk = 1;
+        return 0;
     }
-    return bg_launch(a, st);
+    BgArgs a[BG_MAXGROUP];
+    int bm, bn;
+    bg_group_tile_shape(bm, bn);
+    long long tiles_all = 0;
+    for (int q = 0; q < njobs; ++q) {
+        fill(jobs[q], a[q]);
+        tiles_all += (long long)ceil_div(a[q].M, bm) * ceil_div(a[q].N, bn);
+    }
+    // K slices: the same count for every product of the group (they share K = T*B in practice), chosen so that the
+    // whole grid is a few rounds of the chip's resident workgroups
+    int kmin = a[0].K;
+    for (int q = 1; q < njobs; ++q) kmin = a[q].K < kmin ? a[q].K : kmin;
+    int split = (int)((4 * (long long)gemm_target_wgs() + tiles_all - 1) / tiles_all);
+    const int maxs = kmin / 512 > 0 ? kmin / 512 : 1;
+    if (split > maxs) split = maxs;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    size_t need = 0;
+    if (split > 1)
+        for (int q = 0; q < njobs; ++q) need += (size_t)split * a[q].M * a[q].N;
+    float* ws = split > 1 ? bg_workspace(st, need) : nullptr;
+    if (split > 1 && !ws) split = 1;
+    size_t off = 0;
+    for (int q = 0; q < njobs; ++q) {
+        a[q].splitk = split;
+        a[q].ws = split > 1 ? ws + off : nullptr;
+        off += (size_t)split * a[q].M * a[q].N;
+    }
+    int rc = bg_group_launch(a, njobs, st);
+    if (rc) return rc;
+    if (split > 1)
+        for (int q = 0; q < njobs; ++q) {
+            rc = bg_reduce_launch(a[q], st);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+int parrot_to_bf16(const float* x, void* y, long long n, void* stream) { PH_ENTRY();
+    if (!x || !y || n < 0) return PARROT_ERR_BADARG;
+    return bg_to_bf16_launch(x, y, n, (hipStream_t)stream);
+}
+
+int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                       int accumulate, int split_k, void* stream) { PH_ENTRY();
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1) return PARROT_ERR_BADARG;
+    BgArgs a;
+    a.A = reinterpret_cast<const float*>(A); a.B = reinterpret_cast<const float*>(B); a.C = C; a.bias = nullptr;
+    a.M = M; a.N = N; a.K = K;
+    a.sam = 1; a.sak = lda;   // A(m, k) at A[k * lda + m]: the caller's [K, M] matrix read as its transpose
+    a.sbk = ldb; a.sbn = 1;
+    a.ldc = ldc;
+    a.batchA = a.batchB = a.batchC = 0;
+    a.nbatch = 1;
+    a.accumulate = accumulate; a.alpha = 1.0f; a.act = 0;
+    a.bf16 = 2;
+    return bg_run(a, split_k, (hipStream_t)stream);
 }
 
 int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream) { PH_ENTRY();

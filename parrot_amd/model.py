@@ -945,6 +945,9 @@ class Parrot(Brick):
         H, E, L = self.rnn_h_dim, self.encoded_input_dim, self.num_layers
         sg_ = self.store.storage_grad
         R = (t1 - t0) * B
+        if self._bf16_weight_grads(t0, t1, T):
+            return self._weight_grad_rows_bf16(ws, T, B)
+        jobs = []  # (X [R, in], dPre [R, out], dW [in, out]): dW += X^T . dPre
         for l in range(L):
             ll = l + 1
             hprev = ws['h'][l][t0:t1].view(R, H)
@@ -954,19 +957,69 @@ class Parrot(Brick):
                 gW = sg_[f'{mat}{ll}']
                 # the candidate block of the GRU multiplies r*h_prev, every other block h_prev
                 rec_in = ws['rh'][l][t0:t1].view(R, H) if key == 'c' else hprev
-                ops.gemm(rec_in.t(), dP, out=gW[0:H], accumulate=True)
-                ops.gemm(wsrc.t(), dP, out=gW[H:H + E], accumulate=True)
+                jobs.append((rec_in, dP, gW[0:H]))
+                jobs.append((wsrc, dP, gW[H:H + E]))
                 for j in range(l):
                     r0 = H + E + j * H
                     dPj = dP
                     if self.layer_norm:  # seq_bwd left the gradient wrt the pre-norm projection in ln_y
                         dPj = ws['ln_y' + key][(l, j)][t0:t1].view(R, wd)
-                    ops.gemm(ws['h'][j][t0 + 1:t1 + 1].view(R, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
+                    jobs.append((ws['h'][j][t0 + 1:t1 + 1].view(R, H), dPj, gW[r0:r0 + H]))
+        # One grid for all of them (f32 operands, at most 16 products: every GRU / LSTM stack up to 2 layers); the chip
+        # drains once per window instead of once per product.  Same products, same deterministic split-K sums.
+        if len(jobs) <= 16:
+            ops.gemm_grouped_tn(jobs, accumulate=True)
+        else:
+            for x_, dP_, gW_ in jobs:
+                ops.gemm(x_.t(), dP_, out=gW_, accumulate=True)
         # attention projection (h1_to_att Fork)
         A = self.attention_size
         with ops.gemm_precision(ops.PRECISION_F32):  # the attention window stays f32 in every operand mode
             ops.gemm(ws['dp'][t0:t1].view(R, 3 * A).t(), ws['h'][0][t0 + 1:t1 + 1].view(R, H),
                      out=sg_['dec.WattT'], accumulate=True)
+
+    def _bf16_weight_grads(self, t0, t1, T):
+        """bf16-operand decoders take the whole window's weight gradients from bf16 COPIES of the saved activations and
+        pre-activation gradients (one conversion pass, then parrot_gemm_bf16in: half the operand bytes, 256 x 256 tiles)
+        instead of rounding f32 operands inside the product.  Same rounding (nearest even) of the same values."""
+        H, E = self.rnn_h_dim, self.encoded_input_dim
+        return (self.compute_bf16 and not self.layer_norm and t0 == 0 and t1 == T and H % 8 == 0 and E % 8 == 0
+                and os.environ.get('PARROT_BF16_DW', '1') != '0')
+
+    def _weight_grad_rows_bf16(self, ws, T, B):
+        H, E, L = self.rnn_h_dim, self.encoded_input_dim, self.num_layers
+        sg_ = self.store.storage_grad
+        R = T * B
+        cp = ws.get('bf16_copies')
+        if cp is None:  # allocated once per workspace
+            bf = dict(device=self._dev(), dtype=torch.bfloat16)
+            cp = ws['bf16_copies'] = dict(
+                h=[torch.empty(T + 1, B, H, **bf) for _ in range(L)], w=torch.empty(T + 1, B, E, **bf),
+                rh=[torch.empty(T, B, H, **bf) for _ in range(L)] if self.cell_type != 'lstm' else None,
+                d={key: [torch.empty(T, B, wd, **bf) for _ in range(L)] for key, wd, _, _, _ in self._groups})
+        ops.to_bf16(ws['w'], out=cp['w'])
+        for l in range(L):
+            ops.to_bf16(ws['h'][l], out=cp['h'][l])
+            if cp['rh'] is not None:
+                ops.to_bf16(ws['rh'][l], out=cp['rh'][l])
+            for key, wd, _, _, _ in self._groups:
+                ops.to_bf16(ws['d' + key.upper()][l], out=cp['d'][key][l])
+        for l in range(L):
+            ll = l + 1
+            hprev = cp['h'][l][0:T].view(R, H)
+            wsrc = (cp['w'][0:T] if l == 0 else cp['w'][1:T + 1]).view(R, E)
+            for key, wd, suf, mat, rec in self._groups:
+                dP = cp['d'][key][l].view(R, wd)
+                gW = sg_[f'{mat}{ll}']
+                rec_in = cp['rh'][l].view(R, H) if key == 'c' else hprev  # (the GRU candidate multiplies r * h_prev)
+                ops.gemm_bf16in(rec_in, dP, gW[0:H], accumulate=True)
+                ops.gemm_bf16in(wsrc, dP, gW[H:H + E], accumulate=True)
+                for j in range(l):
+                    r0 = H + E + j * H
+                    ops.gemm_bf16in(cp['h'][j][1:T + 1].view(R, H), dP, gW[r0:r0 + H], accumulate=True)
+        A = self.attention_size
+        with ops.gemm_precision(ops.PRECISION_F32):  # the attention window stays f32 in every operand mode
+            ops.gemm(ws['dp'].view(R, 3 * A).t(), ws['h'][0][1:T + 1].view(R, H), out=sg_['dec.WattT'], accumulate=True)
 
     def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None):
         """The backward scan and the weight-gradient GEMMs that only read what it leaves behind.  When the plan runs

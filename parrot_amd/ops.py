@@ -76,6 +76,53 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate=False
     return out
 
 
+def gemm_grouped_tn(jobs, accumulate=True):
+    """For every (a_t [K, M], b [K, N], out [M, N]) of `jobs`: out (+)= a_t^T @ b, all in ONE launch (f32 operand mode;
+    product by product otherwise): the deferred weight gradients of a training window (parrot_gemm_grouped_tn)."""
+    arr = (_lib.GemmTN * len(jobs))()
+    for q, (a_t, b, out) in enumerate(jobs):
+        _chk(a_t, "a_t"); _chk(b, "b"); _chk(out, "out")
+        if a_t.dim() != 2 or b.dim() != 2 or a_t.stride(1) != 1 or b.stride(1) != 1 or out.stride(1) != 1:
+            raise ValueError("gemm_grouped_tn: 2-d tensors with unit inner stride expected")
+        K, M = a_t.shape
+        K2, N = b.shape
+        if K != K2 or tuple(out.shape) != (M, N):
+            raise ValueError("gemm_grouped_tn: shapes do not match")
+        arr[q].A, arr[q].lda, arr[q].B, arr[q].ldb = a_t.data_ptr(), a_t.stride(0), b.data_ptr(), b.stride(0)
+        arr[q].C, arr[q].ldc, arr[q].M, arr[q].N, arr[q].K = out.data_ptr(), out.stride(0), M, N, K
+        arr[q].accumulate = int(bool(accumulate))
+    _lib.call("parrot_gemm_grouped_tn", arr, len(jobs), _stream())
+
+
+def to_bf16(x: torch.Tensor, out=None) -> torch.Tensor:
+    """bf16 copy (round to nearest even) of a contiguous f32 tensor: the operand copies `gemm_bf16in` reads."""
+    _chk(x, "x")
+    if not x.is_contiguous() or x.numel() % 8:
+        raise ValueError("to_bf16: contiguous tensor with a multiple of 8 elements expected")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    if out.dtype != torch.bfloat16 or out.numel() != x.numel() or not out.is_contiguous() or not out.is_cuda:
+        raise ValueError("to_bf16: bad output tensor")
+    _lib.call("parrot_to_bf16", x.data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def gemm_bf16in(a_t: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulate=False, split_k=0) -> torch.Tensor:
+    """out[M,N] (+)= a_t[K,M]^T @ b[K,N] with a_t and b ALREADY bf16 (row-major, strides multiples of 8), f32
+    accumulation and f32 `out`: the deferred weight gradients dW = X^T . dPre of a bf16-operand decoder."""
+    for x_, n_ in ((a_t, "a_t"), (b, "b")):
+        if not (x_.is_cuda and x_.dtype == torch.bfloat16 and x_.dim() == 2 and x_.stride(1) == 1):
+            raise ValueError(f"gemm_bf16in: {n_} must be a 2-d bf16 GPU tensor with unit inner stride")
+    _chk(out, "out")
+    K, M = a_t.shape
+    K2, N = b.shape
+    if K != K2 or out.shape != (M, N) or out.stride(1) != 1:
+        raise ValueError("gemm_bf16in: shapes do not match")
+    _lib.call("parrot_gemm_bf16in", a_t.data_ptr(), a_t.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+              out.stride(0), M, N, K, int(bool(accumulate)), int(split_k), _stream())
+    return out
+
+
 PRECISION_F32, PRECISION_BF16 = 0, 1
 
 

@@ -8,8 +8,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _host_cores():
+    """Usable host cores: min(affinity, cgroup CPU quota).  The GPU boxes show hundreds of logical CPUs but run the
+    container under a 16-CPU quota; a torch-CPU thread pool sized for the former stalls the oracle for minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    try:
+        import torch
+        torch.set_num_threads(_host_cores())
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -189,3 +189,62 @@ def test_wide_and_tiled_bf16_kernels_agree(dev, monkeypatch):
     for k, v in got["0"][1].items():
         if float(v.abs().max()) > 1e-12:
             assert rel_err(got["2"][1][k], v) < 5e-3, (k, rel_err(got["2"][1][k], v))
+
+
+def test_gemm_bf16in_vs_rounded_operands(dev):
+    """parrot_to_bf16 + parrot_gemm_bf16in (bf16 operands in memory, 256 x 256 tiles, transposed LDS fragment reads):
+    the copy is the round-to-nearest-even of the input bit for bit, and A^T . B equals the float64 product of the rounded
+    operands to f32-accumulation accuracy -- ragged M / N (multiples of 8 only), K not a multiple of the K-tile,
+    automatic and forced split-K, accumulate."""
+    from parrot_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for K, M, N in ((1000, 264, 520), (4104, 1536, 256), (2048, 8, 776)):
+        a = torch.randn(K, M, generator=g).to(dev)
+        b = torch.randn(K, N, generator=g).to(dev)
+        a16, b16 = ops.to_bf16(a), ops.to_bf16(b)
+        assert torch.equal(a16.cpu(), a.cpu().to(torch.bfloat16)) and torch.equal(b16.cpu(), b.cpu().to(torch.bfloat16))
+        ref = a16.cpu().double().t() @ b16.cpu().double()
+        for split in (0, 1, 3):
+            out = torch.full((M, N), 7.0, device=dev)
+            ops.gemm_bf16in(a16, b16, out, accumulate=False, split_k=split)
+            assert_close(out, ref, 2e-5, f"bf16in K={K} M={M} N={N} split={split}")
+            ops.gemm_bf16in(a16, b16, out, accumulate=True, split_k=split)
+            assert_close(out, 2 * ref, 2e-5, "accumulate")
+        # a view with a leading dimension larger than its width (row slices of a history)
+        wide = torch.randn(K, M + 24, generator=g).to(dev)
+        w16 = ops.to_bf16(wide)
+        out = torch.empty(M, N, device=dev)
+        ops.gemm_bf16in(w16[:, 8:8 + M], b16, out)
+        assert_close(out, w16.cpu().double()[:, 8:8 + M].t() @ b16.cpu().double(), 2e-5, "strided A")
+
+
+def test_bf16_weight_grads_match_the_rounding_gemm(dev, monkeypatch):
+    """The bf16-copy weight-gradient path (PARROT_BF16_DW=1, default) and the f32-operand bf16 GEMM it replaces round the
+    same values the same way: every decoder weight gradient agrees to f32 summation order (1e-5 norm-wise)."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=9, scale_by_fan_in=True)
+    feat, fm, lab, lm, spk = make_batch(cfg, 9, 24, 12, seed=10, ragged=True)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PARROT_BF16_DW", mode)
+        for cell in ("lstm", "gru"):
+            kw2 = dict(kw, cell_type=cell)
+            cfg2 = R.default_config(**kw2)
+            p2 = R.init_params(cfg2, seed=9, scale_by_fan_in=True)
+            m = Parrot(device=dev, compute_dtype='bf16', **kw2).allocate()
+            m.set_parameter_values(p2)
+            m.zero_grad()
+            cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, 24)
+            cost.backward()
+            got[(mode, cell)] = {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()}
+            m.close()
+    for cell in ("lstm", "gru"):
+        n = 0
+        for k, v in got[("0", cell)].items():
+            if float(v.abs().max()) > 1e-12:
+                assert rel_err(got[("1", cell)][k], v) < 1e-5, (cell, k, rel_err(got[("1", cell)][k], v))
+                n += 1
+        assert n >= 10

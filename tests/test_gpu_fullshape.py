@@ -218,6 +218,7 @@ def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, cap
     return rep
 
 
+@pytest.mark.timeout(1800)
 def test_cfg2_T800_fan_in_ragged_feedback_matches_oracle(dev, capsys):
     """SURVEY 8d's second parameter set on the benchmarked window: configs[1] at T_dec = 800 with N(0, 1/fan_in) weights
     (saturating gates), ragged lengths T ~ U[600, 800] / U ~ U[120, 200] and weak_feedback=True, vs the fp64 oracle.
@@ -228,6 +229,7 @@ def test_cfg2_T800_fan_in_ragged_feedback_matches_oracle(dev, capsys):
     _window_check(dev, "cfg2v", 800, 'float32', 1e-4, 1e-4, 1e-3, capsys, "T800 variant parity")
 
 
+@pytest.mark.timeout(2400)
 def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
     """BASELINE configs[3] per GPU EXACTLY as `bench.py --config cfg4` runs it -- 3 x LSTM-1536, B = 64, T_enc = 200,
     **T_dec = 800**, bf16 MFMA operands / f32 accumulation -- vs the fp64 oracle.  Tolerances of the bf16 operand mode

@@ -39,8 +39,8 @@ pmc() {  # pmc <suffix> <probe cfg>
 }
 for step in "$@"; do
   case "$step" in
-    tests)   timeout 1500 python -m pytest tests -q -m gpu -x --timeout 600 2>&1 | tail -25 | tee $out/tests.log ;;
-    tests:*) timeout 1200 python -m pytest tests -q -m gpu --timeout 600 -k "${step#tests:}" 2>&1 | tail -40 | tee -a $out/tests_k.log ;;
+    tests)   timeout 3000 python -m pytest tests -q -m gpu -x --timeout 600 2>&1 | tail -25 | tee $out/tests.log ;;
+    tests:*) timeout 2700 python -m pytest tests -q -m gpu --timeout 600 -k "${step#tests:}" 2>&1 | tail -40 | tee -a $out/tests_k.log ;;
     bench)   ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err ) 2> $out/bench.time
              tail -c 3000 $out/bench.json; tail -3 $out/bench.time ;;
     stats)   stats bench 600 python bench.py --no-cpu-baseline --no-parity --no-secondary ;;
