@@ -66,18 +66,6 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
                 int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
                 long long strideA, long long strideB, long long strideC, int split_k, void* stream);
 
-/* Grouped weight-gradient products (round 4): C_q[M_q,N_q] (+)= A_q^T . B_q for q < njobs, A_q [K_q, M_q] and
- * B_q [K_q, N_q] row-major f32 -- the deferred weight gradients dW = X^T . dPre of one training window
- * (train.py:100-108 takes the gradient of model.py:651-724 over all steps), issued as ONE grid so the chip drains once
- * per window instead of once per product.  Deterministic (split-K partial tiles summed in slice order). */
-typedef struct ParrotGemmTN {
-    const float* A; int lda;
-    const float* B; int ldb;
-    float* C; int ldc;
-    int M, N, K, accumulate;
-} ParrotGemmTN;
-int parrot_gemm_grouped_tn(const ParrotGemmTN* jobs, int njobs, void* stream);
-
 /* bf16-IN weight-gradient product (round 4): C[M,N] (+)= A^T . B with A [K, M] and B [K, N] ALREADY bf16 in device
  * memory (row-major, leading dimensions in elements, both multiples of 8; M, N multiples of 8; 16-byte aligned),
  * f32 accumulation, f32 C; deterministic split-K as parrot_gemm (split_k = 0: automatic).  parrot_to_bf16 makes the

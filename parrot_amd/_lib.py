@@ -43,12 +43,6 @@ class LstmSeqDesc(C.Structure):
                [(n, C.c_void_p) for n in ("W", "pre_in", "s", "c", "gates", "dS", "dc", "dP")]
 
 
-class GemmTN(C.Structure):
-    """ParrotGemmTN (include/parrot_hip.h): one product C (+)= A^T . B of a grouped launch."""
-    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p),
-                ("ldc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("accumulate", C.c_int)]
-
-
 class DecoderDesc(C.Structure):
     _fields_ = [
         ("T", C.c_int), ("B", C.c_int), ("H", C.c_int), ("E", C.c_int), ("A", C.c_int),
@@ -180,7 +174,6 @@ SIGNATURES = {
     "parrot_set_gemm_precision": (_i, [_i]),
     "parrot_get_gemm_precision": (_i, []),
     "parrot_set_gemm_lds_pad": (_i, [_i]),
-    "parrot_gemm_grouped_tn": (_i, [_vp, _i, _vp]),
     "parrot_to_bf16": (_i, [_vp, _vp, _ll, _vp]),
     "parrot_gemm_bf16in": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "parrot_stream_create": (_i, [_i, C.POINTER(C.c_void_p)]),

@@ -25,20 +25,7 @@ struct BgArgs {
                      // 2: A and B point at bf16 data (strides in bf16 elements), both x-contiguous: bgh_kernel
 };
 
-enum { BG_MAXGROUP = 16 };
-struct BgGroup {  // kernel arguments of a grouped launch (bgx_group_kernel)
-    BgArgs job[BG_MAXGROUP];
-    int wg_end[BG_MAXGROUP];  // prefix of workgroups per job (tiles x K slices)
-    int vec[BG_MAXGROUP];     // bit 0 / 1: 16-byte loads are legal for A / B
-    int njobs;
-};
-
 int bg_launch(const BgArgs& a, hipStream_t stream);
-// One grid for njobs <= BG_MAXGROUP f32 TN products (A and B x-contiguous, no bias / activation); splitk / ws per job set
-// by the caller.  bg_group_tile_shape: the macro tile it will use; bg_group_enabled: PARROT_GEMM_GROUP != 0.
-int bg_group_launch(const BgArgs* jobs, int njobs, hipStream_t stream);
-void bg_group_tile_shape(int& bm, int& bn);
-bool bg_group_enabled();
 void bg_tile_shape(int bf16, int& bm, int& bn);  // macro tile bg_launch will use (split-K heuristics)
 int bg_to_bf16_launch(const float* x, void* y, long long n, hipStream_t stream);  // f32 -> bf16 copy (RNE), n % 8 == 0
 int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of the deterministic split-K

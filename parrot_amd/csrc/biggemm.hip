@@ -319,214 +319,14 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
     }
 }
 
-// ---- generic macro-tile variant (round 4): BM x BN x BK per 512-thread workgroup, 8 waves as WR x WC --------------
-// The 128 x 128 x 16 kernel above keeps the matrix pipe 80 % busy: every K-tile (2048 MFMA cycles per SIMD) ends in a
-// workgroup barrier behind which all eight waves wait for their first fragment reads, and a wave issues 3 LDS reads per
-// 2 MFMAs.  A 256 x 128 tile gives each wave a 64 x 64 block (4 MFMAs per 4 fragment reads, twice the MFMA work per
-// barrier and per operand byte staged); BK = 32 halves the barriers again.  Same operand layouts, same [k][x] LDS
-// images (pitch BX + 4 floats), same XCD-aware tile order, same deterministic split-K.
-template <int BX, int BKT, bool XC>
-struct BgxSlab {
-    static constexpr int NV = BX * BKT / 4 / 512;  // 16-byte vectors per thread
-    static constexpr int P = BX + 4;
-    static_assert(BX * BKT / 4 % 512 == 0, "slab must be a whole number of vectors per thread");
-    __device__ static __forceinline__ void load(const float* __restrict__ p, int x0, int X, int k0, int kend, long long sx,
-                                                long long sk, bool vec, int t, f32x4 (&v)[NV]) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int id = t + 512 * i;
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (XC) {
-                const int k = k0 + id / (BX / 4), x = x0 + 4 * (id % (BX / 4));
-                if (k < kend) {
-                    const float* q = p + (long long)k * sk + x;
-                    if (vec && x + 3 < X) v[i] = *reinterpret_cast<const f32x4*>(q);
-                    else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (x + u < X) v[i][u] = q[u];
-                    }
-                }
-            } else {
-                const int x = x0 + id / (BKT / 4), k = k0 + 4 * (id % (BKT / 4));
-                if (x < X) {
-                    const float* q = p + (long long)x * sx + k;
-                    if (vec && k + 3 < kend) v[i] = *reinterpret_cast<const f32x4*>(q);
-                    else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (k + u < kend) v[i][u] = q[u];
-                    }
-                }
-            }
-        }
-    }
-    __device__ static __forceinline__ void store(float* __restrict__ s, int t, const f32x4 (&v)[NV]) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int id = t + 512 * i;
-            if (XC) {
-                *reinterpret_cast<f32x4*>(s + (id / (BX / 4)) * P + 4 * (id % (BX / 4))) = v[i];
-            } else {
-                const int x = id / (BKT / 4), kq = id % (BKT / 4);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) s[(4 * kq + u) * P + x] = v[i][u];
-            }
-        }
-    }
-};
-
-template <int BMT, int BNT, int BKT, int WR, int WC, bool AXC, bool BXC>
-__device__ __forceinline__ void bgx_body(const BgArgs& a, int vecA, int vecB, int tiles_m, int tiles_n, int bid, int z) {
-    static_assert(WR * WC == 8, "eight waves");
-    constexpr int WTM = BMT / WR, WTN = BNT / WC, MI = WTM / 32, NI = WTN / 32;
-    using SA = BgxSlab<BMT, BKT, AXC>;
-    using SB = BgxSlab<BNT, BKT, BXC>;
-    constexpr int ASZ = BKT * SA::P, BSZ = BKT * SB::P;
-    extern __shared__ __attribute__((aligned(16))) float bgx_smem[];
-    float* As = bgx_smem;            // [2][ASZ]
-    float* Bs = bgx_smem + 2 * ASZ;  // [2][BSZ]
-    int tm, tn;
-    bg_tile_of_block(bid, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BMT, n0 = tn * BNT;
-    const int batch = z / a.splitk, ks = z % a.splitk;
-    int kchunk = (a.K + a.splitk - 1) / a.splitk;
-    kchunk = (kchunk + BKT - 1) / BKT * BKT;
-    const int kbeg = ks * kchunk;
-    const int kend = min(a.K, kbeg + kchunk);
-    const float* A = a.A + (long long)batch * a.batchA;
-    const float* B = a.B + (long long)batch * a.batchB;
-    float* C = a.C + (long long)batch * a.batchC;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave / WC, wn = wave % WC;
-    const int kk = lane >> 5, li = lane & 31;
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    f32x4 ra[SA::NV], rb[SB::NV];
-    const int nk = (kend - kbeg + BKT - 1) / BKT;
-    if (nk > 0) {
-        SA::load(A, m0, a.M, kbeg, kend, a.sam, a.sak, vecA, t, ra);
-        SB::load(B, n0, a.N, kbeg, kend, a.sbn, a.sbk, vecB, t, rb);
-        SA::store(As, t, ra);
-        SB::store(Bs, t, rb);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            SA::load(A, m0, a.M, kbeg + (kt + 1) * BKT, kend, a.sam, a.sak, vecA, t, ra);
-            SB::load(B, n0, a.N, kbeg + (kt + 1) * BKT, kend, a.sbn, a.sbk, vecB, t, rb);
-        }
-        const float* as = As + cur * ASZ + wm * WTM + li;
-        const float* bs = Bs + cur * BSZ + wn * WTN + li;
-#pragma unroll
-        for (int kp = 0; kp < BKT / 2; ++kp) {
-            float fa[MI], fb[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = as[(2 * kp + kk) * SA::P + 32 * i];
-#pragma unroll
-            for (int j = 0; j < NI; ++j) fb[j] = bs[(2 * kp + kk) * SB::P + 32 * j];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            SA::store(As + (cur ^ 1) * ASZ, t, ra);
-            SB::store(Bs + (cur ^ 1) * BSZ, t, rb);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * WTN + j * 32 + li;
-            if (n >= a.N) continue;
-            const float bias = (a.bias && ks == 0) ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int m = m0 + wm * WTM + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
-                if (m >= a.M) continue;
-                float v = a.alpha * acc[i][j][q] + bias;
-                float* c = C + (long long)m * a.ldc + n;
-                if (a.splitk > 1) {
-                    a.ws[((long long)z * a.M + m) * a.N + n] = a.alpha * acc[i][j][q];  // bias added by the reducer
-                } else {
-                    if (a.accumulate) v += *c;
-                    if (a.act == 1) v = fmaxf(v, 0.f);
-                    else if (a.act == 2) v = tanhf(v);
-                    else if (a.act == 3) v = 1.f / (1.f + expf(-v));
-                    *c = v;
-                }
-            }
-        }
-}
-
-template <int BMT, int BNT, int BKT, int WR, int WC, bool AXC, bool BXC>
-__global__ __launch_bounds__(512) void bgx_kernel(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n) {
-    bgx_body<BMT, BNT, BKT, WR, WC, AXC, BXC>(a, vecA, vecB, tiles_m, tiles_n, blockIdx.x, blockIdx.y);
-}
-
-// Grouped launch: the tiles of up to BG_MAXGROUP independent TN products (the deferred weight gradients of one window:
-// 10 products at cfg2) in ONE grid, so the chip drains once per window instead of once per product.  Workgroup ->
-// (job, K slice, tile) through a prefix table in the kernel arguments; within a job the slices are the slow index, so
-// the workgroups resident at any time share operand panels as in the single-product launch.
-template <int BMT, int BNT, int BKT, int WR, int WC>
-__global__ __launch_bounds__(512) void bgx_group_kernel(const BgGroup g) {
-    int j = 0, bx = blockIdx.x;
-#pragma unroll
-    for (int q = 0; q < BG_MAXGROUP - 1; ++q)
-        if (q < g.njobs - 1 && bx >= g.wg_end[q]) j = q + 1;
-    bx -= (j > 0 ? g.wg_end[j - 1] : 0);
-    const BgArgs& a = g.job[j];
-    const int tiles_m = (a.M + BMT - 1) / BMT, tiles_n = (a.N + BNT - 1) / BNT;
-    const int tiles = tiles_m * tiles_n;
-    bgx_body<BMT, BNT, BKT, WR, WC, true, true>(a, g.vec[j] & 1, (g.vec[j] >> 1) & 1, tiles_m, tiles_n, bx % tiles, bx / tiles);
-}
-
-template <int BMT, int BNT, int BKT, int WR, int WC>
-static int bgx_group_dispatch(const BgGroup& g, int total, size_t pad, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)BKT * ((BMT + 4) + (BNT + 4)) * sizeof(float) + pad;
-    static bool allowed = false;
-    if (!allowed) {
-        (void)hipFuncSetAttribute((const void*)bgx_group_kernel<BMT, BNT, BKT, WR, WC>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        allowed = true;
-    }
-    hipLaunchKernelGGL((bgx_group_kernel<BMT, BNT, BKT, WR, WC>), dim3(total), dim3(512), lds, stream, g);
-    return (int)hipGetLastError();
-}
-
-template <int BMT, int BNT, int BKT, int WR, int WC>
-static int bgx_dispatch(const BgArgs& a, int vecA, int vecB, bool axc, bool bxc, size_t pad, hipStream_t stream) {
-    const int tiles_m = ceil_div(a.M, BMT), tiles_n = ceil_div(a.N, BNT);
-    const dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk), blk(512);
-    const size_t lds = 2 * (size_t)BKT * ((BMT + 4) + (BNT + 4)) * sizeof(float) + pad;
-#define BGX_GO(AX, BX_)                                                                                                     \
-    do {                                                                                                                    \
-        static bool allowed = false;                                                                                        \
-        if (!allowed) {                                                                                                     \
-            (void)hipFuncSetAttribute((const void*)bgx_kernel<BMT, BNT, BKT, WR, WC, AX, BX_>,                              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-            allowed = true;                                                                                                 \
-        }                                                                                                                   \
-        hipLaunchKernelGGL((bgx_kernel<BMT, BNT, BKT, WR, WC, AX, BX_>), grid, blk, lds, stream, a, vecA, vecB, tiles_m,    \
-                           tiles_n);                                                                                        \
-    } while (0)
-    if (axc && bxc) BGX_GO(true, true);
-    else if (axc && !bxc) BGX_GO(true, false);
-    else if (!axc && bxc) BGX_GO(false, true);
-    else BGX_GO(false, false);
-#undef BGX_GO
-    return (int)hipGetLastError();
-}
+// ---- macro tiles tried in round 4 and dropped (profiles/r04_gemm_tile_variants.txt; the kernels live in commit
+// "bf16-in weight-gradient GEMM ..." of the history): the same loop on 128 x 128 x 32, 256 x 128 x 16 / 32,
+// 128 x 256 x 16 / 32 and 256 x 256 x 16 tiles (64 x 64 and 64 x 128 wave tiles, fewer LDS reads and barriers per MFMA)
+// ran at 86 / 94 / 76 / 97 / 75 / 77 TFLOP/s on the cfg2 products where this kernel runs at 102: what the bigger tiles
+// save per MFMA they lose in resident waves (this kernel: 65 VGPRs and 33 KB of LDS per workgroup = four workgroups,
+// 32 waves per CU).  And the roof is lower than the data-sheet figure: under this kernel the chip sustains 2.09 GHz
+// (GRBM_GUI_ACTIVE / duration, profiles/r04_gemm_clock.txt), where 256 CUs x 4 SIMDs x 64 flop/clk = 136.9 TFLOP/s,
+// not the 157.3 of 2.4 GHz: 102-112 TFLOP/s is 75-82 % of what the clock allows (matrix pipe 80 % busy by the SQ counters).
 
 // ---- bf16-operand variant (BgArgs::bf16): same 128 x 128 output tile and 2 x 4 wave grid, K-tile 32 ------------
 // The operands stay f32 in HBM (they are the scan's saved activations / gradients and the f32 master weights); each
@@ -860,65 +660,9 @@ int bg_reduce_launch(const BgArgs& a, hipStream_t stream) {
 static std::atomic<int> g_bg_lds_pad{0};
 void bg_set_lds_pad(int bytes) { g_bg_lds_pad.store(bytes < 0 ? 0 : bytes, std::memory_order_relaxed); }
 
-// Macro tile of the f32 kernels (PARROT_GEMM_VARIANT; 0 = the 128 x 128 x 16 kernel).
-int bg_f32_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PARROT_GEMM_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
 void bg_tile_shape(int bf16, int& bm, int& bn) {
     bm = bn = 128;
     if (bf16 == 2) { bm = HBMT; bn = HBNT; return; }
-    if (bf16) return;
-    switch (bg_f32_variant()) {
-        case 2: case 3: bm = 256; break;
-        case 4: case 5: bn = 256; break;
-        case 6: bm = bn = 256; break;
-        default: break;
-    }
-}
-
-bool bg_group_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PARROT_GEMM_GROUP");
-        v = e ? atoi(e) : 1;
-    }
-    return v != 0;
-}
-void bg_group_tile_shape(int& bm, int& bn) { bg_tile_shape(0, bm, bn); }
-
-int bg_group_launch(const BgArgs* jobs, int njobs, hipStream_t stream) {
-    if (njobs < 1 || njobs > BG_MAXGROUP) return PH_ERR_BADARG;
-    const size_t pad = (size_t)g_bg_lds_pad.load(std::memory_order_relaxed);
-    BgGroup g;
-    memset(&g, 0, sizeof(g));
-    g.njobs = njobs;
-    int bm, bn;
-    bg_group_tile_shape(bm, bn);
-    int total = 0;
-    for (int q = 0; q < njobs; ++q) {
-        const BgArgs& a = jobs[q];
-        if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch != 1 || a.splitk < 1 || (a.splitk > 1 && !a.ws)) return PH_ERR_BADARG;
-        if (a.sam != 1 || a.sbn != 1 || a.bias || a.act || a.bf16) return PH_ERR_UNSUPPORTED;
-        auto al = [](const float* p, long long stride) { return (((uintptr_t)p & 15) == 0) && (stride % 4 == 0); };
-        g.job[q] = a;
-        g.vec[q] = (al(a.A, a.sak) ? 1 : 0) | (al(a.B, a.sbk) ? 2 : 0);
-        total += ceil_div(a.M, bm) * ceil_div(a.N, bn) * a.splitk;
-        g.wg_end[q] = total;
-    }
-    switch (bg_f32_variant()) {
-        case 1: return bgx_group_dispatch<128, 128, 32, 2, 4>(g, total, pad, stream);
-        case 2: return bgx_group_dispatch<256, 128, 16, 4, 2>(g, total, pad, stream);
-        case 3: return bgx_group_dispatch<256, 128, 32, 4, 2>(g, total, pad, stream);
-        case 4: return bgx_group_dispatch<128, 256, 16, 2, 4>(g, total, pad, stream);
-        case 5: return bgx_group_dispatch<128, 256, 32, 2, 4>(g, total, pad, stream);
-        case 6: return bgx_group_dispatch<256, 256, 16, 4, 2>(g, total, pad, stream);
-        default: return bgx_group_dispatch<128, 128, 16, 2, 4>(g, total, pad, stream);
-    }
 }
 
 int bg_to_bf16_launch(const float* x, void* y, long long n, hipStream_t stream) {
@@ -971,15 +715,6 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
         else if (!axc && bxc) hipLaunchKernelGGL((bg_kernel_bf16<false, true>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
         else hipLaunchKernelGGL((bg_kernel_bf16<false, false>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
         return (int)hipGetLastError();
-    }
-    switch (bg_f32_variant()) {
-        case 1: return bgx_dispatch<128, 128, 32, 2, 4>(a, vecA, vecB, axc, bxc, pad, stream);
-        case 2: return bgx_dispatch<256, 128, 16, 4, 2>(a, vecA, vecB, axc, bxc, pad, stream);
-        case 3: return bgx_dispatch<256, 128, 32, 4, 2>(a, vecA, vecB, axc, bxc, pad, stream);
-        case 4: return bgx_dispatch<128, 256, 16, 2, 4>(a, vecA, vecB, axc, bxc, pad, stream);
-        case 5: return bgx_dispatch<128, 256, 32, 2, 4>(a, vecA, vecB, axc, bxc, pad, stream);
-        case 6: return bgx_dispatch<256, 256, 16, 4, 2>(a, vecA, vecB, axc, bxc, pad, stream);
-        default: break;
     }
     static int w8 = -1;
     if (w8 < 0) {

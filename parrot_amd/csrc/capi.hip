@@ -180,71 +180,6 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     return bg_run(a, split_k, st);
 }
 
-int parrot_gemm_grouped_tn(const ParrotGemmTN* jobs, int njobs, void* stream) { PH_ENTRY();
-    if (!jobs || njobs < 1) return PARROT_ERR_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16.load(std::memory_order_relaxed);
-    auto fill = [&](const ParrotGemmTN& j, BgArgs& a) {
-        a.A = j.A; a.B = j.B; a.C = j.C; a.bias = nullptr;
-        a.M = j.M; a.N = j.N; a.K = j.K;
-        a.sam = 1; a.sak = j.lda; a.sbk = j.ldb; a.sbn = 1;
-        a.ldc = j.ldc;
-        a.batchA = a.batchB = a.batchC = 0;
-        a.nbatch = 1;
-        a.accumulate = j.accumulate; a.alpha = 1.0f; a.act = 0;
-        a.bf16 = bf16;
-        a.splitk = 1; a.ws = nullptr;
-    };
-    for (int q = 0; q < njobs; ++q)
-        if (!jobs[q].A || !jobs[q].B || !jobs[q].C || jobs[q].M < 1 || jobs[q].N < 1 || jobs[q].K < 1) return PARROT_ERR_BADARG;
-    // one grid for the whole group: f32 operands, at most BG_MAXGROUP products; otherwise product by product
-    if (bf16 || njobs > BG_MAXGROUP || !bg_group_enabled()) {
-        for (int q = 0; q < njobs; ++q) {
-            BgArgs a;
-            fill(jobs[q], a);
-            const int rc = bg_run(a, 0, st);
-            if (rc) return rc;
-        }
-        return 0;
-    }
-    BgArgs a[BG_MAXGROUP];
-    int bm, bn;
-    bg_group_tile_shape(bm, bn);
-    long long tiles_all = 0;
-    for (int q = 0; q < njobs; ++q) {
-        fill(jobs[q], a[q]);
-        tiles_all += (long long)ceil_div(a[q].M, bm) * ceil_div(a[q].N, bn);
-    }
-    // K slices: the same count for every product of the group (they share K = T*B in practice), chosen so that the
-    // whole grid is a few rounds of the chip's resident workgroups
-    int kmin = a[0].K;
-    for (int q = 1; q < njobs; ++q) kmin = a[q].K < kmin ? a[q].K : kmin;
-    int split = (int)((4 * (long long)gemm_target_wgs() + tiles_all - 1) / tiles_all);
-    const int maxs = kmin / 512 > 0 ? kmin / 512 : 1;
-    if (split > maxs) split = maxs;
-    if (split > 64) split = 64;
-    if (split < 1) split = 1;
-    size_t need = 0;
-    if (split > 1)
-        for (int q = 0; q < njobs; ++q) need += (size_t)split * a[q].M * a[q].N;
-    float* ws = split > 1 ? bg_workspace(st, need) : nullptr;
-    if (split > 1 && !ws) split = 1;
-    size_t off = 0;
-    for (int q = 0; q < njobs; ++q) {
-        a[q].splitk = split;
-        a[q].ws = split > 1 ? ws + off : nullptr;
-        off += (size_t)split * a[q].M * a[q].N;
-    }
-    int rc = bg_group_launch(a, njobs, st);
-    if (rc) return rc;
-    if (split > 1)
-        for (int q = 0; q < njobs; ++q) {
-            rc = bg_reduce_launch(a[q], st);
-            if (rc) return rc;
-        }
-    return 0;
-}
-
 int parrot_to_bf16(const float* x, void* y, long long n, void* stream) { PH_ENTRY();
     if (!x || !y || n < 0) return PARROT_ERR_BADARG;
     return bg_to_bf16_launch(x, y, n, (hipStream_t)stream);

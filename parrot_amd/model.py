@@ -947,7 +947,6 @@ class Parrot(Brick):
         R = (t1 - t0) * B
         if self._bf16_weight_grads(t0, t1, T):
             return self._weight_grad_rows_bf16(ws, T, B)
-        jobs = []  # (X [R, in], dPre [R, out], dW [in, out]): dW += X^T . dPre
         for l in range(L):
             ll = l + 1
             hprev = ws['h'][l][t0:t1].view(R, H)
@@ -957,21 +956,16 @@ class Parrot(Brick):
                 gW = sg_[f'{mat}{ll}']
                 # the candidate block of the GRU multiplies r*h_prev, every other block h_prev
                 rec_in = ws['rh'][l][t0:t1].view(R, H) if key == 'c' else hprev
-                jobs.append((rec_in, dP, gW[0:H]))
-                jobs.append((wsrc, dP, gW[H:H + E]))
+                ops.gemm(rec_in.t(), dP, out=gW[0:H], accumulate=True)
+                ops.gemm(wsrc.t(), dP, out=gW[H:H + E], accumulate=True)
                 for j in range(l):
                     r0 = H + E + j * H
                     dPj = dP
                     if self.layer_norm:  # seq_bwd left the gradient wrt the pre-norm projection in ln_y
                         dPj = ws['ln_y' + key][(l, j)][t0:t1].view(R, wd)
-                    jobs.append((ws['h'][j][t0 + 1:t1 + 1].view(R, H), dPj, gW[r0:r0 + H]))
-        # One grid for all of them (f32 operands, at most 16 products: every GRU / LSTM stack up to 2 layers); the chip
-        # drains once per window instead of once per product.  Same products, same deterministic split-K sums.
-        if len(jobs) <= 16:
-            ops.gemm_grouped_tn(jobs, accumulate=True)
-        else:
-            for x_, dP_, gW_ in jobs:
-                ops.gemm(x_.t(), dP_, out=gW_, accumulate=True)
+                    ops.gemm(ws['h'][j][t0 + 1:t1 + 1].view(R, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
+        # (Measured in round 4: all of these as ONE grouped grid -- 74.47 vs 74.43 ms per cfg2 step, no gain: the
+        # products are long enough that the chip's drain between them does not show; the grouped launch was removed.)
         # attention projection (h1_to_att Fork)
         A = self.attention_size
         with ops.gemm_precision(ops.PRECISION_F32):  # the attention window stays f32 in every operand mode

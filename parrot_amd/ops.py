@@ -76,24 +76,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate=False
     return out
 
 
-def gemm_grouped_tn(jobs, accumulate=True):
-    """For every (a_t [K, M], b [K, N], out [M, N]) of `jobs`: out (+)= a_t^T @ b, all in ONE launch (f32 operand mode;
-    product by product otherwise): the deferred weight gradients of a training window (parrot_gemm_grouped_tn)."""
-    arr = (_lib.GemmTN * len(jobs))()
-    for q, (a_t, b, out) in enumerate(jobs):
-        _chk(a_t, "a_t"); _chk(b, "b"); _chk(out, "out")
-        if a_t.dim() != 2 or b.dim() != 2 or a_t.stride(1) != 1 or b.stride(1) != 1 or out.stride(1) != 1:
-            raise ValueError("gemm_grouped_tn: 2-d tensors with unit inner stride expected")
-        K, M = a_t.shape
-        K2, N = b.shape
-        if K != K2 or tuple(out.shape) != (M, N):
-            raise ValueError("gemm_grouped_tn: shapes do not match")
-        arr[q].A, arr[q].lda, arr[q].B, arr[q].ldb = a_t.data_ptr(), a_t.stride(0), b.data_ptr(), b.stride(0)
-        arr[q].C, arr[q].ldc, arr[q].M, arr[q].N, arr[q].K = out.data_ptr(), out.stride(0), M, N, K
-        arr[q].accumulate = int(bool(accumulate))
-    _lib.call("parrot_gemm_grouped_tn", arr, len(jobs), _stream())
-
-
 def to_bf16(x: torch.Tensor, out=None) -> torch.Tensor:
     """bf16 copy (round to nearest even) of a contiguous f32 tensor: the operand copies `gemm_bf16in` reads."""
     _chk(x, "x")

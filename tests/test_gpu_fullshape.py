@@ -183,8 +183,6 @@ def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, cap
         c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
     else:  # (the tolerances of the bf16 operand mode are 100 x the oracle's float32 drift: tools/oracle_f32_drift.py cfg4)
         c32, av32 = rc, rav
-        for k in p32:
-            p32[k].grad = p[k].grad
     rep = [f"{which} T_dec={T} B={B} U={U} ragged={ragged} operands={compute_dtype}",
            f"cost: hip {cost:.8f} oracle {float(rc):.8f} rel {abs(cost - float(rc)) / abs(float(rc)):.2e} "
            f"(oracle-f32 {abs(float(c32) - float(rc)) / abs(float(rc)):.2e})"]
@@ -201,7 +199,8 @@ def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, cap
             assert float(grads[name].abs().max()) < 1e-6, name
             continue
         e = rel_err(grads[name], ref.grad)
-        worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
+        if yardstick:
+            worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
         if e > worst[1]:
             worst = (name, e)
         n_checked += 1

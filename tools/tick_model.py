@@ -105,8 +105,61 @@ def price(jobs, cell):
     return t, what
 
 
+def whatif(L=2, H=1024, E=256, B=64, T=800):
+    """Round 4: prices two re-arrangements of the BACKWARD tick against today's, from the same
+    measured constants, before anything is built.  Work unit = one 32 x 32 output tile over K = 1024 (4.8 us of CU time)."""
+    rows = math.ceil(B / 32)
+    cols = lambda n: math.ceil(n / 32) * rows            # 32 x 32 tiles of an [B, n] output
+    # products of one backward tick (GRU): per layer l, on the chain: d(rh) = dC.Wc[0:H]^T (K = H) and
+    # dh_prev += dG.Wg[0:H]^T (K = 2H); towards the attention: dw (+)= dC.Wc[H:H+E]^T, dG.Wg[H:H+E]^T; towards every
+    # lower layer p < l: dhup_p (+)= dC.Wc[..]^T, dG.Wg[..]^T
+    kH = H / 1024.0
+    chain_x = sum(cols(H) for l in range(L))                              # d(rh), K = H
+    chain_y = sum(cols(H) * 2 for l in range(L))                          # dG -> dh_prev, K = 2H = two K = H units
+    dw = sum((cols(E)) * 3 for l in range(L))                             # dC part + the two dG halves
+    down = sum(cols(H) * 3 * l for l in range(L))                         # the same three parts per lower layer
+    units = (chain_x + chain_y + dw + down)
+    print(f"backward tick, L={L} H={H} B={B}: {units} units of 32x32xK{H} "
+          f"({chain_x} d(rh) + {chain_y} dG->dh_prev on the chain, {dw} dw, {down} downward) = {units / 256:.2f} rounds of 256")
+    unit_us = SLOPE22 * kH
+    today = ATT_BWD + (FIXED + unit_us) + (FIXED + 2 * unit_us)
+    print(f"  today (S | X: K=H | Y: K=2H, 224 workgroups each): {ATT_BWD} + {FIXED + unit_us:.1f} + {FIXED + 2 * unit_us:.1f} "
+          f"= {today:.1f} us/tick -> {today * T / 1000:.1f} ms   (measured 28.7 ms)")
+    # (a) K-balanced launches: every K = 2H product cut into its z and r halves writing separate buffers (the consumer adds
+    #     them); X = d(rh) + dG_z->dh_prev (both only need the state backward), Y = dG_r->dh_prev + dw0 + the dC share of the
+    #     downward products, and -- with layer l two ticks ahead of layer l-1 -- the other downward products ride in the NEXT
+    #     tick's attention launch as GEMM workgroups beside the 64 attention blocks (heterogeneous, as ska_kernel forward).
+    x_a = chain_x + chain_y // 2
+    y_a = chain_y // 2 + (dw // L) + (cols(H) + cols(E)) * (L - 1)
+    s_a = units - x_a - y_a
+    ok = x_a <= 256 and y_a <= 256 and s_a + 64 <= 256
+    t_a = max(ATT_HETERO, FIXED + unit_us) + (FIXED + unit_us) * 2
+    print(f"  (a) K-balanced launches + heterogeneous attention launch: X {x_a} / Y {y_a} / S {s_a}+64 workgroups "
+          f"({'all <= 256' if ok else 'DOES NOT FIT one round'}), every K = H: {max(ATT_HETERO, FIXED + unit_us):.1f} + "
+          f"{FIXED + unit_us:.1f} + {FIXED + unit_us:.1f} = {t_a:.1f} us/tick -> {t_a * T / 1000:.1f} ms "
+          f"({(today - t_a) * T / 1000:+.1f} ms)")
+    # (b) resident workgroups pulling units from per-XCD queues (VERDICT r03 item 5).  Measured ingredients (DESIGN 3.4,
+    #     profiles/r02_persist_*): a unit carries ~3.5 us of fixed cost next to its K loop (descriptor + first operand round
+    #     trip 1.5-2 + split-K reduce 0.5 + write-through drain 1.2); a dependent hand-off between CUs on different XCDs =
+    #     producer drain 1.2 + sc1 visibility round trip 1.5 + dequeue 0.3-1.3 (guide: sharded dequeue idle / streaming).
+    UNIT_FIXED, HANDOFF = 3.5, 1.2 + 1.5 + 0.8
+    link = HANDOFF + 1.0 + unit_us                      # hand-off + first operand fetch + K loop of a K = H unit
+    chain_b = ATT_BWD + 2 * link                        # attention/state chain, then d(rh), then the dG_r half of dh_prev
+    fill_b = units * (unit_us + UNIT_FIXED) / 256       # all units packed perfectly on 256 CUs
+    t_b = max(chain_b, fill_b)
+    print(f"  (b) queue-fed units: dependent chain {ATT_BWD} + 2 x {link:.1f} = {chain_b:.1f} us, perfectly packed work "
+          f"{fill_b:.1f} us -> {t_b:.1f} us/tick -> {t_b * T / 1000:.1f} ms ({(today - t_b) * T / 1000:+.1f} ms); the "
+          f"forward tick is chain-bound already (10.7 + 8.3 + 12.1 = sum of its three dependent launches): no gain there")
+    print(f"  verdict: (b) predicts {(today - t_b) * T / 1000:.1f} ms AT BEST -- every hand-off at its measured minimum and the "
+          f"{units} units packed perfectly -- i.e. at the 4 ms bar, not above it; the one resident design built so far (the "
+          f"round-2 phase machine, same hand-off costs) only matched the launches.  (a) gets {(today - t_a) * T / 1000:.1f} ms "
+          f"of it inside the launch design, at the price of a second heterogeneous kernel (attention BACKWARD blocks beside "
+          f"GEMM workgroups), a two-tick layer skew and three partial buffers per cross-layer gradient.")
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--whatif", action="store_true", help="price the round-4 re-arrangements of the backward tick")
     ap.add_argument("--schedule", type=int, default=5)
     ap.add_argument("--L", type=int, default=2)
     ap.add_argument("--H", type=int, default=1024)
@@ -114,6 +167,8 @@ def main():
     ap.add_argument("--T", type=int, default=800)
     ap.add_argument("--cell", default="gru")
     a = ap.parse_args()
+    if a.whatif:
+        return whatif(L=a.L, H=a.H, B=a.B, T=a.T)
     from parrot_amd import _lib as L_
     lib = L_.load()
     plan = fake_plan(L_, lib, a)
