@@ -558,7 +558,8 @@ def main():
         sched_id = None
     sched_names = {0: "0 (merged wavefront launches)", 2: "2 (chunked layer pipeline)", 3: "3 (chunk-skewed wavefront)",
                    5: "5 (balanced wavefront: attention + upper layers' input projections in one heterogeneous launch)",
-                   6: "6 (attention inside the gate launch, in-launch hand-off)"}
+                   6: "6 (attention inside the gate launch, in-launch hand-off)",
+                   7: "7 (LSTM: one launch per tick, the attention at its head, layer 0's w rows behind an in-launch flag)"}
     kappa_end = float(model._carry[a.B]['k'].mean()) if a.B in model._carry else None
     # second timed run, outside the headline region: the attention kernels read ALL context rows (no window support)
     dense = None

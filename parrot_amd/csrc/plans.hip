@@ -734,9 +734,9 @@ struct DecoderPlan : PlanBase {
         return note(run_parts(which, part, part + 1, s));
     }
 
-    // Records what the plan's launches of direction `which` read and write (see Tracer); schedules 0, 5 and 6 only.
+    // Records what the plan's launches of direction `which` read and write (see Tracer); schedules 0, 5, 6 and 7 only.
     int trace(int which, std::vector<TraceRec>& out, std::vector<TraceJob>* jobs_out = nullptr) {
-        if (persist_ok || (schedule != 0 && schedule != 5 && schedule != 6) || d.layer_norm) return PARROT_ERR_UNSUPPORTED;
+        if (persist_ok || (schedule != 0 && schedule < 5) || d.layer_norm) return PARROT_ERR_UNSUPPORTED;
         Tracer tr;
         g_tracer = &tr;
         const Strand keep = cur;
@@ -756,6 +756,7 @@ struct DecoderPlan : PlanBase {
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
         if (schedule == 5) return which == 0 ? fwd5(s) : bwd(s);
         if (schedule == 6) return which == 0 ? fwd6(s) : bwd(s);
+        if (schedule == 7) return which == 0 ? fwd7(s) : bwd(s);
         return which == 0 ? fwd(s) : bwd(s);
     }
 
@@ -780,11 +781,15 @@ struct DecoderPlan : PlanBase {
             // bound by total work rather than by its longest K, and cutting it in two only adds fixed cost -- cfg4 bf16
             // 118.9 vs 127.5 ms (the wide kernel has ~10 us of fixed cost per launch), cfg4 f32 256.5 vs 265.4 ms.
             want = (pipe_ok && d.cell == 0 && !d.layer_norm && strands_wanted <= 1) ? 5 : 0;
+            // LSTM stacks with bf16 operands (BASELINE configs[3]): the attention inside the tick's one launch (7), where
+            // the wide step kernel takes the launch (checked in parrot_decoder_create)
+            if (d.cell == 1 && d.bf16 && !d.layer_norm && strands_wanted <= 1) want = 7;
         }
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
-        if (want >= 2 && !pipe_ok && !(want == 6 && d.L == 1)) want = 0;
+        if (want >= 2 && want != 7 && !pipe_ok && !(want == 6 && d.L == 1)) want = 0;
         if (want == 1 && d.cell == 1) want = 0;
         if (want == 6 && (d.cell != 0 || d.bf16)) want = 5;                  // the in-launch hand-off: f32 GRU layers
+        if (want == 7 && d.cell != 1) want = pipe_ok ? 5 : 0;                // one launch per tick: LSTM layers
         if (want >= 5 && d.layer_norm) want = 0;
         schedule = want;
         try_persist = want_persist && d.cell == 0 && !d.layer_norm && !d.bf16;
@@ -1070,7 +1075,7 @@ struct DecoderPlan : PlanBase {
 
     // The additive-input buffer of layer l is live when the caller filled it (seq_init bit) or when the
     // pipeline schedule batches the lower layers' projections into it.
-    bool has_seq(int l, const float* p) const { return p && (((d.seq_init >> l) & 1) || (schedule >= 2 && l > 0)); }
+    bool has_seq(int l, const float* p) const { return p && (((d.seq_init >> l) & 1) || (schedule >= 2 && schedule != 7 && l > 0)); }
 
     void gates_job(SkJob& j, int l, int t) const {
         const size_t BH = (size_t)d.B * d.H;
@@ -1332,6 +1337,50 @@ struct DecoderPlan : PlanBase {
                     input_job(jobs[n++], l, t, 1);
                 }
             if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs, s6_btile));
+        }
+        return 0;
+    }
+
+    // ---- schedule 7: ONE launch per tick for LSTM layers (round 4) ---------------------------------------------------
+    // Schedule 0 runs an LSTM tick as the fused launch of all layers (wk_kernel at cfg4: ~35 us, bound by its total work)
+    // followed by the attention step ALONE (~12.6 us: a chain of dependent round trips on 64 CUs, the other 192 idle).
+    // The attention of step q-1 only feeds the LAST K = E rows of layer 0's product at step q (and the upper layers a
+    // tick later), and an LSTM launch is three times as long as the attention chain.  So the attention rides at the head
+    // of the next tick's launch: its blocks are dispatched first and publish w write-through plus an arrival count
+    // (att_fwd_body.h, as in schedule 6); layer 0's workgroups -- the shortest K of the launch -- come LAST in the grid,
+    // start on the CUs the attention blocks free, walk their h rows and take the w rows behind the flag (wk_body's tail;
+    // sk_body's for f32 operands).  The upper layers lag one tick more than in schedule 0 so that the w they read was
+    // published by an EARLIER launch:  tick q:  attention(q-1) || lstm(l0, q) [w rows flagged], lstm(l, q - lag7(l)),
+    // lag7 = 0, 2, 3.  Same terms in the same order per output element as schedule 0 (bit-identical).
+    int lag7(int l) const { return l == 0 ? 0 : l + 1; }
+    int nticks7() const { return d.T + std::max(1, lag7(d.L - 1)); }
+    int fwd7(hipStream_t st) {
+        if (!att_flags) return PARROT_ERR_BADARG;  // (allocated by parrot_decoder_create, outside any stream capture)
+        if (!g_tracer) PL_TRY(sk_zero_words_launch(att_flags, d.T + 2, st));
+        const int Q = nticks7();
+        for (int q = 0; q < Q; ++q) {
+            SkJob jobs[PARROT_MAX_LAYERS];
+            int n = 0;
+            const bool att_on = q >= 1 && q - 1 < d.T;
+            AttFwdArgs ag{};
+            if (att_on) {
+                ag = att_fwd_args(q - 1);
+                ag.esplit = 1;  // beside GEMM workgroups: one attention workgroup per batch row
+            }
+            for (int l = 0; l < d.L; ++l) {
+                const int t = q - lag7(l);
+                if (t < 0 || t >= d.T) continue;
+                SkJob& j = jobs[n++];
+                lstm_job(j, l, t);
+                if (l == 0 && att_on) {  // w_{q-1} arrives inside this launch: its segment goes last and waits
+                    if (j.nseg != 2) return PARROT_ERR_BADARG;
+                    j.wait_flag = att_flags + q;
+                    j.wait_target = (unsigned)(ag.B * ag.esplit);
+                    ag.flag = att_flags + q;
+                }
+            }
+            if (att_on) PL_TRY(launch_jobs_att(jobs, n, ag, st, 0));
+            else if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
         }
         return 0;
     }
@@ -2599,6 +2648,13 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         }
     }
     if (p->schedule == 6 && !p->tiled) p->schedule = 5;  // the in-launch hand-off reads fragment-major weights
+    if (p->schedule == 7) {
+        // bf16 operands: only the wide step kernel takes a launch with a waiting job (skinny.hip wk_try_launch): every
+        // launch of the scan must qualify, the first tick's (layer 0 alone) included.  f32 operands run on ska_kernel.
+        const bool ok = p->tiled && desc->B <= 64 && (desc->bf16 ? sk_wide_takes(desc->B, 4 * desc->H, desc->H, desc->E)
+                                                                 : getenv("PARROT_SCHEDULE") != nullptr);
+        if (!ok) p->schedule = 0;
+    }
     if (p->schedule == 5 && desc->L < 2) p->schedule = 0;
     {
         const char* e = getenv("PARROT_BWD_SPLIT");
@@ -2610,7 +2666,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         e = getenv("PARROT_S5_SPLIT");
         p->s5_split = e ? atoi(e) != 0 : true;
     }
-    if (p->schedule == 6) {
+    if (p->schedule == 6 || p->schedule == 7) {
         if (hipMalloc(&p->att_flags, sizeof(unsigned) * (size_t)(desc->T + 2)) != hipSuccess) {
             if (!getenv("PARROT_TRACE_ONLY")) {  // (schedule tracing on a box without a GPU: a placeholder address)
                 delete p;
@@ -2630,7 +2686,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     p->setup_strands();
     if (desc->layer_norm && desc->L >= 2) {
-        bool ok = p->schedule >= 2;
+        bool ok = p->schedule >= 2 && p->schedule != 7;
         for (int l = 1; l < desc->L && ok; ++l)
             for (int j = 0; j < l; ++j) {
                 const int pj = l * PARROT_MAX_LAYERS + j;

@@ -92,3 +92,6 @@ int sk_tile_weights_bf16_launch(const float* W, int rows, int cols, int ld, void
 void sk_job_init(SkJob& j);
 void sk_finalize_job(SkJob& j);  // computes `aligned`
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs);
+
+// bf16 launches: would the wide step kernel (wk_kernel) take jobs of M rows, ncols columns in total, K segments of H / E?
+bool sk_wide_takes(int M, int ncols, int H, int E);

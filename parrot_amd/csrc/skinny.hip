@@ -685,7 +685,9 @@ void sk_finalize_job(SkJob& j) {
         if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
-    if (j.wait_flag && (!al || j.nseg < 2 || j.seg[0].b_kcontig != 2 || !SK_A_PERMUTE)) j.aligned = -1;  // rejected by sk_make_launch
+    // a waiting job: fragment-major weights, f32 (sk_body's tail) or bf16 (wk_body's tail: sk_launch_att refuses the
+    // launch if the wide kernel does not take it); anything else is rejected by sk_make_launch
+    if (j.wait_flag && (!al || j.nseg < 2 || j.seg[0].b_kcontig < 2 || !SK_A_PERMUTE)) j.aligned = -1;
 }
 
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
@@ -899,8 +901,13 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
 
     // K stages over the concatenated segments.  The two operand streams run ahead of the MFMAs by different distances,
     // so each has its own (wave-uniform) cursor into the segment list; past the end a cursor stays on the last stage.
+    // A job whose LAST segment's activations are produced by the attention blocks of the same launch (SkJob::wait_flag,
+    // plans.hip schedule 7) walks its other segments through the pipelined ring and takes that segment afterwards
+    // (wk_tail): same terms in the same order as the unflagged job, bit for bit.
+    const bool flagged = job.wait_flag != nullptr;
+    const int nseg_main = flagged ? job.nseg - 1 : job.nseg;
     int total = 0;
-    for (int q = 0; q < job.nseg; ++q) total += job.seg[q].K / WK_STAGE;
+    for (int q = 0; q < nseg_main; ++q) total += job.seg[q].K / WK_STAGE;
     struct Cursor { const float* A; const float* B; int lda, ldb, left, seg, k; };
     auto cursor_init = [&](Cursor& c) __attribute__((always_inline)) {
         c.seg = 0; c.k = 0;
@@ -909,7 +916,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     };
     auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
         if (c.left > 1) { --c.left; c.k += WK_STAGE; return; }
-        if (c.seg + 1 < job.nseg) {
+        if (c.seg + 1 < nseg_main) {
             ++c.seg;
             const SkSeg& sg = job.seg[c.seg];
             c.A = sg.A; c.B = sg.B; c.lda = sg.lda; c.ldb = sg.ldb; c.left = sg.K / WK_STAGE; c.k = 0;
@@ -987,6 +994,41 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
 #pragma unroll
     for (int q = 0; q < WK_PB - 1; ++q)
         if (st + q < total) stage(st + q, ra[(q + 1) % WK_PA], rbv[q]);
+    if (flagged) {
+        // Tail segment: one poller per workgroup waits for the producers' arrival count (they publish their rows
+        // write-through before they arrive), then the stages of the segment run unpipelined through LDS buffer 0: the
+        // activations come through sc1 buffer loads (another XCD's L2 may hold a stale line of a buffer that is
+        // rewritten every window), the weights as in the ring.  The workgroups of such a job have the shortest K of
+        // their launch and sit last in the grid: the few microseconds of this loop are slack.
+        if (tid == 0) sk_wait_flag(job.wait_flag, job.wait_target);
+        __syncthreads();
+        const SkSeg& sg = job.seg[job.nseg - 1];
+        const __amdgpu_buffer_rsrc_t rs = sk_rsrc(sg.A);
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        for (int s2 = 0; s2 < sg.K / WK_STAGE; ++s2) {
+            f32x4 b[WK_KS];
+            const float* pb = sg.B + (size_t)tile * sg.ldb + ((size_t)((s2 * WK_STAGE) >> 5) << 8) + (lane << 2);
+#pragma unroll
+            for (int q = 0; q < WK_KS; ++q) b[q] = *reinterpret_cast<const f32x4*>(pb + 256 * q);
+#pragma unroll
+            for (int p = 0; p < WK_NP; ++p) {
+                const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rs, (unsigned)((min(ar0 + p * WK_RPP, M - 1) * sg.lda + s2 * WK_STAGE + 4 * akq) * 4), 0, 16 /* sc1 */));
+                *reinterpret_cast<bf16x4*>(smem + (ar0 + p * WK_RPP) * WK_PITCH + 8 * akq) = __builtin_convertvector(a, bf16x4);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < WK_KS; ++ks) {
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, b[ks]);
+#pragma unroll
+                for (int rb = 0; rb < MB; ++rb) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(smem + (16 * (rh * MB + rb) + i16) * WK_PITCH + ks * 64 + 16 * kk);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[rb], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
     if (!tile_ok) return;
 
     // fused epilogue, per wave (complete sums).  C layout: column = lane & 15, row = 4 * (lane >> 4) + reg.
@@ -1074,6 +1116,15 @@ __global__ __launch_bounds__(SK_THREADS) void wka_kernel(const WkLaunch L, const
     else wk_body<4>(job, bx, wk_smem);
 }
 
+// Would wk_try_launch take a bf16 launch whose jobs have M rows, ncols output columns in total and K segments of H and E
+// rows?  (plans.hip asks before it commits a plan to a schedule only the wide kernel can run.)
+bool sk_wide_takes(int M, int ncols, int H, int E) {
+    const char* e = getenv("PARROT_WK");
+    const int enabled = e ? atoi(e) : 1;
+    if (!enabled || M < 1 || M > 64 || (H % WK_STAGE) || (E % WK_STAGE)) return false;
+    return ncols >= 4096 || enabled >= 2;
+}
+
 // Takes the launch when every job is a bf16-operand LSTM / LINEAR job over <= 64 rows with 64-deep K segments.
 // att != null: the attention step rides in the same launch (wka_kernel); `reserve` CUs are left to its blocks.
 static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, const AttFwdArgs* att = nullptr) {
@@ -1083,6 +1134,7 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
     long long work = 0;
     for (int q = 0; q < Lin.njobs; ++q) {
         const SkJob& j = Lin.job[q];
+        if (j.wait_flag && (!att || j.nseg < 2)) return false;  // a flag needs its producers in the launch
         if (j.seg[0].b_kcontig != 3 || !j.aligned || j.M > 64 || j.M < 1) return false;
         if (j.epi != SK_EPI_LSTM && j.epi != SK_EPI_LINEAR) return false;
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
@@ -1095,24 +1147,43 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
     memset(&W, 0, sizeof(W));
     W.njobs = Lin.njobs;
     int ksum[SK_MAXJOB], tiles[SK_MAXJOB];
-    int units = 0;
+    int units = 0, units_flagged = 0;
+    bool any_flag = false;
+    {   // jobs that wait for the attention go LAST in the grid: the attention blocks lead it, the other jobs take the
+        // remaining CUs, and the waiting jobs' workgroups start on the CUs the attention frees -- with their flag set
+        int n = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int q = 0; q < Lin.njobs; ++q) {
+                if ((Lin.job[q].wait_flag != nullptr) != (pass == 1)) continue;
+                W.job[n] = Lin.job[q];
+                tiles[n] = Lin.tile_end[q];
+                ++n;
+            }
+    }
     for (int q = 0; q < Lin.njobs; ++q) {
-        W.job[q] = Lin.job[q];
         W.ncw[q] = 4;
         ksum[q] = 0;
-        for (int s = 0; s < Lin.job[q].nseg; ++s) ksum[q] += Lin.job[q].seg[s].K;
-        tiles[q] = Lin.tile_end[q];
+        for (int s = 0; s < W.job[q].nseg; ++s) ksum[q] += W.job[q].seg[s].K;
         units += ceil_div(tiles[q], 4);
+        if (W.job[q].wait_flag) { any_flag = true; units_flagged += ceil_div(tiles[q], 4); }
     }
 
-    // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits
+    // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits (with
+    // waiting jobs: until the OTHER jobs fit beside the attention blocks; the waiting ones, at most a CU round of
+    // their own, follow in the attention's place)
     const int natt = att ? att->B * att->esplit : 0;
-    while (units > 256 - (natt < 128 ? natt : 128)) {
+    auto fits = [&]() {
+        if (any_flag) return units - units_flagged <= 256 - natt && units_flagged <= 256;
+        return units <= 256 - (natt < 128 ? natt : 128);
+    };
+    while (!fits()) {
         int best = -1;
         for (int q = 0; q < Lin.njobs; ++q)
             if (W.ncw[q] == 4 && (best < 0 || ksum[q] < ksum[best])) best = q;
         if (best < 0) break;
-        units -= ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8);
+        const int gain = ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8);
+        units -= gain;
+        if (W.job[best].wait_flag) units_flagged -= gain;
         W.ncw[best] = 8;
     }
     int t = 0;
@@ -1124,11 +1195,12 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
     if (att) {
         const size_t alds = att_fwd_lds(att->U);
         if (alds > lds) lds = alds;
-        static int att_last = -1;
-        if (att_last < 0) {
+        static int att_last_env = -1;
+        if (att_last_env < 0) {
             const char* e2 = getenv("PARROT_SKA_ATT_LAST");
-            att_last = e2 ? atoi(e2) : 1;
+            att_last_env = e2 ? atoi(e2) : 1;
         }
+        const int att_last = any_flag ? 0 : att_last_env;  // producers lead the grid when somebody waits for them
         if (g_prof.on) {
             SkProfRec r;
             (void)hipEventCreate(&r.e0);
@@ -1319,12 +1391,11 @@ int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream
         if (rc != 0) return rc;
     }
     if (Lin.njobs < 1) return att_fwd_launch(att, stream);
-    {   // bf16 launches the wide kernel takes (no job may wait on the attention there)
-        bool flagged = false;
-        for (int q = 0; q < Lin.njobs; ++q)
-            if (Lin.job[q].wait_flag) flagged = true;
+    {   // bf16 launches the wide kernel takes (a job that waits for the attention keeps its place behind it there)
         int rc = 0;
-        if (!flagged && wk_try_launch(Lin, stream, &rc, &g)) return rc;
+        if (wk_try_launch(Lin, stream, &rc, &g)) return rc;
+        for (int q = 0; q < Lin.njobs; ++q)  // (sk_body's flagged tail multiplies f32 operands only)
+            if (Lin.job[q].wait_flag && Lin.job[q].seg[0].b_kcontig == 3) return PH_ERR_UNSUPPORTED;
     }
     SkLaunch L;
     dim3 grid;

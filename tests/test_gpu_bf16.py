@@ -248,3 +248,36 @@ def test_bf16_weight_grads_match_the_rounding_gemm(dev, monkeypatch):
                 assert rel_err(got[("1", cell)][k], v) < 1e-5, (cell, k, rel_err(got[("1", cell)][k], v))
                 n += 1
         assert n >= 10
+
+
+def test_bf16_lstm_one_launch_per_tick_is_schedule_0_bit_for_bit(dev, monkeypatch):
+    """Schedule 7 on the wide bf16 kernel (wk_body's flagged tail; default for bf16 LSTM stacks the wide kernel takes):
+    cost, frames, w and every gradient are bit-identical to schedule 0 -- same terms in the same order -- for partial
+    row blocks, 1-3 layers, graph replay; and the plan really ran it."""
+    from oracle import parrot_ref as R
+    from parrot_amd import _lib
+    from parrot_amd.model import Parrot
+    monkeypatch.setenv("PARROT_WK", "2")
+    for L, B in ((3, 37), (1, 64), (2, 5)):
+        kw = dict(num_layers=L, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
+        cfg = R.default_config(**kw)
+        p = R.init_params(cfg, seed=40 + L, scale_by_fan_in=True)
+        feat, fm, lab, lm, _ = make_batch(cfg, 7, B, 9, seed=50 + L, ragged=True)
+        got = {}
+        for sched in ("0", "7"):
+            monkeypatch.setenv("PARROT_SCHEDULE", sched)
+            m = Parrot(device=dev, compute_dtype='bf16', use_graph=True, **kw).allocate()
+            m.set_parameter_values(p)
+            for rep in range(2):
+                m.zero_grad()
+                cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+                cost.backward()
+            ws = next(iter(m._train_ws.values()))
+            assert int(_lib.load().parrot_decoder_schedule(ws['plan'])) == int(sched)
+            got[sched] = (cost.detach().clone(), av[0].detach().clone(), av[2].detach().clone(),
+                          {k: v.detach().clone() for k, v in m.get_gradient_dict().items()})
+            m.close()
+        for i in range(3):
+            assert torch.equal(got["0"][i], got["7"][i]), (L, B, i)
+        for k, v in got["0"][3].items():
+            assert torch.equal(v, got["7"][3][k]), (L, B, k)

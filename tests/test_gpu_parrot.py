@@ -329,6 +329,35 @@ def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
                           use_graph=True, ragged=True, expect_schedule=5)
 
 
+def test_lstm_one_launch_per_tick_schedule(dev, monkeypatch):
+    """Schedule 7 (LSTM layers: the attention of step q-1 inside the launch of tick q, layer 0's w rows behind the
+    in-launch flag) forced onto f32 operands (ska_kernel + sk_body's flagged tail): oracle parity incl. every gradient
+    for 1-3 layers, ragged masks, feedback + speaker, more than one row tile, eager and graph; and the forward pass is
+    the SAME arithmetic as schedule 0 (cost and frames bit for bit)."""
+    monkeypatch.setenv("PARROT_SCHEDULE", "7")
+    for use_graph in (False, True):
+        _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
+                              use_speaker=True, cell_type='lstm', use_graph=use_graph, ragged=True, expect_schedule=7)
+    _check_cost_and_grads(dev, T=7, B=40, U=6, num_layers=2, encoder_type='bidirectional', cell_type='lstm',
+                          use_graph=True, expect_schedule=7)
+    _check_cost_and_grads(dev, T=6, B=4, U=9, num_layers=1, encoder_type='bidirectional', cell_type='lstm',
+                          use_graph=True, expect_schedule=7)
+    _check_cost_and_grads(dev, T=1, B=4, U=6, num_layers=2, encoder_type='bidirectional', cell_type='lstm',
+                          use_graph=True, expect_schedule=7)
+    # GRU layers are not covered: the plan runs the balanced wavefront instead
+    _check_cost_and_grads(dev, T=5, B=4, U=6, num_layers=2, encoder_type='bidirectional', use_graph=True, expect_schedule=5)
+    got = {}
+    for sched in ("0", "7"):
+        monkeypatch.setenv("PARROT_SCHEDULE", sched)
+        cfg, p, m = _build(dev, use_graph=True, num_layers=3, encoder_type='bidirectional', cell_type='lstm')
+        feat, fm, lab, lm, _ = make_batch(cfg, 9, 20, 7, seed=4, ragged=True)
+        cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, 20)
+        got[sched] = (cost.detach().clone(), av[0].detach().clone(), av[2].detach().clone())
+        m.close()
+    for a, b in zip(got["0"], got["7"]):
+        assert torch.equal(a, b)
+
+
 # ----------------------------------------------------------------------------- strands and parts
 @pytest.mark.parametrize("strands,qpart,overlap", [("2", "3", "1"), ("3", "0", "1"), ("4", "2", "0"), ("1", "4", "1")])
 @pytest.mark.parametrize("cell", ["gru", "lstm"])

@@ -3,13 +3,13 @@ launch and every job in it, the byte ranges it reads and writes (on fake device 
 orderings a schedule has to keep follow from the scan of model.py:651-737 and its gradient:
 
   * no job of a launch touches a range another job of the same launch writes (the jobs of a launch run concurrently) --
-    except a read the job takes behind the in-launch flag of schedule 6, whose writer must then be the attention job;
+    except a read the job takes behind the in-launch flag of schedules 6 and 7, whose writer must then be the attention job;
   * a write-once buffer (states, gates, window parameters, saved activations, pre-activation scratch; in the backward the
     pre-activation gradients) is written exactly once per element and read only by LATER launches;
   * an accumulator (dh, dw, dw0, dhup) is never written again after a job has taken it as a plain input (the state /
     attention backward consuming the total).
 
-Run for schedules 0, 5 and 6, GRU and LSTM layers, 1-3 layers, with and without caller data in the per-step input
+Run for schedules 0, 5, 6 and 7, GRU and LSTM layers, 1-3 layers, with and without caller data in the per-step input
 buffers, forward and backward."""
 import ctypes as C
 import os
@@ -185,8 +185,8 @@ def _check(recs, ar, write_once, accumulators, T, slot_bytes):
     return len(by_launch)
 
 
-@pytest.mark.parametrize("sched", [0, 5, 6])
-@pytest.mark.parametrize("cell,nl,seq_init", [(0, 1, 0), (0, 2, 0), (0, 3, 0), (0, 3, 0b101), (1, 2, 0), (1, 3, 0b010)])
+@pytest.mark.parametrize("sched", [0, 5, 6, 7])
+@pytest.mark.parametrize("cell,nl,seq_init", [(0, 1, 0), (0, 2, 0), (0, 3, 0), (0, 3, 0b101), (1, 1, 0), (1, 2, 0), (1, 3, 0b010)])
 def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_init):
     L, lib = _lib()
     T, B, H, E, A, U = 5, 20, 32, 16, 4, 7
@@ -196,7 +196,9 @@ def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_ini
         want = sched
         if sched == 6 and cell == 1:
             want = 5        # the in-launch hand-off covers GRU layers only
-        if sched == 5 and nl == 1:
+        if sched == 7 and cell == 0:
+            want = 5        # one launch per tick with the attention inside it: LSTM layers only
+        if want == 5 and nl == 1:
             want = 0
         assert got == want, (got, want)
         f = 4
@@ -221,8 +223,8 @@ def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_ini
                     if cell == 0:
                         slot[f"seq_c{l}"] = T * B * H * f
         n_fwd = _check(recs, ar, fwd_once, set(), T, slot)
-        ticks = {0: T + nl - 1, 5: T + nl, 6: T + max(1, 2 * (nl - 1))}[got]
-        per_tick = 2 if cell == 1 else {0: 3, 5: 3, 6: 2}[got]
+        ticks = {0: T + nl - 1, 5: T + nl, 6: T + max(1, 2 * (nl - 1)), 7: T + max(1, nl if nl > 1 else 0)}[got]
+        per_tick = 1 if got == 7 else (2 if cell == 1 else {0: 3, 5: 3, 6: 2}[got])
         assert n_fwd <= ticks * per_tick and n_fwd >= T * per_tick - 2, (n_fwd, ticks, per_tick)
         # backward
         bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)} | ({f"dC{l}" for l in range(nl)} if cell == 0 else set())
