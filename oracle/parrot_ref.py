@@ -159,23 +159,65 @@ def apply_norm(x, layer_norm):
     return simple_norm(x) if layer_norm else x
 
 
+# Operand rounding of the DECODER's matrix products (None = exact).  'bf16' restates the product's bf16 operand mode
+# (BASELINE configs[3]: weights AND activations rounded to bf16, nearest even, where they enter a product of the scan
+# steps, the feedback / speaker projections and the readouts; accumulation, states, the attention window, the encoder and
+# the cost stay in the working precision) so that the tests can tell what the MODE costs against the exact reference
+# from what the kernels add to it.  Set through `operand_rounding(...)`; never set by the reference itself.
+_OPERAND_ROUNDING = None
+
+
+class operand_rounding:
+    def __init__(self, mode):
+        assert mode in (None, 'bf16')
+        self.mode = mode
+
+    def __enter__(self):
+        global _OPERAND_ROUNDING
+        self.prev, _OPERAND_ROUNDING = _OPERAND_ROUNDING, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _OPERAND_ROUNDING
+        _OPERAND_ROUNDING = self.prev
+        return False
+
+
+_ROUNDED_WEIGHTS = {}  # id(W) -> (W, rounded W): a weight is rounded once per compute_cost call, not once per step
+
+
+def _rnd(x):
+    return x if _OPERAND_ROUNDING is None else x.to(torch.bfloat16).to(x.dtype)
+
+
+def _mm(x, W):
+    """x . W with the operand rounding of the active mode (exact by default)."""
+    if _OPERAND_ROUNDING is None:
+        return x @ W
+    hit = _ROUNDED_WEIGHTS.get(id(W))
+    if hit is None or hit[0] is not W:
+        hit = _ROUNDED_WEIGHTS[id(W)] = (W, _rnd(W))
+    return _rnd(x) @ hit[1]
+
+
 def linear(p, name, x):
     """Blocks Linear.apply: x . W + b."""
-    return x @ p[f'/parrot/{name}.W'] + p[f'/parrot/{name}.b']
+    return _mm(x, p[f'/parrot/{name}.W']) + p[f'/parrot/{name}.b']
 
 
 def fork(p, name, x, outs):
     """Blocks Fork.apply: one independent Linear per output name, in output_names order."""
-    return [x @ p[f'/parrot/{name}/fork_{o}.W'] + p[f'/parrot/{name}/fork_{o}.b'] for o in outs]
+    mm = (lambda a, b: a @ b) if name == 'h1_to_att' else _mm  # (the attention window stays exact in every operand mode)
+    return [mm(x, p[f'/parrot/{name}/fork_{o}.W']) + p[f'/parrot/{name}/fork_{o}.b'] for o in outs]
 
 
 def gru_step(inputs, gate_inputs, h, W_ss, W_sg, mask=None):
     """Blocks GatedRecurrent.apply(iterate=False) (call sites model.py:659-662); twin algebra
     sampleRNN/lib/ops.py:364-393.  z = update (first half), r = reset (second half)."""
     H = h.shape[-1]
-    g = torch.sigmoid(h @ W_sg + gate_inputs)
+    g = torch.sigmoid(_mm(h, W_sg) + gate_inputs)
     z, r = g[..., :H], g[..., H:]
-    c = torch.tanh((h * r) @ W_ss + inputs)
+    c = torch.tanh(_mm(h * r, W_ss) + inputs)
     hn = c * z + h * (1 - z)
     if mask is not None:
         hn = mask[..., None] * hn + (1 - mask[..., None]) * h
@@ -186,7 +228,7 @@ def lstm_cell(pre_in, s, c, W_state):
     """sampleRNN/lib/ops.py:505-553 (LSTM step, gate order i|f|o|g) with the forget bias kept in the
     learnable bias of `pre_in` (see init_params)."""
     H = s.shape[-1]
-    g = s @ W_state + pre_in
+    g = _mm(s, W_state) + pre_in
     i, f, o = torch.sigmoid(g[..., :H]), torch.sigmoid(g[..., H:2 * H]), torch.sigmoid(g[..., 2 * H:3 * H])
     gg = torch.tanh(g[..., 3 * H:])
     cn = f * c + i * gg
@@ -220,6 +262,11 @@ def encoder_apply(p, cfg, labels):
     (model.py:645 passes no mask)."""
     if cfg['encoder_type'] is None:
         return labels  # model.py:235-236
+    with operand_rounding(None):  # the encoder is exact in every operand mode
+        return _encoder_apply(p, cfg, labels)
+
+
+def _encoder_apply(p, cfg, labels):
     emb = p['/parrot/encoder/embed_label.W'][labels]  # [B,U,D]
     seq = emb if cfg['encoder_literal'] else emb.transpose(0, 1)
     outs = []
@@ -321,6 +368,7 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
     speaker [B,1] int64 or None.  carry = state left by the previous TBPTT window (used when
     start_flag == 0, model.py:633-643).  Returns (cost, new_carry, attention_vars, extras)."""
     L, H, ln = cfg['num_layers'], cfg['rnn_h_dim'], cfg['layer_norm']
+    _ROUNDED_WEIGHTS.clear()
     dt = p['/parrot.initial_w'].dtype
     target = features[1:]
     mask = features_mask[1:]

@@ -860,6 +860,16 @@ class Parrot(Brick):
         # weight gradients of the readout stack: nothing in the backward scan needs them, so they are handed to
         # _scan_bwd_and_weight_grads, which may run them beside the scan
         def readout_weight_grads():
+            if self._bf16_weight_grads(0, T, T) and R % 8 == 0 and not self.layer_norm:
+                # bf16-operand decoders: from the bf16 copies of the state / context histories (made here, reused by the
+                # scan's weight gradients below) and a bf16 copy of the readout gradient
+                cp = self._bf16_copies(ws, T, B, convert=('h', 'w'))
+                ws['bf16_hw_fresh'] = True
+                d16 = ops.to_bf16(dread)
+                for l in range(L):
+                    ops.gemm_bf16in(cp['h'][l][1:T + 1].view(T * B, H), d16, gWr[l * H:(l + 1) * H], accumulate=True)
+                ops.gemm_bf16in(cp['w'][1:T + 1].view(T * B, E), d16, gWr[L * H:], accumulate=True)
+                return
             for l in range(L):
                 ops.gemm(ws['h'][l][1:].view(T * B, H).t(), dro[l], out=gWr[l * H:(l + 1) * H], accumulate=True)
             ops.gemm(ws['w'][1:].view(T * B, E).t(), dread, out=gWr[L * H:], accumulate=True)
@@ -980,24 +990,37 @@ class Parrot(Brick):
         return (self.compute_bf16 and not self.layer_norm and t0 == 0 and t1 == T and H % 8 == 0 and E % 8 == 0
                 and os.environ.get('PARROT_BF16_DW', '1') != '0')
 
-    def _weight_grad_rows_bf16(self, ws, T, B):
+    def _bf16_copies(self, ws, T, B, convert=()):
+        """bf16 copies of the scan's histories (allocated once per workspace).  convert: 'h' / 'w' (state and context
+        histories: final once the forward scan is done), 'd' (r * h and the pre-activation gradients: after the backward
+        scan)."""
         H, E, L = self.rnn_h_dim, self.encoded_input_dim, self.num_layers
-        sg_ = self.store.storage_grad
-        R = T * B
         cp = ws.get('bf16_copies')
-        if cp is None:  # allocated once per workspace
+        if cp is None:
             bf = dict(device=self._dev(), dtype=torch.bfloat16)
             cp = ws['bf16_copies'] = dict(
                 h=[torch.empty(T + 1, B, H, **bf) for _ in range(L)], w=torch.empty(T + 1, B, E, **bf),
                 rh=[torch.empty(T, B, H, **bf) for _ in range(L)] if self.cell_type != 'lstm' else None,
                 d={key: [torch.empty(T, B, wd, **bf) for _ in range(L)] for key, wd, _, _, _ in self._groups})
-        ops.to_bf16(ws['w'], out=cp['w'])
+        if 'w' in convert:
+            ops.to_bf16(ws['w'], out=cp['w'])
         for l in range(L):
-            ops.to_bf16(ws['h'][l], out=cp['h'][l])
-            if cp['rh'] is not None:
-                ops.to_bf16(ws['rh'][l], out=cp['rh'][l])
-            for key, wd, _, _, _ in self._groups:
-                ops.to_bf16(ws['d' + key.upper()][l], out=cp['d'][key][l])
+            if 'h' in convert:
+                ops.to_bf16(ws['h'][l], out=cp['h'][l])
+            if 'd' in convert:
+                if cp['rh'] is not None:
+                    ops.to_bf16(ws['rh'][l], out=cp['rh'][l])
+                for key, wd, _, _, _ in self._groups:
+                    ops.to_bf16(ws['d' + key.upper()][l], out=cp['d'][key][l])
+        return cp
+
+    def _weight_grad_rows_bf16(self, ws, T, B):
+        H, E, L = self.rnn_h_dim, self.encoded_input_dim, self.num_layers
+        sg_ = self.store.storage_grad
+        R = T * B
+        # (the state / context copies were made by the readout weight gradients when those ran on them)
+        fresh = ('d',) if ws.pop('bf16_hw_fresh', False) else ('h', 'w', 'd')
+        cp = self._bf16_copies(ws, T, B, convert=fresh)
         for l in range(L):
             ll = l + 1
             hprev = cp['h'][l][0:T].view(R, H)

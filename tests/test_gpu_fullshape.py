@@ -156,7 +156,7 @@ def variant_batch(cfg, T, B, U, ragged, seed):
     return feat, fm, lab, lm
 
 
-def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, capsys, tag, yardstick=True):
+def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, capsys, tag):
     """One training window of VARIANTS[which] on the HIP path vs the fp64 oracle (checkpointed BPTT), and -- as the
     yardstick for what ANY float32 evaluation of this map can meet -- the oracle in float32 vs itself in float64."""
     from oracle import parrot_ref as R
@@ -179,10 +179,7 @@ def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, cap
     for v in p.values():
         v.requires_grad_()
     rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=100)
-    if yardstick:
-        c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
-    else:  # (the tolerances of the bf16 operand mode are 100 x the oracle's float32 drift: tools/oracle_f32_drift.py cfg4)
-        c32, av32 = rc, rav
+    c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
     rep = [f"{which} T_dec={T} B={B} U={U} ragged={ragged} operands={compute_dtype}",
            f"cost: hip {cost:.8f} oracle {float(rc):.8f} rel {abs(cost - float(rc)) / abs(float(rc)):.2e} "
            f"(oracle-f32 {abs(float(c32) - float(rc)) / abs(float(rc)):.2e})"]
@@ -199,8 +196,7 @@ def _window_check(dev, which, T, compute_dtype, tol_out, tol_cost, tol_grad, cap
             assert float(grads[name].abs().max()) < 1e-6, name
             continue
         e = rel_err(grads[name], ref.grad)
-        if yardstick:
-            worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
+        worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
         if e > worst[1]:
             worst = (name, e)
         n_checked += 1
@@ -231,9 +227,82 @@ def test_cfg2_T800_fan_in_ragged_feedback_matches_oracle(dev, capsys):
 @pytest.mark.timeout(2400)
 def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
     """BASELINE configs[3] per GPU EXACTLY as `bench.py --config cfg4` runs it -- 3 x LSTM-1536, B = 64, T_enc = 200,
-    **T_dec = 800**, bf16 MFMA operands / f32 accumulation -- vs the fp64 oracle.  Tolerances of the bf16 operand mode
-    (tests/test_gpu_bf16.py, unchanged): 5e-3 cost, 2e-2 frames / kappa / w / phi, 5e-2 norm-wise per gradient."""
-    _window_check(dev, "cfg4", 800, 'bf16', 2e-2, 5e-3, 5e-2, capsys, "cfg4 bf16 T800 parity", yardstick=False)
+    **T_dec = 800**, bf16 MFMA operands / f32 accumulation -- against the oracle.
+
+    What the test has to separate: the operand MODE and the KERNELS.  Rounding every operand of every decoder product to
+    bf16 (4e-3 relative per element) and feeding it through an 800-deep recurrence whose attention position kappa is a
+    running sum moves the trajectory itself: the ORACLE evaluated with bf16-rounded operands (parrot_ref.operand_rounding,
+    fp64 accumulation) ends 800 frames 0.6 (frames), 4e-2 (kappa), 0.35 (w) away from the exact oracle, and the same
+    emulation accumulated in float32 another 0.1 away from that (a state 1e-7 off can round to the other bf16 neighbour;
+    profiles/r04_bf16_mode_drift.txt).  So:
+      * reference = the oracle with bf16 operand rounding, fp64 accumulation (same rounding points as the product);
+      * yardstick = the same emulation accumulated in float32, against that reference;
+      * bar, at every horizon h in (100, 200, 400, 800) frames and for frames / kappa / w / phi: the HIP error over the first
+        h frames <= max(tolerance of the mode, 3 x the yardstick's error over the same frames); cost within 5e-3 of the
+        EXACT oracle; every parameter gradient within max(5e-2, 3 x yardstick) of the reference's.
+    The short-window tolerances of the mode (tests/test_gpu_bf16.py: 2e-2 outputs, 5e-2 gradients) are unchanged."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw, init_kw, kb, B, U, ragged = VARIANTS["cfg4"]
+    T = 800
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=1234, **init_kw)
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(kb)
+    feat, fm, lab, lm = variant_batch(cfg, T, B, U, ragged, seed=77)
+    m = Parrot(device=dev, use_graph=True, compute_dtype='bf16', **kw).allocate()
+    m.set_parameter_values(p)
+    m.zero_grad()
+    cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+    cost.backward()
+    grads = {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()}
+    av = [x.detach().cpu().double() for x in av]
+    cost = float(cost.detach())
+    m.close()
+    with torch.no_grad():  # exact oracle, forward only (cost + how far the MODE moves the trajectory)
+        carry, num, ex = None, 0.0, []
+        for a in range(0, T, 100):
+            c, carry, eav, _ = R.compute_cost(p, cfg, feat[a:a + 101], fm[a:a + 101], lab, lm, None, 1 if a == 0 else 0, carry)
+            num += float(c) * float(fm[a + 1:a + 101].sum() + 1e-5)
+            ex.append(eav)
+        exact_cost = num / float(fm[1:].sum() + 1e-5)
+        exact = [torch.cat([e[j] for e in ex], 0) for j in range(5)]
+    p32 = {k: v.float().requires_grad_() for k, v in p.items()}
+    for v in p.values():
+        v.requires_grad_()
+    with R.operand_rounding('bf16'):
+        rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=100)
+        c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
+    rep = [f"cfg4 T_dec={T} B={B} U={U} operands=bf16",
+           f"cost: hip {cost:.6f}  exact oracle {exact_cost:.6f} (rel {abs(cost - exact_cost) / exact_cost:.2e})  "
+           f"oracle with bf16 operands {float(rc):.6f} (rel {abs(cost - float(rc)) / float(rc):.2e})"]
+    assert abs(cost - exact_cost) <= 5e-3 * exact_cost
+    names = ((0, "predicted frames"), (1, "kappa"), (2, "w"), (4, "phi"))
+    failures = []
+    for h in (100, 200, 400, 800):
+        row = []
+        for i, n in names:
+            e = rel_err(av[i][:h], rav[i][:h])
+            y = rel_err(av32[i][:h], rav[i][:h])
+            mode = rel_err(rav[i][:h], exact[i][:h])
+            row.append(f"{n} {e:.2e} (f32-accumulated emulation {y:.2e}; the mode itself {mode:.2e})")
+            if e > max(2e-2, 3.0 * y):
+                failures.append((h, n, e, y))
+        rep.append(f"first {h} frames vs the bf16-operand oracle: " + "; ".join(row))
+    worst, worst32, n_checked = ("", 0.0), 0.0, 0
+    for name, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+            continue
+        e = rel_err(grads[name], ref.grad)
+        worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
+        if e > worst[1]:
+            worst = (name, e)
+        n_checked += 1
+    rep.append(f"{n_checked} parameter gradients vs the bf16-operand oracle's; worst {worst[0]}: {worst[1]:.2e} norm-wise "
+               f"(f32-accumulated emulation: worst {worst32:.2e})")
+    with capsys.disabled():
+        print("\n[cfg4 bf16 T800 parity] " + "\n[cfg4 bf16 T800 parity] ".join(rep))
+    assert not failures, failures
+    assert n_checked >= 10 and worst[1] <= max(5e-2, 3.0 * worst32), worst
 
 
 def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):

@@ -332,8 +332,8 @@ def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
 def test_lstm_one_launch_per_tick_schedule(dev, monkeypatch):
     """Schedule 7 (LSTM layers: the attention of step q-1 inside the launch of tick q, layer 0's w rows behind the
     in-launch flag) forced onto f32 operands (ska_kernel + sk_body's flagged tail): oracle parity incl. every gradient
-    for 1-3 layers, ragged masks, feedback + speaker, more than one row tile, eager and graph; and the forward pass is
-    the SAME arithmetic as schedule 0 (cost and frames bit for bit)."""
+    for 1-3 layers, ragged masks, feedback + speaker, more than one row tile, eager and graph; and the forward pass
+    agrees with schedule 0 to f32 summation order."""
     monkeypatch.setenv("PARROT_SCHEDULE", "7")
     for use_graph in (False, True):
         _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
@@ -354,8 +354,10 @@ def test_lstm_one_launch_per_tick_schedule(dev, monkeypatch):
         cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, 20)
         got[sched] = (cost.detach().clone(), av[0].detach().clone(), av[2].detach().clone())
         m.close()
-    for a, b in zip(got["0"], got["7"]):
-        assert torch.equal(a, b)
+    # (not bit for bit: the attention beside GEMM workgroups runs one block per batch row instead of column slices, and the
+    # flagged tail deals its K chunks to the waves behind the main ring's -- same terms, other order)
+    for a, b, n in zip(got["0"], got["7"], ("cost", "frames", "w")):
+        assert_close(a, b.double().cpu(), 2e-6, f"schedule 7 vs 0: {n}")
 
 
 # ----------------------------------------------------------------------------- strands and parts
