@@ -1351,7 +1351,8 @@ struct DecoderPlan : PlanBase {
     // start on the CUs the attention blocks free, walk their h rows and take the w rows behind the flag (wk_body's tail;
     // sk_body's for f32 operands).  The upper layers lag one tick more than in schedule 0 so that the w they read was
     // published by an EARLIER launch:  tick q:  attention(q-1) || lstm(l0, q) [w rows flagged], lstm(l, q - lag7(l)),
-    // lag7 = 0, 2, 3.  Same terms in the same order per output element as schedule 0 (bit-identical).
+    // lag7 = 0, 2, 3.  Same terms per output element as schedule 0 (the attention runs one block per batch row here, so
+    // its sums differ from schedule 0's column-sliced blocks in the last bits).
     int lag7(int l) const { return l == 0 ? 0 : l + 1; }
     int nticks7() const { return d.T + std::max(1, lag7(d.L - 1)); }
     int fwd7(hipStream_t st) {

@@ -863,11 +863,15 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
 // LDS once per workgroup: 342 MB per tick, no split-K reduction at all (every wave ends with complete sums and runs
 // its part of the fused epilogue).  Weights: one 1 KB fragment-major block per wave and 32-deep chunk, straight
 // into registers.  One __syncthreads per 64-deep stage, two LDS stage buffers, register rings for both operands.
+// Ring depths 2 / 2 (round 4): 121 VGPRs instead of 157, i.e. four waves per SIMD -- TWO workgroups per CU -- which is what
+// lets the attention blocks of a heterogeneous launch (wka_kernel, plans.hip schedule 7) run BESIDE the wide workgroups
+// instead of in front of them: cfg4 step 104.5 -> 97.9 ms with the attention in the tick's launch, and 106.9 -> 104.6 ms
+// on schedule 0 (measured on one box, profiles/r04_cfg4_schedule7.txt); deeper rings never bought anything (below).
 #ifndef WK_PA_DEPTH
-#define WK_PA_DEPTH 4
+#define WK_PA_DEPTH 2
 #endif
 #ifndef WK_PB_DEPTH
-#define WK_PB_DEPTH 4
+#define WK_PB_DEPTH 2
 #endif
 // K per stage; LDS row pitch in bytes; ring depths in stages.  Measured the same at cfg4 (34.4-36.1 us per launch):
 // ring depths 2/3, 4/4 and 8/8, a stage of 128 instead of 64 K rows.  Measured worse: starting every workgroup at a
