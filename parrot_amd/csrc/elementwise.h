@@ -84,6 +84,32 @@ __device__ __forceinline__ void lstm_state_bwd_row(const LstmStateBwdChain& c, i
     }
 }
 
+// The same row for consumers INSIDE the launch (skinny.hip wkb_kernel): same arithmetic and thread -> column mapping, but
+// the dP row is staged in LDS (`row`, 4H floats) and leaves as 16-byte write-through stores (a 4-byte sc1 store is one
+// fabric write each); the caller drains them (s_waitcnt vmcnt(0) + barrier) before it arrives on the chain's flag.
+__device__ __forceinline__ void lstm_state_bwd_row_pub(const LstmStateBwdChain& c, int m, int H, int tid, int nthr, float* row) {
+    for (int k = tid; k < H; k += nthr) {
+        const size_t idx = (size_t)m * H + k;
+        const float* g = c.gates + (size_t)m * 4 * H;
+        const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
+        const float tc = tanhf(c.c_new[idx]);
+        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f);
+        const float dcv = dhv * go * (1.f - tc * tc) + c.dc[idx];
+        row[k] = dcv * gg * gi * (1.f - gi);
+        row[H + k] = dcv * c.c_prev[idx] * gf * (1.f - gf);
+        row[2 * H + k] = dhv * tc * go * (1.f - go);
+        row[3 * H + k] = dcv * gi * (1.f - gg * gg);
+        c.dc[idx] = dcv * gf;
+    }
+    __syncthreads();
+    float* o = c.dP + (size_t)m * 4 * H;
+    for (int i = tid; i < H; i += nthr) {  // (4H / 4 vectors; H % 4 == 0 and 16-byte aligned rows are the launcher's conditions)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * i);
+        float* q = o + 4 * i;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+    }
+}
+
 // Elementwise half of the LSTM backward step (ops.py:505-553 reversed).  dh: gradient wrt s_t; dc: carry
 // (in: gradient wrt c_t from step t+1, out: gradient wrt c_{t-1}); gates [B,4H] = i|f|o|g; dP [B,4H] out.
 int lstm_state_bwd_launch(const float* dh, const float* dh2, float* dc, const float* gates, const float* c_prev, const float* c_new,

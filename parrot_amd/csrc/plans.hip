@@ -98,7 +98,7 @@ struct Tracer {
         for (int q = 0; q < j.nseg; ++q) ks += j.seg[q].K;
         jobs.push_back({launch, id, j.M, j.N, ks, j.epi});
         for (int q = 0; q < j.nseg; ++q)
-            mat(j.seg[q].A, j.M, j.seg[q].K, j.seg[q].lda, (j.wait_flag && q == j.nseg - 1) ? 3 : 0, id);
+            mat(j.seg[q].A, j.M, j.seg[q].K, j.seg[q].lda, (j.wait_flag && (j.wait_all || q == j.nseg - 1)) ? 3 : 0, id);
         mat(j.add, j.M, j.N, j.ld_add, 0, id);
         const int H = j.H;
         switch (j.epi) {
@@ -201,6 +201,24 @@ int traced_att_state_bwd_launch(const AttBwdArgs* g, const SA& sa, int l0_chain,
         return 0;
     }
     return att_state_bwd_launch(g, sa, l0_chain, s);
+}
+
+// The fused backward tick of schedule 7 (skinny.hip wkb_kernel): attention backward (or null) + the LSTM state backward of
+// all chains as row blocks at the head of ONE launch, the transposed products `jobs` behind them, each waiting (wait_all)
+// on the flag of the chain that writes its dP operand.  PH_ERR_UNSUPPORTED: the wide kernel does not take these jobs.
+int traced_bwd_fused_launch(const AttBwdArgs* g, const LstmStateBwdArgs& sa, int l0_chain, const SkJob* jobs, int n,
+                            unsigned* const* flags, hipStream_t s) {
+    SkLaunch L;
+    PL_TRY(sk_make_launch(L, jobs, n));
+    if (g_tracer) {
+        g_tracer->begin();
+        if (g) g_tracer->att_bwd(*g, TRACE_JOB_ATT);
+        for (int q = 0; q < sa.nchain; ++q)
+            g_tracer->chain(sa.chain[q], sa.B, sa.H, (g && q == l0_chain) ? (int)TRACE_JOB_ATT : TRACE_JOB_CHAIN + q);
+        for (int q = 0; q < n; ++q) g_tracer->sk_job(jobs[q], q);
+        return 0;
+    }
+    return sk_launch_bwd_fused(L, g, sa, l0_chain, flags, s);
 }
 
 // Batch rows [b0, b0 + nb) of a launch argument block: every per-row pointer moves down b0 rows, the row count
@@ -522,6 +540,8 @@ struct DecoderPlan : PlanBase {
         stop_workers();
         if (att_flags && !flags_fake) (void)hipFree(att_flags);
         att_flags = nullptr;
+        if (bwd_flags && !flags_fake) (void)hipFree(bwd_flags);
+        bwd_flags = nullptr;
         for (int w = 0; w < 2; ++w)
             for (hipGraphExec_t e : piece[w])
                 if (e) (void)hipGraphExecDestroy(e);
@@ -1393,10 +1413,15 @@ struct DecoderPlan : PlanBase {
     // for layer 0's share of dw), so no two jobs of a launch update the same element: no atomics, and
     // the result is deterministic.  The consumers add the parts when they read.
     bool bwd_split = true;  // PARROT_BWD_SPLIT=0: the dC products stay in the Y launch (K = 3H jobs), as before round 3
+    // schedule 7 with bf16 operands: the backward tick of LSTM layers as ONE launch (skinny.hip wkb_kernel); bwd_flags =
+    // [ticks x 4 chains] arrival counters, plan-owned, zeroed at the head of the backward scan
+    bool bwd_fused = false;
+    unsigned* bwd_flags = nullptr;
     int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
     int bwd(hipStream_t st, int q0, int q1) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
         const int H = d.H, E = d.E;
+        if (bwd_fused && q0 == 0 && !g_tracer) PL_TRY(sk_zero_words_launch(bwd_flags, 4 * nticks(), st));
         for (int q = q0; q < q1; ++q) {
             int tl[PARROT_MAX_LAYERS];
             for (int l = 0; l < d.L; ++l) tl[l] = d.T - 1 - (q - (d.L - 1 - l));
@@ -1409,9 +1434,12 @@ struct DecoderPlan : PlanBase {
                 int nl = 0;
                 LstmStateBwdArgs la;
                 la.nchain = 0; la.B = d.B; la.H = H;
-                for (int l = d.L - 1; l >= 0; --l) {  // state updates of all active layers + attention: one launch
+                int chain_of[PARROT_MAX_LAYERS];
+                for (int l = d.L - 1; l >= 0; --l) {  // state updates of all active layers + attention
+                    chain_of[l] = -1;
                     const int t = tl[l];
                     if (t < 0 || t >= d.T) continue;
+                    chain_of[l] = la.nchain;
                     LstmStateBwdChain& c = la.chain[la.nchain++];
                     c.dh = d.dh[l] + (t + 1) * BH;
                     c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
@@ -1422,11 +1450,11 @@ struct DecoderPlan : PlanBase {
                     c.dP = d.dG[l] + (size_t)t * 4 * BH;
                 }
                 take_rows(la, cur);
-                if (la.nchain > 0) PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, la, att_on ? la.nchain - 1 : -1, st));
                 for (int l = d.L - 1; l >= 0; --l) {
                     const int t = tl[l];
                     if (t < 0 || t >= d.T) continue;
                     float* dP = d.dG[l] + (size_t)t * 4 * BH;
+                    const int first = nl;
                     {   // previous state of this layer
                         SkJob& j = jl[nl++];
                         sk_job_init(j);
@@ -1451,8 +1479,26 @@ struct DecoderPlan : PlanBase {
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
                     }
+                    if (bwd_fused)  // the products of a layer read what its chain's rows publish inside the launch
+                        for (int q2 = first; q2 < nl; ++q2) {
+                            jl[q2].wait_flag = bwd_flags + (size_t)q * 4 + chain_of[l];
+                            jl[q2].wait_target = (unsigned)cur.nb;
+                            jl[q2].wait_all = 1;
+                        }
                 }
                 for (int q2 = 0; q2 < nl; ++q2) take_rows(jl[q2], cur);
+                const int l0c = att_on ? la.nchain - 1 : -1;
+                if (bwd_fused && la.nchain > 0 && nl > 0) {
+                    unsigned* fl[4] = {nullptr, nullptr, nullptr, nullptr};
+                    for (int c2 = 0; c2 < la.nchain; ++c2) fl[c2] = bwd_flags + (size_t)q * 4 + c2;
+                    const int rc = traced_bwd_fused_launch(att_on ? &g : nullptr, la, l0c, jl, nl, fl, st);
+                    if (rc != PARROT_ERR_UNSUPPORTED) {
+                        PL_TRY(rc);
+                        continue;
+                    }
+                    for (int q2 = 0; q2 < nl; ++q2) { jl[q2].wait_flag = nullptr; jl[q2].wait_target = 0; jl[q2].wait_all = 0; }
+                }
+                if (la.nchain > 0) PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, la, l0c, st));
                 if (nl > 0) PL_TRY(launch_jobs(jl, nl, st, full_wgs));
                 continue;
             }
@@ -2676,6 +2722,13 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             (void)hipGetLastError();
             p->att_flags = reinterpret_cast<unsigned*>((uintptr_t)0x1000);
             p->flags_fake = true;
+        }
+        if (p->schedule == 7 && desc->bf16 && !(getenv("PARROT_BWD_FUSED") && atoi(getenv("PARROT_BWD_FUSED")) == 0)) {
+            // the backward tick as one launch too (wkb_kernel); PARROT_BWD_FUSED=0 keeps the two launches of schedule 0
+            const size_t words = (size_t)4 * (desc->T + desc->L);
+            if (p->flags_fake) p->bwd_flags = reinterpret_cast<unsigned*>((uintptr_t)0x100000);
+            else if (hipMalloc(&p->bwd_flags, sizeof(unsigned) * words) != hipSuccess) { delete p; return PARROT_ERR_BADARG; }
+            p->bwd_fused = true;
         }
         const char* e = getenv("PARROT_S6_ESPLIT");
         p->esplit6 = e && atoi(e) > 0 ? atoi(e) : 1;

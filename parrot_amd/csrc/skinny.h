@@ -46,12 +46,14 @@ struct SkJob {
     float* o1;
     float* o2;
     const float* mask;  // [M] optional step mask (GRU_CAND): h' = m*h' + (1-m)*h_prev
-    int ld_add, ldo, lde0, lde1, ldo1, ldo2, pad0, pad1;
+    int ld_add, ldo, lde0, lde1, ldo1, ldo2, wait_all, pad1;
     // Optional in-launch dependency: the A operand of the LAST segment is produced by other workgroups of the same
     // launch (the attention step of a heterogeneous launch, ska_kernel).  The workgroup multiplies all other segments
     // first, then waits until *wait_flag >= wait_target and takes the last segment with sc1 (L1-bypassing) loads.
     // Fragment-major weights only; the producers must be dispatched BEFORE the waiting workgroups (sk_launch_att
     // puts them first), the wait is bounded (~1 s, then the kernel traps).
+    // wait_all = 1 (wide bf16 kernel only, single-segment jobs): the WHOLE A operand is produced inside the launch (the
+    // state-backward rows at the head of the fused backward tick, wkb_kernel): the workgroup waits before its first load.
     const unsigned* wait_flag;
     unsigned wait_target;
     int colmode;  // 1: a LINEAR job over the gate-interleaved column order of an LSTM matrix (N = 4H; the fragment-major
@@ -75,6 +77,15 @@ void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid, size_t& lds, int& 
 struct AttFwdArgs;
 // The attention forward step and the jobs of L in ONE launch (attention workgroups first, see ska_kernel).
 int sk_launch_att(const SkLaunch& L, const AttFwdArgs& att, hipStream_t stream);
+struct AttBwdArgs;
+struct LstmStateBwdArgs;
+// The fused backward tick of LSTM layers with bf16 operands (plans.hip schedule 7): attention backward (or null) + the
+// state backward of every chain as 1024-thread row blocks at the head of the grid, each chain publishing its dP rows
+// write-through and arriving on flags[chain]; behind them the wide step workgroups of L, whose jobs wait (wait_all) on
+// the flag of the chain that writes their operand.  Returns PH_ERR_UNSUPPORTED when the wide kernel does not take the
+// launch (the caller then runs the two launches one after the other).
+int sk_launch_bwd_fused(const SkLaunch& L, const AttBwdArgs* att, const LstmStateBwdArgs& sa, int l0_chain,
+                        unsigned* const* flags, hipStream_t stream);
 int sk_zero_words_launch(unsigned* p, int n, hipStream_t stream);
 void sk_profile_begin();
 long long sk_profile_end(double* total_us, double* flops, double* bytes);

@@ -22,6 +22,8 @@
 //     sampleRNN/lib/ops.py:364-393), its backward counterpart, or the LSTM cell (ops.py:505-553).
 #include "skinny.h"
 #include "att_fwd_body.h"
+#include "att_bwd_body.h"
+#include "elementwise.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -687,7 +689,8 @@ void sk_finalize_job(SkJob& j) {
     j.aligned = al;
     // a waiting job: fragment-major weights, f32 (sk_body's tail) or bf16 (wk_body's tail: sk_launch_att refuses the
     // launch if the wide kernel does not take it); anything else is rejected by sk_make_launch
-    if (j.wait_flag && (!al || j.nseg < 2 || j.seg[0].b_kcontig < 2 || !SK_A_PERMUTE)) j.aligned = -1;
+    if (j.wait_flag && (!al || (j.wait_all ? (j.nseg != 1 || j.seg[0].b_kcontig != 3) : j.nseg < 2) || j.seg[0].b_kcontig < 2 || !SK_A_PERMUTE))
+        j.aligned = -1;
 }
 
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
@@ -908,7 +911,8 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     // A job whose LAST segment's activations are produced by the attention blocks of the same launch (SkJob::wait_flag,
     // plans.hip schedule 7) walks its other segments through the pipelined ring and takes that segment afterwards
     // (wk_tail): same terms in the same order as the unflagged job, bit for bit.
-    const bool flagged = job.wait_flag != nullptr;
+    const bool wait_all = job.wait_flag != nullptr && job.wait_all;  // the whole operand arrives inside the launch
+    const bool flagged = job.wait_flag != nullptr && !wait_all;
     const int nseg_main = flagged ? job.nseg - 1 : job.nseg;
     int total = 0;
     for (int q = 0; q < nseg_main; ++q) total += job.seg[q].K / WK_STAGE;
@@ -933,10 +937,24 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     Cursor ca, cb;
     cursor_init(ca);
     cursor_init(cb);
+    // wait_all: one poller per workgroup, then every activation load goes through an sc1 buffer load (the rows were
+    // published write-through by another CU, possibly behind another XCD's L2; single segment: wkb_try_launch checks)
+    if (wait_all) {
+        if (tid == 0) sk_wait_flag(job.wait_flag, job.wait_target);
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t rsA = sk_rsrc(job.seg[0].A);
     auto loadA = [&](f32x4 (&a)[WK_NP]) __attribute__((always_inline)) {
+        if (wait_all) {
 #pragma unroll
-        for (int p = 0; p < WK_NP; ++p)
-            a[p] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq);
+            for (int p = 0; p < WK_NP; ++p)
+                a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rsA, (unsigned)((min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq) * 4), 0, 16 /* sc1 */));
+        } else {
+#pragma unroll
+            for (int p = 0; p < WK_NP; ++p)
+                a[p] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq);
+        }
         cursor_next(ca);
     };
     auto loadB = [&](f32x4 (&b)[WK_KS]) __attribute__((always_inline)) {
@@ -1120,6 +1138,60 @@ __global__ __launch_bounds__(SK_THREADS) void wka_kernel(const WkLaunch L, const
     else wk_body<4>(job, bx, wk_smem);
 }
 
+// ---- fused backward tick (plans.hip schedule 7, LSTM layers, bf16 operands) ------------------------------------------
+// Schedule 0 runs a backward tick as two launches: the attention backward + the elementwise state backward of every
+// active layer (att_state_bwd_kernel: a 16 us chain of dependent round trips on 64-192 CUs at cfg4) and then the wide
+// launch of all transposed products (~40 us), every one of which reads the dP rows the first launch wrote.  Here the row
+// blocks LEAD the grid of ONE launch (1024 threads, as in att_state_bwd_kernel); each chain publishes its dP rows
+// write-through and arrives on its flag; the wide workgroups behind them (8 of the block's 16 waves, the others exit at
+// once) wait for the flag of the chain that feeds them before their first load and read dP through sc1 loads.  The
+// upper layers' chains are elementwise and done in a few microseconds, so their products start almost at once; layer
+// 0's products -- the shortest of the launch, last in the grid -- start on the CUs the attention rows free.
+struct WkbProducers {
+    AttBwdArgs att;
+    LstmStateBwdArgs sa;
+    int att_rows, l0_chain, nprod;
+    int row_off;        // floats: where the publishing state backward's staging row starts in LDS (behind the attention's)
+    unsigned* flag[4];  // per chain
+};
+
+__global__ __launch_bounds__(ATTB_THREADS) void wkb_kernel(const WkLaunch L, const WkbProducers P) {
+    extern __shared__ __attribute__((aligned(16))) char wkb_smem[];
+    int bx = blockIdx.x;
+    if (bx < P.nprod) {
+        float* sm = reinterpret_cast<float*>(wkb_smem);
+        float* row = sm + P.row_off;  // [4H] staging row
+        int ch, m;
+        if (bx < P.att_rows) {
+            att_bwd_row(P.att, bx, sm);
+            __syncthreads();
+            ch = P.l0_chain; m = bx;
+        } else {
+            const int idx = bx - P.att_rows;
+            ch = idx / P.sa.B; m = idx % P.sa.B;
+            if (P.att_rows > 0 && P.l0_chain >= 0 && ch >= P.l0_chain) ++ch;  // skip the chain fused behind the attention
+        }
+        if (ch >= 0 && ch < P.sa.nchain) {
+            lstm_state_bwd_row_pub(P.sa.chain[ch], m, P.sa.H, threadIdx.x, ATTB_THREADS, row);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its write-through stores ...
+            __syncthreads();
+            if (threadIdx.x == 0)                              // ... then one lane arrives for the row
+                (void)__hip_atomic_fetch_add(P.flag[ch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (threadIdx.x >= SK_THREADS) return;  // the wide workgroups run on eight waves
+    bx -= P.nprod;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < SK_MAXJOB - 1; ++q)
+        if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
+    bx -= (j > 0 ? L.wg_end[j - 1] : 0);
+    const SkJob& job = L.job[j];
+    if (L.ncw[j] == 8) wk_body<8>(job, bx, wkb_smem);
+    else wk_body<4>(job, bx, wkb_smem);
+}
+
 // Would wk_try_launch take a bf16 launch whose jobs have M rows, ncols output columns in total and K segments of H and E
 // rows?  (plans.hip asks before it commits a plan to a schedule only the wide kernel can run.)
 bool sk_wide_takes(int M, int ncols, int H, int E) {
@@ -1131,14 +1203,18 @@ bool sk_wide_takes(int M, int ncols, int H, int E) {
 
 // Takes the launch when every job is a bf16-operand LSTM / LINEAR job over <= 64 rows with 64-deep K segments.
 // att != null: the attention step rides in the same launch (wka_kernel); `reserve` CUs are left to its blocks.
-static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, const AttFwdArgs* att = nullptr) {
+// Legality + layout of a wide launch: W (jobs that wait go last), its workgroup count t, whether any job waits.
+// nlead = workgroups that lead the grid beside / before the wide ones (attention blocks, state-backward rows);
+// lead_waiters: some job waits for them (then the non-waiting jobs are sized to fit beside them).
+static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W, int& t, bool& any_flag) {
     const char* e = getenv("PARROT_WK");  // 0: never; 1 (default): launches with >= 4096 output columns; 2: whenever legal
     const int enabled = e ? atoi(e) : 1;
     if (!enabled) return false;
     long long work = 0;
     for (int q = 0; q < Lin.njobs; ++q) {
         const SkJob& j = Lin.job[q];
-        if (j.wait_flag && (!att || j.nseg < 2)) return false;  // a flag needs its producers in the launch
+        if (j.wait_flag && !has_lead) return false;  // a flag needs its producers in the launch
+        if (j.wait_flag && (j.wait_all ? j.nseg != 1 : j.nseg < 2)) return false;
         if (j.seg[0].b_kcontig != 3 || !j.aligned || j.M > 64 || j.M < 1) return false;
         if (j.epi != SK_EPI_LSTM && j.epi != SK_EPI_LINEAR) return false;
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
@@ -1147,18 +1223,18 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
         work += (long long)j.N;
     }
     if (work < 4096 && enabled < 2) return false;
-    WkLaunch W;
     memset(&W, 0, sizeof(W));
     W.njobs = Lin.njobs;
     int ksum[SK_MAXJOB], tiles[SK_MAXJOB];
     int units = 0, units_flagged = 0;
-    bool any_flag = false;
-    {   // jobs that wait for the attention go LAST in the grid: the attention blocks lead it, the other jobs take the
-        // remaining CUs, and the waiting jobs' workgroups start on the CUs the attention frees -- with their flag set
+    any_flag = false;
+    {   // jobs that wait for the lead blocks go LAST in the grid -- in the caller's order among themselves -- so that the
+        // others take the CUs beside the lead blocks and the waiting ones start on the CUs those free, their flag set
         int n = 0;
         for (int pass = 0; pass < 2; ++pass)
             for (int q = 0; q < Lin.njobs; ++q) {
-                if ((Lin.job[q].wait_flag != nullptr) != (pass == 1)) continue;
+                const bool late = Lin.job[q].wait_flag != nullptr && !Lin.job[q].wait_all;
+                if (late != (pass == 1)) continue;
                 W.job[n] = Lin.job[q];
                 tiles[n] = Lin.tile_end[q];
                 ++n;
@@ -1169,16 +1245,14 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
         ksum[q] = 0;
         for (int s = 0; s < W.job[q].nseg; ++s) ksum[q] += W.job[q].seg[s].K;
         units += ceil_div(tiles[q], 4);
-        if (W.job[q].wait_flag) { any_flag = true; units_flagged += ceil_div(tiles[q], 4); }
+        if (W.job[q].wait_flag && !W.job[q].wait_all) { any_flag = true; units_flagged += ceil_div(tiles[q], 4); }
     }
-
     // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits (with
-    // waiting jobs: until the OTHER jobs fit beside the attention blocks; the waiting ones, at most a CU round of
-    // their own, follow in the attention's place)
-    const int natt = att ? att->B * att->esplit : 0;
+    // jobs that wait behind their other segments: until the OTHER jobs fit beside the lead blocks; the waiting ones, at
+    // most a CU round of their own, follow in the lead blocks' place)
     auto fits = [&]() {
-        if (any_flag) return units - units_flagged <= 256 - natt && units_flagged <= 256;
-        return units <= 256 - (natt < 128 ? natt : 128);
+        if (any_flag) return units - units_flagged <= 256 - nlead && units_flagged <= 256;
+        return units <= 256 - (nlead < 128 ? nlead : 128);
     };
     while (!fits()) {
         int best = -1;
@@ -1187,14 +1261,25 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
         if (best < 0) break;
         const int gain = ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8);
         units -= gain;
-        if (W.job[best].wait_flag) units_flagged -= gain;
+        if (W.job[best].wait_flag && !W.job[best].wait_all) units_flagged -= gain;
         W.ncw[best] = 8;
     }
-    int t = 0;
+    t = 0;
     for (int q = 0; q < Lin.njobs; ++q) {
         t += ceil_div(tiles[q], W.ncw[q]);
         W.wg_end[q] = t;
     }
+    return true;
+}
+
+static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, const AttFwdArgs* att = nullptr) {
+    for (int q = 0; q < Lin.njobs; ++q)
+        if (Lin.job[q].wait_all) return false;  // (the fused backward tick has its own entry point)
+    const int natt = att ? att->B * att->esplit : 0;
+    WkLaunch W;
+    int t;
+    bool any_flag;
+    if (!wk_build(Lin, natt, att != nullptr, W, t, any_flag)) return false;
     size_t lds = 2 * 64 * WK_PITCH;  // two stage buffers
     if (att) {
         const size_t alds = att_fwd_lds(att->U);
@@ -1230,6 +1315,58 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
     }
     *rc = (int)hipGetLastError();
     return true;
+}
+
+int sk_launch_bwd_fused(const SkLaunch& Lin, const AttBwdArgs* att, const LstmStateBwdArgs& sa, int l0_chain,
+                        unsigned* const* flags, hipStream_t stream) {
+    static_assert(sizeof(WkLaunch) + sizeof(WkbProducers) <= 4096, "kernel arguments of wkb_kernel");
+    if (sa.nchain < 1 || sa.nchain > 4 || sa.B < 1 || (sa.H & 3)) return PH_ERR_UNSUPPORTED;
+    WkbProducers P;
+    memset(&P, 0, sizeof(P));
+    P.sa = sa;
+    P.l0_chain = -1;
+    size_t plds = 0;
+    if (att) {
+        if (att->A < 1 || att->A > ATT_MAXA || att->B != sa.B || att->U < 1 || att->E < 1 || l0_chain < 0 || l0_chain >= sa.nchain)
+            return PH_ERR_BADARG;
+        P.att = *att;
+        P.att_rows = att->B;
+        P.l0_chain = l0_chain;
+        plds = att_bwd_lds(att->U, att->E);
+    }
+    P.row_off = (int)(plds / sizeof(float));
+    plds += (size_t)4 * sa.H * sizeof(float);  // the staging row of the publishing state backward
+    P.nprod = P.att_rows + (sa.nchain - (att ? 1 : 0)) * sa.B;
+    for (int q = 0; q < sa.nchain; ++q) {
+        if (!flags[q] || ((uintptr_t)sa.chain[q].dP & 15)) return PH_ERR_UNSUPPORTED;
+        P.flag[q] = flags[q];
+    }
+    for (int q = 0; q < Lin.njobs; ++q)
+        if (!Lin.job[q].wait_flag || !Lin.job[q].wait_all) return PH_ERR_BADARG;  // every product reads a dP row block
+    WkLaunch W;
+    int t;
+    bool any_flag;
+    // the row blocks are short (a few us, the attention rows ~16): the wide workgroups are sized as if alone on the chip
+    if (!wk_build(Lin, 0, true, W, t, any_flag)) return PH_ERR_UNSUPPORTED;
+    size_t lds = 2 * 64 * WK_PITCH;
+    if (plds > lds) lds = plds;
+    if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
+    static bool allowed = false;
+    if (!allowed) {
+        (void)hipFuncSetAttribute((const void*)wkb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allowed = true;
+    }
+    if (g_prof.on) {
+        SkProfRec r;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        sk_account(Lin, r.flops, r.bytes);
+        hipExtLaunchKernelGGL(wkb_kernel, dim3(P.nprod + t), dim3(ATTB_THREADS), lds, stream, r.e0, r.e1, 0, W, P);
+        g_prof.recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL(wkb_kernel, dim3(P.nprod + t), dim3(ATTB_THREADS), lds, stream, W, P);
+    }
+    return (int)hipGetLastError();
 }
 
 

@@ -39,13 +39,16 @@ class _Arena:
         return lo
 
 
-def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, E=16, A=4, U=7):
-    monkeypatch.setenv("PARROT_SCHEDULE", str(sched))
+def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, E=16, A=4, U=7, bf16=0):
+    if sched is None:
+        monkeypatch.delenv("PARROT_SCHEDULE", raising=False)
+    else:
+        monkeypatch.setenv("PARROT_SCHEDULE", str(sched))
     monkeypatch.setenv("PARROT_TRACE_ONLY", "1")
     ar = _Arena()
     d = L.DecoderDesc()
     d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, nl
-    d.cell, d.use_graph, d.seq_init = cell, 0, seq_init
+    d.cell, d.use_graph, d.seq_init, d.bf16 = cell, 0, seq_init, bf16
     d.eps, d.alignment, d.sharpening, d.timing = 1e-5, 1.0, 1.0, 1.0
     f = 4
     gw = 4 * H if cell == 1 else 2 * H
@@ -128,14 +131,14 @@ def _check(recs, ar, write_once, accumulators, T, slot_bytes):
             for wjob, wlo, whi in writes:
                 if wjob == job or not _overlap((lo, hi), (wlo, whi)):
                     continue
-                if kind == 3:
-                    assert wjob == 100, f"launch {launch}: flagged read of {_owner(ar, lo)} written by job {wjob}"
+                if kind == 3:  # producers of an in-launch hand-off: the attention job (100) or a state-backward chain (200+)
+                    assert wjob >= 100, f"launch {launch}: flagged read of {_owner(ar, lo)} written by job {wjob}"
                     continue
                 raise AssertionError(f"launch {launch}: job {job} ({'rwx?'[kind]}) and job {wjob} (w) overlap in "
                                      f"{_owner(ar, lo)} [{lo:#x}, {hi:#x})")
         flagged = [(lo, hi) for job, kind, lo, hi in rs if kind == 3]
         for lo, hi in flagged:  # a flag without its producer in the launch would wait for ever
-            assert any(wjob == 100 and _overlap((lo, hi), (wlo, whi)) for wjob, wlo, whi in writes), launch
+            assert any(wjob >= 100 and _overlap((lo, hi), (wlo, whi)) for wjob, wlo, whi in writes), launch
     # ---- 2. write-once buffers: one writer per byte, readers strictly later (or behind the flag in the same launch)
     first_write, last_write = {}, {}  # (name, granule) -> launch
     G = 4  # bytes (one float)
@@ -231,6 +234,38 @@ def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_ini
         acc = {"dw", "dw0"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
         recs = _trace(lib, plan, 1)
         _check(recs, ar, bwd_once, acc, T, {})
+    finally:
+        lib.parrot_decoder_destroy(plan)
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3])
+def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
+    """bf16 LSTM stacks the wide kernel takes run schedule 7 by default, with BOTH ticks as one launch: forward, the
+    attention at the head of the next tick's launch (layer 0's w rows behind the flag); backward, the attention backward
+    and the state-backward rows at the head of the launch whose products read the dP rows they publish (every such read
+    is behind a flag whose writer -- the attention job or a chain -- is in the same launch)."""
+    L, lib = _lib()
+    monkeypatch.setenv("PARROT_WK", "2")
+    T, B, H, E, A, U = 5, 20, 64, 64, 4, 7
+    plan, ar, d = _make_plan(L, lib, None, 1, nl, 0, monkeypatch, T, B, H, E, A, U, bf16=1)
+    try:
+        assert lib.parrot_decoder_schedule(plan) == 7
+        f = 4
+        slot = {"w": B * E * f, "kappa": B * A * f}
+        fwd_once = {"w", "kappa", "a", "b", "phi", "att_sup"}
+        for l in range(nl):
+            slot[f"h{l}"] = B * H * f
+            slot[f"cst{l}"] = B * H * f
+            fwd_once |= {f"h{l}", f"cst{l}", f"gate4{l}"}
+        n_fwd = _check(_trace(lib, plan, 0), ar, fwd_once, set(), T, slot)
+        assert n_fwd == T + max(1, nl if nl > 1 else 0)
+        recs = _trace(lib, plan, 1)
+        bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)}
+        acc = {"dw", "dw0"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
+        n_bwd = _check(recs, ar, bwd_once, acc, T, {})
+        assert n_bwd == T + nl - 1  # one launch per tick
+        flagged = [r for r in recs if r[2] == 3]
+        assert flagged and all(_owner(ar, r[3]).startswith("dG") for r in flagged)
     finally:
         lib.parrot_decoder_destroy(plan)
 
