@@ -895,7 +895,8 @@ struct WkLaunch {
     int ncw[SK_MAXJOB];     // 16-column tiles per workgroup: 4 or 8
 };
 
-template <int NCW>
+// WAITALL: the job's whole A operand is produced inside the launch (the fused backward tick, wkb_kernel)
+template <int NCW, bool WAITALL = false>
 __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     constexpr int MB = NCW == 8 ? 4 : 2;  // row blocks per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -911,8 +912,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     // A job whose LAST segment's activations are produced by the attention blocks of the same launch (SkJob::wait_flag,
     // plans.hip schedule 7) walks its other segments through the pipelined ring and takes that segment afterwards
     // (wk_tail): same terms in the same order as the unflagged job, bit for bit.
-    const bool wait_all = job.wait_flag != nullptr && job.wait_all;  // the whole operand arrives inside the launch
-    const bool flagged = job.wait_flag != nullptr && !wait_all;
+    const bool flagged = !WAITALL && job.wait_flag != nullptr;
     const int nseg_main = flagged ? job.nseg - 1 : job.nseg;
     int total = 0;
     for (int q = 0; q < nseg_main; ++q) total += job.seg[q].K / WK_STAGE;
@@ -937,24 +937,20 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     Cursor ca, cb;
     cursor_init(ca);
     cursor_init(cb);
-    // wait_all: one poller per workgroup, then every activation load goes through an sc1 buffer load (the rows were
-    // published write-through by another CU, possibly behind another XCD's L2; single segment: wkb_try_launch checks)
-    if (wait_all) {
+    // WAITALL: one poller per workgroup waits for the rows' arrival count before the first load.  The rows were published
+    // write-through (sc1 stores, drained before the arrival) and are written exactly ONCE per launch, before any read of
+    // them; a kernel starts with its L2s invalidated, so no cache can hold an older copy of these lines and the ring
+    // reads them with ordinary (L2-cached) loads -- sc1 loads, which miss every L2, made every workgroup fetch the whole
+    // [64, 4H] operand from the fabric: 63 us per tick instead of 56 for the two launches (profiles/r04_cfg4_schedule7.txt).
+    // tests/test_gpu_bf16.py::test_in_launch_handoffs_never_see_stale_rows replays a plan on changing data to pin that.
+    if (WAITALL) {
         if (tid == 0) sk_wait_flag(job.wait_flag, job.wait_target);
         __syncthreads();
     }
-    const __amdgpu_buffer_rsrc_t rsA = sk_rsrc(job.seg[0].A);
     auto loadA = [&](f32x4 (&a)[WK_NP]) __attribute__((always_inline)) {
-        if (wait_all) {
 #pragma unroll
-            for (int p = 0; p < WK_NP; ++p)
-                a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rsA, (unsigned)((min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq) * 4), 0, 16 /* sc1 */));
-        } else {
-#pragma unroll
-            for (int p = 0; p < WK_NP; ++p)
-                a[p] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq);
-        }
+        for (int p = 0; p < WK_NP; ++p)
+            a[p] = *reinterpret_cast<const f32x4*>(ca.A + (size_t)min(ar0 + p * WK_RPP, M - 1) * ca.lda + ca.k + 4 * akq);
         cursor_next(ca);
     };
     auto loadB = [&](f32x4 (&b)[WK_KS]) __attribute__((always_inline)) {
@@ -1188,8 +1184,8 @@ __global__ __launch_bounds__(ATTB_THREADS) void wkb_kernel(const WkLaunch L, con
         if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
     bx -= (j > 0 ? L.wg_end[j - 1] : 0);
     const SkJob& job = L.job[j];
-    if (L.ncw[j] == 8) wk_body<8>(job, bx, wkb_smem);
-    else wk_body<4>(job, bx, wkb_smem);
+    if (L.ncw[j] == 8) wk_body<8, true>(job, bx, wkb_smem);
+    else wk_body<4, true>(job, bx, wkb_smem);
 }
 
 // Would wk_try_launch take a bf16 launch whose jobs have M rows, ncols output columns in total and K segments of H and E

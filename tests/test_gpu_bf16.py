@@ -286,3 +286,44 @@ def test_bf16_lstm_one_launch_per_tick_agrees_with_schedule_0(dev, monkeypatch):
         for k, v in got["0"][3].items():
             if float(v.abs().max()) > 1e-12:
                 assert rel_err(got["7"][3][k], v) < 5e-3, (L, B, k, rel_err(got["7"][3][k], v))
+
+
+def test_in_launch_handoffs_never_see_stale_rows(dev, monkeypatch):
+    """The fused ticks of schedule 7 hand rows from one workgroup to another INSIDE a launch (forward: the attention's w
+    rows; backward: the state-backward's dP rows, read with ordinary L2-cached loads).  A cache line of an earlier
+    window surviving in some L2 would be invisible on a replay with the same data -- so one plan (same buffers, captured
+    graphs) is replayed on batch A, then on a different batch B, then on A again, and every result must equal what a
+    fresh model computes on that batch alone, bit for bit.  Shapes small enough that everything would stay cache-resident."""
+    from oracle import parrot_ref as R
+    from parrot_amd import _lib
+    from parrot_amd.model import Parrot
+    monkeypatch.setenv("PARROT_WK", "2")
+    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=61, scale_by_fan_in=True)
+    T, B, U = 6, 48, 9
+    batches = [make_batch(cfg, T, B, U, seed=70 + i) for i in range(2)]
+
+    def run(m, batch):
+        feat, fm, lab, lm, _ = batch
+        m.zero_grad()
+        cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+        cost.backward()
+        return (cost.detach().clone(), av[0].detach().clone(), {k: v.detach().clone() for k, v in m.get_gradient_dict().items()})
+
+    fresh = []
+    for b in batches:
+        m = Parrot(device=dev, compute_dtype='bf16', use_graph=True, **kw).allocate()
+        m.set_parameter_values(p)
+        fresh.append(run(m, b))
+        ws = next(iter(m._train_ws.values()))
+        assert int(_lib.load().parrot_decoder_schedule(ws['plan'])) == 7
+        m.close()
+    m = Parrot(device=dev, compute_dtype='bf16', use_graph=True, **kw).allocate()
+    m.set_parameter_values(p)
+    for which in (0, 1, 0, 1, 1, 0):
+        cost, frames, grads = run(m, batches[which])
+        assert torch.equal(cost, fresh[which][0]) and torch.equal(frames, fresh[which][1]), which
+        for k, v in fresh[which][2].items():
+            assert torch.equal(grads[k], v), (which, k)
+    m.close()
