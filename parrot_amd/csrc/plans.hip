@@ -1483,7 +1483,7 @@ struct DecoderPlan : PlanBase {
                         for (int q2 = first; q2 < nl; ++q2) {
                             jl[q2].wait_flag = bwd_flags + (size_t)q * 4 + chain_of[l];
                             jl[q2].wait_target = (unsigned)cur.nb;
-                            jl[q2].wait_all = 1;
+                            jl[q2].wait_all = (l == 0 && att_on) ? 2 : 1;  // (2: behind the attention rows, last in the grid)
                         }
                 }
                 for (int q2 = 0; q2 < nl; ++q2) take_rows(jl[q2], cur);

@@ -52,8 +52,9 @@ struct SkJob {
     // first, then waits until *wait_flag >= wait_target and takes the last segment with sc1 (L1-bypassing) loads.
     // Fragment-major weights only; the producers must be dispatched BEFORE the waiting workgroups (sk_launch_att
     // puts them first), the wait is bounded (~1 s, then the kernel traps).
-    // wait_all = 1 (wide bf16 kernel only, single-segment jobs): the WHOLE A operand is produced inside the launch (the
+    // wait_all = 1 / 2 (wide bf16 kernel only, single-segment jobs): the WHOLE A operand is produced inside the launch (the
     // state-backward rows at the head of the fused backward tick, wkb_kernel): the workgroup waits before its first load.
+    // 2: the producer is the slow one of the launch (the rows behind the attention backward): such jobs go last in the grid.
     const unsigned* wait_flag;
     unsigned wait_target;
     int colmode;  // 1: a LINEAR job over the gate-interleaved column order of an LSTM matrix (N = 4H; the fragment-major

@@ -944,7 +944,10 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     // [64, 4H] operand from the fabric: 63 us per tick instead of 56 for the two launches (profiles/r04_cfg4_schedule7.txt).
     // tests/test_gpu_bf16.py::test_in_launch_handoffs_never_see_stale_rows replays a plan on changing data to pin that.
     if (WAITALL) {
-        if (tid == 0) sk_wait_flag(job.wait_flag, job.wait_target);
+        if (tid == 0) {
+            sk_wait_flag(job.wait_flag, job.wait_target);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drops this CU's L1 (buffer_inv sc1): one lane, once
+        }
         __syncthreads();
     }
     auto loadA = [&](f32x4 (&a)[WK_NP]) __attribute__((always_inline)) {
@@ -1210,7 +1213,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
     for (int q = 0; q < Lin.njobs; ++q) {
         const SkJob& j = Lin.job[q];
         if (j.wait_flag && !has_lead) return false;  // a flag needs its producers in the launch
-        if (j.wait_flag && (j.wait_all ? j.nseg != 1 : j.nseg < 2)) return false;
+        if (j.wait_flag && (j.wait_all ? j.nseg != 1 : j.nseg < 2)) return false;  // (wait_all: 1, or 2 = behind the attention rows)
         if (j.seg[0].b_kcontig != 3 || !j.aligned || j.M > 64 || j.M < 1) return false;
         if (j.epi != SK_EPI_LSTM && j.epi != SK_EPI_LINEAR) return false;
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
@@ -1229,7 +1232,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         int n = 0;
         for (int pass = 0; pass < 2; ++pass)
             for (int q = 0; q < Lin.njobs; ++q) {
-                const bool late = Lin.job[q].wait_flag != nullptr && !Lin.job[q].wait_all;
+                const bool late = Lin.job[q].wait_flag != nullptr && Lin.job[q].wait_all != 1;
                 if (late != (pass == 1)) continue;
                 W.job[n] = Lin.job[q];
                 tiles[n] = Lin.tile_end[q];
@@ -1241,7 +1244,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         ksum[q] = 0;
         for (int s = 0; s < W.job[q].nseg; ++s) ksum[q] += W.job[q].seg[s].K;
         units += ceil_div(tiles[q], 4);
-        if (W.job[q].wait_flag && !W.job[q].wait_all) { any_flag = true; units_flagged += ceil_div(tiles[q], 4); }
+        if (W.job[q].wait_flag && W.job[q].wait_all != 1) { any_flag = true; units_flagged += ceil_div(tiles[q], 4); }
     }
     // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits (with
     // jobs that wait behind their other segments: until the OTHER jobs fit beside the lead blocks; the waiting ones, at
@@ -1257,7 +1260,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         if (best < 0) break;
         const int gain = ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8);
         units -= gain;
-        if (W.job[best].wait_flag && !W.job[best].wait_all) units_flagged -= gain;
+        if (W.job[best].wait_flag && W.job[best].wait_all != 1) units_flagged -= gain;
         W.ncw[best] = 8;
     }
     t = 0;
@@ -1339,11 +1342,15 @@ int sk_launch_bwd_fused(const SkLaunch& Lin, const AttBwdArgs* att, const LstmSt
     }
     for (int q = 0; q < Lin.njobs; ++q)
         if (!Lin.job[q].wait_flag || !Lin.job[q].wait_all) return PH_ERR_BADARG;  // every product reads a dP row block
+
     WkLaunch W;
     int t;
     bool any_flag;
-    // the row blocks are short (a few us, the attention rows ~16): the wide workgroups are sized as if alone on the chip
-    if (!wk_build(Lin, 0, true, W, t, any_flag)) return PH_ERR_UNSUPPORTED;
+    // The upper layers' row blocks are elementwise and gone in a few microseconds: their products are sized as if they had
+    // the chip beside the attention rows (~16 us on one CU each, 1024 threads: nothing shares a CU with them).  The
+    // products behind the attention rows (wait_all == 2: layer 0's) go last in the grid, at their narrow width, and
+    // start on the CUs those rows free.
+    if (!wk_build(Lin, P.att_rows, true, W, t, any_flag)) return PH_ERR_UNSUPPORTED;
     size_t lds = 2 * 64 * WK_PITCH;
     if (plds > lds) lds = plds;
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
