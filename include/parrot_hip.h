@@ -274,6 +274,16 @@ typedef struct ParrotDecoderDesc {
      * NULL, too small or a non-qualifying configuration: the launch schedules are used. */
     float* persist_ws;
     long long persist_ws_floats;
+    /* Optional second accumulators of the backward scan (round 4; LSTM layers with bf16 operands): [T+1,B,H] per layer
+     * for dh and dhup, [T+1,B,E] for dw and dw0, ZERO-FILLED by the caller once.  With all of them given the transposed
+     * products of a backward tick (dP . W^T, K = 4H) are cut into two K halves handled by different workgroups -- a wide
+     * workgroup's time is the time to stream its [B, K] operand -- and the second half's sums are STORED here instead of
+     * being accumulated into dh / dhup / dw / dw0; the state backward and the attention backward of the next tick add
+     * both parts (so does the caller for slot 0).  NULL: one accumulator per gradient, as before. */
+    float* dh_b[PARROT_MAX_LAYERS];
+    float* dhup_b[PARROT_MAX_LAYERS];
+    float* dw_b;
+    float* dw0_b;
 } ParrotDecoderDesc;
 
 /* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify for the persistent

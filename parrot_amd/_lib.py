@@ -70,6 +70,7 @@ class DecoderDesc(C.Structure):
         ("Wg_r", C.c_void_p * MAX_LAYERS), ("Wc_r", C.c_void_p * MAX_LAYERS),
         ("att_sup", C.c_void_p),
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
+        ("dh_b", C.c_void_p * MAX_LAYERS), ("dhup_b", C.c_void_p * MAX_LAYERS), ("dw_b", C.c_void_p), ("dw0_b", C.c_void_p),
     ]
 
 

@@ -62,6 +62,8 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
         float v = g.dw[(size_t)b * g.lddw + e];
         if (g.dw2) {
             v += g.dw2[(size_t)b * g.lddw + e];
+            if (g.dw3) v += g.dw3[(size_t)b * g.lddw + e];
+            if (g.dw4) v += g.dw4[(size_t)b * g.lddw + e];
             g.dw[(size_t)b * g.lddw + e] = v;  // total, needed later for the deferred d(ctx) GEMM
         }
         s_dw[e] = v;

@@ -102,7 +102,10 @@ struct Tracer {
         mat(j.add, j.M, j.N, j.ld_add, 0, id);
         const int H = j.H;
         switch (j.epi) {
-            case SK_EPI_LINEAR: mat(j.out, j.M, j.N, j.ldo, j.accumulate ? 2 : 1, id); break;
+            case SK_EPI_LINEAR:
+                mat(j.out, j.M, j.N, j.ldo, j.accumulate ? 2 : 1, id);
+                if (j.ksplit > 1) mat(j.o1, j.M, j.N, j.ldo1, 1, id);  // the second K half's sums
+                break;
             case SK_EPI_GRU_GATES:
                 mat(j.e0, j.M, H, j.lde0, 0, id); mat(j.o1, j.M, H, j.ldo1, 1, id); mat(j.o2, j.M, H, j.ldo2, 1, id);
                 mat(j.out, j.M, H, j.ldo, 1, id);
@@ -131,6 +134,7 @@ struct Tracer {
     void att_bwd(const AttBwdArgs& g, int id) {
         jobs.push_back({launch, id, g.B, g.E, g.H, -2});
         mat(g.dw, g.B, g.E, g.lddw, g.dw2 ? 2 : 0, id); mat(g.dw2, g.B, g.E, g.lddw, 0, id);
+        mat(g.dw3, g.B, g.E, g.lddw, 0, id); mat(g.dw4, g.B, g.E, g.lddw, 0, id);
         mat(g.a, g.B, g.A, g.A, 0, id); mat(g.b, g.B, g.A, g.A, 0, id); mat(g.kappa, g.B, g.A, g.A, 0, id);
         mat(g.kappa_prev, g.B, g.A, g.A, 0, id); mat(g.sup, g.B, 2, 2, 0, id);
         mat(g.dkappa, g.B, g.A, g.A, 2, id); mat(g.dp_out, g.B, 3 * g.A, 3 * g.A, 1, id); mat(g.dh1, g.B, g.H, g.lddh, 2, id);
@@ -141,7 +145,8 @@ struct Tracer {
         mat(c.dC, B, H, H, 1, id); mat(c.dG, B, H, 2 * H, 1, id); mat(c.dhprev, B, H, H, 2, id);
     }
     void chain(const LstmStateBwdChain& c, int B, int H, int id) {
-        mat(c.dh, B, H, H, 0, id); mat(c.dh2, B, H, H, 0, id); mat(c.gates, B, 4 * H, 4 * H, 0, id);
+        mat(c.dh, B, H, H, 0, id); mat(c.dh2, B, H, H, 0, id); mat(c.dh3, B, H, H, 0, id); mat(c.dh4, B, H, H, 0, id);
+        mat(c.gates, B, 4 * H, 4 * H, 0, id);
         mat(c.c_prev, B, H, H, 0, id); mat(c.c_new, B, H, H, 0, id);
         mat(c.dc, B, H, H, 2, id); mat(c.dP, B, 4 * H, 4 * H, 1, id);
     }
@@ -149,9 +154,10 @@ struct Tracer {
 thread_local Tracer* g_tracer = nullptr;
 enum { TRACE_JOB_ATT = 100, TRACE_JOB_CHAIN = 200 };
 
-int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0, int force_tile = 0) {
+int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0, int force_tile = 0, int force_wide = 0) {
     SkLaunch L;
     PL_TRY(sk_make_launch(L, jobs, n));
+    L.force_wide = force_wide;
     if (g_tracer) {
         g_tracer->begin();
         for (int q = 0; q < n; ++q) {
@@ -210,6 +216,7 @@ int traced_bwd_fused_launch(const AttBwdArgs* g, const LstmStateBwdArgs& sa, int
                             unsigned* const* flags, hipStream_t s) {
     SkLaunch L;
     PL_TRY(sk_make_launch(L, jobs, n));
+    L.force_wide = 1;
     if (g_tracer) {
         g_tracer->begin();
         if (g) g_tracer->att_bwd(*g, TRACE_JOB_ATT);
@@ -264,7 +271,8 @@ void take_rows(LstmStateBwdArgs& g, const Strand& s) {
     if (s.b0 == 0 && s.nb == g.B) return;
     for (int q = 0; q < g.nchain; ++q) {
         LstmStateBwdChain& c = g.chain[q];
-        shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.dc, s.b0, g.H); shift(c.gates, s.b0, 4 * g.H);
+        shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.dh3, s.b0, g.H); shift(c.dh4, s.b0, g.H);
+        shift(c.dc, s.b0, g.H); shift(c.gates, s.b0, 4 * g.H);
         shift(c.c_prev, s.b0, g.H); shift(c.c_new, s.b0, g.H); shift(c.dP, s.b0, 4 * g.H);
     }
     g.B = s.nb;
@@ -1417,6 +1425,10 @@ struct DecoderPlan : PlanBase {
     // [ticks x 4 chains] arrival counters, plan-owned, zeroed at the head of the backward scan
     bool bwd_fused = false;
     unsigned* bwd_flags = nullptr;
+    // LSTM layers, bf16 operands, second accumulators given (ParrotDecoderDesc::dh_b ...): the backward products in two K
+    // halves.  A wide workgroup streams its whole [B, 4H] operand: 156 workgroups of ~40 us each at cfg4, whatever
+    // their width, and 100 idle CUs; two K halves = 312 workgroups of ~20 us (PARROT_BWD_KSPLIT=0: one part).
+    bool bwd_ksplit = false;
     int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
     int bwd(hipStream_t st, int q0, int q1) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -1429,6 +1441,10 @@ struct DecoderPlan : PlanBase {
             const bool att_on = t0 >= 0 && t0 < d.T;
             AttBwdArgs g{};
             if (att_on) g = att_bwd_args(t0);
+            if (att_on && bwd_ksplit) {  // (LSTM layers) the second K halves' shares of dw
+                g.dw3 = d.dw_b + (size_t)(t0 + 1) * BE;
+                g.dw4 = d.dw0_b + (size_t)(t0 + 1) * BE;
+            }
             if (d.cell == 1) {
                 SkJob jl[SK_MAXJOB];
                 int nl = 0;
@@ -1443,6 +1459,8 @@ struct DecoderPlan : PlanBase {
                     LstmStateBwdChain& c = la.chain[la.nchain++];
                     c.dh = d.dh[l] + (t + 1) * BH;
                     c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
+                    c.dh3 = bwd_ksplit ? d.dh_b[l] + (t + 1) * BH : nullptr;  // the second K halves' sums (below)
+                    c.dh4 = (bwd_ksplit && l + 1 < d.L) ? d.dhup_b[l] + (t + 1) * BH : nullptr;
                     c.dc = d.dcell[l];
                     c.gates = d.gate4[l] + (size_t)t * 4 * BH;
                     c.c_prev = d.cst[l] + t * BH;
@@ -1462,6 +1480,7 @@ struct DecoderPlan : PlanBase {
                         j.seg[0] = rseg(dP, l, 0, 0, 4 * H);
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dh[l] + t * BH; j.ldo = H;
+                        if (bwd_ksplit) { j.ksplit = 2; j.o1 = d.dh_b[l] + t * BH; j.ldo1 = H; }
                     }
                     {   // attention context
                         SkJob& j = jl[nl++];
@@ -1470,6 +1489,10 @@ struct DecoderPlan : PlanBase {
                         j.seg[0] = rseg(dP, l, 0, H, 4 * H);
                         j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
+                        if (bwd_ksplit) {
+                            j.ksplit = 2; j.ldo1 = E;
+                            j.o1 = (l == 0 ? d.dw0_b + (size_t)t * BE : d.dw_b + (size_t)(t + 1) * BE);
+                        }
                     }
                     for (int p = 0; p < l; ++p) {
                         SkJob& j = jl[nl++];
@@ -1478,6 +1501,7 @@ struct DecoderPlan : PlanBase {
                         j.seg[0] = rseg(dP, l, 0, H + E + p * H, 4 * H);
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
+                        if (bwd_ksplit) { j.ksplit = 2; j.o1 = d.dhup_b[p] + (t + 1) * BH; j.ldo1 = H; }
                     }
                     if (bwd_fused)  // the products of a layer read what its chain's rows publish inside the launch
                         for (int q2 = first; q2 < nl; ++q2) {
@@ -1499,7 +1523,7 @@ struct DecoderPlan : PlanBase {
                     for (int q2 = 0; q2 < nl; ++q2) { jl[q2].wait_flag = nullptr; jl[q2].wait_target = 0; jl[q2].wait_all = 0; }
                 }
                 if (la.nchain > 0) PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, la, l0c, st));
-                if (nl > 0) PL_TRY(launch_jobs(jl, nl, st, full_wgs));
+                if (nl > 0) PL_TRY(launch_jobs(jl, nl, st, full_wgs, 0, bwd_ksplit ? 1 : 0));
                 continue;
             }
             GruStateBwdArgs ga;
@@ -2737,8 +2761,16 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         e = getenv("PARROT_S6_BTILE");
         p->s6_btile = e ? atoi(e) : 0;
     }
+    if (desc->cell == 1 && desc->bf16 && p->tiled && !(getenv("PARROT_BWD_KSPLIT") && atoi(getenv("PARROT_BWD_KSPLIT")) == 0)) {
+        bool have = desc->dw_b && desc->dw0_b && desc->B <= 64 && sk_wide_takes(desc->B, 4096, desc->H, desc->E) &&
+                    (4 * desc->H) % 128 == 0;
+        for (int l = 0; l < desc->L; ++l)
+            if (!desc->dh_b[l] || (l + 1 < desc->L && !desc->dhup_b[l])) have = false;
+        p->bwd_ksplit = have;
+    }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     p->setup_strands();
+    if (p->nstrands > 1) p->bwd_ksplit = false;  // (row strands shift every per-row pointer: not wired for the second accumulators)
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule >= 2 && p->schedule != 7;
         for (int l = 1; l < desc->L && ok; ++l)

@@ -46,7 +46,7 @@ struct SkJob {
     float* o1;
     float* o2;
     const float* mask;  // [M] optional step mask (GRU_CAND): h' = m*h' + (1-m)*h_prev
-    int ld_add, ldo, lde0, lde1, ldo1, ldo2, wait_all, pad1;
+    int ld_add, ldo, lde0, lde1, ldo1, ldo2, wait_all, ksplit;
     // Optional in-launch dependency: the A operand of the LAST segment is produced by other workgroups of the same
     // launch (the attention step of a heterogeneous launch, ska_kernel).  The workgroup multiplies all other segments
     // first, then waits until *wait_flag >= wait_target and takes the last segment with sc1 (L1-bypassing) loads.
@@ -55,6 +55,9 @@ struct SkJob {
     // wait_all = 1 / 2 (wide bf16 kernel only, single-segment jobs): the WHOLE A operand is produced inside the launch (the
     // state-backward rows at the head of the fused backward tick, wkb_kernel): the workgroup waits before its first load.
     // 2: the producer is the slow one of the launch (the rows behind the attention backward): such jobs go last in the grid.
+    // ksplit = 2 (wide bf16 kernel only; single-segment LINEAR jobs): the K range is cut in two halves handled by different
+    // workgroups; the first half follows `accumulate` into `out`, the second half is STORED into o1 (ldo1) -- the consumer
+    // adds the two.  A wide workgroup's time is the time to stream its [M, K] operand: halving K halves the launch.
     const unsigned* wait_flag;
     unsigned wait_target;
     int colmode;  // 1: a LINEAR job over the gate-interleaved column order of an LSTM matrix (N = 4H; the fragment-major
@@ -67,6 +70,7 @@ struct SkLaunch {
     int njobs, zmode;  // zmode: grid.z = job index (all jobs have the same number of workgroups)
     int tile_end[SK_MAXJOB];  // 16-column tiles per job; sk_launch turns it into the prefix of workgroups
     int force_tile;  // host-side hint: 10 * MB + NB to use where legal (0 = the heuristic of sk_prepare)
+    int force_wide;  // host-side hint: the wide bf16 kernel takes the launch whenever it is legal (no minimum size)
     int full_wgs;  // host-side hint: workgroups at which the launch counts as filling its share of the chip
                    // (0 = the whole chip, 224); plans that run several launches side by side pass less
 };

@@ -687,6 +687,7 @@ void sk_finalize_job(SkJob& j) {
         if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
+    if (j.ksplit > 1 && (j.seg[0].b_kcontig != 3 || j.nseg != 1)) j.aligned = -1;  // K parts: wide bf16 kernel only
     // a waiting job: fragment-major weights, f32 (sk_body's tail) or bf16 (wk_body's tail: sk_launch_att refuses the
     // launch if the wide kernel does not take it); anything else is rejected by sk_make_launch
     if (j.wait_flag && (!al || (j.wait_all ? (j.nseg != 1 || j.seg[0].b_kcontig != 3) : j.nseg < 2) || j.seg[0].b_kcontig < 2 || !SK_A_PERMUTE))
@@ -893,11 +894,16 @@ struct WkLaunch {
     int njobs;
     int wg_end[SK_MAXJOB];  // prefix of workgroups per job
     int ncw[SK_MAXJOB];     // 16-column tiles per workgroup: 4 or 8
+    int wgh[SK_MAXJOB];     // workgroups per K part of the job (SkJob::ksplit parts follow each other in the grid)
 };
 
 // WAITALL: the job's whole A operand is produced inside the launch (the fused backward tick, wkb_kernel)
 template <int NCW, bool WAITALL = false>
-__device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
+__device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, char* smem) {
+    // K part of a split job (SkJob::ksplit): workgroups [p * wgh, (p + 1) * wgh) take the p-th part of the K range
+    const int nparts = job.ksplit > 1 ? job.ksplit : 1;
+    const int kpart = __builtin_amdgcn_readfirstlane(nparts > 1 ? wg_in / wgh : 0);
+    const int wg = nparts > 1 ? wg_in - kpart * wgh : wg_in;
     constexpr int MB = NCW == 8 ? 4 : 2;  // row blocks per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -916,11 +922,12 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
     const int nseg_main = flagged ? job.nseg - 1 : job.nseg;
     int total = 0;
     for (int q = 0; q < nseg_main; ++q) total += job.seg[q].K / WK_STAGE;
+    total /= nparts;  // (split jobs have one segment whose K is a multiple of nparts stages: wk_build checks)
     struct Cursor { const float* A; const float* B; int lda, ldb, left, seg, k; };
     auto cursor_init = [&](Cursor& c) __attribute__((always_inline)) {
-        c.seg = 0; c.k = 0;
+        c.seg = 0; c.k = kpart * total * WK_STAGE;
         c.A = job.seg[0].A; c.B = job.seg[0].B; c.lda = job.seg[0].lda; c.ldb = job.seg[0].ldb;
-        c.left = job.seg[0].K / WK_STAGE;
+        c.left = nparts > 1 ? total : job.seg[0].K / WK_STAGE;
     };
     auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
         if (c.left > 1) { --c.left; c.k += WK_STAGE; return; }
@@ -1088,13 +1095,13 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg, char* smem) {
             for (int r = 0; r < 4; ++r) {
                 const int m = mb0 + r;
                 if (m >= M || !n_ok) continue;
-                float x = acc[rb][r] + bias;
-                if (job.add) x += job.add[(size_t)m * job.ld_add + n];
+                float x = acc[rb][r] + (kpart ? 0.f : bias);
+                if (job.add && !kpart) x += job.add[(size_t)m * job.ld_add + n];
                 if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
-                float* o = job.out + (size_t)m * job.ldo + n;
-                if (job.accumulate) x += *o;
+                float* o = kpart ? job.o1 + (size_t)m * job.ldo1 + n : job.out + (size_t)m * job.ldo + n;
+                if (job.accumulate && !kpart) x += *o;
                 *o = x;
             }
         }
@@ -1109,8 +1116,8 @@ __global__ __launch_bounds__(SK_THREADS) void wk_kernel(const WkLaunch L) {
         if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
     bx -= (j > 0 ? L.wg_end[j - 1] : 0);
     const SkJob& job = L.job[j];
-    if (L.ncw[j] == 8) wk_body<8>(job, bx, wk_smem);
-    else wk_body<4>(job, bx, wk_smem);
+    if (L.ncw[j] == 8) wk_body<8>(job, bx, L.wgh[j], wk_smem);
+    else wk_body<4>(job, bx, L.wgh[j], wk_smem);
 }
 
 // Heterogeneous variant of wk_kernel: workgroups [0, natt) carry the attention forward step (one batch row each, all
@@ -1133,8 +1140,8 @@ __global__ __launch_bounds__(SK_THREADS) void wka_kernel(const WkLaunch L, const
         if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
     bx -= (j > 0 ? L.wg_end[j - 1] : 0);
     const SkJob& job = L.job[j];
-    if (L.ncw[j] == 8) wk_body<8>(job, bx, wk_smem);
-    else wk_body<4>(job, bx, wk_smem);
+    if (L.ncw[j] == 8) wk_body<8>(job, bx, L.wgh[j], wk_smem);
+    else wk_body<4>(job, bx, L.wgh[j], wk_smem);
 }
 
 // ---- fused backward tick (plans.hip schedule 7, LSTM layers, bf16 operands) ------------------------------------------
@@ -1187,8 +1194,8 @@ __global__ __launch_bounds__(ATTB_THREADS) void wkb_kernel(const WkLaunch L, con
         if (q < L.njobs - 1 && bx >= L.wg_end[q]) j = q + 1;
     bx -= (j > 0 ? L.wg_end[j - 1] : 0);
     const SkJob& job = L.job[j];
-    if (L.ncw[j] == 8) wk_body<8, true>(job, bx, wkb_smem);
-    else wk_body<4, true>(job, bx, wkb_smem);
+    if (L.ncw[j] == 8) wk_body<8, true>(job, bx, L.wgh[j], wkb_smem);
+    else wk_body<4, true>(job, bx, L.wgh[j], wkb_smem);
 }
 
 // Would wk_try_launch take a bf16 launch whose jobs have M rows, ncols output columns in total and K segments of H and E
@@ -1219,9 +1226,11 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
         for (int s = 0; s < j.nseg; ++s)
             if (j.seg[s].K % WK_STAGE) return false;
+        if (j.ksplit > 1 && (j.nseg != 1 || j.epi != SK_EPI_LINEAR || j.act || !j.o1 || j.seg[0].K % (j.ksplit * WK_STAGE)))
+            return false;
         work += (long long)j.N;
     }
-    if (work < 4096 && enabled < 2) return false;
+    if (work < 4096 && enabled < 2 && !Lin.force_wide) return false;
     memset(&W, 0, sizeof(W));
     W.njobs = Lin.njobs;
     int ksum[SK_MAXJOB], tiles[SK_MAXJOB];
@@ -1243,8 +1252,9 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         W.ncw[q] = 4;
         ksum[q] = 0;
         for (int s = 0; s < W.job[q].nseg; ++s) ksum[q] += W.job[q].seg[s].K;
-        units += ceil_div(tiles[q], 4);
-        if (W.job[q].wait_flag && W.job[q].wait_all != 1) { any_flag = true; units_flagged += ceil_div(tiles[q], 4); }
+        const int parts = W.job[q].ksplit > 1 ? W.job[q].ksplit : 1;
+        units += ceil_div(tiles[q], 4) * parts;
+        if (W.job[q].wait_flag && W.job[q].wait_all != 1) { any_flag = true; units_flagged += ceil_div(tiles[q], 4) * parts; }
     }
     // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits (with
     // jobs that wait behind their other segments: until the OTHER jobs fit beside the lead blocks; the waiting ones, at
@@ -1258,14 +1268,15 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         for (int q = 0; q < Lin.njobs; ++q)
             if (W.ncw[q] == 4 && (best < 0 || ksum[q] < ksum[best])) best = q;
         if (best < 0) break;
-        const int gain = ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8);
+        const int gain = (ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8)) * (W.job[best].ksplit > 1 ? W.job[best].ksplit : 1);
         units -= gain;
         if (W.job[best].wait_flag && W.job[best].wait_all != 1) units_flagged -= gain;
         W.ncw[best] = 8;
     }
     t = 0;
     for (int q = 0; q < Lin.njobs; ++q) {
-        t += ceil_div(tiles[q], W.ncw[q]);
+        W.wgh[q] = ceil_div(tiles[q], W.ncw[q]);
+        t += W.wgh[q] * (W.job[q].ksplit > 1 ? W.job[q].ksplit : 1);
         W.wg_end[q] = t;
     }
     return true;
@@ -1472,6 +1483,8 @@ int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
     {
         int rc = 0;
         if (wk_try_launch(Lin, stream, &rc)) return rc;
+        for (int q = 0; q < Lin.njobs; ++q)
+            if (Lin.job[q].ksplit > 1) return PH_ERR_UNSUPPORTED;  // K parts exist in the wide kernel only
     }
     SkLaunch L;
     dim3 grid;

@@ -503,6 +503,12 @@ class Parrot(Brick):
             ws.update(cst=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
                       gate4=[torch.empty(T, B, 4 * H, **f) for _ in range(L)],
                       dcell=[torch.zeros(B, H, **f) for _ in range(L)])
+            if self.compute_bf16:
+                # second accumulators of the backward scan (ParrotDecoderDesc::dh_b ...): the transposed products of a
+                # tick run as two K halves; zero-filled once (the scan stores into every slot it later reads)
+                ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
+                          dhup_b=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
+                          dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f))
         else:
             for n in ('z', 'r', 'rh', 'c'):
                 ws[n] = [torch.empty(T, B, H, **f) for _ in range(L)]
@@ -546,6 +552,9 @@ class Parrot(Brick):
             for n in (('h', 'dh', 'cst', 'gate4', 'dcell') if lstm else ('h', 'dh', 'z', 'r', 'rh', 'c')):
                 getattr(d, n)[l] = ws[n][l].data_ptr()
             d.dhup[l] = ws['dhup'][l].data_ptr() if ws['dhup'][l] is not None else None
+            if 'dh_b' in ws:
+                d.dh_b[l] = ws['dh_b'][l].data_ptr()
+                d.dhup_b[l] = ws['dhup_b'][l].data_ptr() if ws['dhup_b'][l] is not None else None
         tl = self._tiled_weights()
         if tl is not None:
             for l in range(L):
@@ -563,6 +572,8 @@ class Parrot(Brick):
         d.WattT, d.batt, d.ctx = st['dec.WattT'].data_ptr(), st['dec.batt'].data_ptr(), ws['ctx'].data_ptr()
         for n in ('w', 'kappa', 'a', 'b', 'phi', 'dw', 'dw0', 'dkappa', 'dp'):
             setattr(d, n, ws[n].data_ptr())
+        if 'dw_b' in ws:
+            d.dw_b, d.dw0_b = ws['dw_b'].data_ptr(), ws['dw0_b'].data_ptr()
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
@@ -894,6 +905,11 @@ class Parrot(Brick):
                 t_.zero_()
 
         self._scan_bwd_and_weight_grads(ws, save, T, B, before=readout_weight_grads)
+        if 'dh_b' in ws:  # slot 0 (the gradient wrt what entered the window): add the second accumulators' share
+            for l in range(L):
+                ws['dh'][l][0].add_(ws['dh_b'][l][0])
+            ws['dw'][0].add_(ws['dw_b'][0])
+            ws['dw0'][0].add_(ws['dw0_b'][0])
 
         # the rest of the deferred gradients of the scan (biases, per-step additive inputs)
         sg_, sc_ = self.store.storage_grad, self.store.storage

@@ -63,6 +63,10 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
         d.dG[l] = ar.take(f"dG{l}", T * B * gw * f)
         if l < nl - 1:
             d.dhup[l] = ar.take(f"dhup{l}", (T + 1) * B * H * f)
+        if bf16 and cell == 1:  # second accumulators: the backward products run as two K halves
+            d.dh_b[l] = ar.take(f"dh_b{l}", (T + 1) * B * H * f)
+            if l < nl - 1:
+                d.dhup_b[l] = ar.take(f"dhup_b{l}", (T + 1) * B * H * f)
         if l >= 1 or (seq_init >> l) & 1:
             d.seq_g[l] = ar.take(f"seq_g{l}", T * B * gw * f)
         if cell == 0:
@@ -89,6 +93,9 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
     d.phi = ar.take("phi", T * B * U * f)
     d.dw = ar.take("dw", (T + 1) * B * E * f)
     d.dw0 = ar.take("dw0", (T + 1) * B * E * f)
+    if bf16 and cell == 1:
+        d.dw_b = ar.take("dw_b", (T + 1) * B * E * f)
+        d.dw0_b = ar.take("dw0_b", (T + 1) * B * E * f)
     d.dkappa = ar.take("dkappa", B * A * f)
     d.dp = ar.take("dp", T * B * 3 * A * f)
     d.att_sup = ar.take("att_sup", T * B * 2 * 4)
@@ -261,11 +268,16 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         assert n_fwd == T + max(1, nl if nl > 1 else 0)
         recs = _trace(lib, plan, 1)
         bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)}
-        acc = {"dw", "dw0"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
+        acc = {"dw", "dw0", "dw_b", "dw0_b"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
+        acc |= {f"dh_b{l}" for l in range(nl)} | {f"dhup_b{l}" for l in range(nl - 1)}
         n_bwd = _check(recs, ar, bwd_once, acc, T, {})
         assert n_bwd == T + nl - 1  # one launch per tick
         flagged = [r for r in recs if r[2] == 3]
         assert flagged and all(_owner(ar, r[3]).startswith("dG") for r in flagged)
+        # the products really run as two K halves: the second accumulators are written (stored) and read back
+        for name in ["dw0_b"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
+            kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
+            assert 1 in kinds and 0 in kinds, (name, kinds)
     finally:
         lib.parrot_decoder_destroy(plan)
 
