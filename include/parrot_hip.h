@@ -277,9 +277,11 @@ typedef struct ParrotDecoderDesc {
     /* Optional second accumulators of the backward scan (round 4; LSTM layers with bf16 operands): [T+1,B,H] per layer
      * for dh and dhup, [T+1,B,E] for dw and dw0, ZERO-FILLED by the caller once.  With all of them given the transposed
      * products of a backward tick (dP . W^T, K = 4H) are cut into two K halves handled by different workgroups -- a wide
-     * workgroup's time is the time to stream its [B, K] operand -- and the second half's sums are STORED here instead of
-     * being accumulated into dh / dhup / dw / dw0; the state backward and the attention backward of the next tick add
-     * both parts (so does the caller for slot 0).  NULL: one accumulator per gradient, as before. */
+     * workgroup's time is the time to stream its [B, K] operand -- and the second half's sums land here instead of in
+     * dh / dhup / dw / dw0: stored into dh_b and dw0_b (one writer per slot), ADDED into dhup_b and dw_b (every layer above
+     * adds its share: the caller zero-fills these two before every seq_bwd, as it does dhup and dw0); the state backward
+     * and the attention backward of the next tick add both parts (so does the caller for slot 0).  NULL: one accumulator
+     * per gradient, as before. */
     float* dh_b[PARROT_MAX_LAYERS];
     float* dhup_b[PARROT_MAX_LAYERS];
     float* dw_b;

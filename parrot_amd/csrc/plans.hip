@@ -104,7 +104,7 @@ struct Tracer {
         switch (j.epi) {
             case SK_EPI_LINEAR:
                 mat(j.out, j.M, j.N, j.ldo, j.accumulate ? 2 : 1, id);
-                if (j.ksplit > 1) mat(j.o1, j.M, j.N, j.ldo1, 1, id);  // the second K half's sums
+                if (j.ksplit > 1) mat(j.o1, j.M, j.N, j.ldo1, j.ldo2 ? 2 : 1, id);  // the second K half's sums
                 break;
             case SK_EPI_GRU_GATES:
                 mat(j.e0, j.M, H, j.lde0, 0, id); mat(j.o1, j.M, H, j.ldo1, 1, id); mat(j.o2, j.M, H, j.ldo2, 1, id);
@@ -1492,6 +1492,7 @@ struct DecoderPlan : PlanBase {
                         if (bwd_ksplit) {
                             j.ksplit = 2; j.ldo1 = E;
                             j.o1 = (l == 0 ? d.dw0_b + (size_t)t * BE : d.dw_b + (size_t)(t + 1) * BE);
+                            j.ldo2 = l == 0 ? 0 : 1;  // dw_b[t + 1] collects every upper layer's share: added (caller-zeroed)
                         }
                     }
                     for (int p = 0; p < l; ++p) {
@@ -1501,7 +1502,7 @@ struct DecoderPlan : PlanBase {
                         j.seg[0] = rseg(dP, l, 0, H + E + p * H, 4 * H);
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
-                        if (bwd_ksplit) { j.ksplit = 2; j.o1 = d.dhup_b[p] + (t + 1) * BH; j.ldo1 = H; }
+                        if (bwd_ksplit) { j.ksplit = 2; j.o1 = d.dhup_b[p] + (t + 1) * BH; j.ldo1 = H; j.ldo2 = 1; }  // (added: all layers above p)
                     }
                     if (bwd_fused)  // the products of a layer read what its chain's rows publish inside the launch
                         for (int q2 = first; q2 < nl; ++q2) {

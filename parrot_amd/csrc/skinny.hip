@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
                 float* o = kpart ? job.o1 + (size_t)m * job.ldo1 + n : job.out + (size_t)m * job.ldo + n;
-                if (job.accumulate && !kpart) x += *o;
+                if (kpart ? job.ldo2 != 0 : job.accumulate != 0) x += *o;  // (split LINEAR jobs: ldo2 = accumulate into o1)
                 *o = x;
             }
         }

@@ -900,7 +900,7 @@ class Parrot(Brick):
         ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
         ws['dw0'].zero_()
-        for t_ in ws['dhup'] + ws.get('dcell', []):
+        for t_ in ws['dhup'] + ws.get('dcell', []) + ws.get('dhup_b', []) + ([ws['dw_b']] if 'dw_b' in ws else []):
             if t_ is not None:
                 t_.zero_()
 

@@ -277,7 +277,7 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         # the products really run as two K halves: the second accumulators are written (stored) and read back
         for name in ["dw0_b"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
             kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
-            assert 1 in kinds and 0 in kinds, (name, kinds)
+            assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
     finally:
         lib.parrot_decoder_destroy(plan)
 
