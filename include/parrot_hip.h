@@ -286,6 +286,14 @@ typedef struct ParrotDecoderDesc {
     float* dhup_b[PARROT_MAX_LAYERS];
     float* dw_b;
     float* dw0_b;
+    /* Third accumulators (same shapes and rules as dhup_b / dw_b / dw0_b; dw0_c is stored, the other two are added into
+     * and zero-filled by the caller before every seq_bwd).  With all second AND third accumulators given, a 2-layer f32
+     * GRU decoder runs the K-balanced backward tick (plans.hip bwd8): every K = 2H product of a tick is cut into its
+     * update-gate and reset-gate halves writing separate buffers, layer 1 runs two ticks ahead of layer 0, and the
+     * downward products of layer 1 ride in the NEXT tick's attention launch beside the attention backward blocks. */
+    float* dhup_c[PARROT_MAX_LAYERS];
+    float* dw_c;
+    float* dw0_c;
 } ParrotDecoderDesc;
 
 /* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify for the persistent

@@ -4,6 +4,9 @@
 #pragma once
 #include "attention.h"
 #include "att_fwd_body.h"
+#include "elementwise.h"
+
+#include <type_traits>
 
 constexpr int ATTB_THREADS = 1024;  // backward: one workgroup per batch row, 16 waves
 
@@ -64,6 +67,8 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
             v += g.dw2[(size_t)b * g.lddw + e];
             if (g.dw3) v += g.dw3[(size_t)b * g.lddw + e];
             if (g.dw4) v += g.dw4[(size_t)b * g.lddw + e];
+            if (g.dw5) v += g.dw5[(size_t)b * g.lddw + e];
+            if (g.dw6) v += g.dw6[(size_t)b * g.lddw + e];
             g.dw[(size_t)b * g.lddw + e] = v;  // total, needed later for the deferred d(ctx) GEMM
         }
         s_dw[e] = v;
@@ -211,3 +216,62 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
     return false;
 }
 
+// One launch for the attention backward of layer 0's step AND the elementwise GRU state backward of every layer
+// active in this tick of the backward wavefront (plans.hip): blocks [0, att_rows) take one attention row each
+// and then, with the same threads (thread k updated dh1[b][k] itself), layer 0's state backward for that row;
+// the remaining blocks take one (chain, row) pair of the other layers.  Saves a kernel boundary per step.
+__device__ __forceinline__ void state_bwd_row(const GruStateBwdChain& c, int m, int H, int tid, int nthr) {
+    gru_state_bwd_row(c, m, H, tid, nthr);
+}
+__device__ __forceinline__ void state_bwd_row(const LstmStateBwdChain& c, int m, int H, int tid, int nthr) {
+    lstm_state_bwd_row(c, m, H, tid, nthr);
+}
+
+template <class SA>
+__device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const SA& sa, int att_rows, int l0_chain, int bx,
+                                                    float* sm) {
+    if (bx < att_rows) {
+        if constexpr (std::is_same<SA, GruStateBwdArgs>::value) {
+            // Layer 0's state backward needs nothing from the attention backward except dh1 itself: its operands (and
+            // the old dh1 the attention adds to) are requested up front, so that after the attention's chain of
+            // dependent phases only arithmetic and three stores remain (two memory round trips less per tick).
+            const int t = threadIdx.x, H = sa.H;
+            if (l0_chain >= 0 && H <= ATTB_THREADS && 3 * g.A <= 32) {
+                const GruStateBwdChain& c = sa.chain[l0_chain];
+                const size_t i = (size_t)bx * H + t;
+                float dh = 0.f, dh2 = 0.f, hp = 0.f, z = 0.f, cc = 0.f, dhp = 0.f, mk = 1.f;
+                if (t < H) {
+                    dh = c.dh[i];  // (= g.dh1[b][t]: the attention backward's accumulation target)
+                    if (c.dh2) dh2 = c.dh2[i];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (c.dhx[q]) dh2 += c.dhx[q][i];  // (further shares from above: added to the same late term)
+                    hp = c.hprev[i]; z = c.z[i]; cc = c.c[i]; dhp = c.dhprev[i];
+                    if (c.mask) mk = c.mask[bx];
+                }
+                const bool got = att_bwd_row(g, bx, sm, &dh);
+                if (got) {
+                    if (t < H) {
+                        dh += dh2;  // same order as gru_state_bwd_row: (dh1 + attention share) + share from above
+                        float dhp_direct = 0.f;
+                        if (c.mask) { dhp_direct = dh * (1.f - mk); dh *= mk; }
+                        c.dC[i] = dh * z * (1.f - cc * cc);
+                        c.dG[(size_t)bx * 2 * H + t] = dh * (cc - hp) * z * (1.f - z);
+                        c.dhprev[i] = dhp + (dh * (1.f - z) + dhp_direct);
+                    }
+                    return;
+                }
+                state_bwd_row(c, bx, H, t, ATTB_THREADS);
+                return;
+            }
+        }
+        att_bwd_row(g, bx, sm);
+        if (l0_chain >= 0) state_bwd_row(sa.chain[l0_chain], bx, sa.H, threadIdx.x, ATTB_THREADS);
+        return;
+    }
+    const int idx = bx - att_rows;
+    int ch = idx / sa.B;
+    const int m = idx % sa.B;
+    if (att_rows > 0 && l0_chain >= 0 && ch >= l0_chain) ++ch;  // skip the chain fused above
+    if (ch < sa.nchain) state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
+}

@@ -22,8 +22,10 @@ struct AttFwdArgs {
 struct AttBwdArgs {
     float* dw; int lddw;           // [B,E] gradient wrt w_t (in; the total is written back when dw2 != null)
     const float* dw2;              // [B,E] optional second share of the gradient (layer-0 path) or null
-    const float* dw3;              // [B,E] optional further shares (the second K halves of the split backward products)
+    const float* dw3;              // [B,E] optional further shares (the K parts of the split backward products) or null
     const float* dw4;
+    const float* dw5;
+    const float* dw6;
     const float* ctx;              // [B,U,E]
     const float* a; const float* b; const float* kappa; const float* kappa_prev;  // [B,A]
     const float* WattT;            // [3A,H]

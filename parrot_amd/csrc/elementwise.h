@@ -5,6 +5,7 @@
 struct GruStateBwdChain {
     const float* dh;     // [B,H] gradient wrt h_t
     const float* dh2;    // [B,H] optional second share of it (from the layers above) or null
+    const float* dhx[3] = {nullptr, nullptr, nullptr};  // [B,H] optional further shares (K-split backward products, plans.hip bwd8)
     const float* hprev;  // [B,H]
     const float* z;      // [B,H]
     const float* c;      // [B,H]
@@ -25,6 +26,9 @@ __device__ __forceinline__ void gru_state_bwd_row(const GruStateBwdChain& c, int
         const size_t i = (size_t)m * H + k;
         float dh = c.dh[i];
         if (c.dh2) dh += c.dh2[i];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (c.dhx[q]) dh += c.dhx[q][i];
         const float hp = c.hprev[i];
         float dhp_direct = 0.f;
         if (c.mask) {
@@ -55,8 +59,8 @@ int gmm_sample_launch(const float* mu, const float* sig_hat, const float* co_hat
 struct LstmStateBwdChain {
     const float* dh;      // [B,H] gradient wrt s_t
     const float* dh2;     // [B,H] optional second share of it or null
-    const float* dh3;     // [B,H] optional further shares (second K halves of the split backward products) or null
-    const float* dh4;
+    const float* dh3 = nullptr;  // [B,H] optional further shares (second K halves of the split backward products) or null
+    const float* dh4 = nullptr;
     float* dc;            // [B,H] carry: in gradient wrt c_t (from step t+1), out gradient wrt c_{t-1}
     const float* gates;   // [B,4H] saved activations i|f|o|g
     const float* c_prev;  // [B,H]

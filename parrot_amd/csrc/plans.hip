@@ -135,12 +135,14 @@ struct Tracer {
         jobs.push_back({launch, id, g.B, g.E, g.H, -2});
         mat(g.dw, g.B, g.E, g.lddw, g.dw2 ? 2 : 0, id); mat(g.dw2, g.B, g.E, g.lddw, 0, id);
         mat(g.dw3, g.B, g.E, g.lddw, 0, id); mat(g.dw4, g.B, g.E, g.lddw, 0, id);
+        mat(g.dw5, g.B, g.E, g.lddw, 0, id); mat(g.dw6, g.B, g.E, g.lddw, 0, id);
         mat(g.a, g.B, g.A, g.A, 0, id); mat(g.b, g.B, g.A, g.A, 0, id); mat(g.kappa, g.B, g.A, g.A, 0, id);
         mat(g.kappa_prev, g.B, g.A, g.A, 0, id); mat(g.sup, g.B, 2, 2, 0, id);
         mat(g.dkappa, g.B, g.A, g.A, 2, id); mat(g.dp_out, g.B, 3 * g.A, 3 * g.A, 1, id); mat(g.dh1, g.B, g.H, g.lddh, 2, id);
     }
     void chain(const GruStateBwdChain& c, int B, int H, int id) {
         mat(c.dh, B, H, H, 0, id); mat(c.dh2, B, H, H, 0, id); mat(c.hprev, B, H, H, 0, id); mat(c.z, B, H, H, 0, id);
+        for (int q = 0; q < 3; ++q) mat(c.dhx[q], B, H, H, 0, id);
         mat(c.c, B, H, H, 0, id); mat(c.mask, B, 1, 1, 0, id);
         mat(c.dC, B, H, H, 1, id); mat(c.dG, B, H, 2 * H, 1, id); mat(c.dhprev, B, H, H, 2, id);
     }
@@ -209,6 +211,23 @@ int traced_att_state_bwd_launch(const AttBwdArgs* g, const SA& sa, int l0_chain,
     return att_state_bwd_launch(g, sa, l0_chain, s);
 }
 
+// Attention backward (or null) + GRU state backward of all chains + step-GEMM jobs nothing in the launch feeds, in ONE
+// heterogeneous launch (skinny.hip skb_kernel): the attention launch of the K-balanced backward tick (bwd8).
+int traced_bwd_hetero_launch(const AttBwdArgs* g, const GruStateBwdArgs& sa, int l0_chain, const SkJob* jobs, int n,
+                             hipStream_t s) {
+    SkLaunch L;
+    PL_TRY(sk_make_launch(L, jobs, n));
+    if (g_tracer) {
+        g_tracer->begin();
+        if (g) g_tracer->att_bwd(*g, TRACE_JOB_ATT);
+        for (int q = 0; q < sa.nchain; ++q)
+            g_tracer->chain(sa.chain[q], sa.B, sa.H, (g && q == l0_chain) ? (int)TRACE_JOB_ATT : TRACE_JOB_CHAIN + q);
+        for (int q = 0; q < n; ++q) g_tracer->sk_job(jobs[q], q);
+        return 0;
+    }
+    return sk_launch_bwd_hetero(L, g, sa, l0_chain, s);
+}
+
 // The fused backward tick of schedule 7 (skinny.hip wkb_kernel): attention backward (or null) + the LSTM state backward of
 // all chains as row blocks at the head of ONE launch, the transposed products `jobs` behind them, each waiting (wait_all)
 // on the flag of the chain that writes its dP operand.  PH_ERR_UNSUPPORTED: the wide kernel does not take these jobs.
@@ -262,6 +281,7 @@ void take_rows(GruStateBwdArgs& g, const Strand& s) {
     for (int q = 0; q < g.nchain; ++q) {
         GruStateBwdChain& c = g.chain[q];
         shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.hprev, s.b0, g.H); shift(c.z, s.b0, g.H);
+        for (int q2 = 0; q2 < 3; ++q2) shift(c.dhx[q2], s.b0, g.H);
         shift(c.c, s.b0, g.H); shift(c.mask, s.b0, 1); shift(c.dC, s.b0, g.H); shift(c.dG, s.b0, 2 * g.H);
         shift(c.dhprev, s.b0, g.H);
     }
@@ -782,6 +802,7 @@ struct DecoderPlan : PlanBase {
         if (which == 0 && persist_ok) return pm_launch(pm_prog, s);  // schedule 4: the persistent phase machine
         if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
+        if (which == 1 && bwd_hetero && (schedule == 0 || schedule == 5 || schedule == 6)) return bwd8(s);
         if (schedule == 5) return which == 0 ? fwd5(s) : bwd(s);
         if (schedule == 6) return which == 0 ? fwd6(s) : bwd(s);
         if (schedule == 7) return which == 0 ? fwd7(s) : bwd(s);
@@ -1617,6 +1638,124 @@ struct DecoderPlan : PlanBase {
             PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, ga, att_on ? ga.nchain - 1 : -1, st));
             PL_TRY(launch_jobs(jx, nx, st, full_wgs));
             PL_TRY(launch_jobs(jy, ny, st, full_wgs));
+        }
+        return 0;
+    }
+
+    // ---- bwd8: the K-balanced backward tick (2-layer f32 GRU decoders; round 4) ---------------------------------------
+    // The tick of bwd() is three dependent launches: attention + state backward (11.1 us at cfg2: a chain of dependent
+    // round trips on 64-128 CUs, the rest idle), X (d(rh) and the dC products, K = H: 9.5 us) and Y (the dG products,
+    // K = 2H: 14.3 us -- a launch costs ~4.7 us + ~4.8 us per 1024 of its LONGEST K, tools/tick_model.py).  A tick is 672
+    // units of 32 x 32 x K1024 work, 2.6 rounds of 256 CUs, so three launches are the minimum -- but they need not be
+    // one idle launch, one short and one long.  Here
+    //   * every K = 2H product is cut into its update-gate (z) and reset-gate (r) halves, K = H each, writing SEPARATE
+    //     buffers that the consumer adds (second / third accumulators of ParrotDecoderDesc): dG_z exists after the state
+    //     backward, dG_r only after X, so the z halves move up a launch;
+    //   * layer 1 runs TWO ticks ahead of layer 0, so its downward products (into dhup_0 and dw) have a tick of slack;
+    //   * those with dG operands ride in the NEXT tick's attention launch as step-GEMM workgroups beside the attention
+    //     backward blocks (skinny.hip skb_kernel), the dC ones in Y.
+    // Per tick (L = 2, cfg2): S' = 64 attention rows + 64 state rows + 160 GEMM workgroups, X = 256, Y = 256, every K = H:
+    // predicted 12.1 + 9.5 + 9.5 = 31.1 us against 34.9 (profiles/r04_tick_model_whatif.txt).
+    bool bwd_hetero = false;
+    int lag8(int l) const { return 2 * (d.L - 1 - l); }
+    int nticks8() const { return d.T + 2 * (d.L - 1); }
+    // backward product dP[:, k0 : k0 + K] . W[r0 : r0 + N, k0 : k0 + K]^T over the fragment-major reverse copies
+    SkSeg rseg_k(const float* A, int l, int g, int r0, int ldw, int k0, int K) const {
+        const float* Wt = g == 0 ? d.Wg_r[l] : d.Wc_r[l];
+        return sk_seg(A + k0, ldw, Wt + ((size_t)(r0 >> 4) * (ldw >> 4) + (k0 >> 4)) * 256, (ldw >> 4) * 256, K, 2);
+    }
+    static void lin_job(SkJob& j, const SkSeg& sg, int M, int N, int H, float* out, int ldo, int accumulate) {
+        sk_job_init(j);
+        j.nseg = 1;
+        j.seg[0] = sg;
+        j.M = M; j.N = N; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = accumulate;
+        j.out = out; j.ldo = ldo;
+    }
+    int bwd8(hipStream_t st) {
+        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
+        const int H = d.H, E = d.E, Q = nticks8();
+        for (int q = 0; q < Q; ++q) {
+            int tl[PARROT_MAX_LAYERS];
+            for (int l = 0; l < d.L; ++l) tl[l] = d.T - 1 - (q - lag8(l));
+            const int t0 = tl[0];
+            const bool att_on = t0 >= 0 && t0 < d.T;
+            AttBwdArgs g{};
+            if (att_on) {
+                g = att_bwd_args(t0);
+                g.dw3 = d.dw0_b + (size_t)(t0 + 1) * BE; g.dw4 = d.dw0_c + (size_t)(t0 + 1) * BE;
+                g.dw5 = d.dw_b + (size_t)(t0 + 1) * BE;  g.dw6 = d.dw_c + (size_t)(t0 + 1) * BE;
+            }
+            // ---- S': state backward of every active layer (+ attention), and the deferred downward products
+            GruStateBwdArgs ga;
+            ga.nchain = 0; ga.B = d.B; ga.H = H;
+            for (int l = d.L - 1; l >= 0; --l) {
+                const int t = tl[l];
+                if (t < 0 || t >= d.T) continue;
+                GruStateBwdChain& c = ga.chain[ga.nchain++];
+                c.dh = d.dh[l] + (t + 1) * BH;
+                c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
+                c.dhx[0] = d.dh_b[l] + (t + 1) * BH;
+                c.dhx[1] = (l + 1 < d.L) ? d.dhup_b[l] + (t + 1) * BH : nullptr;
+                c.dhx[2] = (l + 1 < d.L) ? d.dhup_c[l] + (t + 1) * BH : nullptr;
+                c.hprev = d.h[l] + t * BH;
+                c.z = d.z[l] + t * BH;
+                c.c = d.c[l] + t * BH;
+                c.mask = nullptr;
+                c.dC = d.dC[l] + t * BH;
+                c.dG = d.dG[l] + t * 2 * BH;
+                c.dhprev = d.dh[l] + t * BH;
+            }
+            SkJob js[SK_MAXJOB], jx[SK_MAXJOB], jy[SK_MAXJOB];
+            int ns = 0, nx = 0, ny = 0;
+            for (int l = d.L - 1; l >= 1; --l) {  // the dG halves of the step layer l handled one tick ago
+                const int s = tl[l] + 1;
+                if (s < 0 || s >= d.T) continue;
+                const float* dG = d.dG[l] + (size_t)s * 2 * BH;
+                for (int p = 0; p < l; ++p) {
+                    lin_job(js[ns++], rseg_k(dG, l, 0, H + E + p * H, 2 * H, 0, H), d.B, H, H, d.dhup_b[p] + (s + 1) * BH, H, 1);
+                    lin_job(js[ns++], rseg_k(dG, l, 0, H + E + p * H, 2 * H, H, H), d.B, H, H, d.dhup_c[p] + (s + 1) * BH, H, 1);
+                }
+                lin_job(js[ns++], rseg_k(dG, l, 0, H, 2 * H, 0, H), d.B, E, H, d.dw_b + (size_t)(s + 1) * BE, E, 1);
+                lin_job(js[ns++], rseg_k(dG, l, 0, H, 2 * H, H, H), d.B, E, H, d.dw_c + (size_t)(s + 1) * BE, E, 1);
+            }
+            // ---- X: d(r*h) (epilogue: dG_r, dh_prev += d(rh) * r) and the update-gate half of dG -> dh_prev (own buffer)
+            // ---- Y: the reset-gate half of dG -> dh_prev, layer 0's context shares, the upper layers' dC shares downward
+            for (int l = d.L - 1; l >= 0; --l) {
+                const int t = tl[l];
+                if (t < 0 || t >= d.T) continue;
+                const float* dG = d.dG[l] + (size_t)t * 2 * BH;
+                const float* dC = d.dC[l] + t * BH;
+                SkJob& x = jx[nx++];
+                sk_job_init(x);
+                x.nseg = 1;
+                x.seg[0] = rseg(dC, l, 1, 0, H);
+                x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
+                x.e0 = d.h[l] + t * BH; x.lde0 = H;
+                x.e1 = d.r[l] + t * BH; x.lde1 = H;
+                x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
+                x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
+                lin_job(jx[nx++], rseg_k(dG, l, 0, 0, 2 * H, 0, H), d.B, H, H, d.dh_b[l] + t * BH, H, 0);
+                lin_job(jy[ny++], rseg_k(dG, l, 0, 0, 2 * H, H, H), d.B, H, H, d.dh[l] + t * BH, H, 1);
+                if (l == 0) {
+                    lin_job(jy[ny++], rseg(dC, 0, 1, H, H), d.B, E, H, d.dw0 + (size_t)t * BE, E, 1);
+                    lin_job(jy[ny++], rseg_k(dG, 0, 0, H, 2 * H, 0, H), d.B, E, H, d.dw0_b + (size_t)t * BE, E, 0);
+                    lin_job(jy[ny++], rseg_k(dG, 0, 0, H, 2 * H, H, H), d.B, E, H, d.dw0_c + (size_t)t * BE, E, 0);
+                } else {
+                    lin_job(jy[ny++], rseg(dC, l, 1, H, H), d.B, E, H, d.dw + (size_t)(t + 1) * BE, E, 1);
+                    for (int p = 0; p < l; ++p)
+                        lin_job(jy[ny++], rseg(dC, l, 1, H + E + p * H, H), d.B, H, H, d.dhup[p] + (t + 1) * BH, H, 1);
+                }
+            }
+            if (ns > SK_MAXJOB || nx > SK_MAXJOB || ny > SK_MAXJOB) return PARROT_ERR_BADARG;
+            if (ga.nchain > 0) {
+                const int l0c = att_on ? ga.nchain - 1 : -1;
+                if (ns > 0) PL_TRY(traced_bwd_hetero_launch(att_on ? &g : nullptr, ga, l0c, js, ns, st));
+                else PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, ga, l0c, st));
+            } else if (ns > 0) {
+                PL_TRY(launch_jobs(js, ns, st, full_wgs));
+            }
+            if (nx > 0) PL_TRY(launch_jobs(jx, nx, st, full_wgs));
+            if (ny > 0) PL_TRY(launch_jobs(jy, ny, st, full_wgs));
         }
         return 0;
     }
@@ -2771,6 +2910,15 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     p->setup_strands();
+    {   // the K-balanced backward tick (bwd8): 2-layer f32 GRU decoders with fragment-major weights and all accumulators
+        const char* e = getenv("PARROT_BWD_HETERO");
+        bool ok = desc->cell == 0 && desc->L == 2 && !desc->bf16 && !desc->layer_norm && p->tiled && desc->B <= 64 &&
+                  p->nstrands == 1 && p->qpart == 0 && desc->dw_b && desc->dw_c && desc->dw0_b && desc->dw0_c &&
+                  desc->dhup_b[0] && desc->dhup_c[0] && (e ? atoi(e) != 0 : true);
+        for (int l = 0; l < desc->L; ++l)
+            if (!desc->dh_b[l]) ok = false;
+        p->bwd_hetero = ok;
+    }
     if (p->nstrands > 1) p->bwd_ksplit = false;  // (row strands shift every per-row pointer: not wired for the second accumulators)
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule >= 2 && p->schedule != 7;

@@ -84,6 +84,10 @@ struct AttFwdArgs;
 // The attention forward step and the jobs of L in ONE launch (attention workgroups first, see ska_kernel).
 int sk_launch_att(const SkLaunch& L, const AttFwdArgs& att, hipStream_t stream);
 struct AttBwdArgs;
+struct GruStateBwdArgs;
+// Attention backward (or null) + the GRU state backward of all chains as row blocks + the jobs of L in ONE launch
+// (skinny.hip skb_kernel; the jobs must not depend on the row blocks): plans.hip bwd8.
+int sk_launch_bwd_hetero(const SkLaunch& L, const AttBwdArgs* att, const GruStateBwdArgs& sa, int l0_chain, hipStream_t stream);
 struct LstmStateBwdArgs;
 // The fused backward tick of LSTM layers with bf16 operands (plans.hip schedule 7): attention backward (or null) + the
 // state backward of every chain as 1024-thread row blocks at the head of the grid, each chain publishing its dP rows

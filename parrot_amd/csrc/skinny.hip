@@ -661,6 +661,37 @@ __global__ __launch_bounds__(SK_THREADS, 4) void ska_kernel(const SkLaunch L, co
     else sk_body<MB, 1, false>(job, tile0, red);
 }
 
+// Heterogeneous BACKWARD launch (plans.hip bwd8, GRU layers): the attention backward + state backward row blocks of
+// att_state_bwd_kernel (1024 threads) lead the grid, the other workgroups are step-GEMM workgroups as in sk_kernel on
+// eight of the block's sixteen waves (the others exit at once).  The row blocks are a chain of dependent round trips on
+// 64-128 CUs; the GEMM jobs riding here are products nothing in this launch depends on (the downward products of the
+// upper layers' previous tick), so the idle CUs of that chain do work that used to lengthen the next two launches.
+template <int MB, int NB>
+__global__ __launch_bounds__(ATTB_THREADS) void skb_kernel(const SkLaunch L, const AttBwdArgs g, const GruStateBwdArgs sa,
+                                                           const int att_rows, const int l0_chain, const int nlead,
+                                                           const int nlead_x) {
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    int bx = blockIdx.x;
+    if (bx < nlead_x) {
+        const int id = blockIdx.y * nlead_x + bx;
+        if (id >= nlead) return;
+        att_state_bwd_block(g, sa, att_rows, l0_chain, id, reinterpret_cast<float*>(sk_smem));
+        return;
+    }
+    if (threadIdx.x >= SK_THREADS) return;
+    bx -= nlead_x;
+    f32x4* red = reinterpret_cast<f32x4*>(sk_smem);
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < SK_MAXJOB - 1; ++q)
+        if (q < L.njobs - 1 && bx >= L.tile_end[q]) j = q + 1;
+    bx -= (j > 0 ? L.tile_end[j - 1] : 0);
+    const SkJob& job = L.job[j];
+    const int tile0 = bx * NB;
+    if (NB > 1 || job.aligned) sk_body<MB, NB, true>(job, tile0, red);
+    else sk_body<MB, 1, false>(job, tile0, red);
+}
+
 namespace {
 __global__ __launch_bounds__(256) void sk_zero_words_kernel(unsigned* p, int n) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0u;
@@ -1596,6 +1627,77 @@ int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream
         case 32: ska_dispatch<3, 2>(L, g, natt_x, grid, lds, stream); break;
         case 41: ska_dispatch<4, 1>(L, g, natt_x, grid, lds, stream); break;
         default: ska_dispatch<4, 2>(L, g, natt_x, grid, lds, stream); break;
+    }
+    return (int)hipGetLastError();
+}
+
+template <int MB, int NB>
+static void skb_dispatch(const SkLaunch& L, const AttBwdArgs& g, const GruStateBwdArgs& sa, int att_rows, int l0_chain,
+                         int nlead, int nlead_x, dim3 grid, size_t lds, hipStream_t stream) {
+    static bool allowed = false;
+    if (!allowed) {
+        (void)hipFuncSetAttribute((const void*)skb_kernel<MB, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        allowed = true;
+    }
+    if (g_prof.on) {
+        SkProfRec r;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        sk_account(L, r.flops, r.bytes);
+        hipExtLaunchKernelGGL((skb_kernel<MB, NB>), grid, dim3(ATTB_THREADS), lds, stream, r.e0, r.e1, 0, L, g, sa, att_rows,
+                              l0_chain, nlead, nlead_x);
+        g_prof.recs.push_back(r);
+    } else {
+        hipLaunchKernelGGL((skb_kernel<MB, NB>), grid, dim3(ATTB_THREADS), lds, stream, L, g, sa, att_rows, l0_chain, nlead,
+                           nlead_x);
+    }
+}
+
+// Attention backward (or null) + GRU state backward of all chains + the step-GEMM jobs of L in ONE launch (skb_kernel).
+int sk_launch_bwd_hetero(const SkLaunch& Lin, const AttBwdArgs* att, const GruStateBwdArgs& sa, int l0_chain,
+                         hipStream_t stream) {
+    static_assert(sizeof(SkLaunch) + sizeof(AttBwdArgs) + sizeof(GruStateBwdArgs) + 32 <= 4096, "kernel arguments of skb_kernel");
+    if (sa.nchain < 1 || sa.nchain > 4 || Lin.njobs < 1) return PH_ERR_BADARG;
+    for (int q = 0; q < Lin.njobs; ++q)
+        if (Lin.job[q].wait_flag || Lin.job[q].ksplit > 1) return PH_ERR_BADARG;
+    AttBwdArgs g{};
+    int att_rows = 0;
+    size_t alds = 0;
+    if (att) {
+        g = *att;
+        if (g.A < 1 || g.A > ATT_MAXA || g.B < 1 || g.U < 1 || g.E < 1 || g.B != sa.B || l0_chain < 0 || l0_chain >= sa.nchain)
+            return PH_ERR_BADARG;
+        alds = att_bwd_lds(g.U, g.E);
+        att_rows = g.B;
+    } else {
+        l0_chain = -1;
+    }
+    const int nlead = att_rows + (sa.nchain - (att ? 1 : 0)) * sa.B;
+    SkLaunch L;
+    dim3 grid;
+    size_t lds;
+    int mbnb;
+    sk_prepare(Lin, L, grid, lds, mbnb);
+    if (L.zmode) {  // this kernel always walks the prefix table
+        const int per = (int)grid.x;
+        for (int q = 0; q < L.njobs; ++q) L.tile_end[q] = per * (q + 1);
+        grid.x = (unsigned)(per * L.njobs);
+        grid.z = 1;
+        L.zmode = 0;
+    }
+    const int nlead_x = ceil_div(nlead, (int)grid.y);
+    grid.x += (unsigned)nlead_x;
+    if (alds > lds) lds = alds;
+    if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
+    switch (mbnb) {
+        case 11: skb_dispatch<1, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 12: skb_dispatch<1, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 21: skb_dispatch<2, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 22: skb_dispatch<2, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 31: skb_dispatch<3, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 32: skb_dispatch<3, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 41: skb_dispatch<4, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        default: skb_dispatch<4, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
     }
     return (int)hipGetLastError();
 }

@@ -518,6 +518,14 @@ class Parrot(Brick):
             # layers >= 2 always get the buffer: the plan batches the lower layers' projections into it
             ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker or l >= 2)
                                 else None for l in range(1, L + 1)]
+        if (not lstm and L == 2 and not self.compute_bf16 and not self.layer_norm
+                and os.environ.get('PARROT_BWD_HETERO', '1') != '0'):
+            # second / third accumulators of the K-balanced backward tick (ParrotDecoderDesc::dh_b ... dw0_c, plans.hip bwd8)
+            ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
+                      dhup_b=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
+                      dhup_c=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
+                      dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f),
+                      dw_c=torch.zeros(T + 1, B, E, **f), dw0_c=torch.zeros(T + 1, B, E, **f))
         ln = self.layer_norm and L >= 2
         if ln:
             # (l, j) pairs, 0-based, j < l: normalised projections of h_j into layer l and their row std
@@ -555,6 +563,8 @@ class Parrot(Brick):
             if 'dh_b' in ws:
                 d.dh_b[l] = ws['dh_b'][l].data_ptr()
                 d.dhup_b[l] = ws['dhup_b'][l].data_ptr() if ws['dhup_b'][l] is not None else None
+                if 'dhup_c' in ws:
+                    d.dhup_c[l] = ws['dhup_c'][l].data_ptr() if ws['dhup_c'][l] is not None else None
         tl = self._tiled_weights()
         if tl is not None:
             for l in range(L):
@@ -574,6 +584,8 @@ class Parrot(Brick):
             setattr(d, n, ws[n].data_ptr())
         if 'dw_b' in ws:
             d.dw_b, d.dw0_b = ws['dw_b'].data_ptr(), ws['dw0_b'].data_ptr()
+        if 'dw_c' in ws:
+            d.dw_c, d.dw0_c = ws['dw_c'].data_ptr(), ws['dw0_c'].data_ptr()
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
@@ -900,7 +912,8 @@ class Parrot(Brick):
         ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
         ws['dw0'].zero_()
-        for t_ in ws['dhup'] + ws.get('dcell', []) + ws.get('dhup_b', []) + ([ws['dw_b']] if 'dw_b' in ws else []):
+        for t_ in (ws['dhup'] + ws.get('dcell', []) + ws.get('dhup_b', []) + ws.get('dhup_c', []) +
+                   [ws[n] for n in ('dw_b', 'dw_c') if n in ws]):
             if t_ is not None:
                 t_.zero_()
 
@@ -910,6 +923,9 @@ class Parrot(Brick):
                 ws['dh'][l][0].add_(ws['dh_b'][l][0])
             ws['dw'][0].add_(ws['dw_b'][0])
             ws['dw0'][0].add_(ws['dw0_b'][0])
+            if 'dw0_c' in ws:
+                ws['dw'][0].add_(ws['dw_c'][0])
+                ws['dw0'][0].add_(ws['dw0_c'][0])
 
         # the rest of the deferred gradients of the scan (biases, per-step additive inputs)
         sg_, sc_ = self.store.storage_grad, self.store.storage

@@ -39,7 +39,7 @@ class _Arena:
         return lo
 
 
-def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, E=16, A=4, U=7, bf16=0):
+def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, E=16, A=4, U=7, bf16=0, hetero=False):
     if sched is None:
         monkeypatch.delenv("PARROT_SCHEDULE", raising=False)
     else:
@@ -63,10 +63,12 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
         d.dG[l] = ar.take(f"dG{l}", T * B * gw * f)
         if l < nl - 1:
             d.dhup[l] = ar.take(f"dhup{l}", (T + 1) * B * H * f)
-        if bf16 and cell == 1:  # second accumulators: the backward products run as two K halves
+        if (bf16 and cell == 1) or hetero:  # second (and third) accumulators: the backward products run as K parts
             d.dh_b[l] = ar.take(f"dh_b{l}", (T + 1) * B * H * f)
             if l < nl - 1:
                 d.dhup_b[l] = ar.take(f"dhup_b{l}", (T + 1) * B * H * f)
+                if hetero:
+                    d.dhup_c[l] = ar.take(f"dhup_c{l}", (T + 1) * B * H * f)
         if l >= 1 or (seq_init >> l) & 1:
             d.seq_g[l] = ar.take(f"seq_g{l}", T * B * gw * f)
         if cell == 0:
@@ -93,9 +95,12 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
     d.phi = ar.take("phi", T * B * U * f)
     d.dw = ar.take("dw", (T + 1) * B * E * f)
     d.dw0 = ar.take("dw0", (T + 1) * B * E * f)
-    if bf16 and cell == 1:
+    if (bf16 and cell == 1) or hetero:
         d.dw_b = ar.take("dw_b", (T + 1) * B * E * f)
         d.dw0_b = ar.take("dw0_b", (T + 1) * B * E * f)
+        if hetero:
+            d.dw_c = ar.take("dw_c", (T + 1) * B * E * f)
+            d.dw0_c = ar.take("dw0_c", (T + 1) * B * E * f)
     d.dkappa = ar.take("dkappa", B * A * f)
     d.dp = ar.take("dp", T * B * 3 * A * f)
     d.att_sup = ar.take("att_sup", T * B * 2 * 4)
@@ -278,6 +283,44 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         for name in ["dw0_b"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
             kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
             assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
+    finally:
+        lib.parrot_decoder_destroy(plan)
+
+
+@pytest.mark.parametrize("sched", [5, 0])
+def test_k_balanced_backward_tick_keeps_the_scan_orderings(monkeypatch, sched):
+    """bwd8 (2-layer f32 GRU decoders with all accumulators given): every K = 2H product of a backward tick in two K = H
+    halves with their own buffers, layer 1 two ticks ahead of layer 0, its dG-fed downward products in the NEXT tick's
+    heterogeneous attention launch.  Same ordering rules as every other schedule; plus: three launches per tick, no job
+    walks more than K = H, and the attention launch carries step-GEMM jobs."""
+    L, lib = _lib()
+    T, B, H, E, A, U = 6, 20, 32, 16, 4, 7
+    plan, ar, d = _make_plan(L, lib, sched, 0, 2, 0, monkeypatch, T, B, H, E, A, U, hetero=True)
+    try:
+        recs = _trace(lib, plan, 1)
+        bwd_once = {"dp", "dG0", "dG1", "dC0", "dC1"}
+        acc = {"dw", "dw0", "dw_b", "dw0_b", "dw_c", "dw0_c", "dh0", "dh1", "dhup0", "dh_b0", "dh_b1", "dhup_b0", "dhup_c0"}
+        n_bwd = _check(recs, ar, bwd_once, acc, T, {})
+        assert n_bwd == 3 * (T + 2), n_bwd  # three launches per tick, T + 2 ticks
+        n = lib.parrot_decoder_trace_jobs(plan, 1, None, 0)
+        buf = (C.c_longlong * (6 * n))()
+        lib.parrot_decoder_trace_jobs(plan, 1, buf, n)
+        jobs = [tuple(buf[6 * i:6 * i + 6]) for i in range(n)]  # (launch, job, M, N, Ksum, epi)
+        assert max(j[4] for j in jobs if j[5] >= 0) == H  # no step-GEMM job walks more than K = H
+        att_launches = {j[0] for j in jobs if j[5] == -2}
+        assert any(j[0] in att_launches and j[5] >= 0 for j in jobs)  # GEMM work rides beside the attention backward
+        for name in ("dh_b0", "dh_b1", "dhup_b0", "dhup_c0", "dw_b", "dw_c", "dw0_b", "dw0_c"):
+            kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
+            assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
+    finally:
+        lib.parrot_decoder_destroy(plan)
+    monkeypatch.setenv("PARROT_BWD_HETERO", "0")  # opt-out: the three-launch tick of bwd()
+    plan, ar, d = _make_plan(L, lib, sched, 0, 2, 0, monkeypatch, T, B, H, E, A, U, hetero=True)
+    try:
+        n = lib.parrot_decoder_trace_jobs(plan, 1, None, 0)
+        buf = (C.c_longlong * (6 * n))()
+        lib.parrot_decoder_trace_jobs(plan, 1, buf, n)
+        assert max(buf[6 * i + 4] for i in range(n) if buf[6 * i + 5] >= 0) == 2 * H
     finally:
         lib.parrot_decoder_destroy(plan)
 

@@ -49,6 +49,10 @@ def fake_plan(L_, lib, a):
         d.dG[l] = take(T * B * gw * 4)
         if l < a.L - 1:
             d.dhup[l] = take((T + 1) * B * H * 4)
+        if not a.no_accumulators:  # second / third accumulators: the K-split backward ticks (LSTM bf16; bwd8 for 2 GRU layers)
+            d.dh_b[l] = take((T + 1) * B * H * 4)
+            if l < a.L - 1:
+                d.dhup_b[l], d.dhup_c[l] = take((T + 1) * B * H * 4), take((T + 1) * B * H * 4)
         if l >= 1:
             d.seq_g[l] = take(T * B * gw * 4)
         if not cell:
@@ -66,6 +70,9 @@ def fake_plan(L_, lib, a):
     d.a, d.b, d.phi = take(T * B * A * 4), take(T * B * A * 4), take(T * B * U * 4)
     d.dw, d.dw0, d.dkappa = take((T + 1) * B * E * 4), take((T + 1) * B * E * 4), take(B * A * 4)
     d.dp, d.att_sup = take(T * B * 3 * A * 4), take(T * B * 8)
+    if not a.no_accumulators:
+        d.dw_b, d.dw_c = take((T + 1) * B * E * 4), take((T + 1) * B * E * 4)
+        d.dw0_b, d.dw0_c = take((T + 1) * B * E * 4), take((T + 1) * B * E * 4)
     plan = C.c_void_p()
     rc = lib.parrot_decoder_create(C.byref(d), C.byref(plan))
     assert rc == 0, rc
@@ -99,9 +106,14 @@ def price(jobs, cell):
     rounds = math.ceil((wgs + (64 if att and att[0][4] == -1 else 0)) / 256)
     t = FIXED + (SLOPE22 if use22 else SLOPE21) * kmax / 1024 * rounds
     what = f"{len(gemm)} jobs, {wgs} workgroups of 32x{'32' if use22 else '16'}, Kmax {kmax}" + (f", {rounds} rounds" if rounds > 1 else "")
-    if att:
-        t = max(t, ATT_HETERO if att[0][4] == -1 else ATT_BWD)
+    if att and att[0][4] == -1:
+        t = max(t, ATT_HETERO)
         what += " + attention"
+    elif att:
+        # bwd8's attention launch: 64 attention rows + 64 state rows of the upper layer lead the grid (1024-thread blocks,
+        # a CU each); the CUs of the short state rows (~3 us) then take the GEMM workgroups that found no free CU
+        t = max(ATT_HETERO, t + (3.0 if wgs + 128 > 256 else 0.0))
+        what += " + attention backward"
     return t, what
 
 
@@ -166,6 +178,8 @@ def main():
     ap.add_argument("--B", type=int, default=64)
     ap.add_argument("--T", type=int, default=800)
     ap.add_argument("--cell", default="gru")
+    ap.add_argument("--no-accumulators", action="store_true",
+                    help="leave the second / third gradient accumulators out of the descriptor: the three-launch backward tick of rounds 1-3")
     a = ap.parse_args()
     if a.whatif:
         return whatif(L=a.L, H=a.H, B=a.B, T=a.T)
