@@ -225,6 +225,7 @@ int traced_bwd_hetero_launch(const AttBwdArgs* g, const GruStateBwdArgs& sa, int
         for (int q = 0; q < n; ++q) g_tracer->sk_job(jobs[q], q);
         return 0;
     }
+    L.full_wgs = 128;  // beside 64 + 64 row blocks: keep the 32 x 32 tiles (160 workgroups at cfg2), one workgroup per CU
     return sk_launch_bwd_hetero(L, g, sa, l0_chain, s);
 }
 

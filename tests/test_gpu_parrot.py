@@ -530,6 +530,7 @@ def test_full_size_cfg2_strands_are_bit_identical(dev, monkeypatch):
 
     def run(strands, qpart, overlap):
         monkeypatch.setenv("PARROT_SCHEDULE", "0")
+        monkeypatch.setenv("PARROT_BWD_HETERO", "0")  # (strands run the three-launch backward tick: so does the base)
         monkeypatch.setenv("PARROT_STRANDS", str(strands))
         monkeypatch.setenv("PARROT_QPART", str(qpart))
         monkeypatch.setenv("PARROT_DW_OVERLAP", str(overlap))
