@@ -33,7 +33,7 @@ for k in sorted(ft, key=lambda k: -ft[k]):
     fetch = 2.0 * ft[k] * 1024 / n
     write = (wt.get(k, 0.0) * 1024 / wc[k]) if wc.get(k) else 0.0
     out["kernels"][k[:80]] = {"launches": n, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write)}
-    if any(f in k for f in ('sk_kernel', 'ska_kernel', 'wk_kernel', 'wka_kernel', 'wkb_kernel')):  # the step-kernel family
+    if any(f in k for f in ('sk_kernel', 'ska_kernel', 'skb_kernel', 'wk_kernel', 'wka_kernel', 'wkb_kernel')):  # the step-kernel family
         sk_bytes += (fetch + write) * n
         sk_n += n
 out["hbm_bytes_per_launch"] = round(sk_bytes / sk_n) if sk_n else None
