@@ -43,6 +43,10 @@ const char* parrot_hip_version(void);
  * summed kernel time [us], flops and bytes. */
 int parrot_profile_begin(void);
 long long parrot_profile_end(double* total_us, double* flops, double* bytes);
+/* As parrot_profile_end; plain4 (or NULL) receives {dispatch time in us, flops, bytes, launch count} of the PLAIN step-GEMM
+ * launches alone (no attention / state row blocks in the grid): the dominant kernel without the latency chains that the
+ * heterogeneous launches carry beside their GEMM workgroups. */
+long long parrot_profile_end2(double* total_us, double* flops, double* bytes, double* plain4);
 
 /* ------------------------------------------------------------------------------------------
  * Dense projections (Blocks Linear / Fork applies, model.py:580-627, 739-755; lib.ops.Linear,

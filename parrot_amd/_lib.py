@@ -135,6 +135,7 @@ SIGNATURES = {
     "parrot_hip_version": (C.c_char_p, []),
     "parrot_profile_begin": (_i, []),
     "parrot_profile_end": (C.c_longlong, [C.POINTER(C.c_double)] * 3),
+    "parrot_profile_end2": (C.c_longlong, [C.POINTER(C.c_double)] * 4),
     "parrot_gemm": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "parrot_colsum": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp]),
     "parrot_gru_step_fwd": (_i, [_vp] * 11 + [_i, _i, _vp]),

@@ -71,6 +71,10 @@ long long parrot_profile_end(double* total_us, double* flops, double* bytes) { P
     return sk_profile_end(total_us, flops, bytes);
 }
 
+long long parrot_profile_end2(double* total_us, double* flops, double* bytes, double* plain4) { PH_ENTRY();
+    return sk_profile_end2(total_us, flops, bytes, plain4);
+}
+
 // Split-K workspace, one per stream: products on different streams (the weight-gradient GEMMs that run beside the
 // backward scan, model.py's _backward) never share partial tiles.  Grows on demand, reused by later calls in stream
 // order.  Under stream capture (or when the memory cannot be had) there is none and the product runs unsplit, so no

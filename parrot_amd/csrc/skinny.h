@@ -99,6 +99,7 @@ int sk_launch_bwd_fused(const SkLaunch& L, const AttBwdArgs* att, const LstmStat
 int sk_zero_words_launch(unsigned* p, int n, hipStream_t stream);
 void sk_profile_begin();
 long long sk_profile_end(double* total_us, double* flops, double* bytes);
+long long sk_profile_end2(double* total_us, double* flops, double* bytes, double* plain);  // + the plain (non-heterogeneous) launches alone
 
 // Helpers to build jobs.
 static inline SkSeg sk_seg(const float* A, int lda, const float* B, int ldb, int K, int b_kcontig) {

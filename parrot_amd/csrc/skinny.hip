@@ -842,7 +842,7 @@ int sk_tile_weights_launch(const float* W, int rows, int cols, int ld, float* ou
 // (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps), and the
 // algorithmic flops / bytes of its jobs are recorded next to them.
 namespace {
-struct SkProfRec { hipEvent_t e0, e1; double flops, bytes; };
+struct SkProfRec { hipEvent_t e0, e1; double flops, bytes; int hetero = 0; };  // hetero: the launch also carries attention / state row blocks
 struct SkProf { bool on = false; std::vector<SkProfRec> recs; } g_prof;
 
 void sk_account(const SkLaunch& L, double& flops, double& bytes) {
@@ -873,13 +873,22 @@ void sk_profile_begin() {
 }
 
 // Must be called after the stream has been synchronised.  Returns the number of launches.
-long long sk_profile_end(double* total_us, double* flops, double* bytes) {
+long long sk_profile_end(double* total_us, double* flops, double* bytes) { return sk_profile_end2(total_us, flops, bytes, nullptr); }
+
+// plain[0..3]: dispatch time (us), flops, bytes and launch count of the PLAIN step-GEMM launches (sk_kernel / wk_kernel:
+// no attention or state row blocks in the grid) -- the dominant kernel on its own; the totals cover the whole family.
+long long sk_profile_end2(double* total_us, double* flops, double* bytes, double* plain) {
     g_prof.on = false;
-    double us = 0.0, fl = 0.0, by = 0.0;
+    double us = 0.0, fl = 0.0, by = 0.0, pus = 0.0, pfl = 0.0, pby = 0.0, pn = 0.0;
     for (auto& r : g_prof.recs) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) us += 1000.0 * ms;
+        const bool ok = hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess;
+        if (ok) us += 1000.0 * ms;
         fl += r.flops; by += r.bytes;
+        if (!r.hetero) {
+            if (ok) pus += 1000.0 * ms;
+            pfl += r.flops; pby += r.bytes; pn += 1.0;
+        }
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     const long long n = (long long)g_prof.recs.size();
@@ -887,6 +896,7 @@ long long sk_profile_end(double* total_us, double* flops, double* bytes) {
     if (total_us) *total_us = us;
     if (flops) *flops = fl;
     if (bytes) *bytes = by;
+    if (plain) { plain[0] = pus; plain[1] = pfl; plain[2] = pby; plain[3] = pn; }
     return n;
 }
 
@@ -1337,7 +1347,8 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
             (void)hipEventCreate(&r.e1);
             sk_account(Lin, r.flops, r.bytes);
             hipExtLaunchKernelGGL(wka_kernel, dim3(t + natt), dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, W, *att, natt, att_last);
-            g_prof.recs.push_back(r);
+            r.hetero = 1;
+        g_prof.recs.push_back(r);
         } else {
             hipLaunchKernelGGL(wka_kernel, dim3(t + natt), dim3(SK_THREADS), lds, stream, W, *att, natt, att_last);
         }
@@ -1407,6 +1418,7 @@ int sk_launch_bwd_fused(const SkLaunch& Lin, const AttBwdArgs* att, const LstmSt
         (void)hipEventCreate(&r.e1);
         sk_account(Lin, r.flops, r.bytes);
         hipExtLaunchKernelGGL(wkb_kernel, dim3(P.nprod + t), dim3(ATTB_THREADS), lds, stream, r.e0, r.e1, 0, W, P);
+        r.hetero = 1;
         g_prof.recs.push_back(r);
     } else {
         hipLaunchKernelGGL(wkb_kernel, dim3(P.nprod + t), dim3(ATTB_THREADS), lds, stream, W, P);
@@ -1565,6 +1577,7 @@ static void ska_dispatch(const SkLaunch& L, const AttFwdArgs& g, int natt_x, dim
         sk_account(L, r.flops, r.bytes);
         hipExtLaunchKernelGGL((ska_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, r.e0, r.e1, 0, L, g, natt_x,
                               att_last);
+        r.hetero = 1;
         g_prof.recs.push_back(r);
     } else {
         hipLaunchKernelGGL((ska_kernel<MB, NB>), grid, dim3(SK_THREADS), lds, stream, L, g, natt_x, att_last);
@@ -1646,6 +1659,7 @@ static void skb_dispatch(const SkLaunch& L, const AttBwdArgs& g, const GruStateB
         sk_account(L, r.flops, r.bytes);
         hipExtLaunchKernelGGL((skb_kernel<MB, NB>), grid, dim3(ATTB_THREADS), lds, stream, r.e0, r.e1, 0, L, g, sa, att_rows,
                               l0_chain, nlead, nlead_x);
+        r.hetero = 1;
         g_prof.recs.push_back(r);
     } else {
         hipLaunchKernelGGL((skb_kernel<MB, NB>), grid, dim3(ATTB_THREADS), lds, stream, L, g, sa, att_rows, l0_chain, nlead,

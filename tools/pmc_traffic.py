@@ -28,6 +28,7 @@ wt, wc = per_kernel(sys.argv[2], 'WRITE_SIZE')
 out = {"recipe": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "kernels": {}}
 sk_bytes, sk_n = 0.0, 0
+pl_bytes, pl_n = 0.0, 0  # the plain step-GEMM launches alone (no attention / state row blocks in the grid)
 for k in sorted(ft, key=lambda k: -ft[k]):
     n = fc[k]
     fetch = 2.0 * ft[k] * 1024 / n
@@ -36,7 +37,12 @@ for k in sorted(ft, key=lambda k: -ft[k]):
     if any(f in k for f in ('sk_kernel', 'ska_kernel', 'skb_kernel', 'wk_kernel', 'wka_kernel', 'wkb_kernel')):  # the step-kernel family
         sk_bytes += (fetch + write) * n
         sk_n += n
+        if 'sk_kernel<' in k or k.startswith('wk_kernel('):
+            pl_bytes += (fetch + write) * n
+            pl_n += n
 out["hbm_bytes_per_launch"] = round(sk_bytes / sk_n) if sk_n else None
+out["hbm_bytes_per_plain_launch"] = round(pl_bytes / pl_n) if pl_n else None
+out["plain_launches"] = pl_n
 # digest of the kernel sources the passes ran on: bench.py refuses the figure once they have changed
 import os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
