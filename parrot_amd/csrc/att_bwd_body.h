@@ -227,9 +227,12 @@ __device__ __forceinline__ void state_bwd_row(const LstmStateBwdChain& c, int m,
     lstm_state_bwd_row(c, m, H, tid, nthr);
 }
 
+// rpb: batch rows per block of the chains that are NOT fused behind the attention (1 in the stand-alone kernel; the
+// heterogeneous backward launch packs 4 so that the upper layers' elementwise rows take 16 CUs instead of 64 and every
+// GEMM workgroup of the launch finds a CU at once).
 template <class SA>
 __device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const SA& sa, int att_rows, int l0_chain, int bx,
-                                                    float* sm) {
+                                                    float* sm, int rpb = 1) {
     if (bx < att_rows) {
         if constexpr (std::is_same<SA, GruStateBwdArgs>::value) {
             // Layer 0's state backward needs nothing from the attention backward except dh1 itself: its operands (and
@@ -270,8 +273,10 @@ __device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const S
         return;
     }
     const int idx = bx - att_rows;
-    int ch = idx / sa.B;
-    const int m = idx % sa.B;
+    const int bpc = (sa.B + rpb - 1) / rpb;  // blocks per chain
+    int ch = idx / bpc;
+    const int m0 = (idx % bpc) * rpb;
     if (att_rows > 0 && l0_chain >= 0 && ch >= l0_chain) ++ch;  // skip the chain fused above
-    if (ch < sa.nchain) state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
+    if (ch < sa.nchain)
+        for (int m = m0; m < m0 + rpb && m < sa.B; ++m) state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
 }

@@ -669,13 +669,13 @@ __global__ __launch_bounds__(SK_THREADS, 4) void ska_kernel(const SkLaunch L, co
 template <int MB, int NB>
 __global__ __launch_bounds__(ATTB_THREADS) void skb_kernel(const SkLaunch L, const AttBwdArgs g, const GruStateBwdArgs sa,
                                                            const int att_rows, const int l0_chain, const int nlead,
-                                                           const int nlead_x) {
+                                                           const int nlead_x, const int rpb) {
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     int bx = blockIdx.x;
     if (bx < nlead_x) {
         const int id = blockIdx.y * nlead_x + bx;
         if (id >= nlead) return;
-        att_state_bwd_block(g, sa, att_rows, l0_chain, id, reinterpret_cast<float*>(sk_smem));
+        att_state_bwd_block(g, sa, att_rows, l0_chain, id, reinterpret_cast<float*>(sk_smem), rpb);
         return;
     }
     if (threadIdx.x >= SK_THREADS) return;
@@ -1646,7 +1646,7 @@ int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream
 
 template <int MB, int NB>
 static void skb_dispatch(const SkLaunch& L, const AttBwdArgs& g, const GruStateBwdArgs& sa, int att_rows, int l0_chain,
-                         int nlead, int nlead_x, dim3 grid, size_t lds, hipStream_t stream) {
+                         int nlead, int nlead_x, int rpb, dim3 grid, size_t lds, hipStream_t stream) {
     static bool allowed = false;
     if (!allowed) {
         (void)hipFuncSetAttribute((const void*)skb_kernel<MB, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1658,12 +1658,12 @@ static void skb_dispatch(const SkLaunch& L, const AttBwdArgs& g, const GruStateB
         (void)hipEventCreate(&r.e1);
         sk_account(L, r.flops, r.bytes);
         hipExtLaunchKernelGGL((skb_kernel<MB, NB>), grid, dim3(ATTB_THREADS), lds, stream, r.e0, r.e1, 0, L, g, sa, att_rows,
-                              l0_chain, nlead, nlead_x);
+                              l0_chain, nlead, nlead_x, rpb);
         r.hetero = 1;
         g_prof.recs.push_back(r);
     } else {
         hipLaunchKernelGGL((skb_kernel<MB, NB>), grid, dim3(ATTB_THREADS), lds, stream, L, g, sa, att_rows, l0_chain, nlead,
-                           nlead_x);
+                           nlead_x, rpb);
     }
 }
 
@@ -1686,7 +1686,15 @@ int sk_launch_bwd_hetero(const SkLaunch& Lin, const AttBwdArgs* att, const GruSt
     } else {
         l0_chain = -1;
     }
-    const int nlead = att_rows + (sa.nchain - (att ? 1 : 0)) * sa.B;
+    // the chains that are not fused behind the attention take 4 batch rows per block: 16 CUs instead of 64 at B = 64, so
+    // that (64 attention rows + 16 + 160 GEMM workgroups at cfg2) every block of the launch finds a CU at once
+    static int rpb_env = -1;
+    if (rpb_env < 0) {
+        const char* e = getenv("PARROT_SKB_RPB");
+        rpb_env = e && atoi(e) > 0 ? atoi(e) : 4;
+    }
+    const int rpb = rpb_env;
+    const int nlead = att_rows + (sa.nchain - (att ? 1 : 0)) * ceil_div(sa.B, rpb);
     SkLaunch L;
     dim3 grid;
     size_t lds;
@@ -1704,14 +1712,14 @@ int sk_launch_bwd_hetero(const SkLaunch& Lin, const AttBwdArgs* att, const GruSt
     if (alds > lds) lds = alds;
     if (lds > 160 * 1024) return PH_ERR_UNSUPPORTED;
     switch (mbnb) {
-        case 11: skb_dispatch<1, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        case 12: skb_dispatch<1, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        case 21: skb_dispatch<2, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        case 22: skb_dispatch<2, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        case 31: skb_dispatch<3, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        case 32: skb_dispatch<3, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        case 41: skb_dispatch<4, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
-        default: skb_dispatch<4, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, grid, lds, stream); break;
+        case 11: skb_dispatch<1, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        case 12: skb_dispatch<1, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        case 21: skb_dispatch<2, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        case 22: skb_dispatch<2, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        case 31: skb_dispatch<3, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        case 32: skb_dispatch<3, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        case 41: skb_dispatch<4, 1>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
+        default: skb_dispatch<4, 2>(L, g, sa, att_rows, l0_chain, nlead, nlead_x, rpb, grid, lds, stream); break;
     }
     return (int)hipGetLastError();
 }

@@ -112,7 +112,7 @@ def price(jobs, cell):
     elif att:
         # bwd8's attention launch: 64 attention rows + 64 state rows of the upper layer lead the grid (1024-thread blocks,
         # a CU each); the CUs of the short state rows (~3 us) then take the GEMM workgroups that found no free CU
-        t = max(ATT_HETERO, t + (3.0 if wgs + 128 > 256 else 0.0))
+        t = max(ATT_HETERO, t + (3.0 if wgs + 80 > 256 else 0.0))  # (64 attention rows + 16 blocks of 4 state rows)
         what += " + attention backward"
     return t, what
 
