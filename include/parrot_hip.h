@@ -298,6 +298,12 @@ typedef struct ParrotDecoderDesc {
     float* dhup_c[PARROT_MAX_LAYERS];
     float* dw_c;
     float* dw0_c;
+    /* Further accumulators of layer 0 (stored; zero-filled once): with dh_c[0], dh_d[0], dw0_c and dw0_d given, a bf16 LSTM
+     * decoder cuts layer 0's backward products -- the ones that start last, behind the attention backward -- into FOUR K
+     * parts instead of two.  Only index 0 of the arrays is read. */
+    float* dh_c[PARROT_MAX_LAYERS];
+    float* dh_d[PARROT_MAX_LAYERS];
+    float* dw0_d;
 } ParrotDecoderDesc;
 
 /* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify for the persistent

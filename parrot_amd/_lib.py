@@ -72,6 +72,7 @@ class DecoderDesc(C.Structure):
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
         ("dh_b", C.c_void_p * MAX_LAYERS), ("dhup_b", C.c_void_p * MAX_LAYERS), ("dw_b", C.c_void_p), ("dw0_b", C.c_void_p),
         ("dhup_c", C.c_void_p * MAX_LAYERS), ("dw_c", C.c_void_p), ("dw0_c", C.c_void_p),
+        ("dh_c", C.c_void_p * MAX_LAYERS), ("dh_d", C.c_void_p * MAX_LAYERS), ("dw0_d", C.c_void_p),
     ]
 
 

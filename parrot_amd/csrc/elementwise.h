@@ -61,6 +61,8 @@ struct LstmStateBwdChain {
     const float* dh2;     // [B,H] optional second share of it or null
     const float* dh3 = nullptr;  // [B,H] optional further shares (second K halves of the split backward products) or null
     const float* dh4 = nullptr;
+    const float* dh5 = nullptr;
+    const float* dh6 = nullptr;
     float* dc;            // [B,H] carry: in gradient wrt c_t (from step t+1), out gradient wrt c_{t-1}
     const float* gates;   // [B,4H] saved activations i|f|o|g
     const float* c_prev;  // [B,H]
@@ -79,7 +81,8 @@ __device__ __forceinline__ void lstm_state_bwd_row(const LstmStateBwdChain& c, i
         const float* g = c.gates + (size_t)m * 4 * H;
         const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
         const float tc = tanhf(c.c_new[idx]);
-        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f) + (c.dh3 ? c.dh3[idx] : 0.f) + (c.dh4 ? c.dh4[idx] : 0.f);
+        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f) + (c.dh3 ? c.dh3[idx] : 0.f) + (c.dh4 ? c.dh4[idx] : 0.f) +
+                          (c.dh5 ? c.dh5[idx] : 0.f) + (c.dh6 ? c.dh6[idx] : 0.f);
         const float dcv = dhv * go * (1.f - tc * tc) + c.dc[idx];
         float* o = c.dP + (size_t)m * 4 * H;
         o[k] = dcv * gg * gi * (1.f - gi);
@@ -99,7 +102,8 @@ __device__ __forceinline__ void lstm_state_bwd_row_pub(const LstmStateBwdChain& 
         const float* g = c.gates + (size_t)m * 4 * H;
         const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
         const float tc = tanhf(c.c_new[idx]);
-        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f) + (c.dh3 ? c.dh3[idx] : 0.f) + (c.dh4 ? c.dh4[idx] : 0.f);
+        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f) + (c.dh3 ? c.dh3[idx] : 0.f) + (c.dh4 ? c.dh4[idx] : 0.f) +
+                          (c.dh5 ? c.dh5[idx] : 0.f) + (c.dh6 ? c.dh6[idx] : 0.f);
         const float dcv = dhv * go * (1.f - tc * tc) + c.dc[idx];
         row[k] = dcv * gg * gi * (1.f - gi);
         row[H + k] = dcv * c.c_prev[idx] * gf * (1.f - gf);

@@ -104,7 +104,9 @@ struct Tracer {
         switch (j.epi) {
             case SK_EPI_LINEAR:
                 mat(j.out, j.M, j.N, j.ldo, j.accumulate ? 2 : 1, id);
-                if (j.ksplit > 1) mat(j.o1, j.M, j.N, j.ldo1, j.ldo2 ? 2 : 1, id);  // the second K half's sums
+                if (j.ksplit > 1) mat(j.o1, j.M, j.N, j.ldo1, j.ldo2 ? 2 : 1, id);  // the second K part's sums
+                if (j.ksplit > 2) mat(j.kout2, j.M, j.N, j.ldo1, 1, id);
+                if (j.ksplit > 3) mat(j.kout3, j.M, j.N, j.ldo1, 1, id);
                 break;
             case SK_EPI_GRU_GATES:
                 mat(j.e0, j.M, H, j.lde0, 0, id); mat(j.o1, j.M, H, j.ldo1, 1, id); mat(j.o2, j.M, H, j.ldo2, 1, id);
@@ -148,6 +150,7 @@ struct Tracer {
     }
     void chain(const LstmStateBwdChain& c, int B, int H, int id) {
         mat(c.dh, B, H, H, 0, id); mat(c.dh2, B, H, H, 0, id); mat(c.dh3, B, H, H, 0, id); mat(c.dh4, B, H, H, 0, id);
+        mat(c.dh5, B, H, H, 0, id); mat(c.dh6, B, H, H, 0, id);
         mat(c.gates, B, 4 * H, 4 * H, 0, id);
         mat(c.c_prev, B, H, H, 0, id); mat(c.c_new, B, H, H, 0, id);
         mat(c.dc, B, H, H, 2, id); mat(c.dP, B, 4 * H, 4 * H, 1, id);
@@ -293,6 +296,7 @@ void take_rows(LstmStateBwdArgs& g, const Strand& s) {
     for (int q = 0; q < g.nchain; ++q) {
         LstmStateBwdChain& c = g.chain[q];
         shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.dh3, s.b0, g.H); shift(c.dh4, s.b0, g.H);
+        shift(c.dh5, s.b0, g.H); shift(c.dh6, s.b0, g.H);
         shift(c.dc, s.b0, g.H); shift(c.gates, s.b0, 4 * g.H);
         shift(c.c_prev, s.b0, g.H); shift(c.c_new, s.b0, g.H); shift(c.dP, s.b0, 4 * g.H);
     }
@@ -1451,6 +1455,7 @@ struct DecoderPlan : PlanBase {
     // halves.  A wide workgroup streams its whole [B, 4H] operand: 156 workgroups of ~40 us each at cfg4, whatever
     // their width, and 100 idle CUs; two K halves = 312 workgroups of ~20 us (PARROT_BWD_KSPLIT=0: one part).
     bool bwd_ksplit = false;
+    bool bwd_k4 = false;  // + layer 0's products (the ones behind the attention rows) in FOUR K parts (dh_c / dh_d / dw0_c / dw0_d given)
     int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
     int bwd(hipStream_t st, int q0, int q1) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -1466,6 +1471,7 @@ struct DecoderPlan : PlanBase {
             if (att_on && bwd_ksplit) {  // (LSTM layers) the second K halves' shares of dw
                 g.dw3 = d.dw_b + (size_t)(t0 + 1) * BE;
                 g.dw4 = d.dw0_b + (size_t)(t0 + 1) * BE;
+                if (bwd_k4) { g.dw5 = d.dw0_c + (size_t)(t0 + 1) * BE; g.dw6 = d.dw0_d + (size_t)(t0 + 1) * BE; }
             }
             if (d.cell == 1) {
                 SkJob jl[SK_MAXJOB];
@@ -1483,6 +1489,8 @@ struct DecoderPlan : PlanBase {
                     c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
                     c.dh3 = bwd_ksplit ? d.dh_b[l] + (t + 1) * BH : nullptr;  // the second K halves' sums (below)
                     c.dh4 = (bwd_ksplit && l + 1 < d.L) ? d.dhup_b[l] + (t + 1) * BH : nullptr;
+                    c.dh5 = (bwd_k4 && l == 0) ? d.dh_c[0] + (t + 1) * BH : nullptr;
+                    c.dh6 = (bwd_k4 && l == 0) ? d.dh_d[0] + (t + 1) * BH : nullptr;
                     c.dc = d.dcell[l];
                     c.gates = d.gate4[l] + (size_t)t * 4 * BH;
                     c.c_prev = d.cst[l] + t * BH;
@@ -1503,6 +1511,9 @@ struct DecoderPlan : PlanBase {
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dh[l] + t * BH; j.ldo = H;
                         if (bwd_ksplit) { j.ksplit = 2; j.o1 = d.dh_b[l] + t * BH; j.ldo1 = H; }
+                        if (bwd_ksplit && l == 0 && bwd_k4) {  // layer 0's products sit behind the attention rows: four K parts
+                            j.ksplit = 4; j.kout2 = d.dh_c[0] + t * BH; j.kout3 = d.dh_d[0] + t * BH;
+                        }
                     }
                     {   // attention context
                         SkJob& j = jl[nl++];
@@ -1515,6 +1526,9 @@ struct DecoderPlan : PlanBase {
                             j.ksplit = 2; j.ldo1 = E;
                             j.o1 = (l == 0 ? d.dw0_b + (size_t)t * BE : d.dw_b + (size_t)(t + 1) * BE);
                             j.ldo2 = l == 0 ? 0 : 1;  // dw_b[t + 1] collects every upper layer's share: added (caller-zeroed)
+                            if (l == 0 && bwd_k4) {
+                                j.ksplit = 4; j.kout2 = d.dw0_c + (size_t)t * BE; j.kout3 = d.dw0_d + (size_t)t * BE;
+                            }
                         }
                     }
                     for (int p = 0; p < l; ++p) {
@@ -2908,6 +2922,8 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         for (int l = 0; l < desc->L; ++l)
             if (!desc->dh_b[l] || (l + 1 < desc->L && !desc->dhup_b[l])) have = false;
         p->bwd_ksplit = have;
+        p->bwd_k4 = have && desc->dh_c[0] && desc->dh_d[0] && desc->dw0_c && desc->dw0_d && (4 * desc->H) % 256 == 0 &&
+                    !(getenv("PARROT_BWD_K4") && atoi(getenv("PARROT_BWD_K4")) == 0);
     }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     p->setup_strands();
@@ -2920,7 +2936,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             if (!desc->dh_b[l]) ok = false;
         p->bwd_hetero = ok;
     }
-    if (p->nstrands > 1) p->bwd_ksplit = false;  // (row strands shift every per-row pointer: not wired for the second accumulators)
+    if (p->nstrands > 1) p->bwd_ksplit = p->bwd_k4 = false;  // (row strands shift every per-row pointer: not wired for the second accumulators)
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule >= 2 && p->schedule != 7;
         for (int l = 1; l < desc->L && ok; ++l)

@@ -55,10 +55,12 @@ struct SkJob {
     // wait_all = 1 / 2 (wide bf16 kernel only, single-segment jobs): the WHOLE A operand is produced inside the launch (the
     // state-backward rows at the head of the fused backward tick, wkb_kernel): the workgroup waits before its first load.
     // 2: the producer is the slow one of the launch (the rows behind the attention backward): such jobs go last in the grid.
-    // ksplit = 2 (wide bf16 kernel only; single-segment LINEAR jobs): the K range is cut in two halves handled by different
+    // ksplit = 2..4 (wide bf16 kernel only; single-segment LINEAR jobs): the K range is cut in equal parts handled by different
     // workgroups; the first half follows `accumulate` into `out`, the second half goes into o1 (ldo1): stored, or added when
     // ldo2 != 0 (a destination several jobs of a window add to; the field is otherwise unused by LINEAR jobs) -- the consumer
     // adds the two.  A wide workgroup's time is the time to stream its [M, K] operand: halving K halves the launch.
+    float* kout2;  // ksplit = 3 / 4: the third / fourth K part's sums are STORED here (leading dimension ldo1)
+    float* kout3;
     const unsigned* wait_flag;
     unsigned wait_target;
     int colmode;  // 1: a LINEAR job over the gate-interleaved column order of an LSTM matrix (N = 4H; the fragment-major

@@ -1141,8 +1141,10 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
                 if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
-                float* o = kpart ? job.o1 + (size_t)m * job.ldo1 + n : job.out + (size_t)m * job.ldo + n;
-                if (kpart ? job.ldo2 != 0 : job.accumulate != 0) x += *o;  // (split LINEAR jobs: ldo2 = accumulate into o1)
+                float* ob = kpart == 0 ? job.out : (kpart == 1 ? job.o1 : (kpart == 2 ? job.kout2 : job.kout3));
+                float* o = ob + (size_t)m * (kpart ? job.ldo1 : job.ldo) + n;
+                // part 0 follows `accumulate`, part 1 the flag in ldo2 (split LINEAR jobs), parts 2 and 3 are stored
+                if (kpart == 0 ? job.accumulate != 0 : (kpart == 1 && job.ldo2 != 0)) x += *o;
                 *o = x;
             }
         }
@@ -1267,7 +1269,8 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
         for (int s = 0; s < j.nseg; ++s)
             if (j.seg[s].K % WK_STAGE) return false;
-        if (j.ksplit > 1 && (j.nseg != 1 || j.epi != SK_EPI_LINEAR || j.act || !j.o1 || j.seg[0].K % (j.ksplit * WK_STAGE)))
+        if (j.ksplit > 1 && (j.ksplit > 4 || j.nseg != 1 || j.epi != SK_EPI_LINEAR || j.act || !j.o1 || (j.ksplit > 2 && !j.kout2) ||
+                             (j.ksplit > 3 && !j.kout3) || j.seg[0].K % (j.ksplit * WK_STAGE)))
             return false;
         work += (long long)j.N;
     }

@@ -508,7 +508,10 @@ class Parrot(Brick):
                 # tick run as two K halves; zero-filled once (the scan stores into every slot it later reads)
                 ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
                           dhup_b=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
-                          dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f))
+                          dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f),
+                          # layer 0's products run as FOUR K parts (they start last, behind the attention backward)
+                          dh_c0=torch.zeros(T + 1, B, H, **f), dh_d0=torch.zeros(T + 1, B, H, **f),
+                          dw0_c=torch.zeros(T + 1, B, E, **f), dw0_d=torch.zeros(T + 1, B, E, **f))
         else:
             for n in ('z', 'r', 'rh', 'c'):
                 ws[n] = [torch.empty(T, B, H, **f) for _ in range(L)]
@@ -586,6 +589,9 @@ class Parrot(Brick):
             d.dw_b, d.dw0_b = ws['dw_b'].data_ptr(), ws['dw0_b'].data_ptr()
         if 'dw_c' in ws:
             d.dw_c, d.dw0_c = ws['dw_c'].data_ptr(), ws['dw0_c'].data_ptr()
+        if 'dh_c0' in ws:
+            d.dh_c[0], d.dh_d[0] = ws['dh_c0'].data_ptr(), ws['dh_d0'].data_ptr()
+            d.dw0_c, d.dw0_d = ws['dw0_c'].data_ptr(), ws['dw0_d'].data_ptr()
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
@@ -923,9 +929,13 @@ class Parrot(Brick):
                 ws['dh'][l][0].add_(ws['dh_b'][l][0])
             ws['dw'][0].add_(ws['dw_b'][0])
             ws['dw0'][0].add_(ws['dw0_b'][0])
-            if 'dw0_c' in ws:
+            if 'dw_c' in ws:
                 ws['dw'][0].add_(ws['dw_c'][0])
+            if 'dw0_c' in ws:
                 ws['dw0'][0].add_(ws['dw0_c'][0])
+            if 'dh_c0' in ws:
+                ws['dh'][0][0].add_(ws['dh_c0'][0]).add_(ws['dh_d0'][0])
+                ws['dw0'][0].add_(ws['dw0_d'][0])
 
         # the rest of the deferred gradients of the scan (biases, per-step additive inputs)
         sg_, sc_ = self.store.storage_grad, self.store.storage

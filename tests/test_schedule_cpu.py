@@ -95,6 +95,11 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
     d.phi = ar.take("phi", T * B * U * f)
     d.dw = ar.take("dw", (T + 1) * B * E * f)
     d.dw0 = ar.take("dw0", (T + 1) * B * E * f)
+    if bf16 and cell == 1:  # layer 0's products as four K parts
+        d.dh_c[0] = ar.take("dh_c0", (T + 1) * B * H * f)
+        d.dh_d[0] = ar.take("dh_d0", (T + 1) * B * H * f)
+        d.dw0_c = ar.take("dw0_c", (T + 1) * B * E * f)
+        d.dw0_d = ar.take("dw0_d", (T + 1) * B * E * f)
     if (bf16 and cell == 1) or hetero:
         d.dw_b = ar.take("dw_b", (T + 1) * B * E * f)
         d.dw0_b = ar.take("dw0_b", (T + 1) * B * E * f)
@@ -273,14 +278,14 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         assert n_fwd == T + max(1, nl if nl > 1 else 0)
         recs = _trace(lib, plan, 1)
         bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)}
-        acc = {"dw", "dw0", "dw_b", "dw0_b"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
+        acc = {"dw", "dw0", "dw_b", "dw0_b", "dw0_c", "dw0_d", "dh_c0", "dh_d0"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
         acc |= {f"dh_b{l}" for l in range(nl)} | {f"dhup_b{l}" for l in range(nl - 1)}
         n_bwd = _check(recs, ar, bwd_once, acc, T, {})
         assert n_bwd == T + nl - 1  # one launch per tick
         flagged = [r for r in recs if r[2] == 3]
         assert flagged and all(_owner(ar, r[3]).startswith("dG") for r in flagged)
         # the products really run as two K halves: the second accumulators are written (stored) and read back
-        for name in ["dw0_b"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
+        for name in ["dw0_b", "dw0_c", "dw0_d", "dh_c0", "dh_d0"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
             kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
             assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
     finally:
