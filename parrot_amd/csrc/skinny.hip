@@ -1102,6 +1102,18 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
 
     // fused epilogue, per wave (complete sums).  C layout: column = lane & 15, row = 4 * (lane >> 4) + reg.
 
+    // Output of this workgroup's K part, picked once with scalar selects over the four (unconditionally loaded) kernel
+    // arguments: a select of POINTERS inside the store loop made the compiler index the argument block dynamically and
+    // copy all 3 KB of it to scratch (3000 bytes per lane, 190 / 390 us per launch instead of 41 / 46).
+    unsigned long long kb_ = (unsigned long long)job.out;
+    {
+        const unsigned long long b1 = (unsigned long long)job.o1, b2 = (unsigned long long)job.kout2, b3 = (unsigned long long)job.kout3;
+        if (kpart == 1) kb_ = b1;
+        if (kpart == 2) kb_ = b2;
+        if (kpart == 3) kb_ = b3;
+    }
+    float* const kbase = reinterpret_cast<float*>(kb_);
+    const int kld = kpart ? job.ldo1 : job.ldo;
     const int g = lane >> 4, jj = lane & 15;
     const int n = sk_jcol(job, tile, jj);
     const bool n_ok = n < N;
@@ -1141,8 +1153,7 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
                 if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
-                float* ob = kpart == 0 ? job.out : (kpart == 1 ? job.o1 : (kpart == 2 ? job.kout2 : job.kout3));
-                float* o = ob + (size_t)m * (kpart ? job.ldo1 : job.ldo) + n;
+                float* o = kbase + (size_t)m * kld + n;
                 // part 0 follows `accumulate`, part 1 the flag in ldo2 (split LINEAR jobs), parts 2 and 3 are stored
                 if (kpart == 0 ? job.accumulate != 0 : (kpart == 1 && job.ldo2 != 0)) x += *o;
                 *o = x;
