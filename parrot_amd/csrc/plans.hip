@@ -1455,7 +1455,10 @@ struct DecoderPlan : PlanBase {
     // halves.  A wide workgroup streams its whole [B, 4H] operand: 156 workgroups of ~40 us each at cfg4, whatever
     // their width, and 100 idle CUs; two K halves = 312 workgroups of ~20 us (PARROT_BWD_KSPLIT=0: one part).
     bool bwd_ksplit = false;
-    bool bwd_k4 = false;  // + layer 0's products (the ones behind the attention rows) in FOUR K parts (dh_c / dh_d / dw0_c / dw0_d given)
+    // + layer 0's products (the ones behind the attention rows) in FOUR K parts (dh_c / dh_d / dw0_c / dw0_d given;
+    // PARROT_BWD_K4=1).  Built and measured in round 4: cfg4 94.6 vs 91.4 ms -- 112 narrow workgroups with a ring fill each
+    // cost more than the shorter stream returns.  Kept opt-in.
+    bool bwd_k4 = false;
     int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
     int bwd(hipStream_t st, int q0, int q1) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -2923,7 +2926,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             if (!desc->dh_b[l] || (l + 1 < desc->L && !desc->dhup_b[l])) have = false;
         p->bwd_ksplit = have;
         p->bwd_k4 = have && desc->dh_c[0] && desc->dh_d[0] && desc->dw0_c && desc->dw0_d && (4 * desc->H) % 256 == 0 &&
-                    !(getenv("PARROT_BWD_K4") && atoi(getenv("PARROT_BWD_K4")) == 0);
+                    (getenv("PARROT_BWD_K4") && atoi(getenv("PARROT_BWD_K4")) != 0);  // opt-in: measured slower (51.4 vs 46.4 us per tick)
     }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     p->setup_strands();

@@ -508,10 +508,10 @@ class Parrot(Brick):
                 # tick run as two K halves; zero-filled once (the scan stores into every slot it later reads)
                 ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
                           dhup_b=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
-                          dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f),
-                          # layer 0's products run as FOUR K parts (they start last, behind the attention backward)
-                          dh_c0=torch.zeros(T + 1, B, H, **f), dh_d0=torch.zeros(T + 1, B, H, **f),
-                          dw0_c=torch.zeros(T + 1, B, E, **f), dw0_d=torch.zeros(T + 1, B, E, **f))
+                          dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f))
+                if os.environ.get('PARROT_BWD_K4', '0') != '0':  # opt-in (measured slower): layer 0's products as FOUR K parts
+                    ws.update(dh_c0=torch.zeros(T + 1, B, H, **f), dh_d0=torch.zeros(T + 1, B, H, **f),
+                              dw0_c=torch.zeros(T + 1, B, E, **f), dw0_d=torch.zeros(T + 1, B, E, **f))
         else:
             for n in ('z', 'r', 'rh', 'c'):
                 ws[n] = [torch.empty(T, B, H, **f) for _ in range(L)]

@@ -263,6 +263,7 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
     is behind a flag whose writer -- the attention job or a chain -- is in the same launch)."""
     L, lib = _lib()
     monkeypatch.setenv("PARROT_WK", "2")
+    monkeypatch.setenv("PARROT_BWD_K4", "1")  # (layer 0's products as four K parts: opt-in, covered here)
     T, B, H, E, A, U = 5, 20, 64, 64, 4, 7
     plan, ar, d = _make_plan(L, lib, None, 1, nl, 0, monkeypatch, T, B, H, E, A, U, bf16=1)
     try:
