@@ -1,9 +1,11 @@
 """TF/s of the batched f32 GEMM on the shapes of one cfg2 training step (deferred weight gradients: TN products with
-K = T*B = 51200; readout / feedback projections: NN and NT), per macro-tile variant (PARROT_GEMM_VARIANT).
+K = T*B = 51200; readout / feedback projections: NN and NT), weighted by how often each runs in a step.
 
-    for v in 0 1 2 3 4 5 6; do PARROT_GEMM_VARIANT=$v python tools/gemm_bench.py; done
+    python tools/gemm_bench.py
 
-Every result is checked against a float64 product of a 256-row sample of the output."""
+Every result is checked against a float64 product of a 64-row sample of the output.  Round 4 ran it once per macro-tile
+variant of the kernel (PARROT_GEMM_VARIANT=0..6 of a build that has since been removed: profiles/r04_gemm_tile_variants.txt);
+the tag printed in front of every line is that variable (v0 = the 128 x 128 x 16 kernel of the library)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
