@@ -5,6 +5,9 @@
 //    Blocks StepClipping -> Adam, Appendix A.1 of SURVEY.md)
 #include "elementwise.h"
 
+#include <map>
+#include <mutex>
+
 namespace {
 
 // dh: total gradient wrt h_t. Emits dC = dh*z*(1-c^2), dGz = dh*(c-hp)*z*(1-z),
@@ -283,26 +286,30 @@ __global__ __launch_bounds__(256) void norm_sum_kernel(const NormSumArgs a, floa
 
 }  // namespace
 
-// Library-owned scratch for the two-stage reductions (grown on demand; the calls that use it are issued eagerly
-// on one stream, never from inside a captured scan plan).
+// Library-owned scratch for the two-stage reductions, ONE PER STREAM (grown on demand; never from inside a captured scan
+// plan): since round 4 the encoder's backward runs on a side stream beside the weight-gradient products of the main
+// stream, and both take column sums -- a shared buffer would have the two finish passes read each other's partials.
 static float* ew_scratch(size_t floats, hipStream_t stream) {
-    static float* buf = nullptr;
-    static size_t cap = 0;
+    struct Buf { float* p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<hipStream_t, Buf> bufs;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cs);
     if (cs != hipStreamCaptureStatusNone) return nullptr;
-    if (floats > cap) {
-        if (buf) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(buf);
-            buf = nullptr;
-            cap = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    Buf& b = bufs[stream];
+    if (floats > b.cap) {
+        if (b.p) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(b.p);
+            b.p = nullptr;
+            b.cap = 0;
         }
         const size_t want = floats < (1u << 20) ? (1u << 20) : floats;
-        if (hipMalloc(&buf, want * sizeof(float)) != hipSuccess) return nullptr;
-        cap = want;
+        if (hipMalloc(&b.p, want * sizeof(float)) != hipSuccess) return nullptr;
+        b.cap = want;
     }
-    return buf;
+    return b.p;
 }
 
 
