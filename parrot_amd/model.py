@@ -923,29 +923,7 @@ class Parrot(Brick):
             if t_ is not None:
                 t_.zero_()
 
-        # The encoder's share (d ctx = phi^T . dw, then the bidirectional encoder's backward scan: two latency chains on a
-        # dozen CUs, 0.5 ms at cfg2) only needs what the backward scan leaves behind: it runs on a side stream BESIDE the
-        # weight-gradient GEMMs (PARROT_ENC_OVERLAP=0: behind them, as before round 4).
-        enc_side = None
-
-        def encoder_share():
-            dctx = torch.empty(B, U, E, device=readouts.device, dtype=torch.float32)
-            with ops.gemm_precision(ops.PRECISION_F32):  # attention + encoder: f32 operands in every operand mode
-                _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
-                          dctx.data_ptr(), E, U, E, T, None, 1.0, 0, 0, B, U, E, U * E, 1, ops._stream())
-                self._encoder_backward(dctx, save)
-
-        def after_scan():
-            nonlocal enc_side
-            if os.environ.get('PARROT_ENC_OVERLAP', '1') == '0' or self.compute_bf16:
-                return  # (the process-wide GEMM precision of bf16 decoders is not a per-stream setting: keep one stream)
-            main = torch.cuda.current_stream()
-            enc_side = self._gemm_side_stream()
-            enc_side.wait_stream(main)
-            with torch.cuda.stream(enc_side):
-                encoder_share()
-
-        self._scan_bwd_and_weight_grads(ws, save, T, B, before=readout_weight_grads, after_scan=after_scan)
+        self._scan_bwd_and_weight_grads(ws, save, T, B, before=readout_weight_grads)
         if 'dh_b' in ws:  # slot 0 (the gradient wrt what entered the window): add the second accumulators' share
             for l in range(L):
                 ws['dh'][l][0].add_(ws['dh_b'][l][0])
@@ -1000,14 +978,16 @@ class Parrot(Brick):
             ops.colsum(ws['dw0'][0], out=self._g('.initial_w'), accumulate=True)
         # attention projection bias (the weight gradient is part of _weight_grad_rows)
         ops.colsum(ws['dp'].view(T * B, 3 * A), out=sg_['dec.batt'], accumulate=True)
-        # encoder output: dctx[b] = phi[:, b, :]^T . dw_total[1:, b, :]   (batched over b), then the encoder's backward
-        if self.use_speaker:
-            with ops.gemm_precision(ops.PRECISION_F32):
+        # encoder output: dctx[b] = phi[:, b, :]^T . dw_total[1:, b, :]   (batched over b).  (Round 4 ran this share -- the
+        # d ctx product and the encoder's backward scan, two latency chains of 0.5 ms -- on a side stream BESIDE the weight-
+        # gradient GEMMs: 76.5 vs 72.3 ms per cfg2 step, the chains and the MFMA-bound products slow each other down; removed.)
+        dctx = torch.empty(B, U, E, device=readouts.device, dtype=torch.float32)
+        with ops.gemm_precision(ops.PRECISION_F32):  # attention + encoder: f32 operands in every operand mode
+            _lib.call('parrot_gemm', ws['phi'].data_ptr(), B * U, 1, ws['dw'][1:].data_ptr(), B * E, 0,
+                      dctx.data_ptr(), E, U, E, T, None, 1.0, 0, 0, B, U, E, U * E, 1, ops._stream())
+            if self.use_speaker:
                 self._scatter_rows_add(self._g('/lookuptable.W'), save['spk_idx'], demb_spk)
-        if enc_side is None:
-            encoder_share()
-        else:
-            torch.cuda.current_stream().wait_stream(enc_side)
+            self._encoder_backward(dctx, save)
         self._saved = None
 
     def _weight_grad_rows(self, ws, save, T, B, t0, t1):
@@ -1102,7 +1082,7 @@ class Parrot(Brick):
         with ops.gemm_precision(ops.PRECISION_F32):  # the attention window stays f32 in every operand mode
             ops.gemm(ws['dp'].view(R, 3 * A).t(), ws['h'][0][1:T + 1].view(R, H), out=sg_['dec.WattT'], accumulate=True)
 
-    def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None, after_scan=None):
+    def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None):
         """The backward scan and the weight-gradient GEMMs that only read what it leaves behind.  When the plan runs
         the window in parts (parrot_decoder_parts > 1) the GEMMs of a finished part are enqueued on a second,
         low-priority stream and run BESIDE the rest of the scan: the scan's step kernels are latency-bound and leave
@@ -1115,8 +1095,6 @@ class Parrot(Brick):
             if before is not None:
                 before()
             _lib.call('parrot_decoder_seq_bwd', plan, ops._stream())
-            if after_scan is not None:
-                after_scan()  # work that only needs the finished scan (forked onto a side stream by the caller)
             self._weight_grad_rows(ws, save, T, B, 0, T)
             return
         main = torch.cuda.current_stream()
