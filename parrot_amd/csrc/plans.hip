@@ -98,8 +98,7 @@ struct Tracer {
         for (int q = 0; q < j.nseg; ++q) ks += j.seg[q].K;
         jobs.push_back({launch, id, j.M, j.N, ks, j.epi});
         for (int q = 0; q < j.nseg; ++q)
-            mat(j.seg[q].A, j.M, j.seg[q].K, j.seg[q].lda,
-                (j.wait_flag && j.wait_all != 3 && (j.wait_all || q == j.nseg - 1)) ? 3 : 0, id);  // (3 = K parts: internal to the job)
+            mat(j.seg[q].A, j.M, j.seg[q].K, j.seg[q].lda, (j.wait_flag && (j.wait_all || q == j.nseg - 1)) ? 3 : 0, id);
         mat(j.add, j.M, j.N, j.ld_add, 0, id);
         const int H = j.H;
         switch (j.epi) {
@@ -167,7 +166,7 @@ int launch_jobs(const SkJob* jobs, int n, hipStream_t s, int full_wgs = 0, int f
     if (g_tracer) {
         g_tracer->begin();
         for (int q = 0; q < n; ++q) {
-            if (jobs[q].wait_flag && jobs[q].wait_all != 3) return PARROT_ERR_BADARG;  // (a flag needs its producers in the launch)
+            if (jobs[q].wait_flag) return PARROT_ERR_BADARG;  // (a flag needs its producers in the launch)
             g_tracer->sk_job(jobs[q], q);
         }
         return 0;
@@ -576,9 +575,6 @@ struct DecoderPlan : PlanBase {
         att_flags = nullptr;
         if (bwd_flags && !flags_fake) (void)hipFree(bwd_flags);
         bwd_flags = nullptr;
-        if (kx_flags && !flags_fake) (void)hipFree(kx_flags);
-        if (kx_scratch && !flags_fake) (void)hipFree(kx_scratch);
-        kx_flags = nullptr; kx_scratch = nullptr;
         for (int w = 0; w < 2; ++w)
             for (hipGraphExec_t e : piece[w])
                 if (e) (void)hipGraphExecDestroy(e);
@@ -1411,19 +1407,12 @@ struct DecoderPlan : PlanBase {
     // published by an EARLIER launch:  tick q:  attention(q-1) || lstm(l0, q) [w rows flagged], lstm(l, q - lag7(l)),
     // lag7 = 0, 2, 3.  Same terms per output element as schedule 0 (the attention runs one block per batch row here, so
     // its sums differ from schedule 0's column-sliced blocks in the last bits).
-    // K parts of the upper layers' jobs (PARROT_FWD_KSPLIT=0: one part): plan-owned scratch for the exchanged partial sums
-    // (one slot per tick and job: nothing is reused inside a window) and per-workgroup arrival counters
-    enum { KX_FLAGS_PER_JOB = 128 };
-    float* kx_scratch = nullptr;
-    unsigned* kx_flags = nullptr;
-    size_t kx_floats_per_job() const { return (size_t)d.H * 256; }  // H / 4 tiles x 4 KB, whatever the workgroup width
     int lag7(int l) const { return l == 0 ? 0 : l + 1; }
     int nticks7() const { return d.T + std::max(1, lag7(d.L - 1)); }
     int fwd7(hipStream_t st) {
         if (!att_flags) return PARROT_ERR_BADARG;  // (allocated by parrot_decoder_create, outside any stream capture)
         if (!g_tracer) PL_TRY(sk_zero_words_launch(att_flags, d.T + 2, st));
         const int Q = nticks7();
-        if (!g_tracer && kx_flags) PL_TRY(sk_zero_words_launch(kx_flags, Q * (d.L - 1) * KX_FLAGS_PER_JOB, st));
         for (int q = 0; q < Q; ++q) {
             SkJob jobs[PARROT_MAX_LAYERS];
             int n = 0;
@@ -1438,15 +1427,6 @@ struct DecoderPlan : PlanBase {
                 if (t < 0 || t >= d.T) continue;
                 SkJob& j = jobs[n++];
                 lstm_job(j, l, t);
-                if (l >= 1 && kx_scratch && ((d.H + d.E + l * d.H) / 64) % 2 == 0) {
-                    // the upper layers walk the longest K of the tick (K = (l + 1) H + E): two K parts on different CUs that
-                    // exchange their partial sums inside the launch (skinny.hip wk_body, wait_all = 3)
-                    j.ksplit = 2;
-                    j.wait_all = 3;
-                    j.kout2 = kx_scratch + ((size_t)q * (d.L - 1) + (l - 1)) * kx_floats_per_job();
-                    j.wait_flag = kx_flags + ((size_t)q * (d.L - 1) + (l - 1)) * KX_FLAGS_PER_JOB;
-                    j.wait_target = 1;
-                }
                 if (l == 0 && att_on) {  // w_{q-1} arrives inside this launch: its segment goes last and waits
                     if (j.nseg != 2) return PARROT_ERR_BADARG;
                     j.wait_flag = att_flags + q;
@@ -2931,19 +2911,6 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             if (p->flags_fake) p->bwd_flags = reinterpret_cast<unsigned*>((uintptr_t)0x100000);
             else if (hipMalloc(&p->bwd_flags, sizeof(unsigned) * words) != hipSuccess) { delete p; return PARROT_ERR_BADARG; }
             p->bwd_fused = true;
-        }
-        if (p->schedule == 7 && desc->bf16 && desc->L >= 2 && desc->H / 4 / 4 <= DecoderPlan::KX_FLAGS_PER_JOB &&
-            !(getenv("PARROT_FWD_KSPLIT") && atoi(getenv("PARROT_FWD_KSPLIT")) == 0)) {
-            const size_t jobs = (size_t)p->nticks7() * (desc->L - 1);
-            if (p->flags_fake) {
-                p->kx_flags = reinterpret_cast<unsigned*>((uintptr_t)0x200000);
-                p->kx_scratch = reinterpret_cast<float*>((uintptr_t)0x40000000);
-            } else if (hipMalloc(&p->kx_flags, sizeof(unsigned) * jobs * DecoderPlan::KX_FLAGS_PER_JOB) != hipSuccess ||
-                       hipMalloc(&p->kx_scratch, sizeof(float) * jobs * p->kx_floats_per_job()) != hipSuccess) {
-                (void)hipGetLastError();  // no room for the scratch: one K part per job, as before
-                if (p->kx_flags) (void)hipFree(p->kx_flags);
-                p->kx_flags = nullptr; p->kx_scratch = nullptr;
-            }
         }
         const char* e = getenv("PARROT_S6_ESPLIT");
         p->esplit6 = e && atoi(e) > 0 ? atoi(e) : 1;

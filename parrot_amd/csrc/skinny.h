@@ -55,9 +55,6 @@ struct SkJob {
     // wait_all = 1 / 2 (wide bf16 kernel only, single-segment jobs): the WHOLE A operand is produced inside the launch (the
     // state-backward rows at the head of the fused backward tick, wkb_kernel): the workgroup waits before its first load.
     // 2: the producer is the slow one of the launch (the rows behind the attention backward): such jobs go last in the grid.
-    // wait_all = 3 with ksplit = P (wide bf16 kernel; any epilogue, e.g. the LSTM cell): the K parts exchange their partial
-    // sums inside the launch -- parts 0 .. P-2 publish their accumulators into kout2 (scratch of P-1 x H KB) and arrive on
-    // wait_flag[workgroup]; the last part adds them in part order and runs the epilogue.
     // ksplit = 2..4 (wide bf16 kernel only; single-segment LINEAR jobs): the K range is cut in equal parts handled by different
     // workgroups; the first half follows `accumulate` into `out`, the second half goes into o1 (ldo1): stored, or added when
     // ldo2 != 0 (a destination several jobs of a window add to; the field is otherwise unused by LINEAR jobs) -- the consumer

@@ -718,12 +718,10 @@ void sk_finalize_job(SkJob& j) {
         if (g.b_kcontig != j.seg[0].b_kcontig) al = 0;  // the fast path assumes one weight layout per job
     }
     j.aligned = al;
-    if (j.ksplit > 1 && (j.seg[0].b_kcontig != 3 || (j.nseg != 1 && j.wait_all != 3))) j.aligned = -1;  // K parts: wide bf16 kernel only
+    if (j.ksplit > 1 && (j.seg[0].b_kcontig != 3 || j.nseg != 1)) j.aligned = -1;  // K parts: wide bf16 kernel only
     // a waiting job: fragment-major weights, f32 (sk_body's tail) or bf16 (wk_body's tail: sk_launch_att refuses the
     // launch if the wide kernel does not take it); anything else is rejected by sk_make_launch
-    if (j.wait_flag && j.wait_all == 3) {
-        if (!al || j.seg[0].b_kcontig != 3) j.aligned = -1;  // exchanging K parts: wide bf16 kernel only
-    } else if (j.wait_flag && (!al || (j.wait_all ? (j.nseg != 1 || j.seg[0].b_kcontig != 3) : j.nseg < 2) || j.seg[0].b_kcontig < 2 || !SK_A_PERMUTE))
+    if (j.wait_flag && (!al || (j.wait_all ? (j.nseg != 1 || j.seg[0].b_kcontig != 3) : j.nseg < 2) || j.seg[0].b_kcontig < 2 || !SK_A_PERMUTE))
         j.aligned = -1;
 }
 
@@ -961,20 +959,16 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
     // A job whose LAST segment's activations are produced by the attention blocks of the same launch (SkJob::wait_flag,
     // plans.hip schedule 7) walks its other segments through the pipelined ring and takes that segment afterwards
     // (wk_tail): same terms in the same order as the unflagged job, bit for bit.
-    // wait_all == 3: the K parts of an LSTM job EXCHANGE their partial sums inside the launch (below): not a flagged tail
-    const bool kx = !WAITALL && job.wait_flag != nullptr && job.wait_all == 3;
-    const bool flagged = !WAITALL && job.wait_flag != nullptr && job.wait_all == 0;
+    const bool flagged = !WAITALL && job.wait_flag != nullptr;
     const int nseg_main = flagged ? job.nseg - 1 : job.nseg;
     int total = 0;
     for (int q = 0; q < nseg_main; ++q) total += job.seg[q].K / WK_STAGE;
-    total /= nparts;  // (the stage count of a split job is a multiple of its parts: wk_build checks)
+    total /= nparts;  // (split jobs have one segment whose K is a multiple of nparts stages: wk_build checks)
     struct Cursor { const float* A; const float* B; int lda, ldb, left, seg, k; };
     auto cursor_init = [&](Cursor& c) __attribute__((always_inline)) {
-        int skip = kpart * total, sgi = 0;  // part p starts p * total stages into the concatenated segments
-        while (sgi + 1 < nseg_main && skip >= job.seg[sgi].K / WK_STAGE) { skip -= job.seg[sgi].K / WK_STAGE; ++sgi; }
-        c.seg = sgi; c.k = skip * WK_STAGE;
-        c.A = job.seg[sgi].A; c.B = job.seg[sgi].B; c.lda = job.seg[sgi].lda; c.ldb = job.seg[sgi].ldb;
-        c.left = job.seg[sgi].K / WK_STAGE - skip;
+        c.seg = 0; c.k = kpart * total * WK_STAGE;
+        c.A = job.seg[0].A; c.B = job.seg[0].B; c.lda = job.seg[0].lda; c.ldb = job.seg[0].ldb;
+        c.left = nparts > 1 ? total : job.seg[0].K / WK_STAGE;
     };
     auto cursor_next = [&](Cursor& c) __attribute__((always_inline)) {
         if (c.left > 1) { --c.left; c.k += WK_STAGE; return; }
@@ -1102,38 +1096,6 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
                 }
             }
             __syncthreads();
-        }
-    }
-    if (kx) {
-        // K parts of a job whose epilogue needs COMPLETE sums (the LSTM cell): parts 0 .. P-2 publish their accumulators --
-        // lane for lane, the parts tile identically -- with 16-byte write-through stores into the job's scratch and arrive
-        // on the workgroup's counter; the last part waits for P-1 arrivals, adds them in part order and runs the epilogue.
-        // A wide workgroup's time is the time to stream its [64, K] operand: two parts halve the launch's longest stream.
-        float* scr = job.kout2;
-        const size_t slot = (((size_t)wg * 8 + wave) * MB) * 256 + (size_t)lane * 4;  // floats; + rb * 256, + part stride
-        const size_t pstride = (size_t)wgh * 8 * MB * 256;
-        if (kpart < nparts - 1) {
-#pragma unroll
-            for (int rb = 0; rb < MB; ++rb) {
-                float* q = scr + (size_t)kpart * pstride + slot + (size_t)rb * 256;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(acc[rb]) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0)
-                (void)__hip_atomic_fetch_add(const_cast<unsigned*>(job.wait_flag) + wg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-        if (tid == 0) sk_wait_flag(job.wait_flag + wg, (unsigned)(nparts - 1));
-        __syncthreads();
-        const __amdgpu_buffer_rsrc_t rs = sk_rsrc(scr);
-        for (int p = 0; p < nparts - 1; ++p) {
-#pragma unroll
-            for (int rb = 0; rb < MB; ++rb) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    rs, (unsigned)(((size_t)p * pstride + slot + (size_t)rb * 256) * 4), 0, 16 /* sc1 */));
-                acc[rb] += v;
-            }
         }
     }
     if (!tile_ok) return;
@@ -1311,22 +1273,16 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
     long long work = 0;
     for (int q = 0; q < Lin.njobs; ++q) {
         const SkJob& j = Lin.job[q];
-        const bool kx = j.wait_all == 3;  // K parts that exchange partial sums among themselves: no lead blocks involved
-        if (j.wait_flag && !kx && !has_lead) return false;  // a flag needs its producers in the launch
-        if (j.wait_flag && !kx && (j.wait_all ? j.nseg != 1 : j.nseg < 2)) return false;  // (wait_all: 1, or 2 = behind the attention rows)
+        if (j.wait_flag && !has_lead) return false;  // a flag needs its producers in the launch
+        if (j.wait_flag && (j.wait_all ? j.nseg != 1 : j.nseg < 2)) return false;  // (wait_all: 1, or 2 = behind the attention rows)
         if (j.seg[0].b_kcontig != 3 || !j.aligned || j.M > 64 || j.M < 1) return false;
         if (j.epi != SK_EPI_LSTM && j.epi != SK_EPI_LINEAR) return false;
         if (j.epi == SK_EPI_LINEAR && (j.N & 15)) return false;
         for (int s = 0; s < j.nseg; ++s)
             if (j.seg[s].K % WK_STAGE) return false;
-        if (j.ksplit > 1 && kx) {  // exchanging parts: any epilogue, any segments; scratch + per-workgroup counters given
-            int stages = 0;
-            for (int s = 0; s < j.nseg; ++s) stages += j.seg[s].K / WK_STAGE;
-            if (j.ksplit > 4 || !j.kout2 || !j.wait_flag || stages % j.ksplit) return false;
-        } else if (j.ksplit > 1 && (j.ksplit > 4 || j.nseg != 1 || j.epi != SK_EPI_LINEAR || j.act || !j.o1 || (j.ksplit > 2 && !j.kout2) ||
-                                    (j.ksplit > 3 && !j.kout3) || j.seg[0].K % (j.ksplit * WK_STAGE)))
+        if (j.ksplit > 1 && (j.ksplit > 4 || j.nseg != 1 || j.epi != SK_EPI_LINEAR || j.act || !j.o1 || (j.ksplit > 2 && !j.kout2) ||
+                             (j.ksplit > 3 && !j.kout3) || j.seg[0].K % (j.ksplit * WK_STAGE)))
             return false;
-        if (kx && j.ksplit < 2) return false;
         work += (long long)j.N;
     }
     if (work < 4096 && enabled < 2 && !Lin.force_wide) return false;
@@ -1340,7 +1296,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         int n = 0;
         for (int pass = 0; pass < 2; ++pass)
             for (int q = 0; q < Lin.njobs; ++q) {
-                const bool late = Lin.job[q].wait_flag != nullptr && (Lin.job[q].wait_all == 0 || Lin.job[q].wait_all == 2);
+                const bool late = Lin.job[q].wait_flag != nullptr && Lin.job[q].wait_all != 1;
                 if (late != (pass == 1)) continue;
                 W.job[n] = Lin.job[q];
                 tiles[n] = Lin.tile_end[q];
@@ -1353,7 +1309,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         for (int s = 0; s < W.job[q].nseg; ++s) ksum[q] += W.job[q].seg[s].K;
         const int parts = W.job[q].ksplit > 1 ? W.job[q].ksplit : 1;
         units += ceil_div(tiles[q], 4) * parts;
-        if (W.job[q].wait_flag && (W.job[q].wait_all == 0 || W.job[q].wait_all == 2)) { any_flag = true; units_flagged += ceil_div(tiles[q], 4) * parts; }
+        if (W.job[q].wait_flag && W.job[q].wait_all != 1) { any_flag = true; units_flagged += ceil_div(tiles[q], 4) * parts; }
     }
     // one workgroup per CU and launch: widen the jobs with the shortest K to 128 columns until the launch fits (with
     // jobs that wait behind their other segments: until the OTHER jobs fit beside the lead blocks; the waiting ones, at
@@ -1369,7 +1325,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
         if (best < 0) break;
         const int gain = (ceil_div(tiles[best], 4) - ceil_div(tiles[best], 8)) * (W.job[best].ksplit > 1 ? W.job[best].ksplit : 1);
         units -= gain;
-        if (W.job[best].wait_flag && (W.job[best].wait_all == 0 || W.job[best].wait_all == 2)) units_flagged -= gain;
+        if (W.job[best].wait_flag && W.job[best].wait_all != 1) units_flagged -= gain;
         W.ncw[best] = 8;
     }
     t = 0;
@@ -1383,7 +1339,7 @@ static bool wk_build(const SkLaunch& Lin, int nlead, bool has_lead, WkLaunch& W,
 
 static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, const AttFwdArgs* att = nullptr) {
     for (int q = 0; q < Lin.njobs; ++q)
-        if (Lin.job[q].wait_all == 1 || Lin.job[q].wait_all == 2) return false;  // (the fused backward tick has its own entry point)
+        if (Lin.job[q].wait_all) return false;  // (the fused backward tick has its own entry point)
     const int natt = att ? att->B * att->esplit : 0;
     WkLaunch W;
     int t;
@@ -1580,7 +1536,7 @@ void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid_out, size_t& lds_ou
 
 int sk_launch(const SkLaunch& Lin, hipStream_t stream) {
     for (int q = 0; q < Lin.njobs; ++q)
-        if (Lin.job[q].wait_flag && Lin.job[q].wait_all != 3) return PH_ERR_BADARG;  // a flag needs its producers in the launch: sk_launch_att
+        if (Lin.job[q].wait_flag) return PH_ERR_BADARG;  // a flag needs its producers in the launch: sk_launch_att
     {
         int rc = 0;
         if (wk_try_launch(Lin, stream, &rc)) return rc;
