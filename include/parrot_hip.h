@@ -424,10 +424,25 @@ typedef struct ParrotSampleDesc {
     const float* Wr_t; const float* Wo_t; const float* bo_pad; const float* oadd_pad;
     float* persist_ws;
     long long persist_ws_floats;
+    /* Optional (round 4): with the MSE head and no layer norm, readout -> output is linear in the readout's operands
+     * (model.py:992-1013).  Given
+     *   Wro_t:    fragment-major copy of Wr . Wo, [L*H + E, 64] (columns >= O zero), and
+     *   ro_const: [B, 64] row-major = (br + radd) . Wo + bo + oadd (columns >= O zero),
+     * the machine computes x[t+1] straight from [h_0 .. h_{L-1} ; w] in ONE phase and cuts every product of the step
+     * along K by the age of its operands (2L + 2 phases per step, each walking only the rows of its newest operand;
+     * plans.hip, build_persist_pieces).  NULL, or PARROT_PM_PIECES=0: the 2L + 3 whole-K phases above. */
+    const float* Wro_t;
+    const float* ro_const;
 } ParrotSampleDesc;
 
 long long parrot_sample_persist_floats(const ParrotSampleDesc* desc);
 int parrot_sample_is_persistent(void* plan);
+/* Plans the decode machine for `desc` with `nwg` workgroups WITHOUT touching device memory (pointers are only used for
+ * address arithmetic) and replays the unit table symbolically: every read must find its value written in an earlier
+ * phase, every buffer element is written once.  info16: [0] phases per step, [1] partial-sum buffers, [2] checker
+ * verdict (0 ok), [3] units per step, [4 + s] units in phase s, [14] units that stream their weights.
+ * 0, or PARROT_ERR_UNSUPPORTED when the configuration does not take this plan.  Used by the CPU tests. */
+int parrot_sample_plan_pieces_dry(const ParrotSampleDesc* desc, int nwg, int* info16);
 /* Like parrot_decoder_status, for a decode plan. */
 int parrot_sample_status(void* plan);
 

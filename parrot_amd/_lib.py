@@ -109,6 +109,7 @@ class SampleDesc(C.Structure):
         ("Wg_t", C.c_void_p * MAX_LAYERS), ("Wc_t", C.c_void_p * MAX_LAYERS),
         ("Wr_t", C.c_void_p), ("Wo_t", C.c_void_p), ("bo_pad", C.c_void_p), ("oadd_pad", C.c_void_p),
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
+        ("Wro_t", C.c_void_p), ("ro_const", C.c_void_p),
     ]
 
 
@@ -167,6 +168,7 @@ SIGNATURES = {
     "parrot_sample_create": (_i, [C.POINTER(SampleDesc), C.POINTER(C.c_void_p)]),
     "parrot_sample_persist_floats": (C.c_longlong, [C.POINTER(SampleDesc)]),
     "parrot_sample_is_persistent": (_i, [_vp]),
+    "parrot_sample_plan_pieces_dry": (_i, [C.POINTER(SampleDesc), _i, C.POINTER(C.c_int)]),
     "parrot_sample_status": (_i, [_vp]),
     "parrot_decoder_status": (_i, [_vp]),
     "parrot_sample_run": (_i, [_vp, _vp]),

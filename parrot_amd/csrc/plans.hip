@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -2378,14 +2379,20 @@ struct SamplePlan : PlanBase {
     PmProgram pm_prog;
     float* hist_h[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
 
-    static bool persist_eligible(const ParrotSampleDesc& d) {
+    static bool persist_eligible_shape(const ParrotSampleDesc& d) {  // (no device query: the CPU tests plan too)
         if (d.cell != 0 || d.layer_norm || d.gmm_K > 0 || d.B > 64 || (d.H % 16) || (d.E % 16) || (d.R % 16) ||
             d.U > PM_ATT_MAXU || d.A > PM_ATT_MAXA || d.S < 1 || d.O > 64 || d.ldx < 64 || (d.ldx % 4))
             return false;
-        if (2 * d.L + 3 > PM_MAXSLOTS || !d.Wr_t || !d.Wo_t || !d.bo_pad) return false;
         for (int l = 0; l < d.L; ++l)
             if (!d.Wg_t[l] || !d.Wc_t[l]) return false;
-        if ((d.oadd != nullptr) != (d.oadd_pad != nullptr)) return false;
+        return true;
+    }
+    static bool legacy_eligible(const ParrotSampleDesc& d) {
+        if (2 * d.L + 3 > PM_MAXSLOTS || !d.Wr_t || !d.Wo_t || !d.bo_pad) return false;
+        return (d.oadd != nullptr) == (d.oadd_pad != nullptr);
+    }
+    static bool persist_eligible(const ParrotSampleDesc& d) {
+        if (!persist_eligible_shape(d) || !(legacy_eligible(d) || pieces_wanted(d))) return false;
         return pm_max_workgroups() >= 64;
     }
     static int fb_rows(const ParrotSampleDesc& d, int l) { return d.Wfg[l] ? 64 : 0; }
@@ -2399,7 +2406,7 @@ struct SamplePlan : PlanBase {
         n += S * rows * ((long long)d.L * d.H + d.E) + S * rows * d.R;
         n += (long long)d.L * (S + 1) * d.B * d.H + (long long)d.L * S * d.B * d.H;   // h and z histories (row-major)
         n += S * d.B * d.R + S * d.B * d.A;
-        return n + 4096;
+        return n + piece_floats(d) + 4096;
     }
 
     int build_persist() {
@@ -2407,6 +2414,11 @@ struct SamplePlan : PlanBase {
         const char* e = getenv("PARROT_SAMPLE_PERSIST");
         if (e && atoi(e) == 0) return 0;
         if (!persist_eligible(d) || !d.persist_ws) return 0;
+        if (pieces_wanted(d)) {  // the step cut along K by the age of its operands (below); else the 2L + 3 whole-K phases
+            build_persist_pieces(false, 0);
+            if (persist_ok) return 0;
+        }
+        if (!legacy_eligible(d)) return 0;
         const int nwg = pm_max_workgroups();
         if (d.persist_ws_floats < persist_floats(d, nwg)) return 0;
         const int H = d.H, E = d.E, B = d.B, L = d.L, S = d.S, R = d.R;
@@ -2591,6 +2603,442 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < d.L; ++l)  // row-major initial state for the epilogues (r * h_prev, state blend)
             PL_TRY((int)hipMemcpyAsync(hist_h[l], d.h[l], BH * sizeof(float), hipMemcpyDeviceToDevice, st));
         return pm_launch(pm_prog, st);
+    }
+
+    // ---- round 4: the decode step cut along K by the AGE of its operands ------------------------------------------
+    // With the output fed back (model.py:899-924) a step is one dependency chain x[t] -> G_0 -> C_0 -> attention ->
+    // G_1 -> C_1 .. -> readout -> output -> x[t+1], and above every phase walked the whole K of its product (1600 ..
+    // 2624 rows at configs[2]) although only ONE operand of each product is new when the phase starts.  Here
+    //   * readout and output are one phase: without GMM head and layer norm, x = (XR . Wr + br + radd) . Wo + bo + oadd is
+    //     linear in XR (model.py:992-1013), so the caller hands over Wro = Wr . Wo ([L H + E, 64], fragment-major) and
+    //     ro_const = (br + radd) . Wo + bo + oadd ([B, 64]); the readout itself is not an output of sample_model;
+    //   * every product is cut into pieces along K, one per operand ([h_l ; w ; h_0 .. h_{l-1} ; x] are chunk ranges of
+    //     the unit's slab).  The piece whose operand is produced by the phase just before the product's own is the
+    //     CRITICAL unit (K = 64 for G_0, E for G_1, H for the candidates and the output); every other piece runs as a
+    //     LINEAR unit on workgroups that are idle anyway (the decode loop keeps < 130 of 256 busy per phase), in a phase
+    //     between its operand's and the product's, and leaves its [B, N] partial sums row-major and write-through; the
+    //     critical unit adds them in its epilogue (PmUnit::add, up to 4).
+    // A tick has 2L + 2 phases; main units run step (tick - 1), pieces whose operand dates from the previous step may run
+    // in the previous tick (lag 0), so the launch has S + 1 ticks.  check_pieces() replays the table symbolically (every
+    // read satisfied by a write of a strictly earlier phase, every buffer element written once) before it is used.
+    struct PmPiece {
+        int c0, nch, gp;  // chunk range of the slab; position (phase index over two ticks) after which the operand exists
+        bool crit;
+        int lag, slot, pbuf;
+    };
+    struct PmGroup {
+        int kind, l, slot, N, res;  // kind 0 gates, 1 candidate, 2 output; res = checker resource id of the slab
+        long long ks;
+        std::vector<PmPiece> pc;
+    };
+    struct PmAccess { int res, dstep, c0, nch; };
+    struct PmMeta { int lag, slot; std::vector<PmAccess> rd, wr; };
+    enum { RES_XG = 10, RES_XC = 20, RES_XR = 30, RES_H = 40, RES_Z = 50, RES_X = 60, RES_KAPPA = 61, RES_PART = 100 };
+    bool pieces_ok = false;
+    int pieces_info[16] = {0};
+
+    static int slotG(int l) { return l == 0 ? 0 : 2 * l + 1; }
+    static int slotC(int l) { return slotG(l) + 1; }
+    static bool pieces_wanted(const ParrotSampleDesc& d) {
+        const char* e = getenv("PARROT_PM_PIECES");
+        return d.Wro_t && d.ro_const && !(e && atoi(e) == 0) && 2 * d.L + 2 <= PM_MAXSLOTS;
+    }
+    static bool piece_groups(const ParrotSampleDesc& d, std::vector<PmGroup>& gs) {
+        const int H = d.H, E = d.E, L = d.L, n = 2 * L + 2, sATT = 2, sOUT = 2 * L + 1;
+        const int hc = H / 16, ec = E / 16;
+        auto pos = [&](int delta, int slot) { return (1 + delta) * n + slot; };
+        auto piece = [](int c0, int nch, int gp) { PmPiece p; p.c0 = c0; p.nch = nch; p.gp = gp; p.crit = false; p.lag = 1; p.slot = -1; p.pbuf = -1; return p; };
+        gs.clear();
+        for (int l = 0; l < L; ++l)
+            for (int kind = 0; kind < 2; ++kind) {
+                PmGroup g;
+                g.kind = kind; g.l = l; g.slot = kind == 0 ? slotG(l) : slotC(l); g.N = kind == 0 ? 2 * H : H;
+                g.ks = kslab(d, l); g.res = (kind == 0 ? RES_XG : RES_XC) + l;
+                g.pc.push_back(piece(0, hc, kind == 0 ? pos(-1, slotC(l)) : pos(0, slotG(l))));  // h_l[t] | r * h_l[t]
+                g.pc.push_back(piece(hc, ec, l == 0 ? pos(-1, sATT) : pos(0, sATT)));              // w[t] | w[t+1]
+                for (int j = 0; j < l; ++j) g.pc.push_back(piece(hc + ec + j * hc, hc, pos(0, slotC(j))));  // h_j[t+1]
+                if (fb_rows(d, l)) g.pc.push_back(piece((int)(g.ks / 16) - 4, 4, pos(-1, sOUT)));  // x[t]
+                gs.push_back(g);
+            }
+        {
+            PmGroup o;
+            o.kind = 2; o.l = 0; o.slot = sOUT; o.N = 64; o.ks = (long long)L * H + E; o.res = RES_XR;
+            for (int j = 0; j < L; ++j) o.pc.push_back(piece(j * hc, hc, pos(0, slotC(j))));
+            o.pc.push_back(piece(L * hc, ec, pos(0, sATT)));
+            gs.push_back(o);
+        }
+        for (PmGroup& g : gs) {
+            size_t ci = 0;
+            for (size_t i = 1; i < g.pc.size(); ++i)
+                if (g.pc[i].gp > g.pc[ci].gp) ci = i;
+            if (g.pc[ci].gp >= n + g.slot) return false;
+            g.pc[ci].crit = true;
+            g.pc[ci].slot = g.slot;
+            const int fixed = g.kind == 2 ? 1 : ((g.kind == 0 ? d.seq_g[g.l] : d.seq_c[g.l]) ? 1 : 0);
+            while ((int)g.pc.size() - 1 + fixed > 4) {  // more partial sums than a unit can add: join neighbours
+                int best = -1, bestd = 1 << 30;
+                for (size_t i = 0; i + 1 < g.pc.size(); ++i) {
+                    const PmPiece &a = g.pc[i], &b = g.pc[i + 1];
+                    if (a.crit || b.crit || a.c0 + a.nch != b.c0) continue;
+                    const int dd = a.gp > b.gp ? a.gp - b.gp : b.gp - a.gp;
+                    if (dd < bestd) { bestd = dd; best = (int)i; }
+                }
+                if (best < 0) return false;
+                g.pc[best].nch += g.pc[best + 1].nch;
+                g.pc[best].gp = std::max(g.pc[best].gp, g.pc[best + 1].gp);
+                g.pc.erase(g.pc.begin() + best + 1);
+            }
+        }
+        return true;
+    }
+    // the phase of every non-critical piece: most constrained first; a phase may not take more units than workgroups, and
+    // a piece should not outlast the critical units of its phase (unit cost as in pm_place)
+    static bool piece_slots(const ParrotSampleDesc& d, std::vector<PmGroup>& gs, int nwg) {
+        const int n = 2 * d.L + 2;
+        auto cost = [](int K) { return 3.5 + 3.5 * K / 1024.0; };
+        std::vector<int> cnt(n, 0);
+        std::vector<double> tcrit(n, 0.0);
+        cnt[2] = d.B; tcrit[2] = 9.0;
+        struct Ref { int g, p, ncand, K, tiles; };
+        std::vector<Ref> refs;
+        for (size_t gi = 0; gi < gs.size(); ++gi)
+            for (size_t pi = 0; pi < gs[gi].pc.size(); ++pi) {
+                PmGroup& g = gs[gi];
+                PmPiece& p = g.pc[pi];
+                if (p.crit) {
+                    cnt[g.slot] += g.N / 16;
+                    tcrit[g.slot] = std::max(tcrit[g.slot], cost(p.nch * 16));
+                } else {
+                    refs.push_back({(int)gi, (int)pi, n + g.slot - 1 - p.gp, p.nch * 16, g.N / 16});
+                }
+            }
+        for (int s = 0; s < n; ++s)
+            if (cnt[s] > nwg) return false;
+        std::stable_sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) {
+            if (a.ncand != b.ncand) return a.ncand < b.ncand;
+            if (a.K != b.K) return a.K > b.K;
+            return a.tiles > b.tiles;
+        });
+        for (const Ref& r : refs) {
+            PmGroup& g = gs[r.g];
+            PmPiece& p = g.pc[r.p];
+            int best = -1;
+            double best_score = 0;
+            for (int q = p.gp + 1; q < n + g.slot; ++q) {
+                const int s = q % n;
+                if (cnt[s] + r.tiles > nwg) continue;
+                const double late = cost(r.K) - tcrit[s];
+                const double score = (late > 0 ? late : 0) * 1e3 + cnt[s] + r.tiles;
+                if (best < 0 || score < best_score) { best = q; best_score = score; }
+            }
+            if (best < 0) return false;
+            p.slot = best % n;
+            p.lag = best >= n ? 1 : 0;
+            cnt[p.slot] += r.tiles;
+        }
+        return true;
+    }
+    static long long piece_floats(const ParrotSampleDesc& d) {  // the partial-sum buffers of the pieces (exact)
+        std::vector<PmGroup> gs;
+        if (!pieces_wanted(d) || !piece_groups(d, gs)) return 0;
+        long long n = 0;
+        for (const PmGroup& g : gs)
+            for (const PmPiece& p : g.pc)
+                if (!p.crit) n += (long long)(d.S + 1) * d.B * g.N + 16;
+        return n;
+    }
+    // symbolic replay over S steps: 0 = every read finds its value written in an earlier phase and nothing is written twice
+    static int check_pieces(const std::vector<PmMeta>& metas, const std::vector<PmAccess>& init, int n_slots, int S) {
+        std::vector<std::array<int, 3>> written;  // (res, step, chunk), kept sorted
+        auto has = [&](int r, int t, int c) {
+            const std::array<int, 3> k = {r, t, c};
+            return std::binary_search(written.begin(), written.end(), k);
+        };
+        auto put = [&](int r, int t, int c) {
+            const std::array<int, 3> k = {r, t, c};
+            auto it = std::lower_bound(written.begin(), written.end(), k);
+            if (it != written.end() && *it == k) return false;
+            written.insert(it, k);
+            return true;
+        };
+        for (const PmAccess& a : init)
+            for (int c = a.c0; c < a.c0 + a.nch; ++c)
+                if (!put(a.res, a.dstep, c)) return 1;
+        for (int tick = 0; tick <= S; ++tick)
+            for (int s = 0; s < n_slots; ++s) {
+                for (const PmMeta& m : metas) {
+                    const int t = tick - m.lag;
+                    if (m.slot != s || t < 0 || t >= S) continue;
+                    for (const PmAccess& a : m.rd)
+                        for (int c = a.c0; c < a.c0 + a.nch; ++c)
+                            if (!has(a.res, t + a.dstep, c)) return 2;
+                }
+                for (const PmMeta& m : metas) {
+                    const int t = tick - m.lag;
+                    if (m.slot != s || t < 0 || t >= S) continue;
+                    for (const PmAccess& a : m.wr)
+                        for (int c = a.c0; c < a.c0 + a.nch; ++c)
+                            if (!put(a.res, t + a.dstep, c)) return 3;
+                }
+            }
+        for (int t = 1; t <= S; ++t)
+            if (!has(RES_X, t, 0)) return 4;
+        return 0;
+    }
+
+    // dry = true: plan, place and check only (no device memory is touched; nwg given by the caller) -- the CPU tests
+    int build_persist_pieces(bool dry, int nwg_dry) {
+        pieces_ok = false;
+        if (!pieces_wanted(d) || !persist_eligible_shape(d)) return 0;
+        const int nwg = dry ? nwg_dry : pm_max_workgroups();
+        if (nwg < 64) return 0;
+        if (!dry && (!d.persist_ws || d.persist_ws_floats < persist_floats(d, nwg))) return 0;
+        std::vector<PmGroup> gs;
+        if (!piece_groups(d, gs) || !piece_slots(d, gs, nwg)) return 0;
+        const int H = d.H, E = d.E, B = d.B, L = d.L, S = d.S;
+        const int MB = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
+        const long long rows = (long long)MB * 16, BH = (long long)B * H;
+        const int n_slots = 2 * L + 2, sATT = 2, hc = H / 16, ec = E / 16;
+        float* ws = dry ? reinterpret_cast<float*>((uintptr_t)0x10000000) : d.persist_ws;
+        auto take = [&](long long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
+        unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS + PM_DBG_WORDS));
+        const size_t unit_bytes = (size_t)n_slots * nwg * sizeof(PmUnit);
+        PmUnit* units_dev = reinterpret_cast<PmUnit*>(take((long long)(unit_bytes + 3) / 4 + 16));
+        float* fm_base = ws;
+        float* XG[PARROT_MAX_LAYERS];
+        float* XC[PARROT_MAX_LAYERS];
+        long long kx[PARROT_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) {
+            kx[l] = kslab(d, l);
+            XG[l] = take((S + 1) * rows * kx[l]);
+            XC[l] = take((S + 1) * rows * kx[l]);
+        }
+        const long long kr = (long long)L * H + E;
+        float* XR = take(S * rows * kr);
+        if ((long long)(ws - fm_base) * 4 >= 0xfff00000ll) return 0;
+        float* const fm_end = ws;
+        float* zh[PARROT_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) hist_h[l] = take((S + 1) * BH);
+        for (int l = 0; l < L; ++l) zh[l] = take(S * BH);
+        float* b_hist = take((long long)S * B * d.A);
+        float* const part_base = ws;
+        int npart = 0;
+        std::vector<float*> pbuf;
+        for (PmGroup& g : gs)
+            for (PmPiece& p : g.pc)
+                if (!p.crit) {
+                    p.pbuf = npart++;
+                    pbuf.push_back(take((long long)(S + 1) * B * g.N + 16));
+                }
+        float* const part_end = ws;
+
+        auto boff = [&](const float* p) { return (unsigned)((p - fm_base) * 4); };
+        auto mkdst = [&](float* slab, long long step0, long long ks, int chunk) {
+            PmDst q;
+            q.off = boff(slab + step0 * rows * ks); q.st = (unsigned)(rows * ks * 4); q.nch = (int)(ks / 16); q.chunk = chunk;
+            return q;
+        };
+        auto rm = [](const float* p, long long st, int ld) { PmRM r; r.p = const_cast<float*>(p); r.st = st; r.ld = ld; r.pad = 0; return r; };
+        std::vector<PmReq> reqs;
+        std::vector<PmMeta> metas;
+        auto acc = [](int res, int dstep, int c0, int nch) { PmAccess a; a.res = res; a.dstep = dstep; a.c0 = c0; a.nch = nch; return a; };
+        for (const PmGroup& g : gs) {
+            const int l = g.l, N = g.N, nch_all = (int)(g.ks / 16);
+            float* slab = g.kind == 0 ? XG[l] : (g.kind == 1 ? XC[l] : XR);
+            const float* Wt = g.kind == 0 ? d.Wg_t[l] : (g.kind == 1 ? d.Wc_t[l] : d.Wro_t);
+            for (const PmPiece& p : g.pc) {
+                PmMeta m;
+                m.lag = p.lag; m.slot = p.slot;
+                m.rd.push_back(acc(g.res, 0, p.c0, p.nch));
+                if (!p.crit) {
+                    m.wr.push_back(acc(RES_PART + p.pbuf, 0, 0, 1));
+                } else {
+                    for (const PmPiece& o : g.pc)
+                        if (!o.crit) m.rd.push_back(acc(RES_PART + o.pbuf, 0, 0, 1));
+                    if (g.kind == 0) {
+                        m.rd.push_back(acc(RES_H + l, 0, 0, 1));
+                        m.wr.push_back(acc(RES_Z + l, 0, 0, 1));
+                        m.wr.push_back(acc(RES_XC + l, 0, 0, hc));
+                    } else if (g.kind == 1) {
+                        m.rd.push_back(acc(RES_H + l, 0, 0, 1));
+                        m.rd.push_back(acc(RES_Z + l, 0, 0, 1));
+                        m.wr.push_back(acc(RES_H + l, 1, 0, 1));
+                        m.wr.push_back(acc(RES_XG + l, 1, 0, hc));
+                        for (int m2 = l + 1; m2 < L; ++m2) {
+                            m.wr.push_back(acc(RES_XG + m2, 0, hc + ec + l * hc, hc));
+                            m.wr.push_back(acc(RES_XC + m2, 0, hc + ec + l * hc, hc));
+                        }
+                        m.wr.push_back(acc(RES_XR, 0, l * hc, hc));
+                    } else {
+                        m.wr.push_back(acc(RES_X, 1, 0, 1));
+                        for (int q = 0; q < L; ++q)
+                            if (fb_rows(d, q)) {
+                                m.wr.push_back(acc(RES_XG + q, 1, (int)(kx[q] / 16) - 4, 4));
+                                m.wr.push_back(acc(RES_XC + q, 1, (int)(kx[q] / 16) - 4, 4));
+                            }
+                    }
+                }
+                metas.push_back(m);
+                for (int ct = 0; ct < N / 16; ++ct) {
+                    PmReq q;
+                    memset(&q, 0, sizeof(q));
+                    PmUnit& u = q.u;
+                    u.kind = PM_GEMM; u.M = B; u.w_lds = -1; u.lag = p.lag;
+                    u.a_off = boff(slab); u.a_st = (unsigned)(rows * g.ks * 4); u.a_nch = nch_all; u.a_c0 = p.c0; u.K = p.nch * 16;
+                    u.W = Wt + ((size_t)ct * nch_all + p.c0) * 256;
+                    q.slot = p.slot; q.crit = p.crit ? 1 : 0; q.krows = p.nch * 16;
+                    if (!p.crit) {
+                        u.epi = PM_EPI_LINEAR;
+                        u.out = rm(pbuf[p.pbuf] + 16 * ct, (long long)B * N, N);
+                        reqs.push_back(q);
+                        continue;
+                    }
+                    int na = 0;
+                    for (const PmPiece& o : g.pc)
+                        if (!o.crit) u.add[na++] = rm(pbuf[o.pbuf] + 16 * ct, (long long)B * N, N);
+                    if (g.kind == 0) {
+                        u.bias = d.bg[l] ? d.bg[l] + 16 * ct : nullptr;
+                        if (d.seq_g[l]) u.add[na++] = rm(d.seq_g[l] + 16 * ct, 0, 2 * H);
+                        u.epi = PM_EPI_GATES;
+                        u.rtile = 16 * ct >= H;
+                        if (!u.rtile) {
+                            u.o1 = rm(zh[l] + 16 * ct, BH, H);
+                        } else {
+                            const int j0 = 16 * ct - H;
+                            u.e0 = rm(hist_h[l] + j0, BH, H);
+                            u.dst[u.ndst++] = mkdst(XC[l], 0, kx[l], j0 / 16);
+                        }
+                    } else if (g.kind == 1) {
+                        u.bias = d.bc[l] ? d.bc[l] + 16 * ct : nullptr;
+                        if (d.seq_c[l]) u.add[na++] = rm(d.seq_c[l] + 16 * ct, 0, H);
+                        u.epi = PM_EPI_CAND;
+                        u.e0 = rm(hist_h[l] + 16 * ct, BH, H);
+                        u.e1 = rm(zh[l] + 16 * ct, BH, H);
+                        u.out = rm(hist_h[l] + BH + 16 * ct, BH, H);
+                        u.dst[u.ndst++] = mkdst(XG[l], 1, kx[l], ct);
+                        for (int m2 = l + 1; m2 < L; ++m2) {
+                            const int ch = hc + ec + l * hc + ct;
+                            u.dst[u.ndst++] = mkdst(XG[m2], 0, kx[m2], ch);
+                            u.dst[u.ndst++] = mkdst(XC[m2], 0, kx[m2], ch);
+                        }
+                        u.dst[u.ndst++] = mkdst(XR, 0, kr, l * hc + ct);
+                    } else {
+                        u.add[na++] = rm(d.ro_const + 16 * ct, 0, 64);
+                        u.epi = PM_EPI_LINEAR;
+                        u.out = rm(d.x + (size_t)B * d.ldx + 16 * ct, (long long)B * d.ldx, d.ldx);
+                        for (int q2 = 0; q2 < L; ++q2) {
+                            if (!fb_rows(d, q2)) continue;
+                            const int ch = (int)(kx[q2] / 16) - 4 + ct;
+                            u.dst[u.ndst++] = mkdst(XG[q2], 1, kx[q2], ch);
+                            u.dst[u.ndst++] = mkdst(XC[q2], 1, kx[q2], ch);
+                        }
+                    }
+                    if (na > 4 || u.ndst > PM_MAXDST) return 0;
+                    reqs.push_back(q);
+                }
+            }
+        }
+        {
+            PmMeta m;
+            m.lag = 1; m.slot = sATT;
+            m.rd.push_back(acc(RES_H, 1, 0, 1));
+            m.rd.push_back(acc(RES_KAPPA, 0, 0, 1));
+            m.wr.push_back(acc(RES_KAPPA, 1, 0, 1));
+            m.wr.push_back(acc(RES_XG, 1, hc, ec));
+            m.wr.push_back(acc(RES_XC, 1, hc, ec));
+            for (int l = 1; l < L; ++l) {
+                m.wr.push_back(acc(RES_XG + l, 0, hc, ec));
+                m.wr.push_back(acc(RES_XC + l, 0, hc, ec));
+            }
+            m.wr.push_back(acc(RES_XR, 0, L * hc, ec));
+            metas.push_back(m);
+        }
+        for (int b = 0; b < B; ++b) {
+            PmReq q;
+            memset(&q, 0, sizeof(q));
+            q.u.kind = PM_ATT; q.u.row = b; q.u.w_lds = -1; q.u.lag = 1;
+            q.slot = sATT; q.crit = 1; q.krows = 0;
+            reqs.push_back(q);
+        }
+        std::vector<PmAccess> init;
+        for (int l = 0; l < L; ++l) {
+            init.push_back(acc(RES_XG + l, 0, 0, hc));
+            init.push_back(acc(RES_H + l, 0, 0, 1));
+            if (fb_rows(d, l)) {
+                init.push_back(acc(RES_XG + l, 0, (int)(kx[l] / 16) - 4, 4));
+                init.push_back(acc(RES_XC + l, 0, (int)(kx[l] / 16) - 4, 4));
+            }
+        }
+        init.push_back(acc(RES_XG, 0, hc, ec));
+        init.push_back(acc(RES_XC, 0, hc, ec));
+        init.push_back(acc(RES_KAPPA, 0, 0, 1));
+        if (getenv("PARROT_PM_DUMP_PLAN"))
+            for (const PmGroup& g : gs)
+                for (const PmPiece& p : g.pc)
+                    fprintf(stderr, "[pieces] %s%d phase %d: chunks %d..%d (K %d) %s phase %d lag %d\n",
+                            g.kind == 0 ? "G" : (g.kind == 1 ? "C" : "OUT"), g.l, g.slot, p.c0, p.c0 + p.nch, p.nch * 16,
+                            p.crit ? "CRITICAL" : "piece", p.slot, p.lag);
+        const int chk = check_pieces(metas, init, n_slots, 4);
+        memset(pieces_info, 0, sizeof(pieces_info));
+        pieces_info[0] = n_slots; pieces_info[1] = npart; pieces_info[2] = chk; pieces_info[3] = (int)reqs.size();
+        for (const PmReq& q : reqs) pieces_info[4 + q.slot] += 1;
+        if (chk != 0) return 0;
+        std::vector<PmUnit> table;
+        if (!pm_place(reqs, n_slots, 1, nwg, table)) return 0;
+        for (const PmUnit& u : table)
+            if (u.kind == PM_GEMM && u.w_lds < 0) pieces_info[14] += 1;  // units that stream their weights
+        pieces_ok = true;
+        if (dry) return 0;
+        if (hipMemcpy(units_dev, table.data(), unit_bytes, hipMemcpyHostToDevice) != hipSuccess) { pieces_ok = false; return 0; }
+
+        PmProgram& P = pm_prog;
+        memset(&P, 0, sizeof(P));
+        P.T = S; P.n_ticks = S + 1; P.nwg = nwg; P.MB = MB; P.M = B; P.n_slots = n_slots; P.maxu = 1;
+        P.units = units_dev; P.sync = sync; P.fm_base = fm_base;
+        PmAtt& a = P.att;
+        a.h1 = rm(hist_h[0], BH, H);
+        a.WattT = d.WattT; a.batt = d.batt; a.ctx = d.ctx;
+        a.kappa = d.kappa; a.a = d.a; a.b = b_hist; a.phi = d.phi; a.w = d.w; a.sup = nullptr;
+        a.B = B; a.H = H; a.A = d.A; a.U = d.U; a.E = E; a.att_type = d.att_type; a.dense = 0;
+        a.eps = d.eps; a.alignment = d.alignment; a.sharpening = d.sharpening; a.timing = d.timing;
+        a.wdst[a.nwdst++] = mkdst(XG[0], 1, kx[0], hc);
+        a.wdst[a.nwdst++] = mkdst(XC[0], 1, kx[0], hc);
+        for (int l = 1; l < L; ++l) {
+            a.wdst[a.nwdst++] = mkdst(XG[l], 0, kx[l], hc);
+            a.wdst[a.nwdst++] = mkdst(XC[l], 0, kx[l], hc);
+        }
+        a.wdst[a.nwdst++] = mkdst(XR, 0, kr, L * hc);
+        if (a.nwdst > PM_MAXWDST) { pieces_ok = false; return 0; }
+        int ni = 0;
+        auto add_init = [&](const float* src, int ld, int K, float* slabp, long long ks, int chunk) {
+            PmInit& in = P.init[ni++];
+            in.src = src; in.ld = ld; in.K = K; in.dst_off = boff(slabp); in.nch = (int)(ks / 16); in.chunk = chunk; in.pad = 0;
+        };
+        for (int l = 0; l < L; ++l) add_init(d.h[l], H, H, XG[l], kx[l], 0);
+        add_init(d.w, E, E, XG[0], kx[0], hc);
+        add_init(d.w, E, E, XC[0], kx[0], hc);
+        for (int l = 0; l < L; ++l) {
+            if (!fb_rows(d, l)) continue;
+            if (ni + 2 > PM_MAXINIT) { pieces_ok = false; return 0; }
+            add_init(d.x, d.ldx, 64, XG[l], kx[l], (int)(kx[l] / 16) - 4);
+            add_init(d.x, d.ldx, 64, XC[l], kx[l], (int)(kx[l] / 16) - 4);
+        }
+        P.ninit = ni;
+        {
+            const char* e2 = getenv("PARROT_PM_DATAFLOW");
+            P.dataflow = e2 ? atoi(e2) : 0;
+        }
+        auto add_fill = [&](void* q, long long nfloats) {
+            if (nfloats > 0) { P.fill[P.nfill].p = q; P.fill[P.nfill].bytes = nfloats * 4; ++P.nfill; }
+        };
+        add_fill(fm_base, (long long)(fm_end - fm_base));
+        for (int l = 0; l < L; ++l) {
+            add_fill(hist_h[l] + BH, (long long)S * BH);
+            add_fill(zh[l], (long long)S * BH);
+        }
+        add_fill(part_base, (long long)(part_end - part_base));
+        persist_ok = true;
+        return 0;
     }
 
 
@@ -3045,6 +3493,15 @@ int parrot_sample_create(const ParrotSampleDesc* desc, void** plan) { PH_ENTRY()
     p->build_persist();  // decode on the persistent phase machine when the configuration qualifies
     *plan = p;
     return 0;
+}
+int parrot_sample_plan_pieces_dry(const ParrotSampleDesc* desc, int nwg, int* info16) { PH_ENTRY();
+    if (!desc || !info16 || nwg < 1 || desc->S < 1 || desc->B < 1 || bad_dims(desc->L)) return PARROT_ERR_BADARG;
+    std::unique_ptr<SamplePlan> p(new (std::nothrow) SamplePlan());
+    if (!p) return PARROT_ERR_BADARG;
+    p->d = *desc;
+    p->build_persist_pieces(true, nwg);
+    for (int i = 0; i < 16; ++i) info16[i] = p->pieces_info[i];
+    return p->pieces_ok ? 0 : PARROT_ERR_UNSUPPORTED;
 }
 int parrot_sample_run(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_sample_destroy(void* plan) { PH_ENTRY();

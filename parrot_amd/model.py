@@ -1253,6 +1253,11 @@ class Parrot(Brick):
             if ws['oadd'] is not None:
                 pm['oadd_pad'] = torch.zeros(N, 64, **f)
                 d.oadd_pad = pm['oadd_pad'].data_ptr()
+            # readout -> output is linear here (model.py:992-1013, MSE head, no layer norm): the machine takes the
+            # composed matrix Wr . Wo and the constant rows (br + radd) . Wo + bo + oadd, and x[t+1] costs ONE phase
+            pm['Wro'], pm['Wro_t'] = torch.empty(L * H + E, 64, **f), torch.empty(L * H + E, 64, **f)
+            pm['ro_const'] = torch.zeros(N, 64, **f)
+            d.Wro_t, d.ro_const = pm['Wro_t'].data_ptr(), pm['ro_const'].data_ptr()
             n = int(_lib.load().parrot_sample_persist_floats(C.byref(d)))
             if n > 0:
                 pm['ws'] = torch.zeros(n, **f)
@@ -1347,6 +1352,17 @@ class Parrot(Brick):
             pm['bo_pad'][:O].copy_(self._p('/readout_to_output.b'))
             if 'oadd_pad' in pm:
                 pm['oadd_pad'][:, :O].copy_(ws['oadd'])
+            # composed in float64, rounded once
+            Wo64 = pm['Wo_pad'].double()
+            pm['Wro'].copy_(st['dec.Wr'].double() @ Wo64)
+            tile(pm['Wro'], pm['Wro_t'])
+            rows = ws['br'].double().unsqueeze(0)
+            if ws['radd'] is not None:
+                rows = rows + ws['radd'].double()
+            c = rows @ Wo64 + pm['bo_pad'].double()
+            if 'oadd_pad' in pm:
+                c = c + pm['oadd_pad'].double()
+            pm['ro_const'].copy_(c.expand(pm['ro_const'].shape[0], 64))
 
     def sample_model(self, labels_tr, labels_mask_tr, features_mask_tr, speaker_tr, num_samples, num_steps):
         """Parrot.sample_model (model.py:1061-1083): numpy in, list of numpy arrays out

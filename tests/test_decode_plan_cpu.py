@@ -1,0 +1,57 @@
+"""The decode machine's step cut along K by the age of its operands (plans.hip, build_persist_pieces): planned and
+replayed symbolically on the CPU -- no device memory is touched (parrot_sample_plan_pieces_dry)."""
+import ctypes as C
+
+import pytest
+
+from parrot_amd import _lib
+
+
+def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False):
+    d = _lib.SampleDesc()
+    d.S, d.B, d.H, d.E, d.A, d.U, d.L, d.O, d.R, d.ldx = S, B, H, E, 10, 100, L, 63, R, 64
+    fake = 0x7000_0000_0000  # never dereferenced by the dry run
+    for l in range(L):
+        d.Wg_t[l], d.Wc_t[l] = fake, fake
+        d.bg[l], d.bc[l] = fake, fake
+        if l in fb:
+            d.Wfg[l], d.Wfc[l] = fake, fake
+        if speaker:
+            d.seq_g[l], d.seq_c[l] = fake, fake
+    d.Wro_t, d.ro_const, d.x = fake, fake, fake
+    return d
+
+
+def _plan(d, nwg=256):
+    info = (C.c_int * 16)()
+    rc = _lib.load().parrot_sample_plan_pieces_dry(C.byref(d), nwg, info)
+    return rc, list(info)
+
+
+def test_configs2_plan_is_legal_and_fits_one_unit_per_workgroup():
+    rc, info = _plan(_desc())
+    assert rc == 0 and info[2] == 0
+    assert info[0] == 6                      # 2L + 2 phases per step (7 with whole-K products)
+    assert info[1] == 10                     # partial-sum buffers: G0 2, C0 2, G1 2, C1 2, output 2
+    assert all(0 < n <= 256 for n in info[4:10]), info
+    assert sum(info[4:10]) == info[3]
+
+
+@pytest.mark.parametrize("L,fb,speaker", [(1, (0,), False), (1, (), False), (2, (), False), (2, (0, 1), False),
+                                          (2, (0,), True), (3, (0,), False), (3, (0, 1, 2), True)])
+def test_plans_of_other_stacks_are_legal(L, fb, speaker):
+    d = _desc(L=L, H=256, E=128, B=16, S=50, R=256, fb=fb, speaker=speaker)
+    rc, info = _plan(d)
+    assert rc == 0 and info[2] == 0, info
+    assert info[0] == 2 * L + 2
+
+
+def test_too_few_workgroups_is_refused_not_misplanned():
+    rc, info = _plan(_desc(), nwg=100)       # 128 gate tiles per phase do not fit 100 workgroups
+    assert rc != 0
+
+
+def test_env_switch_keeps_the_whole_k_phases(monkeypatch):
+    monkeypatch.setenv("PARROT_PM_PIECES", "0")
+    rc, info = _plan(_desc())
+    assert rc != 0

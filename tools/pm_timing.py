@@ -47,7 +47,8 @@ else:
         dt = time.perf_counter() - t0
         print(f"decode {1e3 * dt:.2f} ms = {1e6 * dt / S:.2f} us per step")
     pw = m._sample_ws.get((S, N, U))['pm']['ws']
-    ticks, nslots = S, 2 * L + 3
+    pieces = os.environ.get("PARROT_PM_PIECES", "1") != "0"  # plans.hip build_persist_pieces: 2L + 2 phases, S + 1 ticks
+    ticks, nslots = (S + 1, 2 * L + 2) if pieces else (S, 2 * L + 3)
 rawi = pw[1024:1024 + 256 * 48].view(torch.int64).cpu().reshape(256, 24)
 bad = [w for w in range(256) if rawi[w, 0] > 10**12 or rawi[w, 0] < 0]
 print('workgroups with implausible timers (XCC whose s_memrealtime does not tick):', len(bad))
