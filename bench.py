@@ -330,12 +330,17 @@ def secondary_leg(a):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         if rep > 0:
             best = dt if best is None else min(best, dt)
+    from parrot_amd import _lib as _plib
+    kind = int(_plib.load().parrot_sample_is_persistent(next(iter(m._sample_ws.values()))['plan']))
     m.close()
     alg = 58.5e6
     out["decode_cfg3"] = {"workload": "BASELINE configs[2]: greedy decode, batch 16, 1000 frames, 2-layer GRU h=1024, feedback on",
                           "us_per_step": round(1e6 * best / S, 2), "frames_per_s": round(N * S / best, 1),
                           "alg_bytes_per_step": int(alg), "alg_GBps": round(alg * S / best * 1e-9, 1),
-                          "frac": round(alg * S / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000}
+                          "frac": round(alg * S / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000,
+                          "plan": {2: "resident kernel, 6 phases per step (products cut along K by operand age, "
+                                      "readout.output composed)",
+                                   1: "resident kernel, 7 whole-K phases per step", 0: "per-step launches"}[kind]}
     from parrot_amd.sampleRNN import lib
     from parrot_amd.sampleRNN.models.conditional import three_tier as tt
     lib.delete_all_params(); lib.set_device(dev)

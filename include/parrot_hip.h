@@ -436,6 +436,7 @@ typedef struct ParrotSampleDesc {
 } ParrotSampleDesc;
 
 long long parrot_sample_persist_floats(const ParrotSampleDesc* desc);
+/* 0: per-step launches; 1: the machine with 2L + 3 whole-K phases; 2: the machine with the step cut along K (Wro_t given) */
 int parrot_sample_is_persistent(void* plan);
 /* Plans the decode machine for `desc` with `nwg` workgroups WITHOUT touching device memory (pointers are only used for
  * address arithmetic) and replays the unit table symbolically: every read must find its value written in an earlier

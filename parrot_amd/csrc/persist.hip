@@ -362,6 +362,10 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
     const float* h = g.h1.p + (long long)(t + 1) * g.h1.st + (long long)b * g.h1.ld;
     const size_t BA = (size_t)g.B * A;
 
+    // kappa[t] of this row was written a step ago (by this workgroup, or by the host side for t = 0): ask for it now, it
+    // is needed behind the projection
+    float kp_pre = 0.f;
+    if (tid < A) kp_pre = pm_ldf(g.kappa + (size_t)t * BA + (size_t)b * A + tid);
     // 1) projection: wave w owns outputs j = w, w+8, w+16, w+24
     {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -413,7 +417,7 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
         if (g.att_type == 1) av = expf(s_p[tid] - s_red[4]) / s_red[5] + g.eps;
         else av = expf(s_p[tid]) + g.eps;
         const float bv = expf(s_p[A + tid]) * g.sharpening + g.eps;
-        const float kp = pm_ldf(g.kappa + (size_t)t * BA + (size_t)b * A + tid);
+        const float kp = kp_pre;
         const float kv = kp + g.alignment * expf(s_p[2 * A + tid]) / g.timing;
         s_a[tid] = av; s_b[tid] = bv; s_k[tid] = kv;
         g.a[(size_t)t * BA + (size_t)b * A + tid] = av;
@@ -473,6 +477,13 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
             // row group ug takes u = ug (mod G), as in the walk over all rows: skipping the rows with phi == 0 then
             // leaves every partial sum bit-identical (PARROT_ATT_DENSE=1 reads them all)
             int u = u_lo + ((ug - u_lo % G + G) % G);
+            for (; u + 7 * G <= u_hi; u += 8 * G) {  // eight rows in flight (a decode row group walks the whole support)
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
+            }
             for (; u + 3 * G <= u_hi; u += 4 * G) {
                 float v[4];
 #pragma unroll

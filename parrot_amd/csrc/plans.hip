@@ -3413,7 +3413,10 @@ long long parrot_sample_persist_floats(const ParrotSampleDesc* desc) { PH_ENTRY(
     if (!desc || !SamplePlan::persist_eligible(*desc)) return 0;
     return SamplePlan::persist_floats(*desc, pm_max_workgroups());
 }
-int parrot_sample_is_persistent(void* plan) { return static_cast<SamplePlan*>(plan)->persist_ok ? 1 : 0; }
+int parrot_sample_is_persistent(void* plan) {
+    const SamplePlan* p = static_cast<SamplePlan*>(plan);
+    return p->persist_ok ? (p->pieces_ok ? 2 : 1) : 0;
+}
 int parrot_sample_status(void* plan) { PH_ENTRY(); return plan ? static_cast<SamplePlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }
 int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<DecoderPlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }
 

@@ -171,8 +171,10 @@ def test_workspaces_and_plans_are_reused_between_calls(dev):
                                 dict(num_layers=2, weak_feedback=True, sharpening_coeff=1.2, timing_coeff=0.9,
                                      attention_type='softmax')])
 def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
-    """sample_model as one resident kernel (2L + 3 phases per step): every output vs the oracle, the machine really
-    ran, a second call replays it, and the per-step launch path (PARROT_SAMPLE_PERSIST=0) agrees to rounding."""
+    """sample_model as one resident kernel -- 2L + 2 phases per step with every product cut along K by the age of its
+    operands (default), or the 2L + 3 whole-K phases (PARROT_PM_PIECES=0): every output vs the oracle, the plan that was
+    asked for really ran, a second call replays it, and the per-step launch path (PARROT_SAMPLE_PERSIST=0) agrees to
+    rounding with both."""
     from oracle import parrot_ref as R
     from parrot_amd import _lib
     from parrot_amd.model import Parrot
@@ -184,8 +186,9 @@ def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
     with torch.no_grad():
         ref = R.sample_model(p, cfg, lab, lm, spk, S)
     res = {}
-    for mode in ("1", "0"):
+    for mode, pieces in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("PARROT_SAMPLE_PERSIST", mode)
+        monkeypatch.setenv("PARROT_PM_PIECES", pieces)
         m = Parrot(device=dev, use_graph=True, **full).allocate()
         m.set_parameter_values(p)
         for rep in range(2):
@@ -193,13 +196,14 @@ def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
             for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
                 assert_close(o, r, 1e-4, f"persist={mode} pass {rep}: {n}")
         ws = m._sample_ws.get((S, N, U))
-        assert bool(_lib.load().parrot_sample_is_persistent(ws['plan'])) == (mode == "1")
+        assert _lib.load().parrot_sample_is_persistent(ws['plan']) == (0 if mode == "0" else (2 if pieces == "1" else 1))
         if mode == "1":
             assert int(ws['pm']['ws'][832:833].view(torch.int32).item()) == 0, "a spin timed out inside the machine"
-        res[mode] = [o.clone() for o in outs]
+        res[mode + pieces] = [o.clone() for o in outs]
         m.close()
-    for a, b, n in zip(res["1"], res["0"], ("sample_x", "k", "w", "pi", "phi", "pi_att")):
-        assert_close(a, b, 2e-5, f"machine vs launches: {n}")
+    for key in ("11", "10"):
+        for a, b, n in zip(res[key], res["01"], ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+            assert_close(a, b, 2e-5, f"machine ({key}) vs launches: {n}")
 
 
 def test_dataflow_mode_matches_the_barrier_mode_bit_for_bit(dev, monkeypatch):
