@@ -3025,8 +3025,11 @@ struct SamplePlan : PlanBase {
         }
         P.ninit = ni;
         {
+            // no grid barriers by default: with the step cut into pieces a phase is ~3 us of fixed latency + a short K
+            // walk, and the barrier was a quarter of it (43.0 -> 36.1 us per step at configs[2]); the whole-K plan above
+            // measured no gain (57.6 either way).  Bit-identical to the barrier mode (tests/test_gpu_persist.py)
             const char* e2 = getenv("PARROT_PM_DATAFLOW");
-            P.dataflow = e2 ? atoi(e2) : 0;
+            P.dataflow = e2 ? atoi(e2) : 1;
         }
         auto add_fill = [&](void* q, long long nfloats) {
             if (nfloats > 0) { P.fill[P.nfill].p = q; P.fill[P.nfill].bytes = nfloats * 4; ++P.nfill; }
