@@ -7,6 +7,7 @@
 #   stats                     rocprofv3 --kernel-trace --stats of the headline command -> bench_kernel_stats.csv
 #   cfg4stats | secstats      the same for `bench.py --config cfg4` / `bench.py --secondary-only`
 #   pmc | pmc4                FETCH_SIZE / WRITE_SIZE / SQ passes over tools/pmc_probe.py (cfg2 / cfg4) -> pmc_traffic*.json
+#   pmcdecode                 the three counter passes over the configs[2] decode (tools/pm_timing.py) -> pmc_decode_summary.txt
 #   run:<command>             anything else, logged to run_<n>.log
 tag=$1; shift
 cd $GRAFT_REPO_ROOT
@@ -37,6 +38,17 @@ pmc() {  # pmc <suffix> <probe cfg>
   rm -f $out/FETCH_SIZE$suf.csv $out/WRITE_SIZE$suf.csv $out/SQ$suf.csv
   head -40 $out/pmc_sq_summary$suf.txt
 }
+pmcx() {  # pmcx <name> <cmd...>: FETCH_SIZE / WRITE_SIZE / SQ passes over any command, per-kernel averages of each
+  name=$1; shift
+  : > $out/pmc_${name}_summary.txt
+  for c in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD"; do
+    timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmcx -- "$@" > $out/pmc_${name}.log 2>&1
+    find /tmp/pmcx -name "*counter_collection.csv" -exec cp {} /tmp/pmcx.csv \;
+    python tools/pmc_summary.py /tmp/pmcx.csv >> $out/pmc_${name}_summary.txt 2>&1
+    rm -rf /tmp/pmcx /tmp/pmcx.csv
+  done
+  grep -A12 "pm_kernel\|srp_kernel" $out/pmc_${name}_summary.txt | head -60
+}
 for step in "$@"; do
   case "$step" in
     tests)   timeout 3000 python -m pytest tests -q -m gpu -x --timeout 600 2>&1 | tail -25 | tee $out/tests.log ;;
@@ -48,6 +60,7 @@ for step in "$@"; do
     secstats) stats secondary 600 python bench.py --secondary-only ;;
     pmc)     pmc "" cfg2 ;;
     pmc4)    pmc _cfg4 cfg4 ;;
+    pmcdecode) MODE=decode pmcx decode python tools/pm_timing.py ;;
     run:*)   n=$((n+1)); ( eval "${step#run:}" ) > $out/run_$n.log 2>&1; tail -30 $out/run_$n.log ;;
     *) echo "unknown step $step" ;;
   esac
