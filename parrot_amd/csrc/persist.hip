@@ -202,15 +202,19 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
     const bool row_ok = m < u.M;
     f32x4 p_bias = {0.f, 0.f, 0.f, 0.f}, p_add = {0.f, 0.f, 0.f, 0.f}, p_e0 = {0.f, 0.f, 0.f, 0.f},
           p_e1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 p_in[4];  // the additive inputs, kept apart until the epilogue (dataflow mode may have to ask again)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p_in[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (fin && row_ok) {
         if (u.bias) p_bias = *reinterpret_cast<const f32x4*>(u.bias + n0);
-        if (!DF) {
+        // requested NOW in both modes: these operands come from phases before the one that produced the unit's A operand,
+        // so they have almost always landed; asked for behind the K loop, one poll loop after the other, they cost a
+        // memory round trip EACH on the step's critical chain (dataflow mode, round 4)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (u.add[q].p) p_add += pm_rm_load(u.add[q], t, m, n0);
-            if (u.e0.p) p_e0 = pm_rm_load(u.e0, t, m, n0);
-            if (u.e1.p) p_e1 = pm_rm_load(u.e1, t, m, n0);
-        }
+        for (int q = 0; q < 4; ++q)
+            if (u.add[q].p) p_in[q] = pm_rm_load(u.add[q], t, m, n0);
+        if (u.e0.p) p_e0 = pm_rm_load(u.e0, t, m, n0);
+        if (u.e1.p) p_e1 = pm_rm_load(u.e1, t, m, n0);
     }
 
     const unsigned long long ts1 = pm_clock();
@@ -254,6 +258,25 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
         for (int d = 0; d < D; ++d) ra[d] = loadA(min(c0 + d, last));
 #pragma unroll
         for (int d = 0; d < DB; ++d) rbv[d] = loadB(min(c0 + d, last));
+        if (DF) {
+            // A wave that got here before its operand sees EMPTY in every ring entry.  Waiting for them one after the other
+            // (takeA below) would cost a round trip per chunk: wait for the first, then ask for all the others again at once
+            bool waited = false;
+            unsigned n = 0;
+            while (__builtin_amdgcn_ballot_w64(row_ok && pm_is_empty(ra[0])) != 0ull) {
+                waited = true;
+                if ((++n & 1023u) == 0u) {
+                    if (pm_ld(sync + PM_S_ABORT)) break;
+                    if (n > PM_POLL_LIMIT) { pm_give_up(sync); break; }
+                }
+                __builtin_amdgcn_s_sleep(1);
+                ra[0] = loadA(c0);
+            }
+            if (waited) {
+#pragma unroll
+                for (int d = 1; d < D; ++d) ra[d] = loadA(min(c0 + d, last));
+            }
+        }
         int c = c0;
         for (; c + D <= c1; c += D) {
 #pragma unroll
@@ -277,13 +300,15 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
         else run(std::false_type{});
     }
     const f32x4 part = acc0 + acc1;
-    if (DF && fin && row_ok) {  // epilogue operands, produced by other workgroups at earlier positions: take them now
+    if (DF && fin && row_ok) {  // whatever had not landed when it was first asked for: poll it now
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (u.add[q].p) p_add += pm_rm_take(u.add[q], t, m, n0, sync);
-        if (u.e0.p) p_e0 = pm_rm_take(u.e0, t, m, n0, sync);
-        if (u.e1.p) p_e1 = pm_rm_take(u.e1, t, m, n0, sync);
+            if (u.add[q].p && pm_is_empty(p_in[q])) p_in[q] = pm_rm_take(u.add[q], t, m, n0, sync);
+        if (u.e0.p && pm_is_empty(p_e0)) p_e0 = pm_rm_take(u.e0, t, m, n0, sync);
+        if (u.e1.p && pm_is_empty(p_e1)) p_e1 = pm_rm_take(u.e1, t, m, n0, sync);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p_add += p_in[q];  // (fixed order, both modes)
     const unsigned long long ts2 = pm_clock();
 
     // split-K reduction through LDS: C layout (col = lane & 15, row = 4 (lane >> 4) + reg) -> [row][col] tiles, rows
@@ -370,25 +395,38 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
     {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t hr = pm_rsrc(h);
-        for (int k = 4 * lane; k < H; k += 256) {
-            f32x4 hv = pm_ld16(hr, (unsigned)k << 2);
-            if (DF) {
-                unsigned n = 0;
-                while (pm_is_empty(hv)) {
-                    if ((++n & 1023u) == 0u) {
-                        if (pm_ld(sync + PM_S_ABORT)) break;
-                        if (n > PM_POLL_LIMIT) { pm_give_up(sync); break; }
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    hv = pm_ld16(hr, (unsigned)k << 2);
-                }
+        for (int k0 = 4 * lane; k0 < H; k0 += 1024) {
+            // four blocks of the row in flight: in dataflow mode every block is polled, and one poll loop after the other
+            // would cost a round trip per block
+            f32x4 hq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 256 * i;
+                hq[i] = k < H ? pm_ld16(hr, (unsigned)k << 2) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = wave + 8 * q;
-                if (j < 3 * A) {
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(g.WattT + (size_t)j * H + k);
-                    acc[q] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + 256 * i;
+                if (k >= H) continue;
+                f32x4 hv = hq[i];
+                if (DF) {
+                    unsigned n = 0;
+                    while (pm_is_empty(hv)) {
+                        if ((++n & 1023u) == 0u) {
+                            if (pm_ld(sync + PM_S_ABORT)) break;
+                            if (n > PM_POLL_LIMIT) { pm_give_up(sync); break; }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        hv = pm_ld16(hr, (unsigned)k << 2);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = wave + 8 * q;
+                    if (j < 3 * A) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(g.WattT + (size_t)j * H + k);
+                        acc[q] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+                    }
                 }
             }
         }
