@@ -404,6 +404,16 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
                 const int k = k0 + 256 * i;
                 hq[i] = k < H ? pm_ld16(hr, (unsigned)k << 2) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            // the projection weights do not depend on h: ask for them before the first poll, not behind it
+            f32x4 wq[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + 256 * i, j = wave + 8 * q;
+                    wq[i][q] = (k < H && j < 3 * A) ? *reinterpret_cast<const f32x4*>(g.WattT + (size_t)j * H + k)
+                                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = k0 + 256 * i;
@@ -424,7 +434,7 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
                 for (int q = 0; q < 4; ++q) {
                     const int j = wave + 8 * q;
                     if (j < 3 * A) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(g.WattT + (size_t)j * H + k);
+                        const f32x4 wv = wq[i][q];
                         acc[q] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
                     }
                 }
