@@ -1352,17 +1352,11 @@ class Parrot(Brick):
             pm['bo_pad'][:O].copy_(self._p('/readout_to_output.b'))
             if 'oadd_pad' in pm:
                 pm['oadd_pad'][:, :O].copy_(ws['oadd'])
-            # composed in float64, rounded once
-            Wo64 = pm['Wo_pad'].double()
-            pm['Wro'].copy_(st['dec.Wr'].double() @ Wo64)
+            Wro, c = compose_readout_output(st['dec.Wr'], pm['Wo_pad'], ws['br'], ws['radd'], pm['bo_pad'],
+                                            pm.get('oadd_pad'), pm['ro_const'].shape[0])
+            pm['Wro'].copy_(Wro)
             tile(pm['Wro'], pm['Wro_t'])
-            rows = ws['br'].double().unsqueeze(0)
-            if ws['radd'] is not None:
-                rows = rows + ws['radd'].double()
-            c = rows @ Wo64 + pm['bo_pad'].double()
-            if 'oadd_pad' in pm:
-                c = c + pm['oadd_pad'].double()
-            pm['ro_const'].copy_(c.expand(pm['ro_const'].shape[0], 64))
+            pm['ro_const'].copy_(c)
 
     def sample_model(self, labels_tr, labels_mask_tr, features_mask_tr, speaker_tr, num_samples, num_steps):
         """Parrot.sample_model (model.py:1061-1083): numpy in, list of numpy arrays out
@@ -1400,6 +1394,21 @@ class Parrot(Brick):
             self._side_stream.synchronize()
             _lib.call('parrot_stream_destroy', h)
             self._side_stream = self._side_stream_handle = None
+
+
+def compose_readout_output(Wr, Wo_pad, br, radd, bo_pad, oadd_pad, n_rows):
+    """readout -> output as ONE affine map of [h_0 .. h_{L-1} ; w] (model.py:992-1013 with the MSE head and no layer norm):
+    x = (XR . Wr + br + radd) . Wo + bo + oadd = XR . (Wr . Wo) + [(br + radd) . Wo + bo + oadd].  Composed in float64 and
+    rounded once.  Returns (Wr . Wo [K, 64], constant rows [n_rows, 64]) in float32."""
+    Wo64 = Wo_pad.double()
+    Wro = Wr.double() @ Wo64
+    rows = br.double().unsqueeze(0)
+    if radd is not None:
+        rows = rows + radd.double()
+    c = rows @ Wo64 + bo_pad.double()
+    if oadd_pad is not None:
+        c = c + oadd_pad.double()
+    return Wro.float(), c.expand(n_rows, Wo_pad.shape[1]).float().contiguous()
 
 
 class SampleRnn(Brick):

@@ -55,3 +55,30 @@ def test_env_switch_keeps_the_whole_k_phases(monkeypatch):
     monkeypatch.setenv("PARROT_PM_PIECES", "0")
     rc, info = _plan(_desc())
     assert rc != 0
+
+
+def test_composed_readout_output_is_the_same_affine_map():
+    """model.compose_readout_output: XR . (Wr . Wo) + const == (XR . Wr + br + radd) . Wo + bo + oadd (model.py:992-1013),
+    with and without the speaker terms, padding columns zero."""
+    import torch
+    from parrot_amd.model import compose_readout_output
+    g = torch.Generator().manual_seed(3)
+    K, R, O, N = 160, 48, 63, 5
+    Wr, Wo = torch.randn(K, R, generator=g) / K ** 0.5, torch.randn(R, O, generator=g) / R ** 0.5
+    br, bo = torch.randn(R, generator=g), torch.randn(O, generator=g)
+    Wo_pad, bo_pad = torch.zeros(R, 64), torch.zeros(64)
+    Wo_pad[:, :O], bo_pad[:O] = Wo, bo
+    XR = torch.randn(N, K, generator=g)
+    for speaker in (False, True):
+        radd = torch.randn(N, R, generator=g) if speaker else None
+        oadd_pad = None
+        if speaker:
+            oadd_pad = torch.zeros(N, 64)
+            oadd_pad[:, :O] = torch.randn(N, O, generator=g)
+        Wro, c = compose_readout_output(Wr, Wo_pad, br, radd, bo_pad, oadd_pad, N)
+        assert Wro.shape == (K, 64) and c.shape == (N, 64) and Wro.dtype == torch.float32
+        ro = XR.double() @ Wr.double() + br.double() + (radd.double() if speaker else 0)
+        ref = ro @ Wo.double() + bo.double() + (oadd_pad[:, :O].double() if speaker else 0)
+        got = XR.double() @ Wro.double() + c.double()
+        assert torch.allclose(got[:, :O], ref, rtol=0, atol=2e-6)
+        assert float(got[:, O:].abs().max()) == 0.0
