@@ -82,3 +82,25 @@ def test_composed_readout_output_is_the_same_affine_map():
         got = XR.double() @ Wro.double() + c.double()
         assert torch.allclose(got[:, :O], ref, rtol=0, atol=2e-6)
         assert float(got[:, O:].abs().max()) == 0.0
+
+
+def test_random_stacks_are_either_planned_legally_or_refused():
+    """Whatever the shape: a returned plan passes the symbolic replay and fits one unit per workgroup and phase; anything
+    else is refused (the caller then builds the whole-K phases or the per-step launches)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=80, deadline=None, derandomize=True)
+    @given(L=st.integers(1, 3), h=st.integers(1, 96), e=st.integers(1, 48), B=st.integers(1, 64),
+           fbmask=st.integers(0, 7), speaker=st.booleans(), nwg=st.sampled_from([64, 128, 208, 256]))
+    def run(L, h, e, B, fbmask, speaker, nwg):
+        fb = tuple(l for l in range(L) if fbmask >> l & 1)
+        d = _desc(L=L, H=16 * h, E=16 * e, B=B, S=7, R=64, fb=fb, speaker=speaker)
+        rc, info = _plan(d, nwg=nwg)
+        if rc == 0:
+            assert info[2] == 0 and info[0] == 2 * L + 2
+            assert all(n <= nwg for n in info[4:4 + info[0]]), (info, nwg)
+            assert sum(info[4:4 + info[0]]) == info[3]
+        else:
+            assert info[2] == 0, (rc, info)   # refused for size, never because the replay found an illegal table
+
+    run()
