@@ -525,18 +525,21 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
             // row group ug takes u = ug (mod G), as in the walk over all rows: skipping the rows with phi == 0 then
             // leaves every partial sum bit-identical (PARROT_ATT_DENSE=1 reads them all)
             int u = u_lo + ((ug - u_lo % G + G) % G);
-            // 32 rows in flight per pass, rows past the support masked (clamped address, no FMA): a decode row group walks
-            // the whole support (G = 1 at E = 512), and with 4 or 8 rows per pass every pass cost an L2 round trip.  Same
-            // FMAs in the same order as the one-row-at-a-time walk.
-            while (u <= u_hi) {
-                float v[32];
+            for (; u + 7 * G <= u_hi; u += 8 * G) {  // eight rows in flight (a decode row group walks the whole support)
+                float v[8];
 #pragma unroll
-                for (int q = 0; q < 32; ++q) v[q] = ctx[(size_t)min(u + q * G, u_hi) * E + e];
+                for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
 #pragma unroll
-                for (int q = 0; q < 32; ++q)
-                    if (u + q * G <= u_hi) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
-                u += 32 * G;
+                for (int q = 0; q < 8; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
             }
+            for (; u + 3 * G <= u_hi; u += 4 * G) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
+            }
+            for (; u <= u_hi; u += G) acc = __builtin_fmaf(s_phi[u], ctx[(size_t)u * E + e], acc);
         }
         __syncthreads();
         s_acc[tid] = acc;
