@@ -442,7 +442,8 @@ def compute_cost(p, cfg, features, features_mask, labels, labels_mask, speaker=N
     return cost, new_carry, attention_vars, extras
 
 
-def cost_and_grads_checkpointed(p, cfg, features, features_mask, labels, labels_mask, speaker=None, chunk=100):
+def cost_and_grads_checkpointed(p, cfg, features, features_mask, labels, labels_mask, speaker=None, chunk=100,
+                                pinned=None):
     """compute_cost(...) followed by cost.backward() for ONE window, with the memory of `chunk` steps: truncated
     nothing, recomputed everything (backpropagation through time with checkpoints at the chunk boundaries).  Pass 1
     walks the window chunk by chunk without a graph and keeps the carried state (h, kappa, w) entering each chunk;
@@ -450,7 +451,14 @@ def cost_and_grads_checkpointed(p, cfg, features, features_mask, labels, labels_
     chunk's share of the masked mean (model.py:784) plus <carried state out, gradient wrt it from the later chunks>.
     Parameter gradients accumulate in p[*].grad exactly as in the one-piece call (tests/test_oracle_cpu.py checks
     that at 1e-12); this exists so that the fp64 oracle fits the host memory at T_dec = 800 (model.py:726-737
-    saves every step).  Returns (cost, attention_vars) with the per-chunk outputs concatenated along time."""
+    saves every step).  Returns (cost, attention_vars) with the per-chunk outputs concatenated along time.
+
+    pinned (test infrastructure for long windows in a reduced-precision operand mode): a function `t -> carry` that hands
+    over the state ENTERING step t as some other evaluation of the same window saved it (dict(h=[...], k=, w=) like
+    `new_carry`).  Every chunk is then rebuilt from that state instead of from this function's own pass 1, so the
+    backward pass differentiates the trajectory the other evaluation walked (re-pinned every `chunk` steps) while the
+    chain of adjoints across the chunk boundaries stays this function's own.  That separates "is the 800-deep backward
+    right" from "did two evaluations of an expansive forward map drift apart"."""
     T = features.shape[0] - 1
     bounds = list(range(0, T, chunk)) + [T]
     spans = list(zip(bounds[:-1], bounds[1:]))
@@ -459,6 +467,9 @@ def cost_and_grads_checkpointed(p, cfg, features, features_mask, labels, labels_
     with torch.no_grad():
         carry = None
         for i, (a, b) in enumerate(spans):
+            if pinned is not None and i > 0:
+                carry = pinned(a)
+                carries[-1] = carry
             c, carry, av, _ = compute_cost(p, cfg, features[a:b + 1], features_mask[a:b + 1], labels, labels_mask,
                                            speaker, 1 if i == 0 else 0, carry)
             carries.append(carry)

@@ -239,7 +239,13 @@ def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
       * yardstick = the same emulation accumulated in float32, against that reference;
       * bar, at every horizon h in (100, 200, 400, 800) frames and for frames / kappa / w / phi: the HIP error over the first
         h frames <= max(tolerance of the mode, 3 x the yardstick's error over the same frames); cost within 5e-3 of the
-        EXACT oracle; every parameter gradient within max(5e-2, 3 x yardstick) of the reference's.
+        EXACT oracle;
+      * gradients (round 5; until then the bar below evaluated to 2.7 norm-wise on the free-running trajectories, which
+        nothing can fail): every parameter gradient within max(5e-2, 3 x yardstick) of the reference's backward ALONG THE
+        TRAJECTORY THE HIP FORWARD WALKED (the oracle's chunks are rebuilt every 50 steps from the states the HIP scan
+        saved, `cost_and_grads_checkpointed(pinned=)`), the bar itself asserted < 0.3; the free-running comparison is
+        printed beside it.  T_dec = 100 and 200, where the trajectories have not separated, are held free-running AND
+        pinned by test_cfg4_bf16_window_T100_T200_gradients_match_oracle.
     The short-window tolerances of the mode (tests/test_gpu_bf16.py: 2e-2 outputs, 5e-2 gradients) are unchanged."""
     from oracle import parrot_ref as R
     from parrot_amd.model import Parrot
@@ -257,6 +263,8 @@ def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
     grads = {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()}
     av = [x.detach().cpu().double() for x in av]
     cost = float(cost.detach())
+    pin_every = 50
+    hip_states = _hip_states(m, T, B, U, pin_every)
     m.close()
     with torch.no_grad():  # exact oracle, forward only (cost + how far the MODE moves the trajectory)
         carry, num, ex = None, 0.0, []
@@ -297,12 +305,123 @@ def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
         if e > worst[1]:
             worst = (name, e)
         n_checked += 1
-    rep.append(f"{n_checked} parameter gradients vs the bf16-operand oracle's; worst {worst[0]}: {worst[1]:.2e} norm-wise "
+    rep.append(f"FREE-RUNNING (reported, not the bar: the two forward trajectories are 5e-2 apart by frame 800): {n_checked} "
+               f"parameter gradients vs the bf16-operand oracle's; worst {worst[0]}: {worst[1]:.2e} norm-wise "
                f"(f32-accumulated emulation: worst {worst32:.2e})")
+    # The gradient bar: the oracle's backward on the trajectory the HIP forward walked.  Every 50 steps
+    # the oracle's chunk is rebuilt from the states the HIP scan saved (h, cells, kappa, w entering step t), so both backward
+    # passes differentiate ONE trajectory; the 800-deep chain of adjoints, the attention backward and the weight-gradient
+    # sums are the oracle's own (fp64 accumulation, bf16-rounded operands).  Yardstick: the same, accumulated in float32.
+    pw, pw32, pn, bar = _pinned_gradient_check(R, p, p32, cfg, feat, fm, lab, lm, hip_states, pin_every, grads, rep)
     with capsys.disabled():
         print("\n[cfg4 bf16 T800 parity] " + "\n[cfg4 bf16 T800 parity] ".join(rep))
     assert not failures, failures
-    assert n_checked >= 10 and worst[1] <= max(5e-2, 3.0 * worst32), worst
+    assert n_checked >= 10
+    assert bar < 0.3, f"a gradient bar of {bar:.2f} norm-wise cannot fail"
+    assert pn >= 10 and pw[1] <= bar, (pw, bar)
+
+
+def _hip_states(m, T, B, U, every):
+    """The states ENTERING step t (t a multiple of `every`) as the HIP scan saved them: {t: oracle-style carry, fp64}."""
+    ws = m._train_workspace(T, B, U)
+    lstm = m.cell_type == 'lstm'
+    out = {}
+    for t in range(every, T, every):
+        cpu = lambda x: x[t].detach().cpu().double().clone()
+        out[t] = dict(h=[(cpu(ws['h'][l]), cpu(ws['cst'][l])) if lstm else cpu(ws['h'][l]) for l in range(m.num_layers)],
+                      k=cpu(ws['kappa']), w=cpu(ws['w']))
+    return out
+
+
+def _pinned_gradient_check(R, p, p32, cfg, feat, fm, lab, lm, hip_states, every, grads, rep):
+    """HIP gradients vs the bf16-operand oracle's backward along the HIP trajectory (cost_and_grads_checkpointed(pinned=)).
+    Returns (worst (name, err), the float32-accumulated emulation's worst error, gradients checked, bar)."""
+    def pin(dt):
+        cast = lambda x: x.to(dt)
+        return lambda t: dict(h=[tuple(cast(y) for y in x) if isinstance(x, tuple) else cast(x) for x in hip_states[t]['h']],
+                              k=cast(hip_states[t]['k']), w=cast(hip_states[t]['w']))
+    for d in (p, p32):
+        for v in d.values():
+            v.grad = None
+    with R.operand_rounding('bf16'):
+        R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=every, pinned=pin(torch.float64))
+        R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=every,
+                                      pinned=pin(torch.float32))
+    worst, worst32, n = ("", 0.0), 0.0, 0
+    for name, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+            continue
+        e = rel_err(grads[name], ref.grad)
+        worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
+        if e > worst[1]:
+            worst = (name, e)
+        n += 1
+    bar = max(5e-2, 3.0 * worst32)
+    rep.append(f"PINNED trajectory (oracle chunks rebuilt from the HIP states every {every} steps): {n} parameter gradients; "
+               f"worst {worst[0]}: {worst[1]:.2e} norm-wise (f32-accumulated emulation on the same trajectory: worst "
+               f"{worst32:.2e}); bar {bar:.2e}")
+    return worst, worst32, n, bar
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("T", [100, 200])
+def test_cfg4_bf16_window_T100_T200_gradients_match_oracle(dev, capsys, T):
+    """BASELINE configs[3] per GPU (3 x LSTM-1536, B = 64, U = 200, bf16 operands: schedule 7, the fused backward tick with
+    its K halves, the bf16-in weight-gradient GEMM) at windows where the bf16 operand MODE has not yet moved the trajectory
+    (profiles/r04_bf16_mode_drift.txt: frames 2.6e-3, kappa 1.6e-5 after 100 frames): cost, frames, kappa, w, phi and EVERY
+    parameter gradient of the free-running HIP window vs the oracle with the same operand rounding (fp64 accumulation).
+    Bars: outputs max(2e-2, 3 x yardstick), gradients max(5e-2, 3 x yardstick) norm-wise, yardstick = the same emulation
+    accumulated in float32 -- and the gradient bar itself must stay below 0.3 (the T = 800 free-running
+    bar evaluated to 2.7, which nothing can fail)."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw, init_kw, kb, B, U, ragged = VARIANTS["cfg4"]
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=1234, **init_kw)
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(kb)
+    feat, fm, lab, lm = variant_batch(cfg, T, B, U, ragged, seed=77)
+    m = Parrot(device=dev, use_graph=True, compute_dtype='bf16', **kw).allocate()
+    m.set_parameter_values(p)
+    m.zero_grad()
+    cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+    cost.backward()
+    grads = {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()}
+    av = [x.detach().cpu().double() for x in av]
+    cost = float(cost.detach())
+    hip_states = _hip_states(m, T, B, U, 50)
+    m.close()
+    p32 = {k: v.float().requires_grad_() for k, v in p.items()}
+    for v in p.values():
+        v.requires_grad_()
+    with R.operand_rounding('bf16'):
+        rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=100)
+        c32, av32 = R.cost_and_grads_checkpointed(p32, cfg, feat.float(), fm.float(), lab, lm.float(), None, chunk=100)
+    rep = [f"cfg4 T_dec={T} B={B} U={U} operands=bf16",
+           f"cost: hip {cost:.6f}  oracle with bf16 operands {float(rc):.6f} (rel {abs(cost - float(rc)) / float(rc):.2e}; "
+           f"f32-accumulated emulation {abs(float(c32) - float(rc)) / float(rc):.2e})"]
+    assert abs(cost - float(rc)) <= 5e-3 * float(rc)
+    for i, n in ((0, "predicted frames"), (1, "kappa"), (2, "w"), (4, "phi")):
+        e, y = rel_err(av[i], rav[i]), rel_err(av32[i], rav[i])
+        rep.append(f"{n}: {e:.2e} (f32-accumulated emulation {y:.2e})")
+        assert e <= max(2e-2, 3.0 * y), (n, e, y)
+    worst, worst32, n_checked = ("", 0.0), 0.0, 0
+    for name, ref in p.items():
+        if ref.grad is None or float(ref.grad.abs().max()) < 1e-12:
+            continue
+        e = rel_err(grads[name], ref.grad)
+        worst32 = max(worst32, rel_err(p32[name].grad, ref.grad))
+        if e > worst[1]:
+            worst = (name, e)
+        n_checked += 1
+    bar = max(5e-2, 3.0 * worst32)
+    rep.append(f"free-running: {n_checked} parameter gradients; worst {worst[0]}: {worst[1]:.2e} norm-wise "
+               f"(f32-accumulated emulation: worst {worst32:.2e}); bar {bar:.2e}")
+    pw, pw32, pn, pbar = _pinned_gradient_check(R, p, p32, cfg, feat, fm, lab, lm, hip_states, 50, grads, rep)
+    with capsys.disabled():
+        print(f"\n[cfg4 bf16 T{T} parity] " + f"\n[cfg4 bf16 T{T} parity] ".join(rep))
+    assert bar < 0.3 and pbar < 0.3, (bar, pbar)
+    assert n_checked >= 10 and worst[1] <= bar, (worst, bar)
+    assert pn >= 10 and pw[1] <= pbar, (pw, pbar)
 
 
 def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):
@@ -315,9 +434,10 @@ def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):
     launch path, which end 1e-2 apart from EACH OTHER after 1000 frames although both are exact fp32 products.  No fp32
     implementation can hold 1e-4 over 1000 free-running frames of this map, so the criterion is split:
       * frames 0..299 at the north star's 1e-4 (measured 1.6e-5);
-      * the whole 1000 frames no worse than what fp32 arithmetic itself costs: at most 30 x the distance of the SAME
-        oracle run in float32 (torch-CPU) from its float64 run, at every horizon (a real defect -- a wrong carry, a
-        stale operand -- shows up as orders of magnitude, at once, not as this slow common drift);
+      * the whole 1000 frames no worse than what fp32 arithmetic itself costs: at most 3 x the distance of the SAME
+        oracle run in float32 (torch-CPU) from its float64 run, at every horizon (measured ratios 0.4-1.3; the factor was
+        30 until round 4; a real defect -- a wrong carry, a stale operand -- shows up as orders of magnitude, at once,
+        not as this slow common drift);
       * the teacher-forced 800-frame training window (test_cfg2_benchmarked_window_T800_matches_oracle) covers the long horizon without
         the feedback amplification."""
     from oracle import parrot_ref as R
@@ -351,7 +471,7 @@ def test_cfg3_decode_1000_steps_matches_oracle(dev, capsys):
             line.append(f"t<{hz}: {e:.1e} (oracle-f32 {e32:.1e})")
             if hz <= 300:
                 assert e <= 1e-4, f"{n}: {e:.2e} over the first {hz} frames"
-            assert e <= max(1e-4, 30.0 * e32), f"{n}: {e:.2e} over {hz} frames, float32 oracle {e32:.2e}"
+            assert e <= max(1e-4, 3.0 * e32), f"{n}: {e:.2e} over {hz} frames, float32 oracle {e32:.2e}"
         report.append(f"{n}: " + "  ".join(line))
     with capsys.disabled():
         print("\n[decode-1000 parity] " + "\n[decode-1000 parity] ".join(report))

@@ -86,6 +86,40 @@ def test_checkpointed_bptt_equals_one_piece_backward():
             assert torch.allclose(p[k].grad, g, rtol=1e-10, atol=1e-13), k
 
 
+def test_checkpointed_bptt_pinned_to_its_own_trajectory_changes_nothing():
+    """cost_and_grads_checkpointed(pinned=...) rebuilds every chunk from a state handed in from outside (the GPU tests
+    hand in the HIP forward's saved states so that a long bf16 window's backward is judged on ONE trajectory).  Pinned to
+    the oracle's own trajectory it must reproduce the unpinned gradients; pinned to a perturbed one it must not."""
+    from tests.util import make_batch
+    for kw in (dict(num_layers=2), dict(num_layers=3, cell_type='lstm')):
+        cfg, p = _tiny(**kw)
+        T, B, U, chunk = 11, 3, 6, 4
+        feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=5, ragged=True)
+        for v in p.values():
+            v.requires_grad_()
+        c, av = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, spk, chunk=chunk)
+        ref = {k: v.grad.clone() for k, v in p.items() if v.grad is not None}
+        with torch.no_grad():  # the states entering every step, from a one-piece forward
+            carry, states = None, {}
+            for t in range(T):
+                _, carry, _, _ = R.compute_cost(p, cfg, feat[t:t + 2], fm[t:t + 2], lab, lm, spk, 1 if t == 0 else 0, carry)
+                states[t + 1] = carry
+        for scale, same in ((0.0, True), (1e-3, False)):
+            for v in p.values():
+                v.grad = None
+
+            def pinned(t):
+                bump = lambda x: x * (1.0 + scale)
+                s = states[t]
+                return dict(h=[tuple(bump(y) for y in x) if isinstance(x, tuple) else bump(x) for x in s['h']],
+                            k=bump(s['k']), w=bump(s['w']))
+            c2, av2 = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, spk, chunk=chunk, pinned=pinned)
+            close = all(torch.allclose(p[k].grad, g, rtol=1e-9, atol=1e-13) for k, g in ref.items())
+            assert close == same, (kw, scale)
+            if same:
+                assert abs(float(c2) - float(c)) < 1e-12 * abs(float(c))
+
+
 def test_sample_step_equals_train_step_under_teacher_forcing():
     """sample_step fed with the data equals the training step."""
     cfg, p = _tiny(num_layers=2)
