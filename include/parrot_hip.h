@@ -70,6 +70,12 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
                 int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
                 long long strideA, long long strideB, long long strideC, int split_k, void* stream);
 
+/* C[M,N] = A . B kept where gate[m,n] > 0 and zeroed elsewhere (gate: row-major, leading dimension ldg >= N): the
+ * backward of y = relu(x . W + b) through the saved activation y, fused into the product that makes the gradient wrt
+ * relu's output (three_tier.py:504-509: the two ReLU layers of sample_level_predictor).  Operand layouts as parrot_gemm. */
+int parrot_gemm_gated(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                      int M, int N, int K, const float* gate, int ldg, void* stream);
+
 /* bf16-IN weight-gradient product (round 4): C[M,N] (+)= A^T . B with A [K, M] and B [K, N] ALREADY bf16 in device
  * memory (row-major, leading dimensions in elements, both multiples of 8; M, N multiples of 8; 16-byte aligned),
  * f32 accumulation, f32 C; deterministic split-K as parrot_gemm (split_k = 0: automatic).  parrot_to_bf16 makes the
@@ -493,6 +499,34 @@ int parrot_adam_clip_step(float* param, const float* grad, float* m, float* v, s
 int parrot_batch_quantize(const float* x, int rows, int n, int ld, double* ws, void* out, int ldo, int mode,
                           int q_levels, void* stream);
 int parrot_mu2linear(const int32_t* q, size_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training-side operators of the SampleRNN sample-level tier (round 5; parrot_amd/csrc/trainops.hip).
+ *
+ * Embedding (sampleRNN/lib/ops.py:252-266) followed by SampleLevel.L1_PrevSamples (three_tier.py:486-497: a
+ * [FS*EMB, DIM] Linear without bias over the FS concatenated embeddings) as a gather-sum over the folded table
+ * tbl[j][q][:] = Embedding[q] . W1[j*EMB:(j+1)*EMB, :] (the form the generation loop uses, SampleRnnGenDesc::emb_tbl):
+ *   parrot_gather_sum_fwd:  y[i,:] = add[i,:] + sum_{j<J} tbl[j][idx[i*J + j]][:]     (add may be NULL; summed in j order)
+ *   parrot_gather_sum_bwd:  dtbl[j][q][:] (+)= sum over the rows i with idx[i*J + j] == q of dy[i,:]
+ * The backward is a SEGMENTED sum, no scatter-add: perm [J,N] lists, per j, the rows sorted by (idx[.,j], row) (a stable
+ * sort, so the order of the addends depends on the indices only) and offs [J,Q+1] the first position of every bin in that
+ * order (offs[j][Q] = N).  ws: parrot_gather_sum_bwd_ws_floats(N,J,Q,D) floats of scratch.  D % 4 == 0, 16-byte aligned.
+ *
+ * Softmax cross-entropy with integer targets (three_tier.py:565-584, T.nnet.categorical_crossentropy(softmax(.), target)):
+ *   parrot_softmax_ce_fwd:  lse[i] = log sum_q exp(logits[i,q]),  ce[i] = lse[i] - logits[i, target[i]]
+ *   parrot_softmax_ce_bwd:  dlogits[i,q] = rowscale[i] * (exp(logits[i,q] - lse[i]) - [q == target[i]])
+ * parrot_relu_gate: out = dy where gate > 0, else 0 (n % 4 == 0; ReLU backward where no product can carry it).
+ * ------------------------------------------------------------------------------------------ */
+int parrot_gather_sum_fwd(const float* tbl, const int* idx, const float* add, int ldadd, float* y, int ldy, long long N,
+                          int J, int Q, int D, void* stream);
+long long parrot_gather_sum_bwd_ws_floats(long long N, int J, int Q, int D);
+int parrot_gather_sum_bwd(const float* dy, int lddy, const int* perm, const int* offs, float* dtbl, float* ws,
+                          long long ws_floats, long long N, int J, int Q, int D, int accumulate, void* stream);
+int parrot_softmax_ce_fwd(const float* logits, int ld, const int* target, long long rows, int Q, float* lse, float* ce,
+                          void* stream);
+int parrot_softmax_ce_bwd(const float* logits, int ld, const int* target, const float* lse, const float* rowscale,
+                          long long rows, int Q, float* dlogits, int ldd, void* stream);
+int parrot_relu_gate(const float* dy, const float* gate, float* out, long long n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conditional three-tier SampleRNN generation: the per-sample loop of generate_and_save_samples

@@ -139,6 +139,13 @@ SIGNATURES = {
     "parrot_profile_end": (C.c_longlong, [C.POINTER(C.c_double)] * 3),
     "parrot_profile_end2": (C.c_longlong, [C.POINTER(C.c_double)] * 4),
     "parrot_gemm": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _f, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
+    "parrot_gemm_gated": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "parrot_gather_sum_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _ll, _i, _i, _i, _vp]),
+    "parrot_gather_sum_bwd_ws_floats": (C.c_longlong, [_ll, _i, _i, _i]),
+    "parrot_gather_sum_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _i, _vp]),
+    "parrot_softmax_ce_fwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp]),
+    "parrot_softmax_ce_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _i, _vp]),
+    "parrot_relu_gate": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "parrot_colsum": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp]),
     "parrot_gru_step_fwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
     "parrot_gru_step_bwd": (_i, [_vp] * 11 + [_i, _i, _vp]),

@@ -21,6 +21,8 @@ struct BgArgs {
     int accumulate;  // C += result (C must hold valid data; with splitk>1 always accumulates)
     float alpha;
     int act;         // SkAct-compatible activation, only when splitk == 1
+    const float* gate;  // optional [M, N] (leading dimension ldg): the result is kept where gate > 0 and zeroed elsewhere --
+    int ldg;            // ReLU backward through the saved activation, fused into the dx product (nbatch == 1 only)
     int bf16;        // 1: operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16, f32 accumulation
                      // 2: A and B point at bf16 data (strides in bf16 elements), both x-contiguous: bgh_kernel
 };

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
                     if (a.act == 1) v = fmaxf(v, 0.f);
                     else if (a.act == 2) v = tanhf(v);
                     else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+                    if (a.gate && !(a.gate[(long long)m * a.ldg + n] > 0.f)) v = 0.f;
                     *c = v;
                 }
             }
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(512) void bg_kernel8(const BgArgs a, int vecA, int 
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 else if (a.act == 2) v = tanhf(v);
                 else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+                if (a.gate && !(a.gate[(long long)m * a.ldg + n] > 0.f)) v = 0.f;
                 *c = v;
             }
         }
@@ -487,6 +489,7 @@ __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, 
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 else if (a.act == 2) v = tanhf(v);
                 else if (a.act == 3) v = 1.f / (1.f + expf(-v));
+                if (a.gate && !(a.gate[(long long)m * a.ldg + n] > 0.f)) v = 0.f;
                 *c = v;
             }
         }
@@ -640,6 +643,7 @@ __global__ __launch_bounds__(256) void bg_reduce_kernel(const BgArgs a) {
         if (a.bias) v += a.bias[n];
         const float* w = a.ws + ((long long)batch * a.splitk) * mn + r;
         for (int ks = 0; ks < a.splitk; ++ks) v += w[(long long)ks * mn];
+        if (a.gate && !(a.gate[(long long)m * a.ldg + n] > 0.f)) v = 0.f;
         *c = v;
     }
 }
@@ -691,7 +695,7 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
     dim3 block(256);
     if (a.bf16 == 2) {  // operands are bf16 in memory, both x-contiguous (TN): bgh_kernel
-        if (!axc || !bxc || a.bias || a.act || (a.M & 7) || (a.N & 7) || (a.sak & 7) || (a.sbk & 7) ||
+        if (!axc || !bxc || a.bias || a.act || a.gate || (a.M & 7) || (a.N & 7) || (a.sak & 7) || (a.sbk & 7) ||
             ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || (a.batchA & 7) || (a.batchB & 7))
             return PH_ERR_UNSUPPORTED;
         const int tm = ceil_div(a.M, HBMT), tn = ceil_div(a.N, HBNT);

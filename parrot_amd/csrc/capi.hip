@@ -153,12 +153,14 @@ static int bg_run(BgArgs a, int split_k, hipStream_t st) {
     return bg_launch(a, st);
 }
 
-int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
-                int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
-                long long strideA, long long strideB, long long strideC, int split_k, void* stream) { PH_ENTRY();
+static int gemm_impl(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                     int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
+                     long long strideA, long long strideB, long long strideC, int split_k, const float* gate, int ldg,
+                     void* stream) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || nbatch < 1) return PARROT_ERR_BADARG;
+    if (gate && (nbatch != 1 || ldg < N)) return PARROT_ERR_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    if (M <= 64 && !transA && nbatch == 1 && split_k <= 1 && alpha == 1.0f) {
+    if (M <= 64 && !transA && nbatch == 1 && split_k <= 1 && alpha == 1.0f && !gate) {
         SkJob j;
         sk_job_init(j);
         j.nseg = 1;
@@ -180,8 +182,22 @@ int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, in
     a.batchA = strideA; a.batchB = strideB; a.batchC = strideC;
     a.nbatch = nbatch;
     a.accumulate = accumulate; a.alpha = alpha; a.act = act;
+    a.gate = gate; a.ldg = ldg;
     a.bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16.load(std::memory_order_relaxed);
     return bg_run(a, split_k, st);
+}
+
+int parrot_gemm(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                int M, int N, int K, const float* bias, float alpha, int accumulate, int act, int nbatch,
+                long long strideA, long long strideB, long long strideC, int split_k, void* stream) { PH_ENTRY();
+    return gemm_impl(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, bias, alpha, accumulate, act, nbatch, strideA, strideB,
+                     strideC, split_k, nullptr, 0, stream);
+}
+
+int parrot_gemm_gated(const float* A, int lda, int transA, const float* B, int ldb, int transB, float* C, int ldc,
+                      int M, int N, int K, const float* gate, int ldg, void* stream) { PH_ENTRY();
+    if (!gate) return PARROT_ERR_BADARG;
+    return gemm_impl(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, nullptr, 1.0f, 0, 0, 1, 0, 0, 0, 0, gate, ldg, stream);
 }
 
 int parrot_to_bf16(const float* x, void* y, long long n, void* stream) { PH_ENTRY();
@@ -201,6 +217,7 @@ int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C,
     a.batchA = a.batchB = a.batchC = 0;
     a.nbatch = 1;
     a.accumulate = accumulate; a.alpha = 1.0f; a.act = 0;
+    a.gate = nullptr; a.ldg = 0;
     a.bf16 = 2;
     return bg_run(a, split_k, (hipStream_t)stream);
 }

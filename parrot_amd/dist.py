@@ -10,8 +10,9 @@ independent through the whole step); two things couple the shards and both are h
   * StepClipping uses the global-norm of the SUMMED gradient (train.py:100-101), so the norm is
     taken after the all-reduce.
 
-Gradients live in one flat float32 buffer (parrot_amd.params.ParamStore), so the exchange is a
-single all-reduce over one bucket: 55.7 MB for BASELINE cfg2, 100.8 MB for the 3-layer model.
+Gradients live in one flat float32 buffer (parrot_amd.params.ParamStore): 55.7 MB for BASELINE cfg2, 100.8 MB for the
+3-layer model, 277.8 MB for configs[3].  `GradientExchange` sums it in two buckets: the readout / output share, complete
+before the backward scan starts, travels while the scan runs; the rest follows when the backward pass ends.
 """
 from __future__ import annotations
 
@@ -89,6 +90,77 @@ def allreduce_flat_(flat: torch.Tensor, group=None, async_op=False):
     if not is_distributed():
         return None
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class GradientExchange:
+    """The gradient sum of one training step over one flat buffer, in up to two buckets (round 5).
+
+    `early = (lo, hi)`: the slice of the flat gradient that is complete BEFORE the backward scan starts -- the readout stack
+    and the output layer (model.py:739-755; `Parrot.early_gradient_range()`).  `start_early()` is called at that moment and
+    issues its all-reduce asynchronously (RCCL runs it on its own stream behind what the compute stream holds so far), so it
+    travels over xGMI while the backward scan and the deferred weight-gradient products run; `finish()` reduces what is left
+    (the recurrent / attention / encoder gradients, complete only when the backward pass ends) and waits for the early
+    bucket.  Every element is summed exactly once by exactly one collective, so at world size 2 the result equals the
+    one-bucket all-reduce bit for bit (tests/test_dist_cpu.py).
+
+    `wire_dtype=torch.bfloat16` (opt-in; SURVEY.md K16 budgets the configs[3] exchange at 138.9 MB in bf16 against 277.8 MB
+    in f32): every rank rounds its f32 gradient to bf16 once, the collective sums bf16 values, the result is widened back
+    into the f32 buffer -- the master gradients, the clip norm and Adam stay f32.  Changes the arithmetic (one rounding per
+    rank and per hop of the collective), so it is a flag, not the default."""
+
+    def __init__(self, flat: torch.Tensor, early=None, wire_dtype=None, group=None):
+        self.flat, self.group = flat, group
+        self.wire = wire_dtype if wire_dtype not in (None, torch.float32) else None
+        n = flat.numel()
+        if early is not None:
+            lo, hi = int(early[0]), int(early[1])
+            if not (0 <= lo < hi <= n):
+                early = None
+            else:
+                early = (lo, hi)
+        self.early = early
+        self._pending = []   # (work, wire tensor or None, destination view)
+        self._early_done = False
+
+    def _issue(self, view, async_op):
+        if view.numel() == 0:
+            return
+        if self.wire is None:
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self._pending.append((w, None, view))
+            return
+        t = view.to(self.wire)
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            self._pending.append((w, t, view))
+        else:
+            view.copy_(t)
+
+    def start_early(self):
+        """Call when flat[lo:hi] is final for this step (at most once per step; a no-op outside a process group)."""
+        if not is_distributed() or self.early is None or self._early_done:
+            return
+        self._early_done = True
+        self._issue(self.flat[self.early[0]:self.early[1]], async_op=True)
+
+    def finish(self):
+        """Reduces whatever `start_early` did not take and waits for everything; the buffer then holds the global sum."""
+        if not is_distributed():
+            self._early_done = False
+            return
+        if self._early_done:
+            lo, hi = self.early
+            self._issue(self.flat[:lo], async_op=False)
+            self._issue(self.flat[hi:], async_op=False)
+        else:
+            self._issue(self.flat, async_op=False)
+        for w, t, view in self._pending:
+            w.wait()
+            if t is not None:
+                view.copy_(t)
+        self._pending = []
+        self._early_done = False
 
 
 def allreduce_cost(num_local: torch.Tensor, den_global: torch.Tensor, group=None):

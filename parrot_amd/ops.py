@@ -197,6 +197,171 @@ def linear(x, W, b=None, act=ACT_NONE):
     return _LinearFn.apply(x, W, b, act)
 
 
+# ----------------------------------------------------------------------------- SampleRNN sample-level tier (training)
+def gemm_gated(a: torch.Tensor, b: torch.Tensor, gate: torch.Tensor, out=None) -> torch.Tensor:
+    """out[M,N] = (a[M,K] @ b[K,N]) where gate[M,N] > 0, else 0: the backward of a ReLU layer through its saved
+    activation, fused into the product that makes the gradient wrt the layer's output (parrot_gemm_gated)."""
+    pa, M, K, lda, ta = _mat(a, "a")
+    pb, K2, N, ldb, tb = _mat(b, "b")
+    _chk(gate, "gate")
+    if K != K2 or gate.shape != (M, N) or gate.stride(1) != 1:
+        raise ValueError("gemm_gated: shapes do not match")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _chk(out, "out")
+    if out.shape != (M, N) or out.stride(1) != 1:
+        raise ValueError("gemm_gated: bad output tensor")
+    _lib.call("parrot_gemm_gated", pa, lda, ta, pb, ldb, tb, out.data_ptr(), out.stride(0), M, N, K,
+              gate.data_ptr(), gate.stride(0), _stream())
+    return out
+
+
+def _int32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HipCallError(f"{name}: the parrot_amd product path needs a GPU tensor; there is no CPU fallback")
+    return t.to(torch.int32).contiguous()
+
+
+class _EmbedSumFn(torch.autograd.Function):
+    """y[i] = add[i] + sum_j (E . W1[j*EMB:(j+1)*EMB])[idx[i, j]]: lib.ops.Embedding followed by the bias-free Linear
+    SampleLevel.L1_PrevSamples (three_tier.py:486-497) without the [rows, FS*EMB] activation -- the folded table the
+    generation loop uses (SampleRnnGenDesc::emb_tbl), forward as a gather-sum, backward as a segmented sum."""
+
+    @staticmethod
+    def forward(ctx, E, W1, idx, add):
+        Q, EMB = E.shape
+        N, J = idx.shape
+        D = W1.shape[1]
+        if W1.shape[0] != J * EMB:
+            raise ValueError("embed_sum: W1 must be [J * EMB, D]")
+        E_, W1_ = E.contiguous(), W1.contiguous()
+        idx32 = _int32(idx, "idx")
+        tbl = torch.empty(J, Q, D, device=E.device, dtype=torch.float32)
+        with gemm_precision(PRECISION_F32):  # (a table of 2.6 M entries: nothing to gain from bf16 operands)
+            gemm_batched(E_.unsqueeze(0).expand(J, -1, -1), W1_.view(J, EMB, D), tbl)
+        y = torch.empty(N, D, device=E.device, dtype=torch.float32)
+        if add is not None:
+            _chk(add, "add")
+            add = add.reshape(N, D)
+            if add.stride(1) != 1:
+                add = add.contiguous()
+        _lib.call("parrot_gather_sum_fwd", tbl.data_ptr(), idx32.data_ptr(), add.data_ptr() if add is not None else None,
+                  add.stride(0) if add is not None else 0, y.data_ptr(), y.stride(0), N, J, Q, D, _stream())
+        ctx.save_for_backward(E_, W1_, idx32)
+        ctx.has_add = add is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        E, W1, idx32 = ctx.saved_tensors
+        Q, EMB = E.shape
+        N, J = idx32.shape
+        D = W1.shape[1]
+        dy = dy.reshape(N, D)
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        # rows sorted by (index, row) per position j, and where every bin starts: integer bookkeeping for the segmented sum
+        vals, perm = torch.sort(idx32.t().contiguous(), dim=1, stable=True)
+        bins = torch.arange(Q + 1, device=E.device, dtype=torch.int32).unsqueeze(0).expand(J, -1).contiguous()
+        offs = torch.searchsorted(vals, bins).to(torch.int32).contiguous()
+        perm = perm.to(torch.int32).contiguous()
+        n_ws = int(_lib.load().parrot_gather_sum_bwd_ws_floats(N, J, Q, D))
+        ws = torch.empty(n_ws, device=E.device, dtype=torch.float32)
+        dtbl = torch.empty(J, Q, D, device=E.device, dtype=torch.float32)
+        _lib.call("parrot_gather_sum_bwd", dy.data_ptr(), dy.stride(0), perm.data_ptr(), offs.data_ptr(), dtbl.data_ptr(),
+                  ws.data_ptr(), n_ws, N, J, Q, D, 0, _stream())
+        dE = dW1 = None
+        with gemm_precision(PRECISION_F32):
+            if ctx.needs_input_grad[0]:  # dE = sum_j dtbl[j] . W1_j^T
+                t = torch.empty(J, Q, EMB, device=E.device, dtype=torch.float32)
+                gemm_batched(dtbl, W1.view(J, EMB, D), t, transB=True)
+                dE = t.sum(0)
+            if ctx.needs_input_grad[1]:  # dW1_j = E^T . dtbl[j]
+                dW1 = torch.empty(J, EMB, D, device=E.device, dtype=torch.float32)
+                gemm_batched(E.unsqueeze(0).expand(J, -1, -1), dtbl, dW1, transA=True)
+                dW1 = dW1.view(J * EMB, D)
+        return dE, dW1, None, (dy if ctx.has_add and ctx.needs_input_grad[3] else None)
+
+
+def embed_sum(E, W1, idx, add=None):
+    """sum_j (E . W1_j)[idx[:, j]] (+ add): see _EmbedSumFn.  E [Q, EMB], W1 [J*EMB, D], idx [N, J] integer, add [N, D]."""
+    return _EmbedSumFn.apply(E, W1, idx, add)
+
+
+class _ReluMlpFn(torch.autograd.Function):
+    """logits = relu(relu(x . W2 + b2) . W3 + b3) . W4 + b4 (three_tier.py:499-515) with bias + ReLU in the products'
+    epilogues and, backward, the ReLU masks in the epilogues of the dx products (parrot_gemm_gated)."""
+
+    @staticmethod
+    def forward(ctx, x, W2, b2, W3, b3, W4, b4):
+        x = x.reshape(-1, x.shape[-1])
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        y2 = gemm(x, W2, bias=b2, act=ACT_RELU)
+        y3 = gemm(y2, W3, bias=b3, act=ACT_RELU)
+        out = gemm(y3, W4, bias=b4)
+        ctx.save_for_backward(x, y2, y3, W2, W3, W4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, y2, y3, W2, W3, W4 = ctx.saved_tensors
+        if not dl.is_contiguous():
+            dl = dl.contiguous()
+        need = ctx.needs_input_grad
+        d3 = gemm_gated(dl, W4.t(), y3)
+        dW4 = gemm(y3.t(), dl) if need[5] else None
+        db4 = colsum(dl) if need[6] else None
+        d2 = gemm_gated(d3, W3.t(), y2)
+        dW3 = gemm(y2.t(), d3) if need[3] else None
+        db3 = colsum(d3) if need[4] else None
+        dW2 = gemm(x.t(), d2) if need[1] else None
+        db2 = colsum(d2) if need[2] else None
+        dx = gemm(d2, W2.t()) if need[0] else None
+        return dx, dW2, db2, dW3, db3, dW4, db4
+
+
+def relu_mlp(x, W2, b2, W3, b3, W4, b4):
+    return _ReluMlpFn.apply(x, W2, b2, W3, b3, W4, b4)
+
+
+class _SoftmaxCeFn(torch.autograd.Function):
+    """ce[i] = logsumexp(logits[i]) - logits[i, target[i]] (three_tier.py:565-584), one HIP pass each way."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _chk(logits, "logits")
+        x = logits.reshape(-1, logits.shape[-1])
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        rows, Q = x.shape
+        t32 = _int32(target.reshape(-1), "target")
+        if t32.numel() != rows:
+            raise ValueError("softmax_ce: one target per row expected")
+        lse = torch.empty(rows, device=x.device, dtype=torch.float32)
+        ce = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _lib.call("parrot_softmax_ce_fwd", x.data_ptr(), x.stride(0), t32.data_ptr(), rows, Q, lse.data_ptr(),
+                  ce.data_ptr(), _stream())
+        ctx.save_for_backward(x, t32, lse)
+        ctx.lshape = logits.shape
+        return ce
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t32, lse = ctx.saved_tensors
+        rows, Q = x.shape
+        g = g.reshape(-1).to(torch.float32).contiguous()
+        dx = torch.empty(rows, Q, device=x.device, dtype=torch.float32)
+        _lib.call("parrot_softmax_ce_bwd", x.data_ptr(), x.stride(0), t32.data_ptr(), lse.data_ptr(), g.data_ptr(), rows, Q,
+                  dx.data_ptr(), dx.stride(0), _stream())
+        return dx.view(ctx.lshape), None
+
+
+def softmax_ce(logits, target):
+    """Per-row softmax cross-entropy with integer targets, natural log: [rows]."""
+    return _SoftmaxCeFn.apply(logits, target)
+
+
 # ----------------------------------------------------------------------------- GRU step / scan
 def gru_step_fwd(h, inputs, gate_inputs, Wg, Wc, mask=None):
     """One GatedRecurrent step; returns (h_new, saved) with saved = (z, r, rh, c)."""

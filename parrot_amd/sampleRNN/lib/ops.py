@@ -91,6 +91,8 @@ def Embedding(name, n_symbols, output_dim, indices):
     """ops.py:252-266: vectors[indices]."""
     vectors = lib.param(name, _rng.randn(n_symbols, output_dim).astype('float32')) \
         if name not in lib._params else lib.param(name)
+    if indices is None:  # (extension) the table itself: callers that fold the gather into a fused operator
+        return vectors
     return vectors[indices.reshape(-1).long()].reshape(*indices.shape, output_dim)
 
 

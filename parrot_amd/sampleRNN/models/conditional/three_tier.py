@@ -112,14 +112,23 @@ def frame_level_rnn(input_sequences, other_input, h0, reset):
 def sample_level_predictor(frame_level_outputs, prev_samples):
     """three_tier.py:452-515: logits [rows, Q_LEVELS]."""
     assert EMB_SIZE > 0, 'no support for one-hot in three_tier (three_tier.py:458)'
-    emb = lops.Embedding('SampleLevel.Embedding', Q_LEVELS, EMB_SIZE, prev_samples)
-    emb = emb.reshape(-1, FRAME_SIZE * EMB_SIZE)
-    out = lops.Linear('SampleLevel.L1_PrevSamples', FRAME_SIZE * EMB_SIZE, DIM, emb, biases=False,
-                      initialization='he', weightnorm=WEIGHT_NORM)
-    out = out + frame_level_outputs
-    out = torch.relu(lops.Linear('SampleLevel.L2', DIM, DIM, out, initialization='he', weightnorm=WEIGHT_NORM))
-    out = torch.relu(lops.Linear('SampleLevel.L3', DIM, DIM, out, initialization='he', weightnorm=WEIGHT_NORM))
-    return lops.Linear('SampleLevel.Output', DIM, Q_LEVELS, out, weightnorm=WEIGHT_NORM)
+    # Same parameters, created in the reference's order (Embedding, L1_PrevSamples, L2, L3, Output); the arithmetic runs
+    # on the fused HIP operators (round 5):
+    #   * Embedding -> reshape -> L1_PrevSamples (no bias) -> + frame_level_outputs is, row by row, a sum of FRAME_SIZE rows
+    #     of the folded table (Embedding . W1_j) plus the frame-tier row: hip.embed_sum (gather-sum forward, segmented-sum
+    #     backward; no [rows, FRAME_SIZE * EMB_SIZE] activation and no K = FRAME_SIZE * EMB_SIZE product);
+    #   * relu(L2) -> relu(L3) -> Output: hip.relu_mlp (bias + ReLU in the products' epilogues, the ReLU masks of the
+    #     backward pass in the epilogues of the dx products).
+    vectors = lops.Embedding('SampleLevel.Embedding', Q_LEVELS, EMB_SIZE, None)
+    lops.Linear('SampleLevel.L1_PrevSamples', FRAME_SIZE * EMB_SIZE, DIM, None, biases=False, initialization='he',
+                weightnorm=WEIGHT_NORM, just_params=True)
+    out = hip.embed_sum(vectors, lops.effective_weight('SampleLevel.L1_PrevSamples', 0, WEIGHT_NORM),
+                        prev_samples.reshape(-1, FRAME_SIZE), frame_level_outputs.reshape(-1, DIM))
+    wb = []
+    for name, dout, init in (('SampleLevel.L2', DIM, 'he'), ('SampleLevel.L3', DIM, 'he'), ('SampleLevel.Output', Q_LEVELS, None)):
+        lops.Linear(name, DIM, dout, None, initialization=init, weightnorm=WEIGHT_NORM, just_params=True)
+        wb += [lops.effective_weight(name, 0, WEIGHT_NORM), lib.param(name + '.b')]
+    return hip.relu_mlp(out, *wb)
 
 
 def compute_cost(sequences, features, h0, big_h0, reset, mask):
@@ -139,7 +148,7 @@ def compute_cost(sequences, features, h0, big_h0, reset, mask):
     log2e = float(numpy.log2(numpy.e))
 
     def ce_bits(logits):
-        ce = torch.logsumexp(logits, -1) - logits.gather(1, tgt)[:, 0]
+        ce = hip.softmax_ce(logits, tgt)  # logsumexp - picked logit, one HIP pass (and one for its gradient)
         ce = ce.reshape(target_sequences.shape) * target_mask
         return ce.sum() / (target_mask.sum() + 1e-5) * log2e
 

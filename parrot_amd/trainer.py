@@ -13,8 +13,19 @@ from . import ops
 
 
 class Trainer:
-    def __init__(self, parrot, learning_rate=1e-4, grad_clip=0.9, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, parrot, learning_rate=1e-4, grad_clip=0.9, beta1=0.9, beta2=0.999, eps=1e-8,
+                 bucketed=None, allreduce_dtype=None):
+        """bucketed (default: PARROT_DP_BUCKETS != 0): the decoder's gradient sum in two buckets, the readout / output share
+        overlapped with the backward scan (dist.GradientExchange).  allreduce_dtype='bf16' (default: PARROT_ALLREDUCE_BF16):
+        bf16 on the wire, f32 master gradients (opt-in; changes the arithmetic)."""
+        import os
         self.parrot = parrot.allocate()
+        if bucketed is None:
+            bucketed = os.environ.get('PARROT_DP_BUCKETS', '1') != '0'
+        if allreduce_dtype is None and os.environ.get('PARROT_ALLREDUCE_BF16', '0') != '0':
+            allreduce_dtype = 'bf16'
+        wire = torch.bfloat16 if allreduce_dtype in ('bf16', 'bfloat16', torch.bfloat16) else None
+        self._wire = wire
         self.lr = float(learning_rate)
         self.clip = 10.0 * float(grad_clip)  # train.py:100-101: "for adam is 10x"
         self.beta1, self.beta2, self.eps = beta1, beta2, eps
@@ -24,6 +35,9 @@ class Trainer:
             flat, flat_grad = srn_lib.flatten_params()  # SampleRNN head: same clip + Adam, same global norm
             parrot.sampleRnn.parameters = srn_lib.get_params(lambda n, p_: getattr(p_, 'param', False))
             self.groups.append((flat, flat_grad))
+        early = parrot.early_gradient_range() if (bucketed and hasattr(parrot, 'early_gradient_range')) else None
+        self.exchanges = [pdist.GradientExchange(g_, early if i == 0 else None, wire)
+                          for i, (_, g_) in enumerate(self.groups)]
         self.ms = [torch.zeros_like(p_) for p_, _ in self.groups]
         self.vs = [torch.zeros_like(p_) for p_, _ in self.groups]
         self.m, self.v = self.ms[0], self.vs[0]
@@ -47,9 +61,13 @@ class Trainer:
         den_local = features_mask[1:].to(cost.device, torch.float32).sum()
         if pdist.is_distributed():
             scale, den_global = pdist.global_cost_scale(den_local)
-            cost.backward(gradient=scale.to(cost.dtype))
-            for _, g_ in self.groups:
-                pdist.allreduce_flat_(g_)
+            p.on_early_gradients = self.exchanges[0].start_early  # fired by the backward pass (model.py side)
+            try:
+                cost.backward(gradient=scale.to(cost.dtype))
+            finally:
+                p.on_early_gradients = None
+            for ex in self.exchanges:
+                ex.finish()
             gcost = pdist.allreduce_cost(cost.detach() * (den_local + pdist.COST_EPS), den_global)
         else:
             cost.backward()
