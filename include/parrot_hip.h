@@ -84,6 +84,13 @@ int parrot_gemm_gated(const float* A, int lda, int transA, const float* B, int l
 int parrot_to_bf16(const float* x, void* y, long long n, void* stream);
 int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                        int accumulate, int split_k, void* stream);
+/* Round 5: the same bf16-in product for every operand layout parrot_gemm takes (A(m,k) at A[m*lda + k], or A[k*lda + m]
+ * when transA; B(k,n) at B[k*ldb + n], or B[n*ldb + k] when transB; leading dimensions in bf16 elements, multiples of 8;
+ * K % 8 == 0; the contiguous extent of an operand a multiple of 8), plus an optional f32 bias [N]: the readout products
+ * h . Wr and dread . Wr^T of a bf16-operand decoder (model.py:739-755) on bf16 copies instead of f32 operands rounded
+ * inside the product.  parrot_gemm_bf16in(A, ...) == parrot_gemm_bf16in_ex(A, lda, 1, B, ldb, 0, ..., NULL, ...). */
+int parrot_gemm_bf16in_ex(const void* A, int lda, int transA, const void* B, int ldb, int transB, float* C, int ldc, int M,
+                          int N, int K, const float* bias, int accumulate, int split_k, void* stream);
 
 /* Products that run BESIDE the scan (the weight-gradient GEMMs of the backward window, ordered behind
  * parrot_decoder_seq_bwd_part on a second stream): parrot_stream_create makes a non-blocking stream of the lowest

@@ -189,6 +189,7 @@ SIGNATURES = {
     "parrot_set_gemm_lds_pad": (_i, [_i]),
     "parrot_to_bf16": (_i, [_vp, _vp, _ll, _vp]),
     "parrot_gemm_bf16in": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "parrot_gemm_bf16in_ex": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "parrot_stream_create": (_i, [_i, C.POINTER(C.c_void_p)]),
     "parrot_stream_destroy": (_i, [_vp]),
     "parrot_simple_norm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _ll, _i, _f, _vp, _i, _vp]),

@@ -24,7 +24,7 @@ struct BgArgs {
     const float* gate;  // optional [M, N] (leading dimension ldg): the result is kept where gate > 0 and zeroed elsewhere --
     int ldg;            // ReLU backward through the saved activation, fused into the dx product (nbatch == 1 only)
     int bf16;        // 1: operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16, f32 accumulation
-                     // 2: A and B point at bf16 data (strides in bf16 elements), both x-contiguous: bgh_kernel
+                     // 2: A and B point at bf16 data (strides in bf16 elements), any "one stride is 1" layout: bgh_kernel
 };
 
 int bg_launch(const BgArgs& a, hipStream_t stream);

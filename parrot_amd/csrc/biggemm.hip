@@ -505,14 +505,73 @@ __global__ __launch_bounds__(512) void bg_kernel_bf16(const BgArgs a, int vecA, 
 // are [k][x] with a row pitch of 272 bf16 (544 B = 32 B mod 256: the four k rows of a ds_read_b64_tr_b16 group fall
 // on disjoint bank octets), written with one ds_write_b128 per 8 elements; fragments as in bg_frag16<true>.
 constexpr int HBMT = 256, HBNT = 256, HPITCH = 272;
+// Round 5: the same kernel for k-CONTIGUOUS bf16 operands (element (x, k) at p[x * ld + k]: the A operand of x . W, both
+// operands of dy . W^T), so that the readout products of a bf16-operand decoder (model.py:739-755, 1.5 TFLOP per cfg4
+// window) run on bf16 copies too instead of rounding f32 operands inside bg_kernel_bf16 (~270 TFLOP/s).  Such an operand
+// is staged into an [x][k] image (row pitch BKT + 8 bf16: 16-byte rows of the 32 lanes of a fragment read fall on
+// disjoint bank groups, as PITCH16 above), 16 bytes = 8 consecutive k per thread and vector, and its MFMA fragment is
+// one plain ds_read_b128 (row xb + li, k = 16 s + 8 kk .. + 7).  XC = x-contiguous (the round-4 path), else k-contiguous.
+template <int BKT, bool XC>
+struct BghOperand {
+    static constexpr int PK = BKT + 8;                                  // [x][k] row pitch (bf16)
+    static constexpr int SZ = XC ? BKT * HPITCH : 256 * PK;             // bf16 per image
+    static constexpr int NV = BKT / 16;                                 // 16-byte vectors per thread and K-tile
+    // element strides of the operand: ld = elements between consecutive k (XC) or consecutive x (!XC)
+    static __device__ __forceinline__ void load(const __bf16* __restrict__ p, long long ld, int x0, int X, int k0, int kend,
+                                                int t, bf16x8 (&v)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bf16x8 r;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = (__bf16)0.f;
+            if (XC) {  // vector id = t + 512 i -> k row id / 32, x = 8 * (id % 32): a wave reads two whole 512-byte rows
+                const int k = k0 + (t >> 5) + 16 * i, x = x0 + 8 * (t & 31);
+                if (k < kend && x < X) r = *reinterpret_cast<const bf16x8*>(p + (long long)k * ld + x);  // (X % 8 == 0)
+            } else {   // vector id = t + 512 i -> row id / (BKT / 8), k group id % (BKT / 8)
+                const int id = t + 512 * i;
+                const int x = x0 + id / (BKT / 8), k = k0 + 8 * (id % (BKT / 8));
+                if (x < X && k < kend) r = *reinterpret_cast<const bf16x8*>(p + (long long)x * ld + k);  // (K % 8 == 0)
+            }
+            v[i] = r;
+        }
+    }
+    static __device__ __forceinline__ void store(__bf16* __restrict__ s, int t, const bf16x8 (&v)[NV]) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (XC) {
+                *reinterpret_cast<bf16x8*>(s + ((t >> 5) + 16 * i) * HPITCH + 8 * (t & 31)) = v[i];
+            } else {
+                const int id = t + 512 * i;
+                *reinterpret_cast<bf16x8*>(s + (id / (BKT / 8)) * PK + 8 * (id % (BKT / 8))) = v[i];
+            }
+        }
+    }
+    // MFMA 32x32x16 operand of lane (kk, li): row xb + li, k = 16 s + 8 kk .. +7
+    static __device__ __forceinline__ bf16x8 frag(const __bf16* __restrict__ img, int xb, int s_, int kk, int li) {
+        if (XC) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(3))) s16x4* lds4;
+            const int k0 = 16 * s_ + 8 * kk, q = (li >> 2) & 3, xg = xb + (li & 16) + 4 * (li & 3);
+            const __bf16* p = img + (k0 + q) * HPITCH + xg;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 4 * HPITCH));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            return *reinterpret_cast<const bf16x8*>(img + (xb + li) * PK + 16 * s_ + 8 * kk);
+        }
+    }
+};
 
-template <int BKT>
+template <int BKT, bool AXC, bool BXC>
 __global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, int tiles_n) {
-    constexpr int NV = BKT / 16;         // 16-byte vectors per thread, operand and K-tile
-    constexpr int SZ = BKT * HPITCH;     // bf16 per image
+    typedef BghOperand<BKT, AXC> OA;
+    typedef BghOperand<BKT, BXC> OB;
+    constexpr int NV = BKT / 16;
     extern __shared__ __attribute__((aligned(16))) __bf16 bgh_smem[];
-    __bf16* As = bgh_smem;            // [2][SZ]
-    __bf16* Bs = bgh_smem + 2 * SZ;   // [2][SZ]
+    __bf16* As = bgh_smem;                 // [2][OA::SZ]
+    __bf16* Bs = bgh_smem + 2 * OA::SZ;    // [2][OB::SZ]
     int tm, tn;
     bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * HBMT, n0 = tn * HBNT;
@@ -525,6 +584,7 @@ __global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, i
     const __bf16* A = reinterpret_cast<const __bf16*>(a.A) + (long long)batch * a.batchA;
     const __bf16* B = reinterpret_cast<const __bf16*>(a.B) + (long long)batch * a.batchB;
     float* C = a.C + (long long)batch * a.batchC;
+    const long long lda = AXC ? a.sak : a.sam, ldb = BXC ? a.sbk : a.sbn;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int kk = lane >> 5, li = lane & 31;
@@ -535,59 +595,30 @@ __global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, i
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    // staging role: vector id = t + 512 i -> k row id / 32, x = 8 * (id % 32): a wave reads two whole 512-byte rows
-    const int sk = t >> 5, sx = 8 * (t & 31);
-    auto load = [&](const __bf16* __restrict__ p, long long ld, int x0, int X, int k0, bf16x8 (&v)[NV]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int k = k0 + sk + 16 * i, x = x0 + sx;
-            bf16x8 r;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = (__bf16)0.f;
-            if (k < kend && x < X) r = *reinterpret_cast<const bf16x8*>(p + (long long)k * ld + x);  // (X % 8 == 0)
-            v[i] = r;
-        }
-    };
-    auto store = [&](__bf16* __restrict__ s, const bf16x8 (&v)[NV]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<bf16x8*>(s + (sk + 16 * i) * HPITCH + sx) = v[i];
-    };
-    // MFMA 32x32x16 operand of lane (kk, li): row xb + li, k = 16 s + 8 kk .. +7, from a [k][x] image
-    auto frag = [&](const __bf16* __restrict__ img, int xb, int s_) __attribute__((always_inline)) -> bf16x8 {
-        typedef short s16x4 __attribute__((ext_vector_type(4)));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
-        typedef __attribute__((address_space(3))) s16x4* lds4;
-        const int k0 = 16 * s_ + 8 * kk, q = (li >> 2) & 3, xg = xb + (li & 16) + 4 * (li & 3);
-        const __bf16* p = img + (k0 + q) * HPITCH + xg;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 4 * HPITCH));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
-    };
     bf16x8 ra[NV], rb[NV];
     const int nk = (kend - kbeg + BKT - 1) / BKT;
     if (nk > 0) {
-        load(A, a.sak, m0, a.M, kbeg, ra);
-        load(B, a.sbk, n0, a.N, kbeg, rb);
-        store(As, ra);
-        store(Bs, rb);
+        OA::load(A, lda, m0, a.M, kbeg, kend, t, ra);
+        OB::load(B, ldb, n0, a.N, kbeg, kend, t, rb);
+        OA::store(As, t, ra);
+        OB::store(Bs, t, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load(A, a.sak, m0, a.M, kbeg + (kt + 1) * BKT, ra);
-            load(B, a.sbk, n0, a.N, kbeg + (kt + 1) * BKT, rb);
+            OA::load(A, lda, m0, a.M, kbeg + (kt + 1) * BKT, kend, t, ra);
+            OB::load(B, ldb, n0, a.N, kbeg + (kt + 1) * BKT, kend, t, rb);
         }
-        const __bf16* as = As + cur * SZ;
-        const __bf16* bs = Bs + cur * SZ;
+        const __bf16* as = As + cur * OA::SZ;
+        const __bf16* bs = Bs + cur * OB::SZ;
 #pragma unroll
         for (int s_ = 0; s_ < BKT / 16; ++s_) {
             bf16x8 fa[4], fb[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = frag(bs, wn * 64 + 32 * j, s_);
+            for (int j = 0; j < 2; ++j) fb[j] = OB::frag(bs, wn * 64 + 32 * j, s_, kk, li);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = frag(as, wm * 128 + 32 * i, s_);
+            for (int i = 0; i < 4; ++i) fa[i] = OA::frag(as, wm * 128 + 32 * i, s_, kk, li);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -595,8 +626,8 @@ __global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, i
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            store(As + (cur ^ 1) * SZ, ra);
-            store(Bs + (cur ^ 1) * SZ, rb);
+            OA::store(As + (cur ^ 1) * OA::SZ, t, ra);
+            OB::store(Bs + (cur ^ 1) * OB::SZ, t, rb);
         }
         __syncthreads();
     }
@@ -606,16 +637,17 @@ __global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, i
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + li;
             if (n >= a.N) continue;
+            const float bias = (a.bias && ks == 0) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int m = m0 + wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
                 if (m >= a.M) continue;
                 const float v = a.alpha * acc[i][j][q];
                 if (a.splitk > 1) {
-                    a.ws[((long long)z * a.M + m) * a.N + n] = v;  // summed in slice order by the reducer
+                    a.ws[((long long)z * a.M + m) * a.N + n] = v;  // summed in slice order by the reducer (which adds the bias)
                 } else {
                     float* c = C + (long long)m * a.ldc + n;
-                    *c = a.accumulate ? *c + v : v;
+                    *c = a.accumulate ? *c + v + bias : v + bias;
                 }
             }
         }
@@ -694,21 +726,39 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     const int tiles_m = ceil_div(a.M, BM), tiles_n = ceil_div(a.N, BN);
     dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
     dim3 block(256);
-    if (a.bf16 == 2) {  // operands are bf16 in memory, both x-contiguous (TN): bgh_kernel
-        if (!axc || !bxc || a.bias || a.act || a.gate || (a.M & 7) || (a.N & 7) || (a.sak & 7) || (a.sbk & 7) ||
-            ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || (a.batchA & 7) || (a.batchB & 7))
+    if (a.bf16 == 2) {  // operands ARE bf16 in memory (strides in bf16 elements): bgh_kernel, any "one stride is 1" layout
+        if (a.act || a.gate || (a.K & 7) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || (a.batchA & 7) || (a.batchB & 7))
             return PH_ERR_UNSUPPORTED;
+        if (axc ? ((a.M & 7) || (a.sak & 7)) : (a.sam & 7)) return PH_ERR_UNSUPPORTED;
+        if (bxc ? ((a.N & 7) || (a.sbk & 7)) : (a.sbn & 7)) return PH_ERR_UNSUPPORTED;
         const int tm = ceil_div(a.M, HBMT), tn = ceil_div(a.N, HBNT);
         static int bkt = -1;
         if (bkt < 0) {
             const char* e = getenv("PARROT_GEMM_BF16IN_BK");
-            bkt = e ? atoi(e) : 32;
-            (void)hipFuncSetAttribute((const void*)bgh_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)bgh_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            bkt = (e && atoi(e) == 64) ? 64 : 32;
         }
         const dim3 g2(tm * tn, a.nbatch * a.splitk), b8(512);
-        if (bkt == 64) hipLaunchKernelGGL((bgh_kernel<64>), g2, b8, (size_t)4 * 64 * HPITCH * 2 + pad, stream, a, tm, tn);
-        else hipLaunchKernelGGL((bgh_kernel<32>), g2, b8, (size_t)4 * 32 * HPITCH * 2 + pad, stream, a, tm, tn);
+        auto go = [&](auto kern, size_t lds) {
+            static bool attr_done = false;  // (one flag per kernel instantiation: the lambda's call operator is a template)
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kern, g2, b8, lds + pad, stream, a, tm, tn);
+        };
+#define BGH_GO(BKT, AX, BX) go(bgh_kernel<BKT, AX, BX>, (size_t)4 * (BghOperand<BKT, AX>::SZ + BghOperand<BKT, BX>::SZ))
+        if (bkt == 64) {
+            if (axc && bxc) BGH_GO(64, true, true);
+            else if (axc) BGH_GO(64, true, false);
+            else if (bxc) BGH_GO(64, false, true);
+            else BGH_GO(64, false, false);
+        } else {
+            if (axc && bxc) BGH_GO(32, true, true);
+            else if (axc) BGH_GO(32, true, false);
+            else if (bxc) BGH_GO(32, false, true);
+            else BGH_GO(32, false, false);
+        }
+#undef BGH_GO
         return (int)hipGetLastError();
     }
     if (a.bf16) {

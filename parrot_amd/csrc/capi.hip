@@ -205,14 +205,14 @@ int parrot_to_bf16(const float* x, void* y, long long n, void* stream) { PH_ENTR
     return bg_to_bf16_launch(x, y, n, (hipStream_t)stream);
 }
 
-int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
-                       int accumulate, int split_k, void* stream) { PH_ENTRY();
+int parrot_gemm_bf16in_ex(const void* A, int lda, int transA, const void* B, int ldb, int transB, float* C, int ldc, int M,
+                          int N, int K, const float* bias, int accumulate, int split_k, void* stream) { PH_ENTRY();
     if (!A || !B || !C || M < 1 || N < 1 || K < 1) return PARROT_ERR_BADARG;
     BgArgs a;
-    a.A = reinterpret_cast<const float*>(A); a.B = reinterpret_cast<const float*>(B); a.C = C; a.bias = nullptr;
+    a.A = reinterpret_cast<const float*>(A); a.B = reinterpret_cast<const float*>(B); a.C = C; a.bias = bias;
     a.M = M; a.N = N; a.K = K;
-    a.sam = 1; a.sak = lda;   // A(m, k) at A[k * lda + m]: the caller's [K, M] matrix read as its transpose
-    a.sbk = ldb; a.sbn = 1;
+    a.sam = transA ? 1 : lda; a.sak = transA ? lda : 1;   // as parrot_gemm, in bf16 elements
+    a.sbk = transB ? 1 : ldb; a.sbn = transB ? ldb : 1;
     a.ldc = ldc;
     a.batchA = a.batchB = a.batchC = 0;
     a.nbatch = 1;
@@ -220,6 +220,12 @@ int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C,
     a.gate = nullptr; a.ldg = 0;
     a.bf16 = 2;
     return bg_run(a, split_k, (hipStream_t)stream);
+}
+
+int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                       int accumulate, int split_k, void* stream) {
+    // A(m, k) at A[k * lda + m]: the caller's [K, M] matrix read as its transpose
+    return parrot_gemm_bf16in_ex(A, lda, 1, B, ldb, 0, C, ldc, M, N, K, nullptr, accumulate, split_k, stream);
 }
 
 int parrot_tile_weights(const float* W, int rows, int cols, int ld, float* out, int mode, int lstm_H, void* stream) { PH_ENTRY();

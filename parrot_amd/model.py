@@ -801,6 +801,18 @@ class Parrot(Brick):
                     ops.gemm(ws['h'][l][1:].view(T * B, H), Wr[l * H:(l + 1) * H],
                              bias=self._p(f'/h{l + 1}_to_readout.b')), add_into=readouts)
                 save[('ln_ro', l)] = (y, sig)
+        elif self._bf16_readouts(T, R):
+            # bf16-operand decoders (round 5): the readout products on bf16 COPIES of the state / context histories and of
+            # Wr (parrot_gemm_bf16in_ex, 256 x 256 tiles) instead of f32 operands rounded inside the product -- the same
+            # values rounded the same way (nearest even).  The copies are reused by the backward pass (dread . Wr^T, the
+            # readout and scan weight gradients).
+            cp = self._bf16_copies(ws, T, B, convert=('h', 'w'))
+            save['bf16_hw_done'] = True
+            Wr16 = save['Wr16'] = ops.to_bf16(Wr)
+            ops.gemm16(cp['h'][0][1:T + 1].view(T * B, H), Wr16[0:H], out=readouts, bias=rb)
+            for l in range(1, L):
+                ops.gemm16(cp['h'][l][1:T + 1].view(T * B, H), Wr16[l * H:(l + 1) * H], out=readouts, accumulate=True)
+            ops.gemm16(cp['w'][1:T + 1].view(T * B, E), Wr16[L * H:], out=readouts, accumulate=True)
         else:
             ops.gemm(ws['h'][0][1:].view(T * B, H), Wr[0:H], bias=rb, out=readouts)
             for l in range(1, L):
@@ -913,9 +925,9 @@ class Parrot(Brick):
             if self._bf16_weight_grads(0, T, T) and R % 8 == 0 and not self.layer_norm:
                 # bf16-operand decoders: from the bf16 copies of the state / context histories (made here, reused by the
                 # scan's weight gradients below) and a bf16 copy of the readout gradient
-                cp = self._bf16_copies(ws, T, B, convert=('h', 'w'))
+                cp = self._bf16_copies(ws, T, B, convert=() if save.get('bf16_hw_done') else ('h', 'w'))
                 ws['bf16_hw_fresh'] = True
-                d16 = ops.to_bf16(dread)
+                d16 = save['d16'] if 'd16' in save else ops.to_bf16(dread)
                 for l in range(L):
                     ops.gemm_bf16in(cp['h'][l][1:T + 1].view(T * B, H), d16, gWr[l * H:(l + 1) * H], accumulate=True)
                 ops.gemm_bf16in(cp['w'][1:T + 1].view(T * B, E), d16, gWr[L * H:], accumulate=True)
@@ -932,11 +944,20 @@ class Parrot(Brick):
             ops.colsum(dsum, out=self._g('/speaker_to_readout.b'), accumulate=True)
             ops.gemm(dsum, self._p('/speaker_to_readout.W').t(), out=demb_spk, accumulate=True)
         # gradients entering the scan through the readouts
-        for l in range(L):
-            ws['dh'][l][0].zero_()
-            ops.gemm(dro[l], Wr[l * H:(l + 1) * H].t(), out=ws['dh'][l][1:].view(T * B, H))
-        ws['dw'][0].zero_()
-        ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
+        if 'Wr16' in save:  # bf16-operand decoders: dread . Wr^T on the bf16 copies (one copy of dread, shared with gWr)
+            Wr16 = save['Wr16']
+            d16 = save['d16'] = ops.to_bf16(dread)
+            for l in range(L):
+                ws['dh'][l][0].zero_()
+                ops.gemm16(d16, Wr16[l * H:(l + 1) * H].t(), out=ws['dh'][l][1:].view(T * B, H))
+            ws['dw'][0].zero_()
+            ops.gemm16(d16, Wr16[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
+        else:
+            for l in range(L):
+                ws['dh'][l][0].zero_()
+                ops.gemm(dro[l], Wr[l * H:(l + 1) * H].t(), out=ws['dh'][l][1:].view(T * B, H))
+            ws['dw'][0].zero_()
+            ops.gemm(dread, Wr[L * H:].t(), out=ws['dw'][1:].view(T * B, E))
         ws['dkappa'].zero_()
         ws['dw0'].zero_()
         for t_ in (ws['dhup'] + ws.get('dcell', []) + ws.get('dhup_b', []) + ws.get('dhup_c', []) +
@@ -1054,6 +1075,11 @@ class Parrot(Brick):
         H, E = self.rnn_h_dim, self.encoded_input_dim
         return (self.compute_bf16 and not self.layer_norm and t0 == 0 and t1 == T and H % 8 == 0 and E % 8 == 0
                 and os.environ.get('PARROT_BF16_DW', '1') != '0')
+
+    def _bf16_readouts(self, T, R):
+        """bf16-operand decoders whose readout stack (model.py:739-755) runs on bf16 copies (parrot_gemm_bf16in_ex)."""
+        return (self._bf16_weight_grads(0, T, T) and R % 8 == 0 and not self.use_speaker
+                and os.environ.get('PARROT_BF16_READOUT', '1') != '0')
 
     def _bf16_copies(self, ws, T, B, convert=()):
         """bf16 copies of the scan's histories (allocated once per workspace).  convert: 'h' / 'w' (state and context

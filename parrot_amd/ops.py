@@ -105,6 +105,34 @@ def gemm_bf16in(a_t: torch.Tensor, b: torch.Tensor, out: torch.Tensor, accumulat
     return out
 
 
+def gemm16(a: torch.Tensor, b: torch.Tensor, out=None, bias=None, accumulate=False, split_k=0) -> torch.Tensor:
+    """out[M,N] (+)= a[M,K] @ b[K,N] (+ bias) with a and b ALREADY bf16 (2-d, row-major or transposed views, no copies),
+    f32 accumulation and f32 `out`: parrot_gemm_bf16in_ex.  Strides / K / contiguous extents must be multiples of 8."""
+    pa, M, K, lda, ta = _mat16(a, "a")
+    pb, K2, N, ldb, tb = _mat16(b, "b")
+    if K != K2:
+        raise ValueError(f"gemm16: inner dimensions differ ({K} vs {K2})")
+    if out is None:
+        out = (torch.zeros if accumulate else torch.empty)((M, N), device=a.device, dtype=torch.float32)
+    _chk(out, "out")
+    if out.shape != (M, N) or out.stride(1) != 1:
+        raise ValueError("gemm16: bad output tensor")
+    _lib.call("parrot_gemm_bf16in_ex", pa, lda, ta, pb, ldb, tb, out.data_ptr(), out.stride(0), M, N, K,
+              ptr(bias, "bias"), int(bool(accumulate)), int(split_k), _stream())
+    return out
+
+
+def _mat16(t: torch.Tensor, name: str):
+    _chk(t, name, torch.bfloat16)
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-D tensor")
+    if t.stride(1) == 1 and t.stride(0) >= max(1, t.shape[1]):
+        return t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), 0
+    if t.stride(0) == 1 and t.stride(1) >= max(1, t.shape[0]):
+        return t.data_ptr(), t.shape[0], t.shape[1], t.stride(1), 1
+    raise ValueError(f"{name}: unsupported strides {t.stride()}")
+
+
 PRECISION_F32, PRECISION_BF16 = 0, 1
 
 

@@ -218,6 +218,68 @@ def test_gemm_bf16in_vs_rounded_operands(dev):
         assert_close(out, w16.cpu().double()[:, 8:8 + M].t() @ b16.cpu().double(), 2e-5, "strided A")
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm16_every_layout_vs_rounded_operands(dev, ta, tb):
+    """parrot_gemm_bf16in_ex (round 5: the bf16-in kernel for k-contiguous operands too -- the readout products x . Wr and
+    dread . Wr^T of a bf16-operand decoder): every operand layout parrot_gemm takes, f32 bias, accumulate, forced and
+    automatic split-K, row slices with a leading dimension larger than their width, M / N not multiples of the 256-wide
+    tile, K not a multiple of the K tile -- against the float64 product of the same bf16 values."""
+    from parrot_amd import ops
+    g = torch.Generator().manual_seed(11 + 2 * ta + tb)
+    for M, N, K in ((264, 520, 1000), (1544, 256, 4104), (8, 776, 2048), (640, 1536, 1792)):
+        a = torch.randn(M, K, generator=g)
+        b = torch.randn(K, N, generator=g)
+        bias = torch.randn(N, generator=g).to(dev)
+        # memory images: [M, K + 16] or [K, M + 24] for A, [K, N + 8] or [N, K + 32] for B; the operand is a slice
+        am = torch.zeros(K, M + 24) if ta else torch.zeros(M, K + 16)
+        (am[:, 8:8 + M] if ta else am[:, :K]).copy_(a.t() if ta else a)
+        bm = torch.zeros(N, K + 32) if tb else torch.zeros(K, N + 8)
+        (bm[:, 16:16 + K] if tb else bm[:, :N]).copy_(b.t() if tb else b)
+        a16m, b16m = ops.to_bf16(am.to(dev)), ops.to_bf16(bm.to(dev))
+        a16 = a16m[:, 8:8 + M].t() if ta else a16m[:, :K]
+        b16 = b16m[:, 16:16 + K].t() if tb else b16m[:, :N]
+        assert a16.shape == (M, K) and b16.shape == (K, N)
+        ref = a16.cpu().double() @ b16.cpu().double()
+        for split in (0, 1, 3):
+            out = torch.full((M, N), 7.0, device=dev)
+            ops.gemm16(a16, b16, out=out, bias=bias, split_k=split)
+            assert_close(out, ref + bias.cpu().double(), 2e-5, f"gemm16 ta={ta} tb={tb} {M}x{N}x{K} split={split}")
+            ops.gemm16(a16, b16, out=out, accumulate=True, split_k=split)
+            assert_close(out, 2 * ref + bias.cpu().double(), 2e-5, "accumulate")
+    with pytest.raises(Exception):  # K must be a multiple of 8 (16-byte vectors along k)
+        ops.gemm16(torch.zeros(16, 20, device=dev, dtype=torch.bfloat16), torch.zeros(20, 16, device=dev, dtype=torch.bfloat16))
+
+
+def test_bf16_readouts_on_copies_match_the_rounding_gemm(dev, monkeypatch):
+    """PARROT_BF16_READOUT=1 (default: h . Wr, dread . Wr^T on bf16 copies, parrot_gemm_bf16in_ex) and the f32-operand bf16
+    GEMM it replaces round the same values the same way: cost, frames and every gradient agree to f32 summation order."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=136, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
+    cfg = R.default_config(**kw)
+    p = R.init_params(cfg, seed=9, scale_by_fan_in=True)
+    feat, fm, lab, lm, spk = make_batch(cfg, 9, 24, 12, seed=10, ragged=True)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PARROT_BF16_READOUT", mode)
+        m = Parrot(device=dev, compute_dtype='bf16', **kw).allocate()
+        m.set_parameter_values(p)
+        m.zero_grad()
+        cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, 24)
+        cost.backward()
+        got[mode] = (float(cost), av[0].detach().cpu().double().clone(),
+                     {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()})
+        m.close()
+    assert abs(got["0"][0] - got["1"][0]) <= 1e-6 * abs(got["0"][0])
+    assert rel_err(got["1"][1], got["0"][1]) < 1e-5
+    n = 0
+    for k, v in got["0"][2].items():
+        if float(v.abs().max()) > 1e-12:
+            assert rel_err(got["1"][2][k], v) < 2e-5, (k, rel_err(got["1"][2][k], v))
+            n += 1
+    assert n >= 10
+
+
 def test_bf16_weight_grads_match_the_rounding_gemm(dev, monkeypatch):
     """The bf16-copy weight-gradient path (PARROT_BF16_DW=1, default) and the f32-operand bf16 GEMM it replaces round the
     same values the same way: every decoder weight gradient agrees to f32 summation order (1e-5 norm-wise)."""
