@@ -727,16 +727,23 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
     dim3 grid(tiles_m * tiles_n, a.nbatch * a.splitk);
     dim3 block(256);
     if (a.bf16 == 2) {  // operands ARE bf16 in memory (strides in bf16 elements): bgh_kernel, any "one stride is 1" layout
-        if (a.act || a.gate || (a.K & 7) || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || (a.batchA & 7) || (a.batchB & 7))
+        if (a.act || a.gate || ((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || (a.batchA & 7) || (a.batchB & 7))
             return PH_ERR_UNSUPPORTED;
-        if (axc ? ((a.M & 7) || (a.sak & 7)) : (a.sam & 7)) return PH_ERR_UNSUPPORTED;
-        if (bxc ? ((a.N & 7) || (a.sbk & 7)) : (a.sbn & 7)) return PH_ERR_UNSUPPORTED;
+        // 16-byte vectors: along x for an x-contiguous operand (its extent and its k stride multiples of 8), along k for a
+        // k-contiguous one (K and its x stride multiples of 8)
+        if (axc ? ((a.M & 7) || (a.sak & 7)) : ((a.K & 7) || (a.sam & 7))) return PH_ERR_UNSUPPORTED;
+        if (bxc ? ((a.N & 7) || (a.sbk & 7)) : ((a.K & 7) || (a.sbn & 7))) return PH_ERR_UNSUPPORTED;
         const int tm = ceil_div(a.M, HBMT), tn = ceil_div(a.N, HBNT);
-        static int bkt = -1;
-        if (bkt < 0) {
+        // K tile: 32 for the TN products (round 4: 833 TFLOP/s; PARROT_GEMM_BF16IN_BK=64 for experiments).  A k-contiguous
+        // operand is fetched as 16-byte vectors along k: with a 32-deep tile a wave load touches 16 rows x 64 bytes = 16 half
+        // cache lines, which the CU's vector-memory path moves at a quarter of the rate of whole lines (first
+        // r05 build: 310 TFLOP/s); with 64 a wave load is 8 rows x one whole 128-byte line.
+        static int bkt_tn = -1;
+        if (bkt_tn < 0) {
             const char* e = getenv("PARROT_GEMM_BF16IN_BK");
-            bkt = (e && atoi(e) == 64) ? 64 : 32;
+            bkt_tn = (e && atoi(e) == 64) ? 64 : 32;
         }
+        const int bkt = (axc && bxc) ? bkt_tn : 64;
         const dim3 g2(tm * tn, a.nbatch * a.splitk), b8(512);
         auto go = [&](auto kern, size_t lds) {
             static bool attr_done = false;  // (one flag per kernel instantiation: the lambda's call operator is a template)
@@ -753,10 +760,7 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
             else if (bxc) BGH_GO(64, false, true);
             else BGH_GO(64, false, false);
         } else {
-            if (axc && bxc) BGH_GO(32, true, true);
-            else if (axc) BGH_GO(32, true, false);
-            else if (bxc) BGH_GO(32, false, true);
-            else BGH_GO(32, false, false);
+            BGH_GO(32, true, true);
         }
 #undef BGH_GO
         return (int)hipGetLastError();
