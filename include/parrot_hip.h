@@ -446,15 +446,27 @@ typedef struct ParrotSampleDesc {
      * plans.hip, build_persist_pieces).  NULL, or PARROT_PM_PIECES=0: the 2L + 3 whole-K phases above. */
     const float* Wro_t;
     const float* ro_const;
+    /* Optional (round 5), on top of Wro_t / ro_const: the fed-back frame out of the step's dependency chain.  With feedback
+     * into layer 0 only (weak feedback, model.py:899-911) and L >= 2, x[t+1] = x_pre + h_{L-1}[t+1] . A with
+     * A = Wro[(L-1)H : L H] and x_pre (the other rows' shares plus ro_const) known two phases before h_{L-1}, so layer 0's
+     * next gates take  x_pre . Wfg  (K = 64, early)  +  h_{L-1} . (A . Wfg)  (K = H, the critical piece) and the output
+     * product leaves the chain: 2L + 1 phases per step.  Given, for l = 0, fragment-major copies of
+     *   Wgx_t[0] / Wcx_t[0]: [H + E + 64 + H, 2H] / [.., H] = the rows of Wg_t[0] / Wc_t[0] followed by A . Wfg / A . Wfc
+     *                        (composed in double precision, rounded once; Wf zero-padded to 64 rows)
+     * the machine plans that way; NULL, other feedback patterns, L = 1 or PARROT_PM_FBC=0: the 2L + 2 phases above. */
+    const float* Wgx_t[PARROT_MAX_LAYERS];
+    const float* Wcx_t[PARROT_MAX_LAYERS];
 } ParrotSampleDesc;
 
 long long parrot_sample_persist_floats(const ParrotSampleDesc* desc);
-/* 0: per-step launches; 1: the machine with 2L + 3 whole-K phases; 2: the machine with the step cut along K (Wro_t given) */
+/* 0: per-step launches; 1: the machine with 2L + 3 whole-K phases; 2: the machine with the step cut along K (Wro_t given);
+ * 3: the same with the fed-back frame out of the chain (Wgx_t / Wcx_t given, 2L + 1 phases) */
 int parrot_sample_is_persistent(void* plan);
 /* Plans the decode machine for `desc` with `nwg` workgroups WITHOUT touching device memory (pointers are only used for
  * address arithmetic) and replays the unit table symbolically: every read must find its value written in an earlier
  * phase, every buffer element is written once.  info16: [0] phases per step, [1] partial-sum buffers, [2] checker
- * verdict (0 ok), [3] units per step, [4 + s] units in phase s, [14] units that stream their weights.
+ * verdict (0 ok), [3] units per step, [4 + s] units in phase s, [14] units that stream their weights, [15] 1 when the
+ * fed-back frame is out of the chain (Wgx_t / Wcx_t).
  * 0, or PARROT_ERR_UNSUPPORTED when the configuration does not take this plan.  Used by the CPU tests. */
 int parrot_sample_plan_pieces_dry(const ParrotSampleDesc* desc, int nwg, int* info16);
 /* Like parrot_decoder_status, for a decode plan. */

@@ -110,6 +110,7 @@ class SampleDesc(C.Structure):
         ("Wr_t", C.c_void_p), ("Wo_t", C.c_void_p), ("bo_pad", C.c_void_p), ("oadd_pad", C.c_void_p),
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
         ("Wro_t", C.c_void_p), ("ro_const", C.c_void_p),
+        ("Wgx_t", C.c_void_p * MAX_LAYERS), ("Wcx_t", C.c_void_p * MAX_LAYERS),
     ]
 
 

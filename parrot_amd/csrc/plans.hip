@@ -2627,14 +2627,33 @@ struct SamplePlan : PlanBase {
         int lag, slot, pbuf;
     };
     struct PmGroup {
-        int kind, l, slot, N, res;  // kind 0 gates, 1 candidate, 2 output; res = checker resource id of the slab
+        int kind, l, slot, N, res;  // kind 0 gates, 1 candidate, 2 output, 3 x_pre (fbc); res = checker resource id of the slab
+        int glag;                   // the group's critical unit runs `glag` ticks after the step's other main units
         long long ks;
         std::vector<PmPiece> pc;
     };
     struct PmAccess { int res, dstep, c0, nch; };
     struct PmMeta { int lag, slot; std::vector<PmAccess> rd, wr; };
-    enum { RES_XG = 10, RES_XC = 20, RES_XR = 30, RES_H = 40, RES_Z = 50, RES_X = 60, RES_KAPPA = 61, RES_PART = 100 };
+    enum { RES_XG = 10, RES_XC = 20, RES_XR = 30, RES_H = 40, RES_Z = 50, RES_X = 60, RES_KAPPA = 61, RES_XPRE = 62,
+           RES_PART = 100 };
     bool pieces_ok = false;
+    bool fbc_on = false;
+    // Round 5 ("fbc"): the fed-back frame out of the chain.  x[t+1] = x_pre + h_{L-1}[t+1] . A (A = the last layer's rows of
+    // Wr . Wo), so layer 0's next gates need  x_pre . Wfg  (x_pre is complete two phases before h_{L-1}) and
+    // h_{L-1} . (A . Wfg)  -- the caller composes A . Wfg / A . Wfc and appends them to layer 0's matrices (Wgx_t / Wcx_t).
+    // The output product then feeds nothing inside the loop: it runs beside the next step's gate phase, and a step is
+    // 2L + 1 dependent phases (G_0 with K = H critical instead of K = 64, but one phase of ~5 us less).
+    static bool fbc_wanted(const ParrotSampleDesc& d) {
+        const char* e = getenv("PARROT_PM_FBC");
+        if (e && atoi(e) == 0) return false;
+        if (d.L < 2 || !d.Wgx_t[0] || !d.Wcx_t[0] || !fb_rows(d, 0)) return false;
+        for (int l = 1; l < d.L; ++l)
+            if (fb_rows(d, l)) return false;
+        return 2 * d.L + 1 <= PM_MAXSLOTS;
+    }
+    static long long kslab_p(const ParrotSampleDesc& d, int l, bool fbc) { return kslab(d, l) + ((fbc && l == 0) ? d.H : 0); }
+    static int n_phases(const ParrotSampleDesc& d, bool fbc) { return fbc ? 2 * d.L + 1 : 2 * d.L + 2; }
+    static int slot_pre(const ParrotSampleDesc& d) { return std::max(slotC(d.L - 2), 2) + 1; }  // (fbc) after x_pre's last operand
     int pieces_info[16] = {0};
 
     static int slotG(int l) { return l == 0 ? 0 : 2 * l + 1; }
@@ -2643,8 +2662,8 @@ struct SamplePlan : PlanBase {
         const char* e = getenv("PARROT_PM_PIECES");
         return d.Wro_t && d.ro_const && !(e && atoi(e) == 0) && 2 * d.L + 2 <= PM_MAXSLOTS;
     }
-    static bool piece_groups(const ParrotSampleDesc& d, std::vector<PmGroup>& gs) {
-        const int H = d.H, E = d.E, L = d.L, n = 2 * L + 2, sATT = 2, sOUT = 2 * L + 1;
+    static bool piece_groups(const ParrotSampleDesc& d, std::vector<PmGroup>& gs, bool fbc) {
+        const int H = d.H, E = d.E, L = d.L, n = n_phases(d, fbc), sATT = 2, sOUT = fbc ? 0 : 2 * L + 1;
         const int hc = H / 16, ec = E / 16;
         auto pos = [&](int delta, int slot) { return (1 + delta) * n + slot; };
         auto piece = [](int c0, int nch, int gp) { PmPiece p; p.c0 = c0; p.nch = nch; p.gp = gp; p.crit = false; p.lag = 1; p.slot = -1; p.pbuf = -1; return p; };
@@ -2652,18 +2671,33 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < L; ++l)
             for (int kind = 0; kind < 2; ++kind) {
                 PmGroup g;
-                g.kind = kind; g.l = l; g.slot = kind == 0 ? slotG(l) : slotC(l); g.N = kind == 0 ? 2 * H : H;
-                g.ks = kslab(d, l); g.res = (kind == 0 ? RES_XG : RES_XC) + l;
+                g.kind = kind; g.l = l; g.slot = kind == 0 ? slotG(l) : slotC(l); g.N = kind == 0 ? 2 * H : H; g.glag = 0;
+                g.ks = kslab_p(d, l, fbc); g.res = (kind == 0 ? RES_XG : RES_XC) + l;
                 g.pc.push_back(piece(0, hc, kind == 0 ? pos(-1, slotC(l)) : pos(0, slotG(l))));  // h_l[t] | r * h_l[t]
                 g.pc.push_back(piece(hc, ec, l == 0 ? pos(-1, sATT) : pos(0, sATT)));              // w[t] | w[t+1]
                 for (int j = 0; j < l; ++j) g.pc.push_back(piece(hc + ec + j * hc, hc, pos(0, slotC(j))));  // h_j[t+1]
-                if (fb_rows(d, l)) g.pc.push_back(piece((int)(g.ks / 16) - 4, 4, pos(-1, sOUT)));  // x[t]
+                if (fb_rows(d, l) && !fbc) g.pc.push_back(piece((int)(g.ks / 16) - 4, 4, pos(-1, sOUT)));  // x[t]
+                if (fb_rows(d, l) && fbc) {  // (l == 0) x_pre of the previous step, and the last layer's state . (A . Wf)
+                    g.pc.push_back(piece(hc + ec, 4, pos(-1, slot_pre(d))));
+                    g.pc.push_back(piece(hc + ec + 4, hc, pos(-1, slotC(L - 1))));
+                }
                 gs.push_back(g);
             }
         {
             PmGroup o;
-            o.kind = 2; o.l = 0; o.slot = sOUT; o.N = 64; o.ks = (long long)L * H + E; o.res = RES_XR;
-            for (int j = 0; j < L; ++j) o.pc.push_back(piece(j * hc, hc, pos(0, slotC(j))));
+            o.kind = 2; o.l = 0; o.slot = sOUT; o.N = 64; o.ks = (long long)L * H + E; o.res = RES_XR; o.glag = fbc ? 1 : 0;
+            if (!fbc) {
+                for (int j = 0; j < L; ++j) o.pc.push_back(piece(j * hc, hc, pos(0, slotC(j))));
+                o.pc.push_back(piece(L * hc, ec, pos(0, sATT)));
+            } else {  // x = x_pre (added in the epilogue) + h_{L-1} . A, beside the NEXT step's gate phase
+                o.pc.push_back(piece((L - 1) * hc, hc, pos(0, slotC(L - 1))));
+            }
+            gs.push_back(o);
+        }
+        if (fbc) {
+            PmGroup o;
+            o.kind = 3; o.l = 0; o.slot = slot_pre(d); o.N = 64; o.ks = (long long)L * H + E; o.res = RES_XR; o.glag = 0;
+            for (int j = 0; j + 1 < L; ++j) o.pc.push_back(piece(j * hc, hc, pos(0, slotC(j))));
             o.pc.push_back(piece(L * hc, ec, pos(0, sATT)));
             gs.push_back(o);
         }
@@ -2671,10 +2705,11 @@ struct SamplePlan : PlanBase {
             size_t ci = 0;
             for (size_t i = 1; i < g.pc.size(); ++i)
                 if (g.pc[i].gp > g.pc[ci].gp) ci = i;
-            if (g.pc[ci].gp >= n + g.slot) return false;
+            if (g.pc[ci].gp >= (1 + g.glag) * n + g.slot) return false;
             g.pc[ci].crit = true;
             g.pc[ci].slot = g.slot;
-            const int fixed = g.kind == 2 ? 1 : ((g.kind == 0 ? d.seq_g[g.l] : d.seq_c[g.l]) ? 1 : 0);
+            g.pc[ci].lag = 1 + g.glag;
+            const int fixed = g.kind >= 2 ? 1 : ((g.kind == 0 ? d.seq_g[g.l] : d.seq_c[g.l]) ? 1 : 0);
             while ((int)g.pc.size() - 1 + fixed > 4) {  // more partial sums than a unit can add: join neighbours
                 int best = -1, bestd = 1 << 30;
                 for (size_t i = 0; i + 1 < g.pc.size(); ++i) {
@@ -2693,8 +2728,8 @@ struct SamplePlan : PlanBase {
     }
     // the phase of every non-critical piece: most constrained first; a phase may not take more units than workgroups, and
     // a piece should not outlast the critical units of its phase (unit cost as in pm_place)
-    static bool piece_slots(const ParrotSampleDesc& d, std::vector<PmGroup>& gs, int nwg) {
-        const int n = 2 * d.L + 2;
+    static bool piece_slots(const ParrotSampleDesc& d, std::vector<PmGroup>& gs, int nwg, bool fbc) {
+        const int n = n_phases(d, fbc);
         auto cost = [](int K) { return 3.5 + 3.5 * K / 1024.0; };
         std::vector<int> cnt(n, 0);
         std::vector<double> tcrit(n, 0.0);
@@ -2709,7 +2744,7 @@ struct SamplePlan : PlanBase {
                     cnt[g.slot] += g.N / 16;
                     tcrit[g.slot] = std::max(tcrit[g.slot], cost(p.nch * 16));
                 } else {
-                    refs.push_back({(int)gi, (int)pi, n + g.slot - 1 - p.gp, p.nch * 16, g.N / 16});
+                    refs.push_back({(int)gi, (int)pi, (1 + g.glag) * n + g.slot - 1 - p.gp, p.nch * 16, g.N / 16});
                 }
             }
         for (int s = 0; s < n; ++s)
@@ -2724,7 +2759,7 @@ struct SamplePlan : PlanBase {
             PmPiece& p = g.pc[r.p];
             int best = -1;
             double best_score = 0;
-            for (int q = p.gp + 1; q < n + g.slot; ++q) {
+            for (int q = p.gp + 1; q < (1 + g.glag) * n + g.slot; ++q) {
                 const int s = q % n;
                 if (cnt[s] + r.tiles > nwg) continue;
                 const double late = cost(r.K) - tcrit[s];
@@ -2733,22 +2768,49 @@ struct SamplePlan : PlanBase {
             }
             if (best < 0) return false;
             p.slot = best % n;
-            p.lag = best >= n ? 1 : 0;
+            p.lag = best / n;
             cnt[p.slot] += r.tiles;
         }
         return true;
     }
-    static long long piece_floats(const ParrotSampleDesc& d) {  // the partial-sum buffers of the pieces (exact)
-        std::vector<PmGroup> gs;
-        if (!pieces_wanted(d) || !piece_groups(d, gs)) return 0;
+    // Joins the two neighbouring non-critical pieces (same product, adjacent chunk ranges) whose operands appear closest in
+    // time -- ties: the widest product first, it frees the most units -- into one piece that waits for the later operand.
+    // The plan with the fed-back frame out of the chain has one phase less to spread its pieces over (round 5).
+    static bool join_closest_pieces(std::vector<PmGroup>& gs) {
+        int bg = -1, bi = -1, bd = 1 << 30, bn = 0;
+        for (size_t gi = 0; gi < gs.size(); ++gi) {
+            const PmGroup& g = gs[gi];
+            for (size_t i = 0; i + 1 < g.pc.size(); ++i) {
+                const PmPiece &a = g.pc[i], &b = g.pc[i + 1];
+                if (a.crit || b.crit || a.c0 + a.nch != b.c0) continue;
+                const int dd = a.gp > b.gp ? a.gp - b.gp : b.gp - a.gp;
+                if (dd < bd || (dd == bd && g.N > bn)) { bd = dd; bn = g.N; bg = (int)gi; bi = (int)i; }
+            }
+        }
+        if (bg < 0) return false;
+        PmGroup& g = gs[bg];
+        g.pc[bi].nch += g.pc[bi + 1].nch;
+        g.pc[bi].gp = std::max(g.pc[bi].gp, g.pc[bi + 1].gp);
+        g.pc.erase(g.pc.begin() + bi + 1);
+        return true;
+    }
+    static long long piece_floats(const ParrotSampleDesc& d) {  // the partial-sum buffers of the pieces (an upper bound:
+        std::vector<PmGroup> gs;                                 // before any capacity-driven joins)
+        const bool fbc = fbc_wanted(d);
+        if (!pieces_wanted(d) || !piece_groups(d, gs, fbc)) return 0;
         long long n = 0;
         for (const PmGroup& g : gs)
             for (const PmPiece& p : g.pc)
                 if (!p.crit) n += (long long)(d.S + 1) * d.B * g.N + 16;
+        if (fbc) {  // the longer layer-0 slabs, x_pre row-major, the zero rows behind x[0]
+            const long long rows = d.B <= 16 ? 16 : (d.B <= 32 ? 32 : 64);
+            n += 2 * (long long)(d.S + 1) * rows * d.H + (long long)(d.S + 2) * d.B * 64 + (long long)d.B * d.H + 64;
+        }
         return n;
     }
     // symbolic replay over S steps: 0 = every read finds its value written in an earlier phase and nothing is written twice
-    static int check_pieces(const std::vector<PmMeta>& metas, const std::vector<PmAccess>& init, int n_slots, int S) {
+    static int check_pieces(const std::vector<PmMeta>& metas, const std::vector<PmAccess>& init, int n_slots, int S,
+                            int n_ticks) {
         std::vector<std::array<int, 3>> written;  // (res, step, chunk), kept sorted
         auto has = [&](int r, int t, int c) {
             const std::array<int, 3> k = {r, t, c};
@@ -2764,7 +2826,7 @@ struct SamplePlan : PlanBase {
         for (const PmAccess& a : init)
             for (int c = a.c0; c < a.c0 + a.nch; ++c)
                 if (!put(a.res, a.dstep, c)) return 1;
-        for (int tick = 0; tick <= S; ++tick)
+        for (int tick = 0; tick < n_ticks; ++tick)
             for (int s = 0; s < n_slots; ++s) {
                 for (const PmMeta& m : metas) {
                     const int t = tick - m.lag;
@@ -2794,11 +2856,16 @@ struct SamplePlan : PlanBase {
         if (nwg < 64) return 0;
         if (!dry && (!d.persist_ws || d.persist_ws_floats < persist_floats(d, nwg))) return 0;
         std::vector<PmGroup> gs;
-        if (!piece_groups(d, gs) || !piece_slots(d, gs, nwg)) return 0;
+        const bool fbc = fbc_wanted(d);
+        fbc_on = false;
+        if (!piece_groups(d, gs, fbc)) return 0;
+        while (!piece_slots(d, gs, nwg, fbc))   // more units than one per workgroup and phase: join two pieces and try again
+            if (!join_closest_pieces(gs)) return 0;
         const int H = d.H, E = d.E, B = d.B, L = d.L, S = d.S;
         const int MB = B <= 16 ? 1 : (B <= 32 ? 2 : 4);
         const long long rows = (long long)MB * 16, BH = (long long)B * H;
-        const int n_slots = 2 * L + 2, sATT = 2, hc = H / 16, ec = E / 16;
+        const int n_slots = n_phases(d, fbc), sATT = 2, hc = H / 16, ec = E / 16;
+        const int fbx = hc + ec, fbh = hc + ec + 4;  // (fbc) layer 0's x_pre chunks / the last layer's state chunks
         float* ws = dry ? reinterpret_cast<float*>((uintptr_t)0x10000000) : d.persist_ws;
         auto take = [&](long long n) { float* p = ws; ws += (n + 3) / 4 * 4; return p; };
         unsigned* sync = reinterpret_cast<unsigned*>(take(PM_SYNC_WORDS + PM_DBG_WORDS));
@@ -2809,7 +2876,7 @@ struct SamplePlan : PlanBase {
         float* XC[PARROT_MAX_LAYERS];
         long long kx[PARROT_MAX_LAYERS];
         for (int l = 0; l < L; ++l) {
-            kx[l] = kslab(d, l);
+            kx[l] = kslab_p(d, l, fbc);
             XG[l] = take((S + 1) * rows * kx[l]);
             XC[l] = take((S + 1) * rows * kx[l]);
         }
@@ -2821,6 +2888,8 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < L; ++l) hist_h[l] = take((S + 1) * BH);
         for (int l = 0; l < L; ++l) zh[l] = take(S * BH);
         float* b_hist = take((long long)S * B * d.A);
+        float* zero_rows = fbc ? take(BH) : nullptr;               // never written: the workspace arrives zero-filled
+        float* xpre_rm = fbc ? take((long long)(S + 1) * B * 64) : nullptr;  // x_pre of step t, row-major (the output unit adds it)
         float* const part_base = ws;
         int npart = 0;
         std::vector<float*> pbuf;
@@ -2845,7 +2914,8 @@ struct SamplePlan : PlanBase {
         for (const PmGroup& g : gs) {
             const int l = g.l, N = g.N, nch_all = (int)(g.ks / 16);
             float* slab = g.kind == 0 ? XG[l] : (g.kind == 1 ? XC[l] : XR);
-            const float* Wt = g.kind == 0 ? d.Wg_t[l] : (g.kind == 1 ? d.Wc_t[l] : d.Wro_t);
+            const float* Wt = g.kind == 0 ? ((fbc && l == 0) ? d.Wgx_t[0] : d.Wg_t[l])
+                                          : (g.kind == 1 ? ((fbc && l == 0) ? d.Wcx_t[0] : d.Wc_t[l]) : d.Wro_t);
             for (const PmPiece& p : g.pc) {
                 PmMeta m;
                 m.lag = p.lag; m.slot = p.slot;
@@ -2869,13 +2939,22 @@ struct SamplePlan : PlanBase {
                             m.wr.push_back(acc(RES_XC + m2, 0, hc + ec + l * hc, hc));
                         }
                         m.wr.push_back(acc(RES_XR, 0, l * hc, hc));
-                    } else {
+                        if (fbc && l == L - 1) {
+                            m.wr.push_back(acc(RES_XG, 1, fbh, hc));
+                            m.wr.push_back(acc(RES_XC, 1, fbh, hc));
+                        }
+                    } else if (g.kind == 2) {
                         m.wr.push_back(acc(RES_X, 1, 0, 1));
-                        for (int q = 0; q < L; ++q)
+                        if (fbc) m.rd.push_back(acc(RES_XPRE, 0, 0, 1));
+                        for (int q = 0; q < L && !fbc; ++q)
                             if (fb_rows(d, q)) {
                                 m.wr.push_back(acc(RES_XG + q, 1, (int)(kx[q] / 16) - 4, 4));
                                 m.wr.push_back(acc(RES_XC + q, 1, (int)(kx[q] / 16) - 4, 4));
                             }
+                    } else {  // x_pre
+                        m.wr.push_back(acc(RES_XPRE, 0, 0, 1));
+                        m.wr.push_back(acc(RES_XG, 1, fbx, 4));
+                        m.wr.push_back(acc(RES_XC, 1, fbx, 4));
                     }
                 }
                 metas.push_back(m);
@@ -2922,11 +3001,22 @@ struct SamplePlan : PlanBase {
                             u.dst[u.ndst++] = mkdst(XC[m2], 0, kx[m2], ch);
                         }
                         u.dst[u.ndst++] = mkdst(XR, 0, kr, l * hc + ct);
-                    } else {
+                        if (fbc && l == L - 1) {  // ... and the operand of layer 0's composed feedback rows, next step
+                            if (u.ndst + 2 > PM_MAXDST) return 0;
+                            u.dst[u.ndst++] = mkdst(XG[0], 1, kx[0], fbh + ct);
+                            u.dst[u.ndst++] = mkdst(XC[0], 1, kx[0], fbh + ct);
+                        }
+                    } else if (g.kind == 3) {  // x_pre = ro_const + the shares of every operand but the last layer's state
                         u.add[na++] = rm(d.ro_const + 16 * ct, 0, 64);
                         u.epi = PM_EPI_LINEAR;
+                        u.out = rm(xpre_rm + 16 * ct, (long long)B * 64, 64);
+                        u.dst[u.ndst++] = mkdst(XG[0], 1, kx[0], fbx + ct);
+                        u.dst[u.ndst++] = mkdst(XC[0], 1, kx[0], fbx + ct);
+                    } else {
+                        u.add[na++] = fbc ? rm(xpre_rm + 16 * ct, (long long)B * 64, 64) : rm(d.ro_const + 16 * ct, 0, 64);
+                        u.epi = PM_EPI_LINEAR;
                         u.out = rm(d.x + (size_t)B * d.ldx + 16 * ct, (long long)B * d.ldx, d.ldx);
-                        for (int q2 = 0; q2 < L; ++q2) {
+                        for (int q2 = 0; q2 < L && !fbc; ++q2) {
                             if (!fb_rows(d, q2)) continue;
                             const int ch = (int)(kx[q2] / 16) - 4 + ct;
                             u.dst[u.ndst++] = mkdst(XG[q2], 1, kx[q2], ch);
@@ -2964,10 +3054,14 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < L; ++l) {
             init.push_back(acc(RES_XG + l, 0, 0, hc));
             init.push_back(acc(RES_H + l, 0, 0, 1));
-            if (fb_rows(d, l)) {
+            if (fb_rows(d, l) && !fbc) {
                 init.push_back(acc(RES_XG + l, 0, (int)(kx[l] / 16) - 4, 4));
                 init.push_back(acc(RES_XC + l, 0, (int)(kx[l] / 16) - 4, 4));
             }
+        }
+        if (fbc) {  // step 0: x[0] in the x_pre chunks, zero rows where the last layer's state would go
+            init.push_back(acc(RES_XG, 0, fbx, 4 + hc));
+            init.push_back(acc(RES_XC, 0, fbx, 4 + hc));
         }
         init.push_back(acc(RES_XG, 0, hc, ec));
         init.push_back(acc(RES_XC, 0, hc, ec));
@@ -2976,11 +3070,13 @@ struct SamplePlan : PlanBase {
             for (const PmGroup& g : gs)
                 for (const PmPiece& p : g.pc)
                     fprintf(stderr, "[pieces] %s%d phase %d: chunks %d..%d (K %d) %s phase %d lag %d\n",
-                            g.kind == 0 ? "G" : (g.kind == 1 ? "C" : "OUT"), g.l, g.slot, p.c0, p.c0 + p.nch, p.nch * 16,
+                            g.kind == 0 ? "G" : (g.kind == 1 ? "C" : (g.kind == 2 ? "OUT" : "XPRE")), g.l, g.slot, p.c0, p.c0 + p.nch, p.nch * 16,
                             p.crit ? "CRITICAL" : "piece", p.slot, p.lag);
-        const int chk = check_pieces(metas, init, n_slots, 4);
+        const int n_extra = fbc ? 2 : 1;  // ticks beyond S: main units lag one tick, the output unit of the fbc plan two
+        const int chk = check_pieces(metas, init, n_slots, 4, 4 + n_extra);
         memset(pieces_info, 0, sizeof(pieces_info));
         pieces_info[0] = n_slots; pieces_info[1] = npart; pieces_info[2] = chk; pieces_info[3] = (int)reqs.size();
+        pieces_info[15] = fbc ? 1 : 0;
         for (const PmReq& q : reqs) pieces_info[4 + q.slot] += 1;
         if (chk != 0) return 0;
         std::vector<PmUnit> table;
@@ -2988,12 +3084,13 @@ struct SamplePlan : PlanBase {
         for (const PmUnit& u : table)
             if (u.kind == PM_GEMM && u.w_lds < 0) pieces_info[14] += 1;  // units that stream their weights
         pieces_ok = true;
+        fbc_on = fbc;
         if (dry) return 0;
         if (hipMemcpy(units_dev, table.data(), unit_bytes, hipMemcpyHostToDevice) != hipSuccess) { pieces_ok = false; return 0; }
 
         PmProgram& P = pm_prog;
         memset(&P, 0, sizeof(P));
-        P.T = S; P.n_ticks = S + 1; P.nwg = nwg; P.MB = MB; P.M = B; P.n_slots = n_slots; P.maxu = 1;
+        P.T = S; P.n_ticks = S + n_extra; P.nwg = nwg; P.MB = MB; P.M = B; P.n_slots = n_slots; P.maxu = 1;
         P.units = units_dev; P.sync = sync; P.fm_base = fm_base;
         PmAtt& a = P.att;
         a.h1 = rm(hist_h[0], BH, H);
@@ -3017,11 +3114,18 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < L; ++l) add_init(d.h[l], H, H, XG[l], kx[l], 0);
         add_init(d.w, E, E, XG[0], kx[0], hc);
         add_init(d.w, E, E, XC[0], kx[0], hc);
-        for (int l = 0; l < L; ++l) {
+        for (int l = 0; l < L && !fbc; ++l) {
             if (!fb_rows(d, l)) continue;
             if (ni + 2 > PM_MAXINIT) { pieces_ok = false; return 0; }
             add_init(d.x, d.ldx, 64, XG[l], kx[l], (int)(kx[l] / 16) - 4);
             add_init(d.x, d.ldx, 64, XC[l], kx[l], (int)(kx[l] / 16) - 4);
+        }
+        if (fbc) {
+            if (ni + 4 > PM_MAXINIT) { pieces_ok = false; return 0; }
+            add_init(d.x, d.ldx, 64, XG[0], kx[0], fbx);
+            add_init(d.x, d.ldx, 64, XC[0], kx[0], fbx);
+            add_init(zero_rows, H, H, XG[0], kx[0], fbh);
+            add_init(zero_rows, H, H, XC[0], kx[0], fbh);
         }
         P.ninit = ni;
         {
@@ -3040,6 +3144,7 @@ struct SamplePlan : PlanBase {
             add_fill(zh[l], (long long)S * BH);
         }
         add_fill(part_base, (long long)(part_end - part_base));
+        if (fbc) add_fill(xpre_rm, (long long)(S + 1) * B * 64);
         persist_ok = true;
         return 0;
     }
@@ -3418,7 +3523,7 @@ long long parrot_sample_persist_floats(const ParrotSampleDesc* desc) { PH_ENTRY(
 }
 int parrot_sample_is_persistent(void* plan) {
     const SamplePlan* p = static_cast<SamplePlan*>(plan);
-    return p->persist_ok ? (p->pieces_ok ? 2 : 1) : 0;
+    return p->persist_ok ? (p->pieces_ok ? (p->fbc_on ? 3 : 2) : 1) : 0;
 }
 int parrot_sample_status(void* plan) { PH_ENTRY(); return plan ? static_cast<SamplePlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }
 int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<DecoderPlan*>(plan)->persist_status() : PARROT_ERR_BADARG; }

@@ -1308,6 +1308,14 @@ class Parrot(Brick):
             pm['Wro'], pm['Wro_t'] = torch.empty(L * H + E, 64, **f), torch.empty(L * H + E, 64, **f)
             pm['ro_const'] = torch.zeros(N, 64, **f)
             d.Wro_t, d.ro_const = pm['Wro_t'].data_ptr(), pm['ro_const'].data_ptr()
+            # round 5: the fed-back frame out of the step's chain (weak feedback, L >= 2): layer 0's matrices with the rows
+            # A . Wf appended, A = the last layer's rows of Wr . Wo (ParrotSampleDesc::Wgx_t / Wcx_t)
+            if L >= 2 and self._fb_layers == [1] and os.environ.get('PARROT_PM_FBC', '1') != '0':
+                for key, wd, suf, mat, rec in self._groups:
+                    rows = H + E + 64 + H
+                    pm['cat'][('x', key)] = torch.zeros(rows, wd, **f)
+                    pm['tiled'][('x', key)] = torch.empty(rows, wd, **f)
+                    getattr(d, f'W{key}x_t')[0] = pm['tiled'][('x', key)].data_ptr()
             n = int(_lib.load().parrot_sample_persist_floats(C.byref(d)))
             if n > 0:
                 pm['ws'] = torch.zeros(n, **f)
@@ -1407,6 +1415,15 @@ class Parrot(Brick):
             pm['Wro'].copy_(Wro)
             tile(pm['Wro'], pm['Wro_t'])
             pm['ro_const'].copy_(c)
+            for key, wd, suf, mat, rec in self._groups:
+                if ('x', key) not in pm['cat']:
+                    continue
+                # x . Wf = x_pre . Wf + h_{L-1} . (A . Wf) with A = Wro[(L-1)H : L H]: composed in double, rounded once
+                cat, base = pm['cat'][('x', key)], pm['cat'][(0, key)]
+                cat[:H + E + 64].copy_(base)
+                A_last = Wro[(L - 1) * H:L * H].double()
+                cat[H + E + 64:].copy_((A_last @ base[H + E:H + E + 64].double()).float())
+                tile(cat, pm['tiled'][('x', key)])
 
     def sample_model(self, labels_tr, labels_mask_tr, features_mask_tr, speaker_tr, num_samples, num_steps):
         """Parrot.sample_model (model.py:1061-1083): numpy in, list of numpy arrays out

@@ -7,7 +7,7 @@ import pytest
 from parrot_amd import _lib
 
 
-def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False):
+def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False, fbc=False):
     d = _lib.SampleDesc()
     d.S, d.B, d.H, d.E, d.A, d.U, d.L, d.O, d.R, d.ldx = S, B, H, E, 10, 100, L, 63, R, 64
     fake = 0x7000_0000_0000  # never dereferenced by the dry run
@@ -19,6 +19,8 @@ def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False):
         if speaker:
             d.seq_g[l], d.seq_c[l] = fake, fake
     d.Wro_t, d.ro_const, d.x = fake, fake, fake
+    if fbc:  # layer 0's matrices with the composed feedback rows appended (ParrotSampleDesc::Wgx_t / Wcx_t, round 5)
+        d.Wgx_t[0], d.Wcx_t[0] = fake, fake
     return d
 
 
@@ -35,6 +37,28 @@ def test_configs2_plan_is_legal_and_fits_one_unit_per_workgroup():
     assert info[1] == 10                     # partial-sum buffers: G0 2, C0 2, G1 2, C1 2, output 2
     assert all(0 < n <= 256 for n in info[4:10]), info
     assert sum(info[4:10]) == info[3]
+
+
+def test_fed_back_frame_out_of_the_chain_plan_is_legal():
+    """Round 5 (Wgx_t / Wcx_t given, weak feedback, L >= 2): 2L + 1 phases, the output product beside the next step's gate
+    phase, x_pre as a group of its own; the symbolic replay passes; other feedback patterns / L = 1 keep 2L + 2 phases."""
+    rc, info = _plan(_desc(fbc=True))
+    assert rc == 0 and info[2] == 0 and info[15] == 1, info
+    assert info[0] == 5
+    assert all(0 < n <= 256 for n in info[4:9]), info
+    assert sum(info[4:9]) == info[3]
+    for L, fb in ((3, (0,)), (2, (0,))):
+        rc, info = _plan(_desc(L=L, H=256, E=128, B=16, S=50, R=256, fb=fb, fbc=True))
+        assert rc == 0 and info[2] == 0 and info[15] == 1 and info[0] == 2 * L + 1, info
+    for L, fb in ((1, (0,)), (2, (0, 1)), (2, ())):  # not the pattern the composition covers: the 2L + 2 phases
+        rc, info = _plan(_desc(L=L, H=256, E=128, B=16, S=50, R=256, fb=fb, fbc=True))
+        assert rc == 0 and info[2] == 0 and info[15] == 0 and info[0] == 2 * L + 2, info
+
+
+def test_fbc_env_switch(monkeypatch):
+    monkeypatch.setenv("PARROT_PM_FBC", "0")
+    rc, info = _plan(_desc(fbc=True))
+    assert rc == 0 and info[15] == 0 and info[0] == 6
 
 
 @pytest.mark.parametrize("L,fb,speaker", [(1, (0,), False), (1, (), False), (2, (), False), (2, (0, 1), False),
@@ -91,13 +115,13 @@ def test_random_stacks_are_either_planned_legally_or_refused():
 
     @settings(max_examples=80, deadline=None, derandomize=True)
     @given(L=st.integers(1, 3), h=st.integers(1, 96), e=st.integers(1, 48), B=st.integers(1, 64),
-           fbmask=st.integers(0, 7), speaker=st.booleans(), nwg=st.sampled_from([64, 128, 208, 256]))
-    def run(L, h, e, B, fbmask, speaker, nwg):
+           fbmask=st.integers(0, 7), speaker=st.booleans(), nwg=st.sampled_from([64, 128, 208, 256]), fbc=st.booleans())
+    def run(L, h, e, B, fbmask, speaker, nwg, fbc):
         fb = tuple(l for l in range(L) if fbmask >> l & 1)
-        d = _desc(L=L, H=16 * h, E=16 * e, B=B, S=7, R=64, fb=fb, speaker=speaker)
+        d = _desc(L=L, H=16 * h, E=16 * e, B=B, S=7, R=64, fb=fb, speaker=speaker, fbc=fbc)
         rc, info = _plan(d, nwg=nwg)
         if rc == 0:
-            assert info[2] == 0 and info[0] == 2 * L + 2
+            assert info[2] == 0 and info[0] == (2 * L + 1 if info[15] else 2 * L + 2)
             assert all(n <= nwg for n in info[4:4 + info[0]]), (info, nwg)
             assert sum(info[4:4 + info[0]]) == info[3]
         else:

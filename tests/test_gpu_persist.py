@@ -172,7 +172,8 @@ def test_workspaces_and_plans_are_reused_between_calls(dev):
                                      attention_type='softmax')])
 def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
     """sample_model as one resident kernel -- 2L + 2 phases per step with every product cut along K by the age of its
-    operands (default), or the 2L + 3 whole-K phases (PARROT_PM_PIECES=0): every output vs the oracle, the plan that was
+    operands, 2L + 1 with the fed-back frame out of the chain where that applies (default; PARROT_PM_FBC=0 for the former),
+    or the 2L + 3 whole-K phases (PARROT_PM_PIECES=0): every output vs the oracle, the plan that was
     asked for really ran, a second call replays it, and the per-step launch path (PARROT_SAMPLE_PERSIST=0) agrees to
     rounding with both."""
     from oracle import parrot_ref as R
@@ -186,9 +187,13 @@ def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
     with torch.no_grad():
         ref = R.sample_model(p, cfg, lab, lm, spk, S)
     res = {}
-    for mode, pieces in (("1", "1"), ("1", "0"), ("0", "1")):
+    fbc_applies = full['num_layers'] >= 2 and full.get('weak_feedback') and not full.get('full_feedback')
+    for mode, pieces, fbc in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "1"), ("0", "1", "1")):
+        if fbc == "0" and not fbc_applies:
+            continue
         monkeypatch.setenv("PARROT_SAMPLE_PERSIST", mode)
         monkeypatch.setenv("PARROT_PM_PIECES", pieces)
+        monkeypatch.setenv("PARROT_PM_FBC", fbc)
         m = Parrot(device=dev, use_graph=True, **full).allocate()
         m.set_parameter_values(p)
         for rep in range(2):
@@ -196,13 +201,17 @@ def test_decode_on_the_persistent_machine(dev, monkeypatch, kw):
             for o, r, n in zip(outs, ref, ("sample_x", "k", "w", "pi", "phi", "pi_att")):
                 assert_close(o, r, 1e-4, f"persist={mode} pass {rep}: {n}")
         ws = m._sample_ws.get((S, N, U))
-        assert _lib.load().parrot_sample_is_persistent(ws['plan']) == (0 if mode == "0" else (2 if pieces == "1" else 1))
+        # 3: the step cut along K with the fed-back frame out of the chain (weak feedback, L >= 2; round 5), 2: cut along K
+        want = 0 if mode == "0" else ((3 if (fbc == "1" and fbc_applies) else 2) if pieces == "1" else 1)
+        assert _lib.load().parrot_sample_is_persistent(ws['plan']) == want
         if mode == "1":
             assert int(ws['pm']['ws'][832:833].view(torch.int32).item()) == 0, "a spin timed out inside the machine"
-        res[mode + pieces] = [o.clone() for o in outs]
+        res[mode + pieces + fbc] = [o.clone() for o in outs]
         m.close()
-    for key in ("11", "10"):
-        for a, b, n in zip(res[key], res["01"], ("sample_x", "k", "w", "pi", "phi", "pi_att")):
+    for key in ("111", "110", "101"):
+        if key not in res:
+            continue
+        for a, b, n in zip(res[key], res["011"], ("sample_x", "k", "w", "pi", "phi", "pi_att")):
             assert_close(a, b, 2e-5, f"machine ({key}) vs launches: {n}")
 
 
