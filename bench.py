@@ -338,9 +338,11 @@ def secondary_leg(a):
                           "us_per_step": round(1e6 * best / S, 2), "frames_per_s": round(N * S / best, 1),
                           "alg_bytes_per_step": int(alg), "alg_GBps": round(alg * S / best * 1e-9, 1),
                           "frac": round(alg * S / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000,
-                          "plan": {2: "resident kernel, 6 phases per step (products cut along K by operand age, "
+                          "plan": {3: "resident kernel, 5 phases per step (products cut along K by operand age, "
+                                      "readout.output composed, the fed-back frame out of the chain: x = x_pre + h_last.A)",
+                                   2: "resident kernel, 6 phases per step (products cut along K by operand age, "
                                       "readout.output composed)",
-                                   1: "resident kernel, 7 whole-K phases per step", 0: "per-step launches"}[kind]}
+                                   1: "resident kernel, 7 whole-K phases per step", 0: "per-step launches"}.get(kind, str(kind))}
     from parrot_amd.sampleRNN import lib
     from parrot_amd.sampleRNN.models.conditional import three_tier as tt
     lib.delete_all_params(); lib.set_device(dev)

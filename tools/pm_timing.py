@@ -48,7 +48,10 @@ else:
         print(f"decode {1e3 * dt:.2f} ms = {1e6 * dt / S:.2f} us per step")
     pw = m._sample_ws.get((S, N, U))['pm']['ws']
     pieces = os.environ.get("PARROT_PM_PIECES", "1") != "0"  # plans.hip build_persist_pieces: 2L + 2 phases, S + 1 ticks
-    ticks, nslots = (S + 1, 2 * L + 2) if pieces else (S, 2 * L + 3)
+    from parrot_amd import _lib as _plib
+    kind = int(_plib.load().parrot_sample_is_persistent(m._sample_ws.get((S, N, U))['plan']))
+    ticks, nslots = {3: (S + 2, 2 * L + 1), 2: (S + 1, 2 * L + 2)}.get(kind, (S, 2 * L + 3))
+    print(f"plan kind {kind}: {nslots} phases per step")
 rawi = pw[1024:1024 + 256 * 48].view(torch.int64).cpu().reshape(256, 24)
 bad = [w for w in range(256) if rawi[w, 0] > 10**12 or rawi[w, 0] < 0]
 print('workgroups with implausible timers (XCC whose s_memrealtime does not tick):', len(bad))
