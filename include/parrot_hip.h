@@ -92,15 +92,6 @@ int parrot_gemm_bf16in(const void* A, int lda, const void* B, int ldb, float* C,
 int parrot_gemm_bf16in_ex(const void* A, int lda, int transA, const void* B, int ldb, int transB, float* C, int ldc, int M,
                           int N, int K, const float* bias, int accumulate, int split_k, void* stream);
 
-/* Products that run BESIDE the scan (the weight-gradient GEMMs of the backward window, ordered behind
- * parrot_decoder_seq_bwd_part on a second stream): parrot_stream_create makes a non-blocking stream of the lowest
- * (priority > 0), default (0) or highest (< 0) priority the device offers; parrot_set_gemm_lds_pad reserves `bytes`
- * of unused LDS per workgroup of the batched GEMM (process-wide, takes effect for later calls), which caps how many
- * of its workgroups share a CU and so leaves room for the scan's latency-bound step kernels.  0 restores the default. */
-int parrot_stream_create(int priority, void** stream);
-int parrot_stream_destroy(void* stream);
-int parrot_set_gemm_lds_pad(int bytes);
-
 /* out[n] (+)= sum_m x[m, n]  -- bias gradients. */
 int parrot_colsum(const float* x, long long M, int N, int ld, float* out, int accumulate, void* stream);
 
@@ -208,9 +199,7 @@ int parrot_gmm_attention_bwd(const float* dw, const float* ctx, const float* a, 
  * ------------------------------------------------------------------------------------------ */
 typedef struct ParrotDecoderDesc {
     int T, B, H, E, A, U, L, att_type, use_graph;
-    int reserved; /* > 1: advance the batch as this many independent row ranges ("strands", one stream each; the
-                     scan of model.py:651-724 never mixes batch rows, results are bit-identical); 0 / 1: one chain.
-                     PARROT_STRANDS overrides. */
+    int reserved; /* 0 (rounds 3-4: independent row "strands" on their own streams; measured slower, removed in round 5) */
     float eps, alignment, sharpening, timing;
     const float* Wg[PARROT_MAX_LAYERS];
     const float* Wc[PARROT_MAX_LAYERS];
@@ -311,12 +300,6 @@ typedef struct ParrotDecoderDesc {
     float* dhup_c[PARROT_MAX_LAYERS];
     float* dw_c;
     float* dw0_c;
-    /* Further accumulators of layer 0 (stored; zero-filled once): with dh_c[0], dh_d[0], dw0_c and dw0_d given, a bf16 LSTM
-     * decoder cuts layer 0's backward products -- the ones that start last, behind the attention backward -- into FOUR K
-     * parts instead of two.  Only index 0 of the arrays is read. */
-    float* dh_c[PARROT_MAX_LAYERS];
-    float* dh_d[PARROT_MAX_LAYERS];
-    float* dw0_d;
 } ParrotDecoderDesc;
 
 /* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify for the persistent
@@ -348,18 +331,6 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
 int parrot_decoder_seq_fwd(void* plan, void* stream);
 int parrot_decoder_seq_bwd(void* plan, void* stream);
 int parrot_decoder_destroy(void* plan);
-/* The scan of model.py:726-737 cut along time.  A window runs as parrot_decoder_parts() consecutive parts (one
- * hipGraph per part and strand); seq_fwd / seq_bwd run all of them, the *_part calls run one, in order 0, 1, ...
- * (backward: part 0 covers the LAST steps of the window).  After part p of direction `which` (0 forward, 1
- * backward) has been enqueued on `stream`, every layer has finished the steps [t_lo, t_hi) reported by
- * parrot_decoder_part_steps -- work that only needs those rows (the weight-gradient products X^T.dPre of the
- * reference's theano.grad through the scan) can be ordered behind an event on `stream` and run beside the rest of
- * the scan.  *strands receives the number of independent row ranges the plan advances side by side. */
-int parrot_decoder_parts(void* plan, int* strands);
-int parrot_decoder_part_steps(void* plan, int which, int part, int* t_lo, int* t_hi);
-int parrot_decoder_seq_fwd_part(void* plan, int part, void* stream);
-int parrot_decoder_seq_bwd_part(void* plan, int part, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Autoregressive decode: the theano.scan over `sample_step` of Parrot.sample_model_fun
  * (model.py:882-1057) for the MSE ("greedy") head: x_t = readout_to_output(readouts_t).

@@ -72,7 +72,6 @@ class DecoderDesc(C.Structure):
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
         ("dh_b", C.c_void_p * MAX_LAYERS), ("dhup_b", C.c_void_p * MAX_LAYERS), ("dw_b", C.c_void_p), ("dw0_b", C.c_void_p),
         ("dhup_c", C.c_void_p * MAX_LAYERS), ("dw_c", C.c_void_p), ("dw0_c", C.c_void_p),
-        ("dh_c", C.c_void_p * MAX_LAYERS), ("dh_d", C.c_void_p * MAX_LAYERS), ("dw0_d", C.c_void_p),
     ]
 
 
@@ -169,10 +168,6 @@ SIGNATURES = {
     "parrot_decoder_seq_fwd": (_i, [_vp, _vp]),
     "parrot_decoder_seq_bwd": (_i, [_vp, _vp]),
     "parrot_decoder_destroy": (_i, [_vp]),
-    "parrot_decoder_parts": (_i, [_vp, C.POINTER(C.c_int)]),
-    "parrot_decoder_part_steps": (_i, [_vp, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "parrot_decoder_seq_fwd_part": (_i, [_vp, _i, _vp]),
-    "parrot_decoder_seq_bwd_part": (_i, [_vp, _i, _vp]),
     "parrot_sample_create": (_i, [C.POINTER(SampleDesc), C.POINTER(C.c_void_p)]),
     "parrot_sample_persist_floats": (C.c_longlong, [C.POINTER(SampleDesc)]),
     "parrot_sample_is_persistent": (_i, [_vp]),
@@ -187,12 +182,9 @@ SIGNATURES = {
     "parrot_tile_weights_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "parrot_set_gemm_precision": (_i, [_i]),
     "parrot_get_gemm_precision": (_i, []),
-    "parrot_set_gemm_lds_pad": (_i, [_i]),
     "parrot_to_bf16": (_i, [_vp, _vp, _ll, _vp]),
     "parrot_gemm_bf16in": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "parrot_gemm_bf16in_ex": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
-    "parrot_stream_create": (_i, [_i, C.POINTER(C.c_void_p)]),
-    "parrot_stream_destroy": (_i, [_vp]),
     "parrot_simple_norm_fwd": (_i, [_vp, _i, _vp, _i, _vp, _ll, _i, _f, _vp, _i, _vp]),
     "parrot_simple_norm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _ll, _i, _f, _i, _vp]),
     "parrot_adam_clip_step": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),

@@ -31,7 +31,6 @@ int bg_launch(const BgArgs& a, hipStream_t stream);
 void bg_tile_shape(int bf16, int& bm, int& bn);  // macro tile bg_launch will use (split-K heuristics)
 int bg_to_bf16_launch(const float* x, void* y, long long n, hipStream_t stream);  // f32 -> bf16 copy (RNE), n % 8 == 0
 int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of the deterministic split-K
-void bg_set_lds_pad(int bytes);  // unused dynamic LDS per workgroup: limits co-residency (see biggemm.hip)
 
 // Operand precision of parrot_gemm's batched path: the process-wide mode (parrot_set_gemm_precision) unless a scan
 // plan running on this thread pins its own (a plan built for bf16 operands keeps them whatever the caller's mode is).

@@ -690,12 +690,6 @@ int bg_reduce_launch(const BgArgs& a, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-// Extra (unused) dynamic LDS per workgroup of the batched GEMM kernels: caps how many of them share a CU, so that a
-// product running BESIDE the latency-bound scan (the weight-gradient GEMMs) leaves wave slots and LDS
-// for the scan's workgroups.  0 = as many as fit (the stand-alone optimum).
-static std::atomic<int> g_bg_lds_pad{0};
-void bg_set_lds_pad(int bytes) { g_bg_lds_pad.store(bytes < 0 ? 0 : bytes, std::memory_order_relaxed); }
-
 void bg_tile_shape(int bf16, int& bm, int& bn) {
     bm = bn = 128;
     if (bf16 == 2) { bm = HBMT; bn = HBNT; return; }
@@ -712,7 +706,7 @@ int bg_to_bf16_launch(const float* x, void* y, long long n, hipStream_t stream) 
 }
 
 int bg_launch(const BgArgs& a, hipStream_t stream) {
-    const size_t pad = (size_t)g_bg_lds_pad.load(std::memory_order_relaxed);
+    const size_t pad = 0;
     if (a.M <= 0 || a.N <= 0 || a.K < 0 || a.nbatch < 1 || a.splitk < 1 || (a.splitk > 1 && !a.ws)) return PH_ERR_BADARG;
     const bool axc = (a.sam == 1), bxc = (a.sbn == 1);
     if (!axc && a.sak != 1) return PH_ERR_BADARG;

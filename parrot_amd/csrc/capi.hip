@@ -37,30 +37,7 @@ int parrot_set_gemm_precision(int mode) { PH_ENTRY();
 
 int parrot_get_gemm_precision(void) { PH_ENTRY(); return g_gemm_bf16.load(std::memory_order_relaxed); }
 
-int parrot_set_gemm_lds_pad(int bytes) { PH_ENTRY();
-    if (bytes < 0 || bytes > 128 * 1024) return PARROT_ERR_BADARG;
-    bg_set_lds_pad(bytes);
-    return 0;
-}
-
-int parrot_stream_create(int priority, void** stream) { PH_ENTRY();
-    if (!stream) return PARROT_ERR_BADARG;
-    int least = 0, greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (e != hipSuccess) return (int)e;
-    const int prio = priority < 0 ? greatest : (priority > 0 ? least : (least + greatest) / 2);
-    hipStream_t s = nullptr;
-    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio);
-    if (e != hipSuccess) return (int)e;
-    *stream = s;
-    return 0;
-}
-
-int parrot_stream_destroy(void* stream) { PH_ENTRY();
-    return stream ? (int)hipStreamDestroy((hipStream_t)stream) : PARROT_ERR_BADARG;
-}
-
-const char* parrot_hip_version(void) { PH_ENTRY(); return "parrot_hip 0.1.0 gfx950"; }
+const char* parrot_hip_version(void) { PH_ENTRY(); return "parrot_hip 0.5.0 gfx950"; }
 
 int parrot_profile_begin(void) { PH_ENTRY();
     sk_profile_begin();

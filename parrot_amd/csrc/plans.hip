@@ -252,57 +252,6 @@ int traced_bwd_fused_launch(const AttBwdArgs* g, const LstmStateBwdArgs& sa, int
     return sk_launch_bwd_fused(L, g, sa, l0_chain, flags, s);
 }
 
-// Batch rows [b0, b0 + nb) of a launch argument block: every per-row pointer moves down b0 rows, the row count
-// becomes nb.  The recurrence never mixes batch rows, so a window can be advanced as several independent row
-// ranges ("strands", see DecoderPlan) without touching any kernel.
-struct Strand { int b0, nb; };
-template <class P>
-static inline void shift(P*& p, long long rows, long long ld) { if (p) p += rows * ld; }
-void take_rows(SkJob& j, const Strand& s) {
-    if (s.b0 == 0 && s.nb == j.M) return;
-    for (int q = 0; q < j.nseg; ++q) shift(j.seg[q].A, s.b0, j.seg[q].lda);
-    shift(j.add, s.b0, j.ld_add); shift(j.out, s.b0, j.ldo);
-    shift(j.e0, s.b0, j.lde0); shift(j.e1, s.b0, j.lde1);
-    shift(j.o1, s.b0, j.ldo1); shift(j.o2, s.b0, j.ldo2);
-    shift(j.mask, s.b0, 1);
-    j.M = s.nb;
-}
-void take_rows(AttFwdArgs& g, const Strand& s) {
-    if (s.b0 == 0 && s.nb == g.B) return;
-    shift(g.h1, s.b0, g.ldh); shift(g.kappa_prev, s.b0, g.A); shift(g.ctx, s.b0, (long long)g.U * g.E);
-    shift(g.a_out, s.b0, g.A); shift(g.b_out, s.b0, g.A); shift(g.kappa_out, s.b0, g.A);
-    shift(g.phi_out, s.b0, g.U); shift(g.w_out, s.b0, g.ldw); shift(g.sup_out, s.b0, 2);
-    g.B = s.nb;
-}
-void take_rows(AttBwdArgs& g, const Strand& s) {
-    if (s.b0 == 0 && s.nb == g.B) return;
-    shift(g.dw, s.b0, g.lddw); shift(g.dw2, s.b0, g.lddw); shift(g.ctx, s.b0, (long long)g.U * g.E);
-    shift(g.a, s.b0, g.A); shift(g.b, s.b0, g.A); shift(g.kappa, s.b0, g.A); shift(g.kappa_prev, s.b0, g.A);
-    shift(g.dkappa, s.b0, g.A); shift(g.dp_out, s.b0, 3 * g.A); shift(g.dh1, s.b0, g.lddh); shift(g.sup, s.b0, 2);
-    g.B = s.nb;
-}
-void take_rows(GruStateBwdArgs& g, const Strand& s) {
-    if (s.b0 == 0 && s.nb == g.B) return;
-    for (int q = 0; q < g.nchain; ++q) {
-        GruStateBwdChain& c = g.chain[q];
-        shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.hprev, s.b0, g.H); shift(c.z, s.b0, g.H);
-        for (int q2 = 0; q2 < 3; ++q2) shift(c.dhx[q2], s.b0, g.H);
-        shift(c.c, s.b0, g.H); shift(c.mask, s.b0, 1); shift(c.dC, s.b0, g.H); shift(c.dG, s.b0, 2 * g.H);
-        shift(c.dhprev, s.b0, g.H);
-    }
-    g.B = s.nb;
-}
-void take_rows(LstmStateBwdArgs& g, const Strand& s) {
-    if (s.b0 == 0 && s.nb == g.B) return;
-    for (int q = 0; q < g.nchain; ++q) {
-        LstmStateBwdChain& c = g.chain[q];
-        shift(c.dh, s.b0, g.H); shift(c.dh2, s.b0, g.H); shift(c.dh3, s.b0, g.H); shift(c.dh4, s.b0, g.H);
-        shift(c.dh5, s.b0, g.H); shift(c.dh6, s.b0, g.H);
-        shift(c.dc, s.b0, g.H); shift(c.gates, s.b0, 4 * g.H);
-        shift(c.c_prev, s.b0, g.H); shift(c.c_new, s.b0, g.H); shift(c.dP, s.b0, 4 * g.H);
-    }
-    g.B = s.nb;
-}
 
 // ----------------------------------------------------------------------------- GRU scan
 struct GruSeqPlan : PlanBase {
@@ -552,251 +501,14 @@ struct DecoderPlan : PlanBase {
     int schedule = 0, chunk = 50;
     bool try_persist = false;
 
-    // ---- strands and parts (schedule 0) -----------------------------------------------------------------------
-    // A step kernel of the scan is latency-bound: the matrix pipes idle while a launch waits for
-    // its first operands, reduces its partial tiles and drains.  Utterances never interact inside the scan
-    // (model.py:651-724 is row-wise), so the batch is cut into `nstrands` row ranges that advance as INDEPENDENT
-    // chains of launches, one hipStream each: while one strand sits in a launch boundary the other strands'
-    // workgroups own the CUs.  Every strand runs exactly the arithmetic of the single-chain scan on its rows (the
-    // split-K order inside a workgroup does not depend on the tile shape), so the results are bit-identical.
-    // The window is also cut along time into `parts` of `qpart` wavefront ticks, one hipGraph per (strand, part):
-    // the host can start strand 1 while strand 0's later parts are still being enqueued, and the caller can hang
-    // work that only needs the finished part (the deferred weight-gradient GEMMs) on another stream.
-    int nstrands = 1, qpart = 0, full_wgs = 0;
-    Strand cur = {0, 0};
-    std::vector<Strand> strands;
-    std::vector<hipStream_t> sside;         // streams of strands 1..n-1 (strand 0 runs on the caller's stream)
-    std::vector<hipEvent_t> ev_join;
-    hipEvent_t ev_fork = nullptr;
-    std::vector<hipGraphExec_t> piece[2];   // [which][strand * nparts + part]
-
-    void free_strands() {
-        stop_workers();
-        if (att_flags && !flags_fake) (void)hipFree(att_flags);
-        att_flags = nullptr;
-        if (bwd_flags && !flags_fake) (void)hipFree(bwd_flags);
-        bwd_flags = nullptr;
-        for (int w = 0; w < 2; ++w)
-            for (hipGraphExec_t e : piece[w])
-                if (e) (void)hipGraphExecDestroy(e);
-        for (hipStream_t s : sside) (void)hipStreamDestroy(s);
-        for (hipEvent_t e : ev_join) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-    }
-
-    int nparts() const { return qpart > 0 ? ceil_div(nticks(), qpart) : 1; }
-    void part_ticks(int part, int& q0, int& q1) const {
-        const int Q = nticks();
-        if (qpart <= 0) { q0 = 0; q1 = Q; return; }
-        q0 = part * qpart;
-        q1 = q0 + qpart < Q ? q0 + qpart : Q;
-    }
-    // Steps [t_lo, t_hi) that EVERY layer has finished once parts 0..part of direction `which` have run
-    // (forward: layer l lags l ticks; backward: layer l lags L-1-l ticks, walking down from T-1).
-    void part_steps(int which, int part, int& t_lo, int& t_hi) const {
-        int q0, q1;
-        part_ticks(part, q0, q1);
-        if (which == 0) {
-            t_lo = 0;
-            t_hi = q1 >= nticks() ? d.T : std::max(0, q1 - (d.L - 1));
-        } else {
-            t_hi = d.T;
-            t_lo = q1 >= nticks() ? 0 : std::min(d.T, d.T - q1 + (d.L - 1));
-        }
-    }
-
-    void setup_strands() {
-        strands.clear();
-        const char* e = getenv("PARROT_STRANDS");
-        int want = e ? atoi(e) : (d.reserved > 0 ? d.reserved : 1);
-        if (schedule != 0 || d.layer_norm || want < 1) want = 1;
-        const int blocks = ceil_div(d.B, 16);
-        if (want > blocks) want = blocks;
-        if (want > 8) want = 8;
-        const int per = ceil_div(blocks, want) * 16;
-        for (int b0 = 0; b0 < d.B; b0 += per) strands.push_back(Strand{b0, std::min(per, d.B - b0)});
-        nstrands = (int)strands.size();
-        cur = Strand{0, d.B};
-        const char* qp = getenv("PARROT_QPART");
-        qpart = qp ? atoi(qp) : (nstrands > 1 && d.T >= 200 ? 100 : 0);  // parts only where strands asked for them
-        if (schedule != 0) qpart = 0;
-        const char* th = getenv("PARROT_STRAND_THREADS");
-        use_threads = th ? atoi(th) != 0 : true;
-        const char* fw = getenv("PARROT_SK_FULL");
-        full_wgs = fw ? atoi(fw) : (nstrands > 1 ? std::max(64, 224 / nstrands) : 0);
-    }
-
-    int enqueue_piece(int which, int k, int part, hipStream_t s) {
-        BgPrecisionScope precision(d.bf16);
-        int q0, q1;
-        part_ticks(part, q0, q1);
-        cur = strands[k];  // (the attention keeps the column split of the whole batch: its sums depend on it)
-        const int rc = which == 0 ? fwd(s, q0, q1) : bwd(s, q0, q1);
-        cur = Strand{0, d.B};
-        return rc;
-    }
-
-    // Graph of one (strand, part) piece; captured on first use, on the caller's thread.
-    int capture_piece(int which, int k, int part) {
-        const int np = nparts();
-        if (piece[which].empty()) piece[which].assign((size_t)nstrands * np, nullptr);
-        hipGraphExec_t& ex = piece[which][(size_t)k * np + part];
-        if (ex) return 0;
-        if (!cap_stream) {
-            hipError_t e = hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipError_t e = hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed);
-        if (e != hipSuccess) return (int)e;
-        const int rc = enqueue_piece(which, k, part, cap_stream);
-        hipGraph_t graph = nullptr;
-        e = hipStreamEndCapture(cap_stream, &graph);
-        if (rc != 0) {
-            if (graph) (void)hipGraphDestroy(graph);
-            return rc;
-        }
-        if (e != hipSuccess) return (int)e;
-        e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
-            ex = nullptr;
-            return (int)e;
-        }
-        return 0;
-    }
-
-    // Parts [p0, p1) of strand k on stream s: replays of their graphs, or the launches themselves.
-    int run_strand(int which, int k, int p0, int p1, hipStream_t s) {
-        const int np = nparts();
-        for (int part = p0; part < p1; ++part) {
-            if (!use_graph) PL_TRY(enqueue_piece(which, k, part, s));
-            else PL_TRY((int)hipGraphLaunch(piece[which][(size_t)k * np + part], s));
-        }
-        return 0;
-    }
-
-    // A host thread per side strand: replaying a graph costs host time per kernel node, and one thread feeding
-    // several streams hands the device its strands one piece after the other (measured: the queues then alternate
-    // piece by piece instead of running side by side).  The workers only replay instantiated graphs.
-    struct Worker {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv;
-        int which = 0, p0 = 0, p1 = 0, rc = 0, device = 0;
-        bool pending = false, quit = false;
-    };
-    std::vector<std::unique_ptr<Worker>> workers;
-    bool use_threads = false;
-
-    void worker_main(int k) {
-        Worker& w = *workers[k - 1];
-        (void)hipSetDevice(w.device);
-        std::unique_lock<std::mutex> lock(w.mu);
-        for (;;) {
-            w.cv.wait(lock, [&] { return w.pending || w.quit; });
-            if (w.quit) return;
-            hipStream_t st = sside[k - 1];
-            int rc = (int)hipStreamWaitEvent(st, ev_fork, 0);
-            if (rc == 0) rc = run_strand(w.which, k, w.p0, w.p1, st);
-            if (rc == 0) rc = (int)hipEventRecord(ev_join[k - 1], st);
-            w.rc = rc;
-            w.pending = false;
-            w.cv.notify_all();
-        }
-    }
-    void stop_workers() {
-        for (auto& w : workers) {
-            {
-                std::lock_guard<std::mutex> lock(w->mu);
-                w->quit = true;
-            }
-            w->cv.notify_all();
-            if (w->th.joinable()) w->th.join();
-        }
-        workers.clear();
-    }
-
-    bool stranded(int which) const { return schedule == 0 && !(which == 0 && persist_ok) && (nstrands > 1 || qpart > 0); }
-
-    int ensure_strand_streams() {
-        if ((int)sside.size() >= nstrands - 1 && ev_fork) return 0;
-        if (!ev_fork) PL_TRY((int)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        while ((int)sside.size() < nstrands - 1) {
-            hipStream_t s = nullptr;
-            hipEvent_t e = nullptr;
-            int least = 0, greatest = 0;
-            PL_TRY((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const char* pe = getenv("PARROT_STRAND_PRIO");  // -1 highest, 0 default (default), 1 lowest
-            const int pr = pe ? atoi(pe) : 0;
-            PL_TRY((int)hipStreamCreateWithPriority(&s, hipStreamNonBlocking,
-                                                    pr < 0 ? greatest : (pr > 0 ? least : (least + greatest) / 2)));
-            sside.push_back(s);
-            PL_TRY((int)hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ev_join.push_back(e);
-        }
-        return 0;
-    }
-
-    // Parts [p0, p1) of direction `which` for all strands: the side streams fork from `s` and join it again.
-    int run_parts(int which, int p0, int p1, hipStream_t s) {
-        if (use_graph)  // all captures on this thread, before anything is handed to the workers
-            for (int part = p0; part < p1; ++part)
-                for (int k = 0; k < nstrands; ++k) PL_TRY(capture_piece(which, k, part));
-        if (nstrands == 1) return run_strand(which, 0, p0, p1, s);
-        PL_TRY(ensure_strand_streams());
-        PL_TRY((int)hipEventRecord(ev_fork, s));
-        const bool threaded = use_threads && use_graph;
-        if (threaded) {
-            if (workers.empty()) {
-                int dev = 0;
-                PL_TRY((int)hipGetDevice(&dev));
-                for (int k = 1; k < nstrands; ++k) {
-                    workers.emplace_back(new Worker());
-                    workers.back()->device = dev;
-                }
-                for (int k = 1; k < nstrands; ++k) workers[k - 1]->th = std::thread([this, k] { worker_main(k); });
-            }
-            for (int k = 1; k < nstrands; ++k) {
-                Worker& w = *workers[k - 1];
-                {
-                    std::lock_guard<std::mutex> lock(w.mu);
-                    w.which = which; w.p0 = p0; w.p1 = p1; w.pending = true;
-                }
-                w.cv.notify_all();
-            }
-            int rc = run_strand(which, 0, p0, p1, s);
-            for (int k = 1; k < nstrands; ++k) {  // the join events are recorded once the workers are through
-                Worker& w = *workers[k - 1];
-                std::unique_lock<std::mutex> lock(w.mu);
-                w.cv.wait(lock, [&] { return !w.pending; });
-                if (rc == 0) rc = w.rc;
-            }
-            PL_TRY(rc);
-        } else {
-            for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipStreamWaitEvent(sside[k - 1], ev_fork, 0));
-            for (int part = p0; part < p1; ++part)
-                for (int k = 0; k < nstrands; ++k) PL_TRY(run_strand(which, k, part, part + 1, k == 0 ? s : sside[k - 1]));
-            for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipEventRecord(ev_join[k - 1], sside[k - 1]));
-        }
-        for (int k = 1; k < nstrands; ++k) PL_TRY((int)hipStreamWaitEvent(s, ev_join[k - 1], 0));
-        return 0;
-    }
-
-    int run_part(int which, int part, hipStream_t s) {
-        if (!stranded(which)) return part == 0 ? run(which, s) : note(PARROT_ERR_BADARG);
-        if (part < 0 || part >= nparts()) return note(PARROT_ERR_BADARG);
-        return note(run_parts(which, part, part + 1, s));
-    }
+    int full_wgs = 0;  // (launch_jobs: 0 = the step kernel's own tile heuristic)
 
     // Records what the plan's launches of direction `which` read and write (see Tracer); schedules 0, 5, 6 and 7 only.
     int trace(int which, std::vector<TraceRec>& out, std::vector<TraceJob>* jobs_out = nullptr) {
         if (persist_ok || (schedule != 0 && schedule < 5) || d.layer_norm) return PARROT_ERR_UNSUPPORTED;
         Tracer tr;
         g_tracer = &tr;
-        const Strand keep = cur;
-        cur = Strand{0, d.B};
         const int rc = enqueue(which, nullptr);
-        cur = keep;
         g_tracer = nullptr;
         out.swap(tr.recs);
         if (jobs_out) jobs_out->swap(tr.jobs);
@@ -806,11 +518,9 @@ struct DecoderPlan : PlanBase {
     int enqueue(int which, hipStream_t s) override {
         BgPrecisionScope precision(d.bf16);  // the hoisted projections follow the plan's operand mode
         if (which == 0 && persist_ok) return pm_launch(pm_prog, s);  // schedule 4: the persistent phase machine
-        if (schedule == 1) return which == 0 ? fwd_streams(s) : bwd_streams(s);
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
-        if (which == 1 && bwd_hetero && (schedule == 0 || schedule == 5 || schedule == 6)) return bwd8(s);
+        if (which == 1 && bwd_hetero && (schedule == 0 || schedule == 5)) return bwd8(s);
         if (schedule == 5) return which == 0 ? fwd5(s) : bwd(s);
-        if (schedule == 6) return which == 0 ? fwd6(s) : bwd(s);
         if (schedule == 7) return which == 0 ? fwd7(s) : bwd(s);
         return which == 0 ? fwd(s) : bwd(s);
     }
@@ -818,7 +528,6 @@ struct DecoderPlan : PlanBase {
     void choose_schedule() {
         const char* e = getenv("PARROT_SCHEDULE");
         int want = e ? atoi(e) : -1;
-        if (getenv("PARROT_LAYER_STREAMS") && atoi(getenv("PARROT_LAYER_STREAMS"))) want = 1;
         bool pipe_ok = d.L >= 2;
         for (int l = 1; l < d.L; ++l)
             if (!d.seq_g[l] || (d.cell == 0 && !d.seq_c[l])) pipe_ok = false;
@@ -827,28 +536,26 @@ struct DecoderPlan : PlanBase {
         const bool want_persist = want == 4;  // opt-in: measured at cfg2 it only matches the launch schedules
         if (want_persist) want = -1;
         if (want < 0) {
-            // default: the balanced wavefront (5) where it pays -- GRU layers, L >= 2, no layer_norm -- unless the caller asked
-            // for independent row strands (a schedule-0 feature); measured at cfg2: forward scan 29.2 -> 25.2 ms
-            const char* se = getenv("PARROT_STRANDS");
-            const int strands_wanted = se ? atoi(se) : d.reserved;
+            // default: the balanced wavefront (5) where it pays -- GRU layers, L >= 2, no layer_norm; measured at cfg2:
+            // forward scan 29.2 -> 25.2 ms
             // GRU stacks, f32 or bf16 operands (cfg2: 82.7 -> 74.6 ms f32, 59.8 -> 54.0 ms bf16; 3 layers 122.5 -> 115.0).
             // LSTM stacks stay on schedule 0 (5 covers them, opt-in): their tick is ONE fused launch of > 1000 workgroups,
             // bound by total work rather than by its longest K, and cutting it in two only adds fixed cost -- cfg4 bf16
             // 118.9 vs 127.5 ms (the wide kernel has ~10 us of fixed cost per launch), cfg4 f32 256.5 vs 265.4 ms.
-            want = (pipe_ok && d.cell == 0 && !d.layer_norm && strands_wanted <= 1) ? 5 : 0;
+            want = (pipe_ok && d.cell == 0 && !d.layer_norm) ? 5 : 0;
             // LSTM stacks with bf16 operands (BASELINE configs[3]): the attention inside the tick's one launch (7), where
             // the wide step kernel takes the launch (checked in parrot_decoder_create)
-            if (d.cell == 1 && d.bf16 && !d.layer_norm && strands_wanted <= 1) want = 7;
+            if (d.cell == 1 && d.bf16 && !d.layer_norm) want = 7;
         }
         if (d.layer_norm && d.L >= 2 && want < 2) want = 3;  // the in-scan normalisations need the hoisted projections
-        if (want >= 2 && want != 7 && !pipe_ok && !(want == 6 && d.L == 1)) want = 0;
-        if (want == 1 && d.cell == 1) want = 0;
-        if (want == 6 && (d.cell != 0 || d.bf16)) want = 5;                  // the in-launch hand-off: f32 GRU layers
+        if (want != 0 && want != 3 && want != 5 && want != 7) want = 0;      // (schedules 1, 2 and 6 of rounds 1-3 were removed:
+                                                                             //  measured losers, numbers in DESIGN.md 3.2)
+        if (want >= 2 && want != 7 && !pipe_ok) want = 0;
         if (want == 7 && d.cell != 1) want = pipe_ok ? 5 : 0;                // one launch per tick: LSTM layers
         if (want >= 5 && d.layer_norm) want = 0;
         schedule = want;
         try_persist = want_persist && d.cell == 0 && !d.layer_norm && !d.bf16;
-        const char* c = getenv("PARROT_CHUNK");
+        const char* c = getenv("PARROT_CHUNK");  // (tests: several chunks and a ragged last one on short windows)
         if (c && atoi(c) > 0) chunk = atoi(c);
     }
 
@@ -1143,7 +850,6 @@ struct DecoderPlan : PlanBase {
         j.o1 = d.z[l] + t * BH; j.ldo1 = d.H;
         j.o2 = d.r[l] + t * BH; j.ldo2 = d.H;
         j.out = d.rh[l] + t * BH; j.ldo = d.H;
-        take_rows(j, cur);
     }
 
     void cand_job(SkJob& j, int l, int t) const {
@@ -1157,7 +863,6 @@ struct DecoderPlan : PlanBase {
         j.e1 = d.z[l] + t * BH; j.lde1 = d.H;
         j.o1 = d.c[l] + t * BH; j.ldo1 = d.H;
         j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
-        take_rows(j, cur);
     }
 
     void lstm_job(SkJob& j, int l, int t) const {
@@ -1171,7 +876,6 @@ struct DecoderPlan : PlanBase {
         j.o1 = d.cst[l] + (t + 1) * BH; j.ldo1 = d.H;
         j.o2 = d.gate4[l] + t * 4 * BH; j.ldo2 = 4 * d.H;
         j.out = d.h[l] + (t + 1) * BH; j.ldo = d.H;
-        take_rows(j, cur);
     }
 
     AttFwdArgs att_fwd_args(int t) const {
@@ -1188,7 +892,6 @@ struct DecoderPlan : PlanBase {
         g.att_type = d.att_type; g.eps = d.eps; g.alignment = d.alignment;
         g.sharpening = d.sharpening; g.timing = d.timing;
         g.sup_out = d.att_sup ? d.att_sup + (size_t)t * d.B * 2 : nullptr;
-        take_rows(g, cur);
         return g;
     }
     int att_fwd_step(int t, hipStream_t st) const { return traced_att_fwd_launch(att_fwd_args(t), st); }
@@ -1262,7 +965,6 @@ struct DecoderPlan : PlanBase {
         float* sq = (g == 0 ? d.seq_g[l] : d.seq_c[l]) + (size_t)t * d.B * wd;
         j.out = sq; j.ldo = wd;
         j.accumulate = part == 2 ? 1 : ((d.seq_init >> l) & 1);  // caller data (feedback / speaker terms) already there
-        take_rows(j, cur);
     }
     int fwd5(hipStream_t st) {
         const int Q = nticks5();
@@ -1315,86 +1017,6 @@ struct DecoderPlan : PlanBase {
         return 0;
     }
 
-    // ---- schedule 6: two launches per tick (GRU layers, fragment-major weights) --------------------------------------
-    // The dependent chain of a decoder step is cand(t) -> h_t -> attention -> w_t -> gates(t+1) -> r -> cand(t+1): three
-    // launches per step in schedules 0 and 5, each with ~4.7 us of fixed cost.  But only the LAST K = E rows of layer 0's
-    // gate product depend on the attention; its first K = H rows need h_t alone.  So the attention of step q-1 and the
-    // gate product of step q share ONE heterogeneous launch (skinny.hip ska_kernel): the attention workgroups are
-    // dispatched first and publish w_q write-through plus an arrival count; layer 0's gate workgroups multiply their
-    // h rows meanwhile, wait for the count, and finish with the w rows (SkJob::wait_flag).  The launch also carries the
-    // upper layers' recurrent gate products and input projections (independent work for the CUs the wait leaves idle):
-    //   A'(q): attention(q-1) || gates(l0, q) [waits], gates_rec(l, q - lag_l), input(l, q - lag_l + 1)   (l >= 1)
-    //   B'(q): cand(l0, q), cand_rec(l, q - lag_l)                                                      lag_l = 2l + 1
-    // Same arithmetic per output element as schedule 5 (layer 0: as schedule 0, bit for bit).
-    unsigned* att_flags = nullptr;  // [T + 2] arrival counters, one per tick (plan-owned, zeroed at the head of the scan)
-    bool flags_fake = false;        // (placeholder for CPU-only schedule tracing: never dereferenced, never freed)
-    int esplit6 = 0;
-    // s6_ib: the input projections ride in B' instead of A' (then lag_l = 2l): A' keeps one workgroup per CU
-    bool s6_ib = true;
-    int s6_btile = 0;
-    int lag6(int l) const { return l == 0 ? 0 : (s6_ib ? 2 * l : 2 * l + 1); }
-    int nticks6() const { return d.T + std::max(1, lag6(d.L - 1)); }
-    int fwd6(hipStream_t st) {
-        if (!att_flags) return PARROT_ERR_BADARG;  // (allocated by parrot_decoder_create, outside any stream capture)
-        if (!g_tracer) PL_TRY(sk_zero_words_launch(att_flags, d.T + 2, st));
-        const int Q = nticks6();
-        const char* fe = getenv("PARROT_S5_FULL");
-        const int cfull = fe ? atoi(fe) : 160;
-        // A'(q): 1 gate job of layer 0 + (1 recurrent gate job + 2 input jobs) per upper layer
-        static_assert(1 + 3 * (PARROT_MAX_LAYERS - 1) <= SK_MAXJOB, "fwd6: jobs[] too short");
-        for (int q = 0; q < Q; ++q) {
-            SkJob jobs[SK_MAXJOB];
-            int n = 0;
-            const bool att_on = q >= 1 && q - 1 < d.T;
-            AttFwdArgs ag{};
-            if (att_on) {
-                ag = att_fwd_args(q - 1);
-                ag.esplit = esplit6;
-            }
-            if (q < d.T) {
-                SkJob& j = jobs[n++];
-                gates_job(j, 0, q);
-                if (att_on) {  // w_q arrives inside this launch
-                    j.wait_flag = att_flags + q;
-                    j.wait_target = (unsigned)(ag.B * ag.esplit);
-                    ag.flag = att_flags + q;
-                }
-            }
-            for (int l = 1; l < d.L; ++l) {
-                const int t = q - lag6(l);
-                if (t < 0 || t >= d.T) continue;
-                SkJob& j = jobs[n++];
-                gates_job(j, l, t);
-                j.nseg = 1;  // recurrent block; the rest arrives through seq_g (has_seq)
-            }
-            if (!s6_ib)
-                for (int l = 1; l < d.L; ++l) {
-                    const int t = q - lag6(l) + 1;
-                    if (t < 0 || t >= d.T) continue;
-                    input_job(jobs[n++], l, t, 0);
-                    input_job(jobs[n++], l, t, 1);
-                }
-            if (att_on) PL_TRY(launch_jobs_att(jobs, n, ag, st, cfull));
-            else if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
-            n = 0;
-            for (int l = 0; l < d.L; ++l) {
-                const int t = q - lag6(l);
-                if (t < 0 || t >= d.T) continue;
-                SkJob& j = jobs[n++];
-                cand_job(j, l, t);
-                if (l > 0) j.nseg = 1;
-            }
-            if (s6_ib)
-                for (int l = 1; l < d.L; ++l) {
-                    const int t = q - lag6(l) + 1;
-                    if (t < 0 || t >= d.T) continue;
-                    input_job(jobs[n++], l, t, 0);
-                    input_job(jobs[n++], l, t, 1);
-                }
-            if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs, s6_btile));
-        }
-        return 0;
-    }
 
     // ---- schedule 7: ONE launch per tick for LSTM layers (round 4) ---------------------------------------------------
     // Schedule 0 runs an LSTM tick as the fused launch of all layers (wk_kernel at cfg4: ~35 us, bound by its total work)
@@ -1450,16 +1072,16 @@ struct DecoderPlan : PlanBase {
     bool bwd_split = true;  // PARROT_BWD_SPLIT=0: the dC products stay in the Y launch (K = 3H jobs), as before round 3
     // schedule 7 with bf16 operands: the backward tick of LSTM layers as ONE launch (skinny.hip wkb_kernel); bwd_flags =
     // [ticks x 4 chains] arrival counters, plan-owned, zeroed at the head of the backward scan
+    unsigned* att_flags = nullptr;  // [T + 2] arrival counters, one per tick (plan-owned, zeroed at the head of the scan)
+    bool flags_fake = false;        // (placeholder for CPU-only schedule tracing: never dereferenced, never freed)
     bool bwd_fused = false;
     unsigned* bwd_flags = nullptr;
     // LSTM layers, bf16 operands, second accumulators given (ParrotDecoderDesc::dh_b ...): the backward products in two K
     // halves.  A wide workgroup streams its whole [B, 4H] operand: 156 workgroups of ~40 us each at cfg4, whatever
     // their width, and 100 idle CUs; two K halves = 312 workgroups of ~20 us (PARROT_BWD_KSPLIT=0: one part).
     bool bwd_ksplit = false;
-    // + layer 0's products (the ones behind the attention rows) in FOUR K parts (dh_c / dh_d / dw0_c / dw0_d given;
-    // PARROT_BWD_K4=1).  Built and measured in round 4: cfg4 94.6 vs 91.4 ms -- 112 narrow workgroups with a ring fill each
-    // cost more than the shorter stream returns.  Kept opt-in.
-    bool bwd_k4 = false;
+    // (Layer 0's products in FOUR K parts were built and measured in round 4: cfg4 94.6 vs 91.4 ms -- 112 narrow workgroups
+    // with a ring fill each cost more than the shorter stream returns; removed in round 5.)
     int bwd(hipStream_t st) { return bwd(st, 0, nticks()); }
     int bwd(hipStream_t st, int q0, int q1) {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
@@ -1475,7 +1097,6 @@ struct DecoderPlan : PlanBase {
             if (att_on && bwd_ksplit) {  // (LSTM layers) the second K halves' shares of dw
                 g.dw3 = d.dw_b + (size_t)(t0 + 1) * BE;
                 g.dw4 = d.dw0_b + (size_t)(t0 + 1) * BE;
-                if (bwd_k4) { g.dw5 = d.dw0_c + (size_t)(t0 + 1) * BE; g.dw6 = d.dw0_d + (size_t)(t0 + 1) * BE; }
             }
             if (d.cell == 1) {
                 SkJob jl[SK_MAXJOB];
@@ -1493,15 +1114,13 @@ struct DecoderPlan : PlanBase {
                     c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
                     c.dh3 = bwd_ksplit ? d.dh_b[l] + (t + 1) * BH : nullptr;  // the second K halves' sums (below)
                     c.dh4 = (bwd_ksplit && l + 1 < d.L) ? d.dhup_b[l] + (t + 1) * BH : nullptr;
-                    c.dh5 = (bwd_k4 && l == 0) ? d.dh_c[0] + (t + 1) * BH : nullptr;
-                    c.dh6 = (bwd_k4 && l == 0) ? d.dh_d[0] + (t + 1) * BH : nullptr;
+                    c.dh5 = c.dh6 = nullptr;
                     c.dc = d.dcell[l];
                     c.gates = d.gate4[l] + (size_t)t * 4 * BH;
                     c.c_prev = d.cst[l] + t * BH;
                     c.c_new = d.cst[l] + (t + 1) * BH;
                     c.dP = d.dG[l] + (size_t)t * 4 * BH;
                 }
-                take_rows(la, cur);
                 for (int l = d.L - 1; l >= 0; --l) {
                     const int t = tl[l];
                     if (t < 0 || t >= d.T) continue;
@@ -1515,9 +1134,6 @@ struct DecoderPlan : PlanBase {
                         j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
                         j.out = d.dh[l] + t * BH; j.ldo = H;
                         if (bwd_ksplit) { j.ksplit = 2; j.o1 = d.dh_b[l] + t * BH; j.ldo1 = H; }
-                        if (bwd_ksplit && l == 0 && bwd_k4) {  // layer 0's products sit behind the attention rows: four K parts
-                            j.ksplit = 4; j.kout2 = d.dh_c[0] + t * BH; j.kout3 = d.dh_d[0] + t * BH;
-                        }
                     }
                     {   // attention context
                         SkJob& j = jl[nl++];
@@ -1530,9 +1146,6 @@ struct DecoderPlan : PlanBase {
                             j.ksplit = 2; j.ldo1 = E;
                             j.o1 = (l == 0 ? d.dw0_b + (size_t)t * BE : d.dw_b + (size_t)(t + 1) * BE);
                             j.ldo2 = l == 0 ? 0 : 1;  // dw_b[t + 1] collects every upper layer's share: added (caller-zeroed)
-                            if (l == 0 && bwd_k4) {
-                                j.ksplit = 4; j.kout2 = d.dw0_c + (size_t)t * BE; j.kout3 = d.dw0_d + (size_t)t * BE;
-                            }
                         }
                     }
                     for (int p = 0; p < l; ++p) {
@@ -1547,11 +1160,10 @@ struct DecoderPlan : PlanBase {
                     if (bwd_fused)  // the products of a layer read what its chain's rows publish inside the launch
                         for (int q2 = first; q2 < nl; ++q2) {
                             jl[q2].wait_flag = bwd_flags + (size_t)q * 4 + chain_of[l];
-                            jl[q2].wait_target = (unsigned)cur.nb;
+                            jl[q2].wait_target = (unsigned)d.B;
                             jl[q2].wait_all = (l == 0 && att_on) ? 2 : 1;  // (2: behind the attention rows, last in the grid)
                         }
                 }
-                for (int q2 = 0; q2 < nl; ++q2) take_rows(jl[q2], cur);
                 const int l0c = att_on ? la.nchain - 1 : -1;
                 if (bwd_fused && la.nchain > 0 && nl > 0) {
                     unsigned* fl[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1651,9 +1263,6 @@ struct DecoderPlan : PlanBase {
             }
             if (ga.nchain == 0) continue;
             // layer 0's chain (if active) is the last one added; attention + all state updates in one launch
-            take_rows(ga, cur);
-            for (int q2 = 0; q2 < nx; ++q2) take_rows(jx[q2], cur);
-            for (int q2 = 0; q2 < ny; ++q2) take_rows(jy[q2], cur);
             PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, ga, att_on ? ga.nchain - 1 : -1, st));
             PL_TRY(launch_jobs(jx, nx, st, full_wgs));
             PL_TRY(launch_jobs(jy, ny, st, full_wgs));
@@ -1855,28 +1464,6 @@ struct DecoderPlan : PlanBase {
 
     // Kernels of layer l for the steps of chunk c (forward): batched projections from below, then the
     // layer's own sequential chain.
-    int fwd_piece(int l, int c, hipStream_t st) const {
-        const size_t BH = (size_t)d.B * d.H;
-        const int t0 = c * chunk, t1 = (t0 + chunk < d.T) ? t0 + chunk : d.T;
-        if (l > 0) PL_TRY(hoist_fwd(l, t0, t1, st));
-        for (int t = t0; t < t1; ++t) {
-            SkJob j;
-            if (d.cell == 1) {
-                lstm_job(j, l, t);
-                own_segs(j, l, t, d.h[l] + t * BH, 0, 4 * d.H);
-                PL_TRY(launch_jobs(&j, 1, st));
-            } else {
-                gates_job(j, l, t);
-                own_segs(j, l, t, d.h[l] + t * BH, 0, 2 * d.H);
-                PL_TRY(launch_jobs(&j, 1, st));
-                cand_job(j, l, t);
-                own_segs(j, l, t, d.rh[l] + t * BH, 1, d.H);
-                PL_TRY(launch_jobs(&j, 1, st));
-            }
-            if (l == 0) PL_TRY(att_fwd_step(t, st));
-        }
-        return 0;
-    }
 
     // Arguments of the attention backward of step t0 (one place: four schedules use it).
     AttBwdArgs att_bwd_args(int t0) const {
@@ -1892,89 +1479,10 @@ struct DecoderPlan : PlanBase {
         g.sup = d.att_sup ? d.att_sup + (size_t)t0 * d.B * 2 : nullptr;
         g.dh1 = d.dh[0] + (t0 + 1) * BH; g.lddh = d.H;
         g.B = d.B; g.H = d.H; g.A = d.A; g.U = d.U; g.E = d.E; g.att_type = d.att_type; g.eps = d.eps;
-        take_rows(g, cur);
         return g;
     }
     int att_bwd_step(int t0, hipStream_t st) const { return att_bwd_launch(att_bwd_args(t0), st); }
 
-    int bwd_piece(int l, int c, hipStream_t st) const {
-        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
-        const int H = d.H, E = d.E;
-        const int t0 = c * chunk, t1 = (t0 + chunk < d.T) ? t0 + chunk : d.T;
-        for (int t = t1 - 1; t >= t0; --t) {
-            if (l == 0) PL_TRY(att_bwd_step(t, st));
-            const float* dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
-            SkJob jy[2];
-            int ny = 0;
-            if (d.cell == 1) {
-                float* dP = d.dG[l] + (size_t)t * 4 * BH;
-                PL_TRY(lstm_state_bwd_launch(d.dh[l] + (t + 1) * BH, dh2, d.dcell[l],
-                                             d.gate4[l] + (size_t)t * 4 * BH, d.cst[l] + t * BH,
-                                             d.cst[l] + (t + 1) * BH, dP, d.B, H, st));
-                SkJob& j = jy[ny++];
-                sk_job_init(j);
-                j.nseg = 1;
-                j.seg[0] = rseg(dP, l, 0, 0, 4 * H);
-                j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                j.out = d.dh[l] + t * BH; j.ldo = H;
-                if (l == 0) {
-                    SkJob& k = jy[ny++];
-                    sk_job_init(k);
-                    k.nseg = 1;
-                    k.seg[0] = rseg(dP, 0, 0, H, 4 * H);
-                    k.M = d.B; k.N = E; k.H = H; k.epi = SK_EPI_LINEAR; k.accumulate = 1;
-                    k.out = d.dw0 + (size_t)t * BE; k.ldo = E;
-                }
-                PL_TRY(launch_jobs(jy, ny, st));
-                continue;
-            }
-            GruStateBwdArgs ga;
-            ga.nchain = 1; ga.B = d.B; ga.H = H;
-            GruStateBwdChain& ch = ga.chain[0];
-            ch.dh = d.dh[l] + (t + 1) * BH;
-            ch.dh2 = dh2;
-            ch.hprev = d.h[l] + t * BH;
-            ch.z = d.z[l] + t * BH;
-            ch.c = d.c[l] + t * BH;
-            ch.mask = nullptr;
-            ch.dC = d.dC[l] + t * BH;
-            ch.dG = d.dG[l] + t * 2 * BH;
-            ch.dhprev = d.dh[l] + t * BH;
-            PL_TRY(gru_state_bwd_launch(ga, st));
-            SkJob x;
-            sk_job_init(x);
-            x.nseg = 1;
-            x.seg[0] = rseg(d.dC[l] + t * BH, l, 1, 0, H);
-            x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
-            x.e0 = d.h[l] + t * BH; x.lde0 = H;
-            x.e1 = d.r[l] + t * BH; x.lde1 = H;
-            x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
-            x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
-            PL_TRY(launch_jobs(&x, 1, st));
-            const float* dG = d.dG[l] + t * 2 * BH;
-            const float* dC = d.dC[l] + t * BH;
-            {
-                SkJob& j = jy[ny++];
-                sk_job_init(j);
-                j.nseg = 1;
-                j.seg[0] = rseg(dG, l, 0, 0, 2 * H);
-                j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                j.out = d.dh[l] + t * BH; j.ldo = H;
-            }
-            if (l == 0) {
-                SkJob& j = jy[ny++];
-                sk_job_init(j);
-                j.nseg = 2;
-                j.seg[0] = rseg(dG, 0, 0, H, 2 * H);
-                j.seg[1] = rseg(dC, 0, 1, H, H);
-                j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                j.out = d.dw0 + (size_t)t * BE; j.ldo = E;
-            }
-            PL_TRY(launch_jobs(jy, ny, st));
-        }
-        if (l > 0) PL_TRY(hoist_bwd(l, t0, t1, st));
-        return 0;
-    }
 
     // ---- schedule 3: skewed wavefront with hoisting -------------------------------------------------
     // Merged launches as in schedule 0, but layer l lags layer l-1 by one CHUNK of steps instead of one step.
@@ -2128,234 +1636,15 @@ struct DecoderPlan : PlanBase {
         return 0;
     }
 
-    // One linear hipGraph per (layer, chunk) piece; the pieces of a layer are launched back to back on the
-    // layer's stream and an event per piece carries the dependency to the neighbouring layer.  (A single
-    // graph with parallel branches replays its branches one after the other on this runtime -- measured --
-    // while launches on different streams do overlap.)
-    std::vector<hipGraphExec_t> pieces[2];
-
-    int capture_pieces(int which) {
-        const int C = ceil_div(d.T, chunk);
-        if (!cap_stream) PL_TRY((int)hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-        pieces[which].assign((size_t)C * d.L, nullptr);
-        for (int c = 0; c < C; ++c)
-            for (int l = 0; l < d.L; ++l) {
-                PL_TRY((int)hipStreamBeginCapture(cap_stream, hipStreamCaptureModeRelaxed));
-                const int rc = which == 0 ? fwd_piece(l, c, cap_stream) : bwd_piece(l, c, cap_stream);
-                hipGraph_t graph = nullptr;
-                hipError_t e = hipStreamEndCapture(cap_stream, &graph);
-                if (rc != 0 || e != hipSuccess) {
-                    if (graph) hipGraphDestroy(graph);
-                    return rc != 0 ? rc : (int)e;
-                }
-                e = hipGraphInstantiate(&pieces[which][(size_t)c * d.L + l], graph, nullptr, nullptr, 0);
-                hipGraphDestroy(graph);
-                if (e != hipSuccess) return (int)e;
-            }
-        return 0;
-    }
-
-    int run_pipe(int which, hipStream_t main) {
-        const int C = ceil_div(d.T, chunk);
-        if (use_graph && pieces[which].empty()) {
-            const int rc = capture_pieces(which);
-            if (rc != 0) {
-                for (auto g : pieces[which])
-                    if (g) hipGraphExecDestroy(g);
-                pieces[which].clear();
-                return rc;
-            }
-        }
-        PL_TRY(fork(main));
-        hipEvent_t done[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-        for (int ci = 0; ci < C; ++ci) {
-            const int c = which == 0 ? ci : C - 1 - ci;
-            for (int li = 0; li < d.L; ++li) {
-                const int l = which == 0 ? li : d.L - 1 - li;
-                const int dep = which == 0 ? l - 1 : l + 1;   // the layer whose chunk-c results this piece consumes
-                const int user = which == 0 ? l + 1 : l - 1;  // the layer that consumes this piece's results
-                hipStream_t st = stream_of(l, main);
-                if (dep >= 0 && dep < d.L) PL_TRY((int)hipStreamWaitEvent(st, done[dep], 0));
-                if (use_graph) PL_TRY((int)hipGraphLaunch(pieces[which][(size_t)c * d.L + l], st));
-                else PL_TRY(which == 0 ? fwd_piece(l, c, st) : bwd_piece(l, c, st));
-                if (user >= 0 && user < d.L) {
-                    done[l] = next_event();
-                    PL_TRY((int)hipEventRecord(done[l], st));
-                }
-            }
-        }
-        return join(main);
-    }
 
     int run(int which, hipStream_t s) override {
         BgPrecisionScope precision(d.bf16);
-        if (stranded(which)) return note(run_parts(which, 0, nparts(), s));
-        if (schedule != 2) return PlanBase::run(which, s);
-        return note(run_pipe(which, s));
+        return PlanBase::run(which, s);
     }
-
-    // ---- alternative schedule, kept for experiments (PARROT_LAYER_STREAMS=1) ----------------------------
-    // Measured on MI355X (cfg2, T=800): the merged wavefront launches above run the scan in 50 ms fwd /
-    // 81 ms bwd, the stream-per-layer pipeline below in 69 / 105 ms when replayed from a hipGraph (parallel
-    // graph branches are not overlapped by the runtime) and is host-bound when launched eagerly.
-    // ---- layer-parallel streams ------------------------------------------------------------------
-    // Layer 0 runs on the caller's stream, layer l >= 1 on its own side stream.  Layer l at step t only
-    // waits for layer l-1 at step t (event), so while layer 0 is busy with the attention of step t the
-    // upper layers fill the chip with their GEMMs of earlier steps: the per-step critical path is one
-    // layer's chain instead of the sum over layers.  Under stream capture the side streams join the
-    // capture through the event waits, which turns the events into graph edges.
-    hipStream_t side[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-    std::vector<hipEvent_t> events;
-    size_t ev_next = 0;
 
     ~DecoderPlan() override {
-        free_strands();
-        for (int w = 0; w < 2; ++w)
-            for (auto g : pieces[w])
-                if (g) hipGraphExecDestroy(g);
-        for (auto e : events) hipEventDestroy(e);
-        for (int l = 0; l < PARROT_MAX_LAYERS; ++l)
-            if (side[l]) hipStreamDestroy(side[l]);
-    }
-
-    int ensure_streams() {
-        for (int l = 1; l < d.L; ++l)
-            if (!side[l]) {
-                hipError_t e = hipStreamCreateWithFlags(&side[l], hipStreamNonBlocking);
-                if (e != hipSuccess) return (int)e;
-            }
-        return 0;
-    }
-    hipEvent_t next_event() {
-        if (ev_next == events.size()) {
-            hipEvent_t e = nullptr;
-            hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            events.push_back(e);
-        }
-        return events[ev_next++];
-    }
-    hipStream_t stream_of(int l, hipStream_t main) const { return l == 0 ? main : side[l]; }
-
-    int fork(hipStream_t main) {
-        PL_TRY(ensure_streams());
-        ev_next = 0;
-        if (d.L > 1) {
-            hipEvent_t e = next_event();
-            PL_TRY((int)hipEventRecord(e, main));
-            for (int l = 1; l < d.L; ++l) PL_TRY((int)hipStreamWaitEvent(side[l], e, 0));
-        }
-        return 0;
-    }
-    int join(hipStream_t main) {
-        for (int l = 1; l < d.L; ++l) {
-            hipEvent_t e = next_event();
-            PL_TRY((int)hipEventRecord(e, side[l]));
-            PL_TRY((int)hipStreamWaitEvent(main, e, 0));
-        }
-        return 0;
-    }
-
-    int fwd_streams(hipStream_t main) {
-        PL_TRY(fork(main));
-        hipEvent_t done[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-        for (int t = 0; t < d.T; ++t) {
-            for (int l = 0; l < d.L; ++l) {
-                hipStream_t st = stream_of(l, main);
-                if (l > 0) PL_TRY((int)hipStreamWaitEvent(st, done[l - 1], 0));  // h_{l-1}(t) and w_t are ready
-                SkJob j;
-                gates_job(j, l, t);
-                PL_TRY(launch_jobs(&j, 1, st));
-                cand_job(j, l, t);
-                PL_TRY(launch_jobs(&j, 1, st));
-                if (l == 0) PL_TRY(att_fwd_step(t, st));
-                if (l + 1 < d.L) {
-                    done[l] = next_event();
-                    PL_TRY((int)hipEventRecord(done[l], st));
-                }
-            }
-        }
-        return join(main);
-    }
-
-    // Backward: same stream-per-layer pipeline in reverse time.  Layer l at step t waits for layer l+1
-    // at step t.  Cross-layer gradient contributions land in separate buffers (dhup[l] for the state,
-    // dw0 for layer 0's share of dw), so concurrent kernels never update the same element and no
-    // atomics are needed; the consumers add the two parts when they read.
-    int bwd_streams(hipStream_t main) {
-        const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E, BA = (size_t)d.B * d.A;
-        const int H = d.H, E = d.E;
-        PL_TRY(fork(main));
-        hipEvent_t done[PARROT_MAX_LAYERS] = {nullptr, nullptr, nullptr};
-        for (int t = d.T - 1; t >= 0; --t) {
-            for (int l = d.L - 1; l >= 0; --l) {
-                hipStream_t st = stream_of(l, main);
-                if (l + 1 < d.L) PL_TRY((int)hipStreamWaitEvent(st, done[l + 1], 0));
-                if (l == 0) PL_TRY(att_bwd_step(t, st));
-                GruStateBwdArgs ga;
-                ga.nchain = 1; ga.B = d.B; ga.H = H;
-                GruStateBwdChain& c = ga.chain[0];
-                c.dh = d.dh[l] + (t + 1) * BH;
-                c.dh2 = (l + 1 < d.L) ? d.dhup[l] + (t + 1) * BH : nullptr;
-                c.hprev = d.h[l] + t * BH;
-                c.z = d.z[l] + t * BH;
-                c.c = d.c[l] + t * BH;
-                c.mask = nullptr;
-                c.dC = d.dC[l] + t * BH;
-                c.dG = d.dG[l] + t * 2 * BH;
-                c.dhprev = d.dh[l] + t * BH;
-                PL_TRY(gru_state_bwd_launch(ga, st));
-
-                // X: d(r*h_prev) = dC . Wc[0:H,:]^T ; epilogue -> dG_r, dh_prev += d(rh) * r
-                SkJob x;
-                sk_job_init(x);
-                x.nseg = 1;
-                x.seg[0] = rseg(d.dC[l] + t * BH, l, 1, 0, H);
-                x.M = d.B; x.N = H; x.H = H; x.epi = SK_EPI_BWD_RH;
-                x.e0 = d.h[l] + t * BH; x.lde0 = H;
-                x.e1 = d.r[l] + t * BH; x.lde1 = H;
-                x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
-                x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
-                PL_TRY(launch_jobs(&x, 1, st));
-
-                // Y: gradients flowing to the layer's inputs, one job per destination.
-                SkJob jy[2 + PARROT_MAX_LAYERS];
-                int ny = 0;
-                const float* dG = d.dG[l] + t * 2 * BH;
-                const float* dC = d.dC[l] + t * BH;
-                {   // previous state of this layer: only the gate GEMM (rh part handled by X)
-                    SkJob& j = jy[ny++];
-                    sk_job_init(j);
-                    j.nseg = 1;
-                    j.seg[0] = rseg(dG, l, 0, 0, 2 * H);
-                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                    j.out = d.dh[l] + t * BH; j.ldo = H;
-                }
-                {   // attention context
-                    SkJob& j = jy[ny++];
-                    sk_job_init(j);
-                    j.nseg = 2;
-                    j.seg[0] = rseg(dG, l, 0, H, 2 * H);
-                    j.seg[1] = rseg(dC, l, 1, H, H);
-                    j.M = d.B; j.N = E; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                    j.out = (l == 0 ? d.dw0 + (size_t)t * BE : d.dw + (size_t)(t + 1) * BE); j.ldo = E;
-                }
-                for (int p = 0; p < l; ++p) {  // lower layers' states of the same step -> their dhup buffers
-                    SkJob& j = jy[ny++];
-                    sk_job_init(j);
-                    j.nseg = 2;
-                    j.seg[0] = rseg(dG, l, 0, H + E + p * H, 2 * H);
-                    j.seg[1] = rseg(dC, l, 1, H + E + p * H, H);
-                    j.M = d.B; j.N = H; j.H = H; j.epi = SK_EPI_LINEAR; j.accumulate = 1;
-                    j.out = d.dhup[p] + (t + 1) * BH; j.ldo = H;
-                }
-                PL_TRY(launch_jobs(jy, ny, st));
-                if (l > 0) {
-                    done[l] = next_event();
-                    PL_TRY((int)hipEventRecord(done[l], st));
-                }
-            }
-        }
-        return join(main);
+        if (att_flags && !flags_fake) (void)hipFree(att_flags);
+        if (bwd_flags && !flags_fake) (void)hipFree(bwd_flags);
     }
 };
 
@@ -3432,7 +2721,6 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             p->tiled = true;
         }
     }
-    if (p->schedule == 6 && !p->tiled) p->schedule = 5;  // the in-launch hand-off reads fragment-major weights
     if (p->schedule == 7) {
         // bf16 operands: only the wide step kernel takes a launch with a waiting job (skinny.hip wk_try_launch): every
         // launch of the scan must qualify, the first tick's (layer 0 alone) included.  f32 operands run on ska_kernel.
@@ -3451,7 +2739,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         e = getenv("PARROT_S5_SPLIT");
         p->s5_split = e ? atoi(e) != 0 : true;
     }
-    if (p->schedule == 6 || p->schedule == 7) {
+    if (p->schedule == 7) {
         if (hipMalloc(&p->att_flags, sizeof(unsigned) * (size_t)(desc->T + 2)) != hipSuccess) {
             if (!getenv("PARROT_TRACE_ONLY")) {  // (schedule tracing on a box without a GPU: a placeholder address)
                 delete p;
@@ -3468,12 +2756,6 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             else if (hipMalloc(&p->bwd_flags, sizeof(unsigned) * words) != hipSuccess) { delete p; return PARROT_ERR_BADARG; }
             p->bwd_fused = true;
         }
-        const char* e = getenv("PARROT_S6_ESPLIT");
-        p->esplit6 = e && atoi(e) > 0 ? atoi(e) : 1;
-        e = getenv("PARROT_S6_IB");
-        p->s6_ib = e ? atoi(e) != 0 : true;
-        e = getenv("PARROT_S6_BTILE");
-        p->s6_btile = e ? atoi(e) : 0;
     }
     if (desc->cell == 1 && desc->bf16 && p->tiled && !(getenv("PARROT_BWD_KSPLIT") && atoi(getenv("PARROT_BWD_KSPLIT")) == 0)) {
         bool have = desc->dw_b && desc->dw0_b && desc->B <= 64 && sk_wide_takes(desc->B, 4096, desc->H, desc->E) &&
@@ -3481,21 +2763,17 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
         for (int l = 0; l < desc->L; ++l)
             if (!desc->dh_b[l] || (l + 1 < desc->L && !desc->dhup_b[l])) have = false;
         p->bwd_ksplit = have;
-        p->bwd_k4 = have && desc->dh_c[0] && desc->dh_d[0] && desc->dw0_c && desc->dw0_d && (4 * desc->H) % 256 == 0 &&
-                    (getenv("PARROT_BWD_K4") && atoi(getenv("PARROT_BWD_K4")) != 0);  // opt-in: measured slower (51.4 vs 46.4 us per tick)
     }
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
-    p->setup_strands();
     {   // the K-balanced backward tick (bwd8): 2-layer f32 GRU decoders with fragment-major weights and all accumulators
         const char* e = getenv("PARROT_BWD_HETERO");
         bool ok = desc->cell == 0 && desc->L == 2 && !desc->bf16 && !desc->layer_norm && p->tiled && desc->B <= 64 &&
-                  p->nstrands == 1 && p->qpart == 0 && desc->dw_b && desc->dw_c && desc->dw0_b && desc->dw0_c &&
+                  desc->dw_b && desc->dw_c && desc->dw0_b && desc->dw0_c &&
                   desc->dhup_b[0] && desc->dhup_c[0] && (e ? atoi(e) != 0 : true);
         for (int l = 0; l < desc->L; ++l)
             if (!desc->dh_b[l]) ok = false;
         p->bwd_hetero = ok;
     }
-    if (p->nstrands > 1) p->bwd_ksplit = p->bwd_k4 = false;  // (row strands shift every per-row pointer: not wired for the second accumulators)
     if (desc->layer_norm && desc->L >= 2) {
         bool ok = p->schedule >= 2 && p->schedule != 7;
         for (int l = 1; l < desc->L && ok; ++l)
@@ -3560,26 +2838,6 @@ long long parrot_decoder_trace(void* plan, int which, long long* out, long long 
 
 int parrot_decoder_seq_fwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(0, (hipStream_t)stream); }
 int parrot_decoder_seq_bwd(void* plan, void* stream) { PH_ENTRY(); return static_cast<PlanBase*>(plan)->run(1, (hipStream_t)stream); }
-int parrot_decoder_parts(void* plan, int* strands) { PH_ENTRY();
-    if (!plan) return 0;
-    DecoderPlan* p = static_cast<DecoderPlan*>(plan);
-    if (strands) *strands = p->nstrands;
-    return p->stranded(1) ? p->nparts() : 1;
-}
-int parrot_decoder_part_steps(void* plan, int which, int part, int* t_lo, int* t_hi) { PH_ENTRY();
-    if (!plan || !t_lo || !t_hi || which < 0 || which > 1) return PARROT_ERR_BADARG;
-    DecoderPlan* p = static_cast<DecoderPlan*>(plan);
-    if (!p->stranded(which)) { *t_lo = 0; *t_hi = p->d.T; return part == 0 ? 0 : PARROT_ERR_BADARG; }
-    if (part < 0 || part >= p->nparts()) return PARROT_ERR_BADARG;
-    p->part_steps(which, part, *t_lo, *t_hi);
-    return 0;
-}
-int parrot_decoder_seq_fwd_part(void* plan, int part, void* stream) { PH_ENTRY();
-    return plan ? static_cast<DecoderPlan*>(plan)->run_part(0, part, (hipStream_t)stream) : PARROT_ERR_BADARG;
-}
-int parrot_decoder_seq_bwd_part(void* plan, int part, void* stream) { PH_ENTRY();
-    return plan ? static_cast<DecoderPlan*>(plan)->run_part(1, part, (hipStream_t)stream) : PARROT_ERR_BADARG;
-}
 int parrot_decoder_destroy(void* plan) { PH_ENTRY();
     delete static_cast<PlanBase*>(plan);
     return 0;

@@ -114,7 +114,7 @@ class Parrot(Brick):
             raw_output=False,
             # --- extensions (not in the reference) ---
             num_layers=3, encoder_literal=True, use_graph=True, seed=1234,
-            cell_type='gru', lstm_forget_bias=3.0, compute_dtype='float32', strands=0,
+            cell_type='gru', lstm_forget_bias=3.0, compute_dtype='float32',
             **kwargs):
         kwargs.setdefault('name', 'parrot')
         kwargs.setdefault('weights_init', IsotropicGaussian(0.01))  # train.py:30
@@ -146,9 +146,6 @@ class Parrot(Brick):
         self.num_speakers, self.speaker_dim = num_speakers, speaker_dim
         self.k_gmm, self.sampling_bias = k_gmm, sampling_bias
         self.num_layers, self.encoder_literal, self.use_graph = num_layers, encoder_literal, use_graph
-        # strands: independent batch-row ranges the training scan advances side by side (0: the library's default;
-        # see ParrotDecoderDesc.reserved).  Results do not depend on it.
-        self.strands = int(strands)
         # Pre-activation groups of a decoder layer: (key, width, Fork output suffix, packed matrix, name of the
         # recurrent block).  GRU (Blocks GatedRecurrent): gates 2H + candidate H.  LSTM (cell_type='lstm', the
         # BASELINE configs[3] generalisation; cell algebra of sampleRNN/lib/ops.py:505-553): one 4H group.
@@ -530,9 +527,6 @@ class Parrot(Brick):
                 ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
                           dhup_b=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
                           dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f))
-                if os.environ.get('PARROT_BWD_K4', '0') != '0':  # opt-in (measured slower): layer 0's products as FOUR K parts
-                    ws.update(dh_c0=torch.zeros(T + 1, B, H, **f), dh_d0=torch.zeros(T + 1, B, H, **f),
-                              dw0_c=torch.zeros(T + 1, B, E, **f), dw0_d=torch.zeros(T + 1, B, E, **f))
         else:
             for n in ('z', 'r', 'rh', 'c'):
                 ws[n] = [torch.empty(T, B, H, **f) for _ in range(L)]
@@ -571,7 +565,7 @@ class Parrot(Brick):
         d.T, d.B, d.H, d.E, d.A, d.U, d.L = T, B, H, E, A, U, L
         d.att_type = 1 if self.attention_type == 'softmax' else 0
         d.use_graph = int(self.use_graph)
-        d.reserved = self.strands
+        d.reserved = 0
         d.eps, d.alignment, d.sharpening, d.timing = self.epsilon, self.attention_alignment, 1.0, 1.0
         st = self.store.storage
         for l in range(L):
@@ -610,9 +604,6 @@ class Parrot(Brick):
             d.dw_b, d.dw0_b = ws['dw_b'].data_ptr(), ws['dw0_b'].data_ptr()
         if 'dw_c' in ws:
             d.dw_c, d.dw0_c = ws['dw_c'].data_ptr(), ws['dw0_c'].data_ptr()
-        if 'dh_c0' in ws:
-            d.dh_c[0], d.dh_d[0] = ws['dh_c0'].data_ptr(), ws['dh_d0'].data_ptr()
-            d.dw0_c, d.dw0_d = ws['dw0_c'].data_ptr(), ws['dw0_d'].data_ptr()
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
@@ -975,9 +966,6 @@ class Parrot(Brick):
                 ws['dw'][0].add_(ws['dw_c'][0])
             if 'dw0_c' in ws:
                 ws['dw0'][0].add_(ws['dw0_c'][0])
-            if 'dh_c0' in ws:
-                ws['dh'][0][0].add_(ws['dh_c0'][0]).add_(ws['dh_d0'][0])
-                ws['dw0'][0].add_(ws['dw0_d'][0])
 
         # the rest of the deferred gradients of the scan (biases, per-step additive inputs)
         sg_, sc_ = self.store.storage_grad, self.store.storage
@@ -1130,69 +1118,16 @@ class Parrot(Brick):
             ops.gemm(ws['dp'].view(R, 3 * A).t(), ws['h'][0][1:T + 1].view(R, H), out=sg_['dec.WattT'], accumulate=True)
 
     def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None):
-        """The backward scan and the weight-gradient GEMMs that only read what it leaves behind.  When the plan runs
-        the window in parts (parrot_decoder_parts > 1) the GEMMs of a finished part are enqueued on a second,
-        low-priority stream and run BESIDE the rest of the scan: the scan's step kernels are latency-bound and leave
-        most of the matrix pipes idle.  Same sums either way, taken in part order."""
-        plan = ws['plan']
-        lib = _lib.load()
-        nparts = int(lib.parrot_decoder_parts(plan, None))
-        overlap = nparts > 1 and os.environ.get('PARROT_DW_OVERLAP', '0') != '0'  # opt-in: measured slower (DESIGN 3.2)
-        if not overlap:
-            if before is not None:
-                before()
-            hook = getattr(self, 'on_early_gradients', None)
-            if hook is not None:  # data-parallel runs: the readout / output gradients are final -> their all-reduce starts
-                hook()            # now and travels beside the backward scan (dist.GradientExchange)
-            _lib.call('parrot_decoder_seq_bwd', plan, ops._stream())
-            self._weight_grad_rows(ws, save, T, B, 0, T)
-            return
-        main = torch.cuda.current_stream()
-        side = self._gemm_side_stream()
-        lo, hi = C.c_int(0), C.c_int(0)
-        done = T  # steps [done, T) have their weight-gradient GEMMs enqueued
-        pad = int(os.environ.get('PARROT_DW_LDS_PAD', '0'))
-        if before is not None:  # `before`: weight-gradient GEMMs whose operands are ready before the scan starts
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                if pad:
-                    _lib.call('parrot_set_gemm_lds_pad', pad)
-                try:
-                    before()
-                finally:
-                    if pad:
-                        _lib.call('parrot_set_gemm_lds_pad', 0)
-        for p_ in range(nparts):
-            _lib.call('parrot_decoder_seq_bwd_part', plan, p_, main.cuda_stream)
-            _lib.call('parrot_decoder_part_steps', plan, 1, p_, C.byref(lo), C.byref(hi))
-            if lo.value < done:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    if pad:
-                        _lib.call('parrot_set_gemm_lds_pad', pad)
-                    try:
-                        self._weight_grad_rows(ws, save, T, B, lo.value, done)
-                    finally:
-                        if pad:
-                            _lib.call('parrot_set_gemm_lds_pad', 0)
-                done = lo.value
-        main.wait_stream(side)
-
-    def _gemm_side_stream(self):
-        st = getattr(self, '_side_stream', None)
-        if st is None:
-            h = C.c_void_p()
-            _lib.call('parrot_stream_create', int(os.environ.get('PARROT_DW_PRIORITY', '1')), C.byref(h))
-            self._side_stream_handle = h
-            st = self._side_stream = torch.cuda.ExternalStream(h.value, device=self._dev())
-        return st
-
-    @staticmethod
-    def _split(rows):
-        s = 1
-        while s < 8 and rows // (s * 2) >= 2048:
-            s *= 2
-        return s
+        """`before()` (the readout weight gradients: operands ready before the scan starts), the backward scan, then the
+        deferred weight-gradient GEMMs that only read what the scan leaves behind.  (Rounds 2-4 could also run those GEMMs
+        part by part BESIDE the scan on a second stream: measured slower every time -- DESIGN.md 3.2 -- and removed.)"""
+        if before is not None:
+            before()
+        hook = getattr(self, 'on_early_gradients', None)
+        if hook is not None:  # data-parallel runs: the readout / output gradients are final -> their all-reduce starts
+            hook()            # now and travels beside the backward scan (dist.GradientExchange)
+        _lib.call('parrot_decoder_seq_bwd', ws['plan'], ops._stream())
+        self._weight_grad_rows(ws, save, T, B, 0, T)
 
     # ------------------------------------------------------------------ sampling
     def _sample_workspace(self, S, N, U):
@@ -1456,11 +1391,6 @@ class Parrot(Brick):
     def close(self):
         self._train_ws.clear()
         self._sample_ws.clear()
-        h = getattr(self, '_side_stream_handle', None)
-        if h is not None:  # the opt-in weight-gradient side stream (PARROT_DW_OVERLAP=1)
-            self._side_stream.synchronize()
-            _lib.call('parrot_stream_destroy', h)
-            self._side_stream = self._side_stream_handle = None
 
 
 def compose_readout_output(Wr, Wo_pad, br, radd, bo_pad, oadd_pad, n_rows):

@@ -286,12 +286,13 @@ def test_lstm_decoder_sample_model_parity(dev, kw):
 
 
 # ----------------------------------------------------------------------------- scan schedules
-@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("2", "3"), ("2", "50"), ("3", "3"), ("3", "50"), ("5", "50"), ("6", "50")])
+@pytest.mark.parametrize("sched,chunk", [("0", "50"), ("3", "3"), ("3", "50"), ("5", "50")])
 @pytest.mark.parametrize("cell", ["gru", "lstm"])
 def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
-    """The merged-wavefront schedule (0), the chunked layer pipeline (2) and the chunk-skewed wavefront with hoisted
-    projections (3) -- chunk 3 forces several chunks and a ragged last one -- are orders of the same arithmetic:
-    all must match the oracle, eager and graph."""
+    """The merged-wavefront schedule (0), the chunk-skewed wavefront with hoisted projections (3: what layer_norm runs on;
+    chunk 3 forces several chunks and a ragged last one) and the balanced wavefront (5) are orders of the same arithmetic:
+    all must match the oracle, eager and graph.  (Schedules 1, 2 and 6 of rounds 1-3 -- measured losers -- were removed
+    in round 5.)"""
     monkeypatch.setenv("PARROT_SCHEDULE", sched)
     monkeypatch.setenv("PARROT_CHUNK", chunk)
     for use_graph in (False, True):
@@ -301,13 +302,11 @@ def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
                           use_graph=True)
 
 
-@pytest.mark.parametrize("sched", [5, 6])
+@pytest.mark.parametrize("sched", [5])
 def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
-    """Schedules 5 (attention in one heterogeneous launch with the upper layers' input projections) and 6 (attention
-    inside the gate launch: layer 0's gate workgroups wait for the attention workgroups of the same launch) on the
-    shapes the other schedules are tested on, plus the cases that stress the in-launch hand-off: one layer (the
-    launch holds nothing but the attention and the waiting gate product), more rows than one row tile, the softmax
-    window, ragged masks, a window of one step, eager and graph."""
+    """Schedule 5 (attention in one heterogeneous launch with the upper layers' input projections) on the shapes the
+    other schedules are tested on, plus: one layer (falls back to 0), more rows than one row tile, the softmax window,
+    ragged masks, a window of one step, eager and graph."""
     monkeypatch.setenv("PARROT_SCHEDULE", str(sched))
     for use_graph in (False, True):
         _check_cost_and_grads(dev, T=9, B=40, U=9, num_layers=2, encoder_type='bidirectional', use_graph=use_graph,
@@ -315,13 +314,13 @@ def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
     _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
                           use_speaker=True, ragged=True, use_graph=True, expect_schedule=sched)
     _check_cost_and_grads(dev, T=6, B=4, U=9, num_layers=1, encoder_type='bidirectional', use_graph=True,
-                          expect_schedule=sched if sched == 6 else 0)
+                          expect_schedule=0)
     _check_cost_and_grads(dev, T=5, B=3, U=8, num_layers=2, encoder_type='bidirectional', attention_type='softmax',
                           use_graph=True, expect_schedule=sched)
     _check_cost_and_grads(dev, T=1, B=4, U=6, num_layers=2, encoder_type='bidirectional', use_graph=True,
                           expect_schedule=sched)
     # LSTM layers: one fused product per layer-step, the input projections keep the gate-interleaved column order of
-    # the tiled weight copies (schedule 6 does not cover them and falls back to 5)
+    # the tiled weight copies
     for use_graph in (False, True):
         _check_cost_and_grads(dev, T=8, B=5, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
                               use_speaker=True, cell_type='lstm', use_graph=use_graph, expect_schedule=5)
@@ -358,25 +357,6 @@ def test_lstm_one_launch_per_tick_schedule(dev, monkeypatch):
     # flagged tail deals its K chunks to the waves behind the main ring's -- same terms, other order)
     for a, b, n in zip(got["0"], got["7"], ("cost", "frames", "w")):
         assert_close(a, b.double().cpu(), 2e-6, f"schedule 7 vs 0: {n}")
-
-
-# ----------------------------------------------------------------------------- strands and parts
-@pytest.mark.parametrize("strands,qpart,overlap", [("2", "3", "1"), ("3", "0", "1"), ("4", "2", "0"), ("1", "4", "1")])
-@pytest.mark.parametrize("cell", ["gru", "lstm"])
-def test_strands_and_parts_agree_with_oracle(dev, monkeypatch, strands, qpart, overlap, cell):
-    """The training scan advanced as several independent batch-row ranges on their own streams (PARROT_STRANDS), cut
-    along time into graph parts (PARROT_QPART ticks) with the weight-gradient GEMMs of finished parts running beside
-    the rest of the backward scan (PARROT_DW_OVERLAP): the same arithmetic per row, so everything must match the
-    oracle -- ragged row ranges (B = 40 -> 32 + 8 / 16 + 16 + 8), a ragged last part, eager and graph."""
-    monkeypatch.setenv("PARROT_SCHEDULE", "0")  # strands and parts are features of the merged wavefront
-    monkeypatch.setenv("PARROT_STRANDS", strands)
-    monkeypatch.setenv("PARROT_QPART", qpart)
-    monkeypatch.setenv("PARROT_DW_OVERLAP", overlap)
-    for use_graph in (False, True):
-        _check_cost_and_grads(dev, T=8, B=40, U=9, num_layers=3, encoder_type='bidirectional', full_feedback=True,
-                              use_speaker=True, cell_type=cell, use_graph=use_graph)
-    _check_cost_and_grads(dev, T=7, B=20, U=6, num_layers=2, encoder_type='bidirectional', cell_type=cell,
-                          use_graph=True, ragged=True)
 
 
 # ----------------------------------------------------------------------------- layer_norm=True (model.py:24-34)
@@ -515,43 +495,3 @@ def test_full_size_cfg2_properties(dev, monkeypatch):
     assert_close(g3, 2.0 * g1, 1e-6, "backward linearity")
 
 
-def test_full_size_cfg2_strands_are_bit_identical(dev, monkeypatch):
-    """BASELINE configs[1] at its real sizes: the scan as 1, 2 and 4 strands gives bitwise the same cost, frames, kappa
-    and -- with the weight-gradient GEMMs taken over the whole window -- bitwise the same flat gradient; with the GEMMs
-    taken part by part beside the scan the gradient agrees to the rounding of the changed summation order."""
-    from parrot_amd.model import Parrot
-    kw = dict(num_layers=2, rnn_h_dim=1024, readouts_dim=1024, encoder_type='bidirectional')
-    T, B, U = 800, 64, 200
-    g = torch.Generator().manual_seed(4321)
-    feat = torch.randn(T + 1, B, 63, generator=g).to(dev)
-    fm = torch.ones(T + 1, B, device=dev)
-    lab = torch.randint(0, 43, (B, U), generator=g).to(dev)
-    lm = torch.ones(B, U, device=dev)
-
-    def run(strands, qpart, overlap):
-        monkeypatch.setenv("PARROT_SCHEDULE", "0")
-        monkeypatch.setenv("PARROT_BWD_HETERO", "0")  # (strands run the three-launch backward tick: so does the base)
-        monkeypatch.setenv("PARROT_STRANDS", str(strands))
-        monkeypatch.setenv("PARROT_QPART", str(qpart))
-        monkeypatch.setenv("PARROT_DW_OVERLAP", str(overlap))
-        m = Parrot(device=dev, use_graph=True, seed=5, **kw).initialize()
-        with torch.no_grad():
-            m.get_parameter_dict()['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.5)
-        m.zero_grad()
-        c, upd, av, _ = m.compute_cost(feat, fm, lab, lm, None, 1, B)
-        c.backward()
-        out = (c.detach().clone(), av[0].clone(), av[1].clone(), m.flat_gradients.clone())
-        m.close()
-        return out
-
-    base = run(1, 0, 0)
-    for strands, qpart, overlap in ((2, 0, 0), (4, 100, 0), (2, 100, 1), (4, 64, 1)):
-        o = run(strands, qpart, overlap)
-        what = f"strands={strands} qpart={qpart} overlap={overlap}"
-        assert torch.equal(o[0], base[0]), what + ": cost"
-        assert torch.equal(o[1], base[1]), what + ": frames"
-        assert torch.equal(o[2], base[2]), what + ": kappa"
-        if not overlap:
-            assert torch.equal(o[3], base[3]), what + ": gradient"
-        else:
-            assert_close(o[3], base[3], 1e-6, what + ": gradient")

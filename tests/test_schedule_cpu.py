@@ -3,13 +3,13 @@ launch and every job in it, the byte ranges it reads and writes (on fake device 
 orderings a schedule has to keep follow from the scan of model.py:651-737 and its gradient:
 
   * no job of a launch touches a range another job of the same launch writes (the jobs of a launch run concurrently) --
-    except a read the job takes behind the in-launch flag of schedules 6 and 7, whose writer must then be the attention job;
+    except a read the job takes behind the in-launch flag of schedule 7, whose writer must then be the attention job;
   * a write-once buffer (states, gates, window parameters, saved activations, pre-activation scratch; in the backward the
     pre-activation gradients) is written exactly once per element and read only by LATER launches;
   * an accumulator (dh, dw, dw0, dhup) is never written again after a job has taken it as a plain input (the state /
     attention backward consuming the total).
 
-Run for schedules 0, 5, 6 and 7, GRU and LSTM layers, 1-3 layers, with and without caller data in the per-step input
+Run for schedules 0, 5 and 7, GRU and LSTM layers, 1-3 layers, with and without caller data in the per-step input
 buffers, forward and backward."""
 import ctypes as C
 import os
@@ -95,11 +95,6 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
     d.phi = ar.take("phi", T * B * U * f)
     d.dw = ar.take("dw", (T + 1) * B * E * f)
     d.dw0 = ar.take("dw0", (T + 1) * B * E * f)
-    if bf16 and cell == 1:  # layer 0's products as four K parts
-        d.dh_c[0] = ar.take("dh_c0", (T + 1) * B * H * f)
-        d.dh_d[0] = ar.take("dh_d0", (T + 1) * B * H * f)
-        d.dw0_c = ar.take("dw0_c", (T + 1) * B * E * f)
-        d.dw0_d = ar.take("dw0_d", (T + 1) * B * E * f)
     if (bf16 and cell == 1) or hetero:
         d.dw_b = ar.take("dw_b", (T + 1) * B * E * f)
         d.dw0_b = ar.take("dw0_b", (T + 1) * B * E * f)
@@ -205,7 +200,7 @@ def _check(recs, ar, write_once, accumulators, T, slot_bytes):
     return len(by_launch)
 
 
-@pytest.mark.parametrize("sched", [0, 5, 6, 7])
+@pytest.mark.parametrize("sched", [0, 5, 7])
 @pytest.mark.parametrize("cell,nl,seq_init", [(0, 1, 0), (0, 2, 0), (0, 3, 0), (0, 3, 0b101), (1, 1, 0), (1, 2, 0), (1, 3, 0b010)])
 def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_init):
     L, lib = _lib()
@@ -214,8 +209,6 @@ def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_ini
     try:
         got = lib.parrot_decoder_schedule(plan)
         want = sched
-        if sched == 6 and cell == 1:
-            want = 5        # the in-launch hand-off covers GRU layers only
         if sched == 7 and cell == 0:
             want = 5        # one launch per tick with the attention inside it: LSTM layers only
         if want == 5 and nl == 1:
@@ -243,8 +236,8 @@ def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_ini
                     if cell == 0:
                         slot[f"seq_c{l}"] = T * B * H * f
         n_fwd = _check(recs, ar, fwd_once, set(), T, slot)
-        ticks = {0: T + nl - 1, 5: T + nl, 6: T + max(1, 2 * (nl - 1)), 7: T + max(1, nl if nl > 1 else 0)}[got]
-        per_tick = 1 if got == 7 else (2 if cell == 1 else {0: 3, 5: 3, 6: 2}[got])
+        ticks = {0: T + nl - 1, 5: T + nl, 7: T + max(1, nl if nl > 1 else 0)}[got]
+        per_tick = 1 if got == 7 else (2 if cell == 1 else 3)
         assert n_fwd <= ticks * per_tick and n_fwd >= T * per_tick - 2, (n_fwd, ticks, per_tick)
         # backward
         bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)} | ({f"dC{l}" for l in range(nl)} if cell == 0 else set())
@@ -263,7 +256,6 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
     is behind a flag whose writer -- the attention job or a chain -- is in the same launch)."""
     L, lib = _lib()
     monkeypatch.setenv("PARROT_WK", "2")
-    monkeypatch.setenv("PARROT_BWD_K4", "1")  # (layer 0's products as four K parts: opt-in, covered here)
     T, B, H, E, A, U = 5, 20, 64, 64, 4, 7
     plan, ar, d = _make_plan(L, lib, None, 1, nl, 0, monkeypatch, T, B, H, E, A, U, bf16=1)
     try:
@@ -279,14 +271,14 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         assert n_fwd == T + max(1, nl if nl > 1 else 0)
         recs = _trace(lib, plan, 1)
         bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)}
-        acc = {"dw", "dw0", "dw_b", "dw0_b", "dw0_c", "dw0_d", "dh_c0", "dh_d0"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
+        acc = {"dw", "dw0", "dw_b", "dw0_b"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
         acc |= {f"dh_b{l}" for l in range(nl)} | {f"dhup_b{l}" for l in range(nl - 1)}
         n_bwd = _check(recs, ar, bwd_once, acc, T, {})
         assert n_bwd == T + nl - 1  # one launch per tick
         flagged = [r for r in recs if r[2] == 3]
         assert flagged and all(_owner(ar, r[3]).startswith("dG") for r in flagged)
         # the products really run as two K halves: the second accumulators are written (stored) and read back
-        for name in ["dw0_b", "dw0_c", "dw0_d", "dh_c0", "dh_d0"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
+        for name in ["dw0_b"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
             kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
             assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
     finally:
