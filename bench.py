@@ -113,7 +113,7 @@ def kernel_source_digest(root=ROOT):
     """sha256 over the sources of the step kernels and their schedules: what a PMC traffic figure is valid for."""
     import hashlib
     hd = hashlib.sha256()
-    for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
+    for name in ("skinny.hip", "skinny.h", "plans.hip", "plans_common.h", "att_fwd_body.h"):
         hd.update(open(os.path.join(root, "parrot_amd", "csrc", name), "rb").read())
     return hd.hexdigest()
 

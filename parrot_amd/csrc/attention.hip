@@ -109,13 +109,7 @@ int att_state_bwd_launch(const AttBwdArgs* gin, const LstmStateBwdArgs& sa, int 
 int att_default_esplit(int B, int E) {
     // aim for >= 256 workgroups while keeping slices >= 32 columns
     // every slice recomputes the projection (reads WattT, 3A*H floats), so more slices = more L2
-    // traffic; fewer = fewer busy CUs.  PARROT_ATT_ESPLIT overrides for experiments.
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("PARROT_ATT_ESPLIT");
-        forced = e ? atoi(e) : 0;
-    }
-    if (forced > 0) return forced;
+    // traffic; fewer = fewer busy CUs.
     int es = 1;
     while (B * es < 128 && E / (es * 2) >= 32) es *= 2;
     return es;

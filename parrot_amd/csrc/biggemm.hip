@@ -732,12 +732,7 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
         // operand is fetched as 16-byte vectors along k: with a 32-deep tile a wave load touches 16 rows x 64 bytes = 16 half
         // cache lines, which the CU's vector-memory path moves at a quarter of the rate of whole lines (first
         // r05 build: 310 TFLOP/s); with 64 a wave load is 8 rows x one whole 128-byte line.
-        static int bkt_tn = -1;
-        if (bkt_tn < 0) {
-            const char* e = getenv("PARROT_GEMM_BF16IN_BK");
-            bkt_tn = (e && atoi(e) == 64) ? 64 : 32;
-        }
-        const int bkt = (axc && bxc) ? bkt_tn : 64;
+        const int bkt = (axc && bxc) ? 32 : 64;
         const dim3 g2(tm * tn, a.nbatch * a.splitk), b8(512);
         auto go = [&](auto kern, size_t lds) {
             static bool attr_done = false;  // (one flag per kernel instantiation: the lambda's call operator is a template)
@@ -768,11 +763,7 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
         else hipLaunchKernelGGL((bg_kernel_bf16<false, false>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);
         return (int)hipGetLastError();
     }
-    static int w8 = -1;
-    if (w8 < 0) {
-        const char* e = getenv("PARROT_GEMM_W8");
-        w8 = e ? atoi(e) : 1;  // measured on MI355X: 113-124 TFLOP/s vs 87-102 for the 4-wave kernel
-    }
+    constexpr bool w8 = true;  // measured on MI355X: 113-124 TFLOP/s vs 87-102 for the 4-wave kernel (kept below for reference)
     if (w8) {
         dim3 b8(512);
         if (axc && bxc) hipLaunchKernelGGL((bg_kernel8<true, true>), grid, b8, pad, stream, a, vecA, vecB, tiles_m, tiles_n);

@@ -14,12 +14,7 @@
 #include <mutex>
 
 static int gemm_target_wgs() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PARROT_GEMM_TARGET_WGS");
-        v = e ? atoi(e) : 1024;  // 8-wave kernel: 1024..4096 measure the same; fewer slices = less partial-sum traffic
-    }
-    return v;
+    return 1024;  // 8-wave kernel: 1024..4096 measure the same; fewer slices = less partial-sum traffic
 }
 
 static std::atomic<int> g_gemm_bf16{0};      // parrot_set_gemm_precision (process-wide; plans override per thread)

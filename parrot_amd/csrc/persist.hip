@@ -726,8 +726,6 @@ int pm_max_workgroups() {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         n = prop.multiProcessorCount > 256 ? 256 : prop.multiProcessorCount;
-        const char* e = getenv("PARROT_PM_WGS");  // development knob
-        if (e && atoi(e) > 0 && atoi(e) < n) n = atoi(e);
     }
     return n;
 }
@@ -738,7 +736,7 @@ int pm_status(const PmProgram& P) {
     PH_CHECK(hipMemcpy(&w, P.sync + PM_S_STICKY, sizeof(w), hipMemcpyDeviceToHost));
     if (w) {
         fprintf(stderr, "[parrot_amd] persistent launch gave up: sticky word 0x%x (site %u)\n", w, w & 15u);
-        if (getenv("PARROT_PM_DUMP")) {  // development aid: the barrier words of the launch that gave up
+        if (getenv("PARROT_PM_DUMP_PLAN")) {  // development aid: the barrier words of the launch that gave up
             unsigned h[PM_SYNC_WORDS];
             if (hipMemcpy(h, P.sync, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
                 fprintf(stderr, "  nwg %d n_ticks %d n_slots %d  TOP %u TOTAL %u ABORT %u\n", P.nwg, P.n_ticks, P.n_slots, h[PM_S_TOP],

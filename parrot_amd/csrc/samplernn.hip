@@ -153,10 +153,6 @@ struct SrPlan {
     int make_tiled() {
         const size_t D = d.D, nfr = d.BFS / d.FS;
         if (d.n_rnn != 0 || (d.D & 15)) return 0;
-        {
-            const char* e = getenv("PARROT_SR_TILED");
-            if (e && atoi(e) == 0) return 0;
-        }
         const size_t per = 3 * D * D + 2 * D * D + D * D;
         const size_t total = 2 * per + D * nfr * D + D * d.FS * D;
         if (hipMalloc(&tiled_slab, total * sizeof(float)) != hipSuccess) { tiled_slab = nullptr; return 0; }

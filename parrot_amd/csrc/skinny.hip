@@ -1349,12 +1349,7 @@ static bool wk_try_launch(const SkLaunch& Lin, hipStream_t stream, int* rc, cons
     if (att) {
         const size_t alds = att_fwd_lds(att->U);
         if (alds > lds) lds = alds;
-        static int att_last_env = -1;
-        if (att_last_env < 0) {
-            const char* e2 = getenv("PARROT_SKA_ATT_LAST");
-            att_last_env = e2 ? atoi(e2) : 1;
-        }
-        const int att_last = any_flag ? 0 : att_last_env;  // producers lead the grid when somebody waits for them
+        const int att_last = any_flag ? 0 : 1;  // producers lead the grid when somebody waits for them
         if (g_prof.on) {
             SkProfRec r;
             (void)hipEventCreate(&r.e0);
@@ -1495,17 +1490,6 @@ void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid_out, size_t& lds_ou
             if (better) { best_mb = mb; best_nb = nb; best_wg = wg; best_cost = cost; }
         }
     }
-    // development knob: PARROT_SK_TILE="mb,nb" forces the tile shape where it is legal for the launch
-    static int force_mb = -1, force_nb = -1;
-    if (force_mb < 0) {
-        force_mb = 0;
-        const char* e = getenv("PARROT_SK_TILE");
-        if (e && sscanf(e, "%d,%d", &force_mb, &force_nb) != 2) force_mb = 0;
-    }
-    if (force_mb >= 1 && force_mb <= 4 && (force_nb == 1 || (force_nb == 2 && nb2_ok)) &&
-        16 * (force_mb - 1) < maxM) {
-        best_mb = force_mb; best_nb = force_nb;
-    }
     if (Lin.force_tile > 0) {  // the plan's choice for this launch
         const int fmb = Lin.force_tile / 10, fnb = Lin.force_tile % 10;
         if (fmb >= 1 && fmb <= 4 && (fnb == 1 || (fnb == 2 && nb2_ok)) && 16 * (fmb - 1) < maxM) {
@@ -1524,13 +1508,7 @@ void sk_prepare(const SkLaunch& Lin, SkLaunch& L, dim3& grid_out, size_t& lds_ou
     }
     L.zmode = equal ? 1 : 0;
     grid_out = dim3(equal ? wmax : t, ceil_div(maxM, 16 * mb), equal ? L.njobs : 1);
-    // development knob: PARROT_SK_LDS_PAD=bytes of extra dynamic LDS per workgroup (caps the workgroups per CU)
-    static long long lds_pad = -1;
-    if (lds_pad < 0) {
-        const char* e = getenv("PARROT_SK_LDS_PAD");
-        lds_pad = e ? atoll(e) : 0;
-    }
-    lds_out = (size_t)SK_NW * mb * nb * 64 * sizeof(f32x4) + (size_t)lds_pad;
+    lds_out = (size_t)SK_NW * mb * nb * 64 * sizeof(f32x4);
     mbnb_out = mb * 10 + nb;
 }
 
@@ -1575,13 +1553,8 @@ static void ska_dispatch(const SkLaunch& L, const AttFwdArgs& g, int natt_x, dim
     // Order of the two kinds of workgroups in the grid.  Without in-launch dependencies the GEMM workgroups (the long
     // ones) go first and the attention fills in behind them (measured: forward scan 28.0 -> 25.3 ms at cfg2); a job that
     // waits for the attention needs its producers dispatched first.
-    static int att_last_env = -1;
-    if (att_last_env < 0) {
-        const char* e = getenv("PARROT_SKA_ATT_LAST");
-        att_last_env = e ? atoi(e) : 1;
-    }
     ska_allow_lds<MB, NB>();
-    int att_last = att_last_env;
+    int att_last = 1;
     for (int q = 0; q < L.njobs; ++q)
         if (L.job[q].wait_flag) att_last = 2;  // producers first, and all of them in grid row 0
     if (g_prof.on) {
@@ -1637,14 +1610,6 @@ int sk_launch_att(const SkLaunch& Lin, const AttFwdArgs& att, hipStream_t stream
     grid.x += (unsigned)natt_x;
     const size_t alds = att_fwd_lds(g.U);
     if (alds > lds) lds = alds;
-    {   // development knob: extra dynamic LDS per workgroup of the heterogeneous launches (caps the workgroups per CU)
-        static long long pad = -1;
-        if (pad < 0) {
-            const char* e = getenv("PARROT_SKA_LDS_PAD");
-            pad = e ? atoll(e) : 0;
-        }
-        lds += (size_t)pad;
-    }
     switch (mbnb) {
         case 11: ska_dispatch<1, 1>(L, g, natt_x, grid, lds, stream); break;
         case 12: ska_dispatch<1, 2>(L, g, natt_x, grid, lds, stream); break;
@@ -1702,12 +1667,7 @@ int sk_launch_bwd_hetero(const SkLaunch& Lin, const AttBwdArgs* att, const GruSt
     }
     // the chains that are not fused behind the attention take 4 batch rows per block: 16 CUs instead of 64 at B = 64, so
     // that (64 attention rows + 16 + 160 GEMM workgroups at cfg2) every block of the launch finds a CU at once
-    static int rpb_env = -1;
-    if (rpb_env < 0) {
-        const char* e = getenv("PARROT_SKB_RPB");
-        rpb_env = e && atoi(e) > 0 ? atoi(e) : 4;
-    }
-    const int rpb = rpb_env;
+    const int rpb = 4;
     const int nlead = att_rows + (sa.nchain - (att ? 1 : 0)) * ceil_div(sa.B, rpb);
     SkLaunch L;
     dim3 grid;

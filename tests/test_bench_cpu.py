@@ -12,7 +12,7 @@ if ROOT not in sys.path:
 def _fake_tree(tmp_path):
     csrc = tmp_path / "parrot_amd" / "csrc"
     csrc.mkdir(parents=True)
-    for name in ("skinny.hip", "skinny.h", "plans.hip", "att_fwd_body.h"):
+    for name in ("skinny.hip", "skinny.h", "plans.hip", "plans_common.h", "att_fwd_body.h"):
         (csrc / name).write_text("// " + name + "\n")
     (tmp_path / "profiles").mkdir()
     return str(tmp_path)

@@ -1,4 +1,4 @@
-"""The decode machine's step cut along K by the age of its operands (plans.hip, build_persist_pieces): planned and
+"""The decode machine's step cut along K by the age of its operands (plans_decode.hip, build_persist_pieces): planned and
 replayed symbolically on the CPU -- no device memory is touched (parrot_sample_plan_pieces_dry)."""
 import ctypes as C
 

@@ -47,7 +47,7 @@ else:
         dt = time.perf_counter() - t0
         print(f"decode {1e3 * dt:.2f} ms = {1e6 * dt / S:.2f} us per step")
     pw = m._sample_ws.get((S, N, U))['pm']['ws']
-    pieces = os.environ.get("PARROT_PM_PIECES", "1") != "0"  # plans.hip build_persist_pieces: 2L + 2 phases, S + 1 ticks
+    pieces = os.environ.get("PARROT_PM_PIECES", "1") != "0"  # plans_decode.hip build_persist_pieces: 2L + 2 phases, S + 1 ticks
     from parrot_amd import _lib as _plib
     kind = int(_plib.load().parrot_sample_is_persistent(m._sample_ws.get((S, N, U))['plan']))
     ticks, nslots = {3: (S + 2, 2 * L + 1), 2: (S + 1, 2 * L + 2)}.get(kind, (S, 2 * L + 3))
