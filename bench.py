@@ -118,7 +118,7 @@ def kernel_source_digest(root=ROOT):
     return hd.hexdigest()
 
 
-def pmc_traffic_figure(root=ROOT, names=("r04_pmc_traffic.json",), key="hbm_bytes_per_launch"):
+def pmc_traffic_figure(root=ROOT, names=("r05_pmc_traffic.json", "r04_pmc_traffic.json"), key="hbm_bytes_per_launch"):
     """(bytes per launch | None, source note).  HBM-side bytes per step-kernel launch come from separate rocprofv3 --pmc
     passes (FETCH_SIZE / WRITE_SIZE cannot share a pass with the timed run), so the number is a committed measurement,
     not one of this run -- and it is only reported while the kernel sources it was measured on are unchanged (digest
@@ -178,7 +178,7 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
         # bf16 operands: 16 x the f32 matrix rate, half the weight bytes -- the step GEMMs (M = 64 rows per weight
         # element) are bound by how fast the weights and the f32 activations arrive, so the roof is HBM / L2 bandwidth
         gbps = by.value / us.value * 1e-3
-        traffic4, traffic4_src = pmc_traffic_figure(names=("r04_pmc_traffic_cfg4.json",))
+        traffic4, traffic4_src = pmc_traffic_figure(names=("r05_pmc_traffic_cfg4.json", "r04_pmc_traffic_cfg4.json"))
         return {
             "kernel": "wk_kernel family (fused LSTM step GEMM, bf16 operands, fwd + bwd ticks as one launch each)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000, "unit": "GB/s", "frac": round(gbps / 8000, 4),
@@ -200,7 +200,11 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
     return {
         "kernel": "sk_kernel (fused GRU gate/candidate/backward step GEMM: the plain launches, fwd + bwd)",
         "bound": "mfma", "achieved": round(ach_d, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(ach_d / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "frac": round(ach_d / peak, 4), "frac_plain": round(ach_d / peak, 4), "frac_family": round(ach / peak, 4),
+        "frac_note": "frac = frac_plain: the plain step-GEMM launches alone (the dominant kernel); frac_family: every step "
+                     "launch incl. the heterogeneous ones, whose time contains the attention forward / backward chains and "
+                     "whose flops do not (the reading of rounds 1-3)",
+        "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_step": int(n_d), "avg_launch_us": round(us_d / n_d, 3),
         "alg_flops_per_launch": round(fl_d / n_d), "alg_bytes_per_launch": round(by_d / n_d),
         "alg_GBps": round(by_d / us_d * 1e-3, 1), "hbm_peak_GBps": 8000,

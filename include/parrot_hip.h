@@ -300,6 +300,11 @@ typedef struct ParrotDecoderDesc {
     float* dhup_c[PARROT_MAX_LAYERS];
     float* dw_c;
     float* dw0_c;
+    /* Optional (round 5; bf16 LSTM decoders whose backward tick is one launch): dG16[l], [T,B,4H] bf16 -- the backward scan
+     * also leaves every pre-activation gradient row rounded to bf16 (nearest even: exactly what parrot_to_bf16 would make
+     * of dG[l]), so the deferred weight-gradient products (parrot_gemm_bf16in) need no conversion pass over 3 x [T,B,4H]
+     * floats.  parrot_decoder_writes_bf16_grads(plan) says whether the plan honours them (all given, fused backward). */
+    void* dG16[PARROT_MAX_LAYERS];
 } ParrotDecoderDesc;
 
 /* Floats of persist_ws a plan for this descriptor needs; 0 when the configuration does not qualify for the persistent
@@ -328,6 +333,7 @@ long long parrot_decoder_trace_jobs(void* plan, int which, long long* out, long 
 int parrot_decoder_status(void* plan);
 
 int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan);
+int parrot_decoder_writes_bf16_grads(void* plan);
 int parrot_decoder_seq_fwd(void* plan, void* stream);
 int parrot_decoder_seq_bwd(void* plan, void* stream);
 int parrot_decoder_destroy(void* plan);

@@ -72,6 +72,7 @@ class DecoderDesc(C.Structure):
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
         ("dh_b", C.c_void_p * MAX_LAYERS), ("dhup_b", C.c_void_p * MAX_LAYERS), ("dw_b", C.c_void_p), ("dw0_b", C.c_void_p),
         ("dhup_c", C.c_void_p * MAX_LAYERS), ("dw_c", C.c_void_p), ("dw0_c", C.c_void_p),
+        ("dG16", C.c_void_p * MAX_LAYERS),
     ]
 
 
@@ -163,6 +164,7 @@ SIGNATURES = {
     "parrot_decoder_persist_floats": (C.c_longlong, [C.POINTER(DecoderDesc)]),
     "parrot_decoder_is_persistent": (_i, [_vp]),
     "parrot_decoder_schedule": (_i, [_vp]),
+    "parrot_decoder_writes_bf16_grads": (_i, [_vp]),
     "parrot_decoder_trace": (C.c_longlong, [_vp, _i, C.POINTER(C.c_longlong), C.c_longlong]),
     "parrot_decoder_trace_jobs": (C.c_longlong, [_vp, _i, C.POINTER(C.c_longlong), C.c_longlong]),
     "parrot_decoder_seq_fwd": (_i, [_vp, _vp]),

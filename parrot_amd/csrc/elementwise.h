@@ -68,6 +68,8 @@ struct LstmStateBwdChain {
     const float* c_prev;  // [B,H]
     const float* c_new;   // [B,H]
     float* dP;            // [B,4H] out: gradient wrt the pre-activations
+    void* dP16 = nullptr; // [B,4H] bf16, optional: the same rows rounded to bf16 (nearest even) for the deferred weight-gradient
+                          // products of a bf16-operand decoder -- written by the in-launch variant below (round 5)
 };
 struct LstmStateBwdArgs {
     LstmStateBwdChain chain[4];
@@ -117,6 +119,12 @@ __device__ __forceinline__ void lstm_state_bwd_row_pub(const LstmStateBwdChain& 
         const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * i);
         float* q = o + 4 * i;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
+    }
+    if (c.dP16) {  // the bf16 copy the weight-gradient GEMMs read after the scan (plain stores: nobody reads it in this launch)
+        __bf16* o16 = reinterpret_cast<__bf16*>(c.dP16) + (size_t)m * 4 * H;
+        for (int i = tid; i < (H >> 1); i += nthr)  // 4H / 8 vectors of eight (H % 2 == 0; bf16 decoders have H % 32 == 0)
+            *reinterpret_cast<bf16x8*>(o16 + 8 * i) = ph_bf16x8(*reinterpret_cast<const f32x4*>(row + 8 * i),
+                                                                *reinterpret_cast<const f32x4*>(row + 8 * i + 4));
     }
 }
 

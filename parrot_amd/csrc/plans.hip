@@ -821,6 +821,7 @@ struct DecoderPlan : PlanBase {
                     c.c_prev = d.cst[l] + t * BH;
                     c.c_new = d.cst[l] + (t + 1) * BH;
                     c.dP = d.dG[l] + (size_t)t * 4 * BH;
+                    c.dP16 = (bwd_fused && d.dG16[l]) ? static_cast<char*>(d.dG16[l]) + (size_t)t * 4 * BH * 2 : nullptr;
                 }
                 for (int l = d.L - 1; l >= 0; --l) {
                     const int t = tl[l];
@@ -1480,6 +1481,13 @@ int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<De
 
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
 int parrot_decoder_schedule(void* plan) { return plan ? static_cast<DecoderPlan*>(plan)->schedule : -1; }
+int parrot_decoder_writes_bf16_grads(void* plan) {
+    const DecoderPlan* p = static_cast<const DecoderPlan*>(plan);
+    if (!p || !p->bwd_fused) return 0;
+    for (int l = 0; l < p->d.L; ++l)
+        if (!p->d.dG16[l]) return 0;
+    return 1;
+}
 long long parrot_decoder_trace_jobs(void* plan, int which, long long* out, long long cap) { PH_ENTRY();
     if (!plan || which < 0 || which > 1) return -PARROT_ERR_BADARG;
     std::vector<TraceRec> recs;

@@ -150,6 +150,7 @@ struct Tracer {
         mat(c.gates, B, 4 * H, 4 * H, 0, id);
         mat(c.c_prev, B, H, H, 0, id); mat(c.c_new, B, H, H, 0, id);
         mat(c.dc, B, H, H, 2, id); mat(c.dP, B, 4 * H, 4 * H, 1, id);
+        mat(c.dP16, B, 4 * H, 4 * H, 1, id, 2);
     }
 };
 thread_local Tracer* g_tracer = nullptr;

@@ -604,9 +604,16 @@ class Parrot(Brick):
             d.dw_b, d.dw0_b = ws['dw_b'].data_ptr(), ws['dw0_b'].data_ptr()
         if 'dw_c' in ws:
             d.dw_c, d.dw0_c = ws['dw_c'].data_ptr(), ws['dw0_c'].data_ptr()
+        if lstm and self._bf16_weight_grads(0, T, T):
+            # the backward scan leaves the pre-activation gradients in bf16 too (ParrotDecoderDesc::dG16): no conversion
+            # pass over 3 x [T,B,4H] floats before the weight-gradient products
+            cp = self._bf16_copies(ws, T, B)
+            for l in range(L):
+                d.dG16[l] = cp['d']['g'][l].data_ptr()
         plan = C.c_void_p()
         _lib.call('parrot_decoder_create', C.byref(d), C.byref(plan))
         ws['plan'], ws['desc'] = plan, d
+        ws['plan_writes_d16'] = bool(_lib.load().parrot_decoder_writes_bf16_grads(plan))
         self._train_ws[ws_key] = ws  # (`key` is the group key of the loops above)
         return ws
 
@@ -1099,6 +1106,8 @@ class Parrot(Brick):
         R = T * B
         # (the state / context copies were made by the readout weight gradients when those ran on them)
         fresh = ('d',) if ws.pop('bf16_hw_fresh', False) else ('h', 'w', 'd')
+        if ws.get('plan_writes_d16'):  # the backward scan wrote the bf16 gradient rows itself
+            fresh = tuple(x for x in fresh if x != 'd')
         cp = self._bf16_copies(ws, T, B, convert=fresh)
         for l in range(L):
             ll = l + 1

@@ -63,6 +63,8 @@ def _make_plan(L, lib, sched, cell, nl, seq_init, monkeypatch, T=5, B=20, H=32, 
         d.dG[l] = ar.take(f"dG{l}", T * B * gw * f)
         if l < nl - 1:
             d.dhup[l] = ar.take(f"dhup{l}", (T + 1) * B * H * f)
+        if bf16 and cell == 1:  # bf16 copies of the pre-activation gradients, written by the fused backward tick (round 5)
+            d.dG16[l] = ar.take(f"dG16_{l}", T * B * gw * 2)
         if (bf16 and cell == 1) or hetero:  # second (and third) accumulators: the backward products run as K parts
             d.dh_b[l] = ar.take(f"dh_b{l}", (T + 1) * B * H * f)
             if l < nl - 1:
@@ -270,7 +272,8 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         n_fwd = _check(_trace(lib, plan, 0), ar, fwd_once, set(), T, slot)
         assert n_fwd == T + max(1, nl if nl > 1 else 0)
         recs = _trace(lib, plan, 1)
-        bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)}
+        assert lib.parrot_decoder_writes_bf16_grads(plan) == 1
+        bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)} | {f"dG16_{l}" for l in range(nl)}
         acc = {"dw", "dw0", "dw_b", "dw0_b"} | {f"dh{l}" for l in range(nl)} | {f"dhup{l}" for l in range(nl - 1)}
         acc |= {f"dh_b{l}" for l in range(nl)} | {f"dhup_b{l}" for l in range(nl - 1)}
         n_bwd = _check(recs, ar, bwd_once, acc, T, {})
@@ -278,6 +281,9 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         flagged = [r for r in recs if r[2] == 3]
         assert flagged and all(_owner(ar, r[3]).startswith("dG") for r in flagged)
         # the products really run as two K halves: the second accumulators are written (stored) and read back
+        for l in range(nl):  # every row of the bf16 gradient copies is written (once), nothing in the scan reads them
+            kinds = {r[2] for r in recs if _owner(ar, r[3]) == f"dG16_{l}"}
+            assert kinds == {1}, (l, kinds)
         for name in ["dw0_b"] + [f"dh_b{l}" for l in range(nl)] + [f"dhup_b{l}" for l in range(nl - 1)]:
             kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
             assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
