@@ -433,6 +433,12 @@ typedef struct ParrotSampleDesc {
      * the machine plans that way; NULL, other feedback patterns, L = 1 or PARROT_PM_FBC=0: the 2L + 2 phases above. */
     const float* Wgx_t[PARROT_MAX_LAYERS];
     const float* Wcx_t[PARROT_MAX_LAYERS];
+    /* Optional (round 5, B <= 16, 3A <= 32): Watt_t = fragment-major copy (parrot_tile_weights, mode 0) of the attention
+     * projection as an [H, 32] matrix (column j < 3A = row j of WattT, the rest zero).  Layer 0's candidate units then also
+     * multiply the h_1 tile they have just computed by their 16 rows of it and publish [B, 32] partial sums; the attention
+     * row adds H / 16 of them instead of reading its state row and the whole projection matrix (model.py:926-930 is the
+     * same sum, associated tile by tile).  NULL or PARROT_PM_ATTFOLD=0: the row computes the projection itself. */
+    const float* Watt_t;
 } ParrotSampleDesc;
 
 long long parrot_sample_persist_floats(const ParrotSampleDesc* desc);
@@ -442,8 +448,8 @@ int parrot_sample_is_persistent(void* plan);
 /* Plans the decode machine for `desc` with `nwg` workgroups WITHOUT touching device memory (pointers are only used for
  * address arithmetic) and replays the unit table symbolically: every read must find its value written in an earlier
  * phase, every buffer element is written once.  info16: [0] phases per step, [1] partial-sum buffers, [2] checker
- * verdict (0 ok), [3] units per step, [4 + s] units in phase s, [14] units that stream their weights, [15] 1 when the
- * fed-back frame is out of the chain (Wgx_t / Wcx_t).
+ * verdict (0 ok), [3] units per step, [4 + s] units in phase s, [14] units that stream their weights, [15] bit 0: the
+ * fed-back frame is out of the chain (Wgx_t / Wcx_t), bit 1: the attention projection is folded into the candidate units (Watt_t).
  * 0, or PARROT_ERR_UNSUPPORTED when the configuration does not take this plan.  Used by the CPU tests. */
 int parrot_sample_plan_pieces_dry(const ParrotSampleDesc* desc, int nwg, int* info16);
 /* Like parrot_decoder_status, for a decode plan. */

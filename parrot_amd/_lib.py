@@ -111,6 +111,7 @@ class SampleDesc(C.Structure):
         ("persist_ws", C.c_void_p), ("persist_ws_floats", C.c_longlong),
         ("Wro_t", C.c_void_p), ("ro_const", C.c_void_p),
         ("Wgx_t", C.c_void_p * MAX_LAYERS), ("Wcx_t", C.c_void_p * MAX_LAYERS),
+        ("Watt_t", C.c_void_p),
     ]
 
 

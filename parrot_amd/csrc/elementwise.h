@@ -120,12 +120,17 @@ __device__ __forceinline__ void lstm_state_bwd_row_pub(const LstmStateBwdChain& 
         float* q = o + 4 * i;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(q), "v"(v) : "memory");
     }
-    if (c.dP16) {  // the bf16 copy the weight-gradient GEMMs read after the scan (plain stores: nobody reads it in this launch)
-        __bf16* o16 = reinterpret_cast<__bf16*>(c.dP16) + (size_t)m * 4 * H;
-        for (int i = tid; i < (H >> 1); i += nthr)  // 4H / 8 vectors of eight (H % 2 == 0; bf16 decoders have H % 32 == 0)
-            *reinterpret_cast<bf16x8*>(o16 + 8 * i) = ph_bf16x8(*reinterpret_cast<const f32x4*>(row + 8 * i),
-                                                                *reinterpret_cast<const f32x4*>(row + 8 * i + 4));
-    }
+}
+
+// The bf16 copy of the same row for the weight-gradient GEMMs that run after the scan (plain stores: nobody reads it in this
+// launch).  Called AFTER the row has arrived on its chain's flag, from the staging row still in LDS, so that the products
+// waiting for the row inside the launch do not wait for these stores as well.
+__device__ __forceinline__ void lstm_state_bwd_row_copy16(const LstmStateBwdChain& c, int m, int H, int tid, int nthr, const float* row) {
+    if (!c.dP16) return;
+    __bf16* o16 = reinterpret_cast<__bf16*>(c.dP16) + (size_t)m * 4 * H;
+    for (int i = tid; i < (H >> 1); i += nthr)  // 4H / 8 vectors of eight (H % 2 == 0; bf16 decoders have H % 32 == 0)
+        *reinterpret_cast<bf16x8*>(o16 + 8 * i) = ph_bf16x8(*reinterpret_cast<const f32x4*>(row + 8 * i),
+                                                            *reinterpret_cast<const f32x4*>(row + 8 * i + 4));
 }
 
 // Elementwise half of the LSTM backward step (ops.py:505-553 reversed).  dh: gradient wrt s_t; dc: carry

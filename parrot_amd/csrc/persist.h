@@ -63,6 +63,13 @@ struct PmUnit {
     PmRM out, o1, o2;            // LINEAR: out;  GATES: o1 = z | o2 = r, out = r*h_prev;  CAND: o1 = c, out = h_new
     int ndst, pad2;              // fragment-major copies of `out` for the consuming units
     PmDst dst[PM_MAXDST];
+    // Round 5 (decode, batch <= 16): the attention projection folded into layer 0's candidate units.  pw[jt] = the
+    // fragment-major block of the padded projection matrix Watt [H, 32] for this unit's 16 state columns and output
+    // column tile jt; the finalising wave multiplies the h_new tile it holds by them (8 MFMAs) and publishes the
+    // [B, 32] partial sums at pp (row-major, write-through) -- the attention row then adds H / 16 partials of 32 values
+    // instead of reading its state row and the 120 KB projection matrix.  pw[0] == null: no fold.
+    const float* pw[2];
+    PmRM pp;
 };
 
 struct PmAtt {
@@ -75,6 +82,8 @@ struct PmAtt {
     int nwdst, pad3;              // fragment-major copies of w[t+1] (slab of step t+1 for layer 0, step t above)
     PmDst wdst[PM_MAXWDST];       // off already points at the slab the value of step t goes to (t * st is added)
     int* sup;                     // [T,B,2] or null
+    const float* pp;              // (round 5) per-tile partial sums of the projection, [T][H / 16][B][32], or null
+    long long pp_st;              // floats per step
     int B, H, A, U, E, att_type, dense, pad;
     float eps, alignment, sharpening, timing;
 };

@@ -205,6 +205,13 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
     f32x4 p_in[4];  // the additive inputs, kept apart until the epilogue (dataflow mode may have to ask again)
 #pragma unroll
     for (int q = 0; q < 4; ++q) p_in[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (round 5) layer 0's candidate units of the decode machine: the two projection-matrix blocks of the fold, asked for now
+    const bool fold = MB == 1 && fin && __builtin_amdgcn_readfirstlane(u.pw[0] != nullptr);
+    f32x4 pwb0 = {0.f, 0.f, 0.f, 0.f}, pwb1 = {0.f, 0.f, 0.f, 0.f};
+    if (fold) {
+        pwb0 = *reinterpret_cast<const f32x4*>(u.pw[0] + (lane << 2));
+        pwb1 = *reinterpret_cast<const f32x4*>(u.pw[1] + (lane << 2));
+    }
     if (fin && row_ok) {
         if (u.bias) p_bias = *reinterpret_cast<const f32x4*>(u.bias + n0);
         // requested NOW in both modes: these operands come from phases before the one that produced the unit's A operand,
@@ -361,6 +368,33 @@ __device__ __forceinline__ void pm_gemm(const PmUnit& u, int t, const float* lds
                                                        __builtin_amdgcn_readfirstlane(so), 16);
             }
         }
+        if (fold) {
+            // fmv IS the A operand of the tile (rows = batch, k = the unit's 16 state columns; zero in the padding rows):
+            // partial[b][j] = sum_k h_new[b][16 ct + k] * Watt[16 ct + k][j], j < 32, as two 16 x 16 output tiles
+            f32x4 pa0 = {0.f, 0.f, 0.f, 0.f}, pa1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fmv[q], pwb0[q], pa0, 0, 0, 0);
+                pa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fmv[q], pwb1[q], pa1, 0, 0, 0);
+            }
+            // C layout (col = lane & 15, row = 4 (lane >> 4) + i) -> [row][32] through LDS (this wave has read all of
+            // lds_red's partial tiles above; LDS operations of a wave execute in order), then 16-byte write-through stores
+            float* tr = lds_red;  // 16 rows x 36 floats
+            const int g4 = lane >> 4, jc = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tr[(4 * g4 + i) * 36 + jc] = pa0[i];
+                tr[(4 * g4 + i) * 36 + 16 + jc] = pa1[i];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int qd = lane + 64 * s2, prow = qd >> 3, pc4 = qd & 7;
+                if (prow < u.M) {
+                    const f32x4 pv = *reinterpret_cast<const f32x4*>(tr + prow * 36 + 4 * pc4);
+                    pm_rm_store<true>(u.pp, t, prow, 4 * pc4, pv);
+                }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long ts4 = pm_clock();
@@ -391,8 +425,37 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
     // is needed behind the projection
     float kp_pre = 0.f;
     if (tid < A) kp_pre = pm_ldf(g.kappa + (size_t)t * BA + (size_t)b * A + tid);
-    // 1) projection: wave w owns outputs j = w, w+8, w+16, w+24
-    {
+    // 1) projection.  (round 5) with the fold: the H / 16 partial sums the candidate units of this step published
+    if (g.pp) {
+        const int nct = H >> 4;
+        const float* base = g.pp + (long long)t * g.pp_st + (long long)b * 32;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        const int c4 = tid & 7;
+        for (int ct0 = 0; ct0 < nct; ct0 += PM_THREADS / 8) {  // 64 tiles per pass: one 16-byte slot per thread
+            const int ct = ct0 + (tid >> 3);
+            if (ct < nct) {
+                PmRM o;
+                o.p = const_cast<float*>(base) + (long long)ct * g.B * 32; o.st = 0; o.ld = 32; o.pad = 0;
+                f32x4 v = pm_rm_load(o, 0, 0, 4 * c4);
+                if (DF && pm_is_empty(v)) v = pm_rm_take(o, 0, 0, 4 * c4, sync);
+                sum += v;  // (tiles ct0 + k, k fixed per thread: ascending order)
+            }
+        }
+        // lanes of a wave: 8 tiles x 8 column quads -> add the 8 tiles (lane bits 3..5), then the 8 waves through LDS
+#pragma unroll
+        for (int sh = 8; sh <= 32; sh <<= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sum[i] += __shfl_xor(sum[i], sh, 64);
+        float* s_w = s_acc;  // [8 waves][32] (s_acc is not live before the weighted sum)
+        if (lane < 8) *reinterpret_cast<f32x4*>(s_w + wave * 32 + 4 * lane) = sum;
+        __syncthreads();
+        if (tid < 3 * A) {
+            float r = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < PM_THREADS / 64; ++w2) r += s_w[w2 * 32 + tid];
+            s_p[tid] = r + (g.batt ? g.batt[tid] : 0.f);
+        }
+    } else {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t hr = pm_rsrc(h);
         for (int k0 = 4 * lane; k0 < H; k0 += 1024) {

@@ -281,8 +281,13 @@ struct SamplePlan : PlanBase {
     };
     struct PmAccess { int res, dstep, c0, nch; };
     struct PmMeta { int lag, slot; std::vector<PmAccess> rd, wr; };
-    enum { RES_XG = 10, RES_XC = 20, RES_XR = 30, RES_H = 40, RES_Z = 50, RES_X = 60, RES_KAPPA = 61, RES_XPRE = 62,
+    enum { RES_XG = 10, RES_XC = 20, RES_XR = 30, RES_H = 40, RES_Z = 50, RES_X = 60, RES_KAPPA = 61, RES_XPRE = 62, RES_PP = 63,
            RES_PART = 100 };
+    // Round 5: the attention projection folded into layer 0's candidate units (PmUnit::pw / pp, persist.hip)
+    static bool attfold_wanted(const ParrotSampleDesc& d) {
+        const char* e = getenv("PARROT_PM_ATTFOLD");
+        return d.Watt_t && d.B <= 16 && 3 * d.A <= 32 && !(e && atoi(e) == 0);
+    }
     bool pieces_ok = false;
     bool fbc_on = false;
     // Round 5 ("fbc"): the fed-back frame out of the chain.  x[t+1] = x_pre + h_{L-1}[t+1] . A (A = the last layer's rows of
@@ -453,6 +458,7 @@ struct SamplePlan : PlanBase {
             const long long rows = d.B <= 16 ? 16 : (d.B <= 32 ? 32 : 64);
             n += 2 * (long long)(d.S + 1) * rows * d.H + (long long)(d.S + 2) * d.B * 64 + (long long)d.B * d.H + 64;
         }
+        if (attfold_wanted(d)) n += (long long)d.S * (d.H / 16) * d.B * 32 + 64;  // the projection's partial sums
         return n;
     }
     // symbolic replay over S steps: 0 = every read finds its value written in an earlier phase and nothing is written twice
@@ -535,6 +541,8 @@ struct SamplePlan : PlanBase {
         for (int l = 0; l < L; ++l) hist_h[l] = take((S + 1) * BH);
         for (int l = 0; l < L; ++l) zh[l] = take(S * BH);
         float* b_hist = take((long long)S * B * d.A);
+        const bool attfold = attfold_wanted(d) && MB == 1;
+        float* pp = attfold ? take((long long)S * hc * B * 32) : nullptr;  // [S][H / 16][B][32] partial projections
         float* zero_rows = fbc ? take(BH) : nullptr;               // never written: the workspace arrives zero-filled
         float* xpre_rm = fbc ? take((long long)(S + 1) * B * 64) : nullptr;  // x_pre of step t, row-major (the output unit adds it)
         float* const part_base = ws;
@@ -586,6 +594,7 @@ struct SamplePlan : PlanBase {
                             m.wr.push_back(acc(RES_XC + m2, 0, hc + ec + l * hc, hc));
                         }
                         m.wr.push_back(acc(RES_XR, 0, l * hc, hc));
+                        if (attfold && l == 0) m.wr.push_back(acc(RES_PP, 0, 0, 1));
                         if (fbc && l == L - 1) {
                             m.wr.push_back(acc(RES_XG, 1, fbh, hc));
                             m.wr.push_back(acc(RES_XC, 1, fbh, hc));
@@ -648,6 +657,11 @@ struct SamplePlan : PlanBase {
                             u.dst[u.ndst++] = mkdst(XC[m2], 0, kx[m2], ch);
                         }
                         u.dst[u.ndst++] = mkdst(XR, 0, kr, l * hc + ct);
+                        if (attfold && l == 0) {  // this tile's share of the attention projection h_1 . Watt
+                            u.pw[0] = d.Watt_t + (size_t)ct * 256;
+                            u.pw[1] = d.Watt_t + (size_t)(hc + ct) * 256;
+                            u.pp = rm(pp + (size_t)ct * B * 32, (long long)hc * B * 32, 32);
+                        }
                         if (fbc && l == L - 1) {  // ... and the operand of layer 0's composed feedback rows, next step
                             if (u.ndst + 2 > PM_MAXDST) return 0;
                             u.dst[u.ndst++] = mkdst(XG[0], 1, kx[0], fbh + ct);
@@ -679,6 +693,7 @@ struct SamplePlan : PlanBase {
             PmMeta m;
             m.lag = 1; m.slot = sATT;
             m.rd.push_back(acc(RES_H, 1, 0, 1));
+            if (attfold) m.rd.push_back(acc(RES_PP, 0, 0, 1));
             m.rd.push_back(acc(RES_KAPPA, 0, 0, 1));
             m.wr.push_back(acc(RES_KAPPA, 1, 0, 1));
             m.wr.push_back(acc(RES_XG, 1, hc, ec));
@@ -723,7 +738,7 @@ struct SamplePlan : PlanBase {
         const int chk = check_pieces(metas, init, n_slots, 4, 4 + n_extra);
         memset(pieces_info, 0, sizeof(pieces_info));
         pieces_info[0] = n_slots; pieces_info[1] = npart; pieces_info[2] = chk; pieces_info[3] = (int)reqs.size();
-        pieces_info[15] = fbc ? 1 : 0;
+        pieces_info[15] = (fbc ? 1 : 0) + (attfold ? 2 : 0);
         for (const PmReq& q : reqs) pieces_info[4 + q.slot] += 1;
         if (chk != 0) return 0;
         std::vector<PmUnit> table;
@@ -745,6 +760,7 @@ struct SamplePlan : PlanBase {
         a.kappa = d.kappa; a.a = d.a; a.b = b_hist; a.phi = d.phi; a.w = d.w; a.sup = nullptr;
         a.B = B; a.H = H; a.A = d.A; a.U = d.U; a.E = E; a.att_type = d.att_type; a.dense = 0;
         a.eps = d.eps; a.alignment = d.alignment; a.sharpening = d.sharpening; a.timing = d.timing;
+        a.pp = pp; a.pp_st = (long long)hc * B * 32;
         a.wdst[a.nwdst++] = mkdst(XG[0], 1, kx[0], hc);
         a.wdst[a.nwdst++] = mkdst(XC[0], 1, kx[0], hc);
         for (int l = 1; l < L; ++l) {
@@ -792,6 +808,7 @@ struct SamplePlan : PlanBase {
         }
         add_fill(part_base, (long long)(part_end - part_base));
         if (fbc) add_fill(xpre_rm, (long long)(S + 1) * B * 64);
+        if (attfold) add_fill(pp, (long long)S * hc * B * 32);
         persist_ok = true;
         return 0;
     }

@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(ATTB_THREADS) void wkb_kernel(const WkLaunch L, con
             __syncthreads();
             if (threadIdx.x == 0)                              // ... then one lane arrives for the row
                 (void)__hip_atomic_fetch_add(P.flag[ch], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lstm_state_bwd_row_copy16(P.sa.chain[ch], m, P.sa.H, threadIdx.x, ATTB_THREADS, row);  // (behind the hand-off)
         }
         return;
     }

@@ -604,7 +604,7 @@ class Parrot(Brick):
             d.dw_b, d.dw0_b = ws['dw_b'].data_ptr(), ws['dw0_b'].data_ptr()
         if 'dw_c' in ws:
             d.dw_c, d.dw0_c = ws['dw_c'].data_ptr(), ws['dw0_c'].data_ptr()
-        if lstm and self._bf16_weight_grads(0, T, T):
+        if lstm and self._bf16_weight_grads(0, T, T) and os.environ.get('PARROT_BF16_DG16', '1') != '0':
             # the backward scan leaves the pre-activation gradients in bf16 too (ParrotDecoderDesc::dG16): no conversion
             # pass over 3 x [T,B,4H] floats before the weight-gradient products
             cp = self._bf16_copies(ws, T, B)
@@ -1252,6 +1252,11 @@ class Parrot(Brick):
             pm['Wro'], pm['Wro_t'] = torch.empty(L * H + E, 64, **f), torch.empty(L * H + E, 64, **f)
             pm['ro_const'] = torch.zeros(N, 64, **f)
             d.Wro_t, d.ro_const = pm['Wro_t'].data_ptr(), pm['ro_const'].data_ptr()
+            if N <= 16 and 3 * A <= 32 and os.environ.get('PARROT_PM_ATTFOLD', '1') != '0':
+                # round 5: the attention projection as an [H, 32] matrix (fragment-major): layer 0's candidate units fold
+                # their tile's share of h_1 . Watt into their epilogue (ParrotSampleDesc::Watt_t)
+                pm['Watt_pad'], pm['Watt_t'] = torch.zeros(H, 32, **f), torch.empty(H, 32, **f)
+                d.Watt_t = pm['Watt_t'].data_ptr()
             # round 5: the fed-back frame out of the step's chain (weak feedback, L >= 2): layer 0's matrices with the rows
             # A . Wf appended, A = the last layer's rows of Wr . Wo (ParrotSampleDesc::Wgx_t / Wcx_t)
             if L >= 2 and self._fb_layers == [1] and os.environ.get('PARROT_PM_FBC', '1') != '0':
@@ -1359,6 +1364,10 @@ class Parrot(Brick):
             pm['Wro'].copy_(Wro)
             tile(pm['Wro'], pm['Wro_t'])
             pm['ro_const'].copy_(c)
+            if 'Watt_t' in pm:
+                A3 = 3 * self.attention_size
+                pm['Watt_pad'][:, :A3].copy_(st['dec.WattT'].t())
+                tile(pm['Watt_pad'], pm['Watt_t'])
             for key, wd, suf, mat, rec in self._groups:
                 if ('x', key) not in pm['cat']:
                     continue

@@ -7,7 +7,7 @@ import pytest
 from parrot_amd import _lib
 
 
-def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False, fbc=False):
+def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False, fbc=False, attfold=False):
     d = _lib.SampleDesc()
     d.S, d.B, d.H, d.E, d.A, d.U, d.L, d.O, d.R, d.ldx = S, B, H, E, 10, 100, L, 63, R, 64
     fake = 0x7000_0000_0000  # never dereferenced by the dry run
@@ -21,6 +21,8 @@ def _desc(L=2, H=1024, E=512, B=16, S=1000, R=1024, fb=(0,), speaker=False, fbc=
     d.Wro_t, d.ro_const, d.x = fake, fake, fake
     if fbc:  # layer 0's matrices with the composed feedback rows appended (ParrotSampleDesc::Wgx_t / Wcx_t, round 5)
         d.Wgx_t[0], d.Wcx_t[0] = fake, fake
+    if attfold:  # the attention projection as a fragment-major [H, 32] matrix (ParrotSampleDesc::Watt_t, round 5)
+        d.Watt_t = fake
     return d
 
 
@@ -53,6 +55,18 @@ def test_fed_back_frame_out_of_the_chain_plan_is_legal():
     for L, fb in ((1, (0,)), (2, (0, 1)), (2, ())):  # not the pattern the composition covers: the 2L + 2 phases
         rc, info = _plan(_desc(L=L, H=256, E=128, B=16, S=50, R=256, fb=fb, fbc=True))
         assert rc == 0 and info[2] == 0 and info[15] == 0 and info[0] == 2 * L + 2, info
+
+
+def test_attention_projection_fold_is_planned_for_small_batches_only():
+    """Watt_t given: layer 0's candidate units publish the projection's partial sums (checked by the symbolic replay: the
+    attention row reads them a phase later); B > 16 (more than one row block per unit) keeps the row's own projection."""
+    for fbc in (False, True):
+        rc, info = _plan(_desc(fbc=fbc, attfold=True))
+        assert rc == 0 and info[2] == 0 and info[15] == (3 if fbc else 2), info
+    rc, info = _plan(_desc(B=32, fbc=True, attfold=True))
+    assert rc == 0 and info[2] == 0 and info[15] == 1, info
+    rc, info = _plan(_desc(L=1, H=256, E=128, S=20, R=256, attfold=True))
+    assert rc == 0 and info[2] == 0 and info[15] == 2, info
 
 
 def test_fbc_env_switch(monkeypatch):
@@ -115,13 +129,14 @@ def test_random_stacks_are_either_planned_legally_or_refused():
 
     @settings(max_examples=80, deadline=None, derandomize=True)
     @given(L=st.integers(1, 3), h=st.integers(1, 96), e=st.integers(1, 48), B=st.integers(1, 64),
-           fbmask=st.integers(0, 7), speaker=st.booleans(), nwg=st.sampled_from([64, 128, 208, 256]), fbc=st.booleans())
-    def run(L, h, e, B, fbmask, speaker, nwg, fbc):
+           fbmask=st.integers(0, 7), speaker=st.booleans(), nwg=st.sampled_from([64, 128, 208, 256]), fbc=st.booleans(),
+           attfold=st.booleans())
+    def run(L, h, e, B, fbmask, speaker, nwg, fbc, attfold):
         fb = tuple(l for l in range(L) if fbmask >> l & 1)
-        d = _desc(L=L, H=16 * h, E=16 * e, B=B, S=7, R=64, fb=fb, speaker=speaker, fbc=fbc)
+        d = _desc(L=L, H=16 * h, E=16 * e, B=B, S=7, R=64, fb=fb, speaker=speaker, fbc=fbc, attfold=attfold)
         rc, info = _plan(d, nwg=nwg)
         if rc == 0:
-            assert info[2] == 0 and info[0] == (2 * L + 1 if info[15] else 2 * L + 2)
+            assert info[2] == 0 and info[0] == (2 * L + 1 if info[15] & 1 else 2 * L + 2)
             assert all(n <= nwg for n in info[4:4 + info[0]]), (info, nwg)
             assert sum(info[4:4 + info[0]]) == info[3]
         else:

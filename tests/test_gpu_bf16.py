@@ -350,20 +350,27 @@ def test_bf16_lstm_one_launch_per_tick_agrees_with_schedule_0(dev, monkeypatch):
                 assert rel_err(got["7"][3][k], v) < 5e-3, (L, B, k, rel_err(got["7"][3][k], v))
 
 
-def test_in_launch_handoffs_never_see_stale_rows(dev, monkeypatch):
+@pytest.mark.parametrize("shape", ["small", "cfg4"])
+def test_in_launch_handoffs_never_see_stale_rows(dev, monkeypatch, shape):
     """The fused ticks of schedule 7 hand rows from one workgroup to another INSIDE a launch (forward: the attention's w
     rows; backward: the state-backward's dP rows, read with ordinary L2-cached loads).  A cache line of an earlier
     window surviving in some L2 would be invisible on a replay with the same data -- so one plan (same buffers, captured
     graphs) is replayed on batch A, then on a different batch B, then on A again, and every result must equal what a
-    fresh model computes on that batch alone, bit for bit.  Shapes small enough that everything would stay cache-resident."""
+    fresh model computes on that batch alone, bit for bit.  "small": shapes at which everything would stay cache-resident;
+    "cfg4" (round 5): BASELINE configs[3]'s own widths (3 x LSTM-1536, B = 64, U = 200), where a tick's dP rows
+    and weights do not fit any L2 and the launches are the ones the benchmark runs."""
     from oracle import parrot_ref as R
     from parrot_amd import _lib
     from parrot_amd.model import Parrot
-    monkeypatch.setenv("PARROT_WK", "2")
-    kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
+    if shape == "small":
+        monkeypatch.setenv("PARROT_WK", "2")
+        kw = dict(num_layers=3, rnn_h_dim=128, readouts_dim=128, encoder_type='bidirectional', encoder_dim=64, cell_type='lstm')
+        T, B, U = 6, 48, 9
+    else:
+        kw = dict(num_layers=3, rnn_h_dim=1536, readouts_dim=1536, encoder_type='bidirectional', cell_type='lstm')
+        T, B, U = 12, 64, 200
     cfg = R.default_config(**kw)
     p = R.init_params(cfg, seed=61, scale_by_fan_in=True)
-    T, B, U = 6, 48, 9
     batches = [make_batch(cfg, T, B, U, seed=70 + i) for i in range(2)]
 
     def run(m, batch):
