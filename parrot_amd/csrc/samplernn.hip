@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void sr_frame_in_kernel(const int* __restrict_
         const float xf = ((float)samples[(size_t)b * len + t - FS + i] / half_q - 1.0f) * 2.0f;
         acc = fmaf(xf, Win[(size_t)i * D + dd], acc);
     }
-    out[(size_t)b * D + dd] = acc + bias[dd] + add[(size_t)b * ld_add + dd];
+    out[(size_t)b * D + dd] = acc + (bias ? bias[dd] : 0.f) + add[(size_t)b * ld_add + dd];
 }
 
 __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
@@ -142,6 +142,34 @@ struct SrPlan {
     Tiled t_big, t_frm;
     float* tiled_slab = nullptr;
     float* t2 = nullptr;  // [Q, D] = emb_tbl[FS-1] . W2 (persistent sample kernel)
+    // Round 5 (single-GRU tiers): the frame tier's input xf . Win + bin + big_out only enters the step through x . U, so
+    //   x . U + bU = xf . (Win . U) + [(bin + big_out) . U + bU].
+    // winu = Win . U [FS, 3D] and pbias = bin . U + bU [3D] are composed once (the weights are fixed for the plan's life);
+    // per 80-sample period ONE product makes pbig[b][f] = big_out[b, f] . U + pbias for all BFS / FS frames, and the two step
+    // GEMMs of a frame walk K = D (their own recurrent product) instead of 2 D, with pin [B, 3D] = xf . winu + pbig[f] as
+    // their additive input -- written by the previous frame's sample kernel (SrpArgs::next_n) or, for the first frame of a
+    // period, by sr_frame_in_kernel at width 3D.
+    float* winu = nullptr; float* pbias = nullptr; float* pbig = nullptr; float* pin = nullptr;
+    int make_winu() {
+        const size_t D = d.D, nfr = d.BFS / d.FS;
+        if (d.n_rnn != 0) return 0;
+        if (hipMalloc(&winu, ((size_t)d.FS * 3 * D + 3 * D + (size_t)d.B * nfr * 3 * D + (size_t)d.B * 3 * D) * sizeof(float)) != hipSuccess) {
+            winu = nullptr;
+            return 0;
+        }
+        pbias = winu + (size_t)d.FS * 3 * D;
+        pbig = pbias + 3 * D;
+        pin = pbig + (size_t)d.B * nfr * 3 * D;
+        BgPrecisionScope f32_only(0);
+        int rc = parrot_gemm(d.frm_Win, (int)D, 0, d.frm_U, 3 * (int)D, 0, winu, 3 * (int)D, d.FS, 3 * (int)D, (int)D, nullptr, 1.f, 0, 0,
+                             1, 0, 0, 0, 1, nullptr);
+        if (rc == 0)
+            rc = parrot_gemm(d.frm_bin, (int)D, 0, d.frm_U, 3 * (int)D, 0, pbias, 3 * (int)D, 1, 3 * (int)D, (int)D, d.frm_bU, 1.f, 0, 0,
+                             1, 0, 0, 0, 1, nullptr);
+        if (rc == 0) rc = (int)hipDeviceSynchronize();
+        if (rc != 0) { (void)hipFree(winu); winu = nullptr; }
+        return 0;
+    }
     int make_t2() {
         if (hipMalloc(&t2, (size_t)d.Q * d.D * sizeof(float)) != hipSuccess) { t2 = nullptr; return 1; }
         BgPrecisionScope f32_only(0);  // whatever the process-wide GEMM precision is: this table feeds an f32 path
@@ -182,6 +210,7 @@ struct SrPlan {
         if (cap) hipStreamDestroy(cap);
         if (tiled_slab) (void)hipFree(tiled_slab);
         if (t2) (void)hipFree(t2);
+        if (winu) (void)hipFree(winu);
     }
 
     int linear(const float* A, int lda, const float* W, int ldw, int K, int N, const float* bias, const float* add,
@@ -203,13 +232,32 @@ struct SrPlan {
     // GRU step of a tier (ops.py:356-393): gates = sigm(h.Wg + x.U[:, :2D] + b[:2D]); cand = tanh((r*h).Wc + x.U[:, 2D:] +
     // b[2D:]); in-place h.  The Input linear rides in the step GEMMs as a second K segment: two launches, not three.
     int gru(const float* x, const float* U, const float* bU, const float* Wg, const float* Wc, float* h, hipStream_t st,
-            const Tiled* t = nullptr) {
+            const Tiled* t = nullptr, const float* pre = nullptr) {
         const int D = d.D;
         const int blk = (D >> 4) * 256;  // floats per column tile of a [D, *] fragment-major copy
         const bool tl = t && t->U;
         SkJob j;
         SkLaunch L;
         sk_job_init(j);
+        if (pre) {  // x . U + bU arrives precomputed ([B, 3D]: gates | candidate): only the recurrent product is left
+            j.nseg = 1;
+            j.seg[0] = tl ? sk_seg(h, D, t->Wg, blk, D, 2) : sk_seg(h, D, Wg, 2 * D, D, 0);
+            j.M = d.B; j.N = 2 * D; j.H = D; j.epi = SK_EPI_GRU_GATES;
+            j.add = pre; j.ld_add = 3 * D;
+            j.e0 = h; j.lde0 = D;
+            j.o1 = d.z; j.ldo1 = D; j.o2 = d.r; j.ldo2 = D; j.out = d.rh; j.ldo = D;
+            SR_TRY(sk_make_launch(L, &j, 1));
+            SR_TRY(sk_launch(L, st));
+            sk_job_init(j);
+            j.nseg = 1;
+            j.seg[0] = tl ? sk_seg(d.rh, D, t->Wc, blk, D, 2) : sk_seg(d.rh, D, Wc, D, D, 0);
+            j.M = d.B; j.N = D; j.H = D; j.epi = SK_EPI_GRU_CAND;
+            j.add = pre + 2 * D; j.ld_add = 3 * D;
+            j.e0 = h; j.lde0 = D; j.e1 = d.z; j.lde1 = D;
+            j.o1 = nullptr; j.out = h; j.ldo = D;
+            SR_TRY(sk_make_launch(L, &j, 1));
+            return sk_launch(L, st);
+        }
         j.nseg = 2;
         j.seg[0] = tl ? sk_seg(h, D, t->Wg, blk, D, 2) : sk_seg(h, D, Wg, 2 * D, D, 0);
         j.seg[1] = tl ? sk_seg(x, D, t->U, blk, D, 2) : sk_seg(x, D, U, 3 * D, D, 0);
@@ -286,16 +334,30 @@ struct SrPlan {
             SR_TRY(stack_step(true, d.gru_in, &top, st));
             SR_TRY(linear(top, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st,
                           nullptr, 0, nullptr, 0, t_big.Wout));
+            if (winu) {  // the big tier's share of every frame's pre-activations, all nfr frames in one product:
+                BgPrecisionScope f32_only(0);  // pbig[(b, f)] = big_out[b, f*D : (f+1)*D] . U + (bin . U + bU)
+                SR_TRY(parrot_gemm(d.big_out, D, 0, d.frm_U, 3 * D, 0, pbig, 3 * D, B * nfr, 3 * D, D, pbias, 1.f, 0, 0, 1, 0, 0,
+                                   0, 1, st));
+            }
         }
         for (int f = 0; f < nfr; ++f) {
             // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
             const int toff = f * FS;
             // (on the persistent path the previous frame's sample kernel has already left this frame's input in gru_in)
-            if (!persist || f == 0)
-                hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(D, 256), B), dim3(256), 0, st, d.samples, len, d.tbase,
-                                   toff, FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
             const float* ftop = nullptr;
-            SR_TRY(stack_step(false, d.gru_in, &ftop, st));
+            if (winu) {  // composed input: pin = xf . (Win . U) + pbig[f]  ([B, 3D]); the step GEMMs walk K = D
+                if (!persist || f == 0)
+                    hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(3 * D, 256), B), dim3(256), 0, st, d.samples, len,
+                                       d.tbase, toff, FS, half_q, winu, (const float*)nullptr, pbig + (size_t)f * 3 * D,
+                                       nfr * 3 * D, pin, 3 * D);
+                SR_TRY(gru(nullptr, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st, &t_frm, pin));
+                ftop = d.frm_h;
+            } else {
+                if (!persist || f == 0)
+                    hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(D, 256), B), dim3(256), 0, st, d.samples, len, d.tbase,
+                                       toff, FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
+                SR_TRY(stack_step(false, d.gru_in, &ftop, st));
+            }
             SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st,
                           nullptr, 0, nullptr, 0, t_frm.Wout));
             if (persist) {
@@ -306,7 +368,10 @@ struct SrPlan {
                 sa.emb_tbl = d.emb_tbl; sa.t2 = t2; sa.frame_out = d.frame_out; sa.ldf = FS * D;
                 sa.W2 = d.W2; sa.b2 = d.b2; sa.W3 = d.W3; sa.b3 = d.b3; sa.W4 = d.W4; sa.b4 = d.b4;
                 sa.logits = d.logits; sa.ws = d.persist_ws; sa.temperature = d.temperature; sa.seed = d.seed;
-                if (f + 1 < nfr) {  // the next frame of this period: its big-tier conditioning is already known
+                if (f + 1 < nfr && winu) {  // the next frame of this period: its big-tier share is already known
+                    sa.next_in = pin; sa.next_Win = winu; sa.next_bias = nullptr;
+                    sa.next_add = pbig + (size_t)(f + 1) * 3 * D; sa.next_ld_add = nfr * 3 * D; sa.next_n = 3 * D;
+                } else if (f + 1 < nfr) {
                     sa.next_in = d.gru_in; sa.next_Win = d.frm_Win; sa.next_bias = d.frm_bin;
                     sa.next_add = d.big_out + (size_t)(f + 1) * D; sa.next_ld_add = nfr * D;
                 }
@@ -388,6 +453,7 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_EN
     if (!p) return PARROT_ERR_BADARG;
     p->d = *desc;
     p->make_tiled();
+    p->make_winu();
     p->persist = desc->persist_ws && srp_eligible(desc->B, desc->D, desc->Q, desc->FS) &&
                  desc->persist_ws_floats >= srp_ws_floats(desc->D, desc->Q) && srp_prepare(desc->D) == 0 &&
                  srp_init_ws(desc->persist_ws, desc->D, desc->Q) == 0 && p->make_t2() == 0;

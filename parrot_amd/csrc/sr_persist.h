@@ -16,7 +16,10 @@ struct SrpArgs {
     // Optional: the frame tier's input for the NEXT frame (three_tier.py:398-411), computed by every team for its own
     // streams from the samples it has just produced: next_in[b][d] = next_bias[d] + next_add[b][d] + sum_i xf_i * next_Win[i][d],
     // xf_i = (sample / (Q/2) - 1) * 2 of the launch's last FS samples.  next_in == null: not computed.
-    float* next_in; const float* next_Win; const float* next_bias; const float* next_add; int next_ld_add, pad1;
+    // Round 5: next_n (0 = D) is the width of that product -- with next_Win = Win . U ([FS, 3D], composed by the plan) and
+    // next_add = the big-tier share of the pre-activations, the kernel leaves the frame tier's additive gate / candidate
+    // inputs themselves ([B, 3D]) and the tier's two step GEMMs walk K = D instead of 2 D.  next_bias may be null.
+    float* next_in; const float* next_Win; const float* next_bias; const float* next_add; int next_ld_add, next_n;
     float* ws;                         // srp_ws_floats() floats, prepared once by srp_init_ws
     float temperature; int pad;
     unsigned long long seed;

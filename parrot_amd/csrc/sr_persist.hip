@@ -372,16 +372,17 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     // ---- the next frame's frame-tier input for this team's streams (saves the launch that would compute it)
     if (a.next_in) {
         const float half_q = (float)(Q / 2);
-        for (int idx = tid; idx < SRP_ROWS * DC; idx += SRP_THREADS) {
-            const int r = idx / DC, col = cu * DC + idx % DC;
+        const int NN = a.next_n > 0 ? a.next_n : D, NC = NN / 32;  // this CU's share: NC of the NN columns
+        for (int idx = tid; idx < SRP_ROWS * NC; idx += SRP_THREADS) {
+            const int r = idx / NC, col = cu * NC + idx % NC;
             const int b = team * SRP_ROWS + r;
             if (b >= a.B) continue;
             float acc = 0.f;
             for (int p = 0; p < a.FS; ++p) {
                 const float xf = ((float)sh->hist[r][a.nsteps + p] / half_q - 1.0f) * 2.0f;
-                acc = fmaf(xf, a.next_Win[(size_t)p * D + col], acc);
+                acc = fmaf(xf, a.next_Win[(size_t)p * NN + col], acc);
             }
-            a.next_in[(size_t)b * D + col] = acc + a.next_bias[col] + a.next_add[(size_t)b * a.next_ld_add + col];
+            a.next_in[(size_t)b * NN + col] = acc + (a.next_bias ? a.next_bias[col] : 0.f) + a.next_add[(size_t)b * a.next_ld_add + col];
         }
     }
 }
