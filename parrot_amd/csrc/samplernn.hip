@@ -334,10 +334,27 @@ struct SrPlan {
             SR_TRY(stack_step(true, d.gru_in, &top, st));
             SR_TRY(linear(top, D, d.big_Wout, nfr * D, D, nfr * D, d.big_bout, nullptr, 0, d.big_out, nfr * D, 0, st,
                           nullptr, 0, nullptr, 0, t_big.Wout));
-            if (winu) {  // the big tier's share of every frame's pre-activations, all nfr frames in one product:
-                BgPrecisionScope f32_only(0);  // pbig[(b, f)] = big_out[b, f*D : (f+1)*D] . U + (bin . U + bU)
-                SR_TRY(parrot_gemm(d.big_out, D, 0, d.frm_U, 3 * D, 0, pbig, 3 * D, B * nfr, 3 * D, D, pbias, 1.f, 0, 0, 1, 0, 0,
-                                   0, 1, st));
+            if (winu) {  // the big tier's share of every frame's pre-activations: pbig[(b, f)] = big_out[b, f*D : (f+1)*D] . U +
+                         // (bin . U + bU), one step-kernel launch with one job per frame (the LDS-tiled GEMM would put the
+                         // [B nfr, 3D] product on 48 workgroups of 128 x 128 x K: measured 75 us per period)
+                SkJob jobs[SK_MAXJOB];
+                const int blk = (D >> 4) * 256;
+                for (int f0 = 0; f0 < nfr; f0 += SK_MAXJOB) {
+                    int nj = 0;
+                    for (int f = f0; f < nfr && nj < SK_MAXJOB; ++f, ++nj) {
+                        SkJob& j = jobs[nj];
+                        sk_job_init(j);
+                        j.nseg = 1;
+                        j.seg[0] = t_frm.U ? sk_seg(d.big_out + (size_t)f * D, nfr * D, t_frm.U, blk, D, 2)
+                                           : sk_seg(d.big_out + (size_t)f * D, nfr * D, d.frm_U, 3 * D, D, 0);
+                        j.M = B; j.N = 3 * D; j.H = 3 * D; j.epi = SK_EPI_LINEAR;
+                        j.bias = pbias;
+                        j.out = pbig + (size_t)f * 3 * D; j.ldo = nfr * 3 * D;
+                    }
+                    SkLaunch L;
+                    SR_TRY(sk_make_launch(L, jobs, nj));
+                    SR_TRY(sk_launch(L, st));
+                }
             }
         }
         for (int f = 0; f < nfr; ++f) {
