@@ -1,5 +1,5 @@
 """Runs bench.py (headline step only) under a list of environment settings, one subprocess each, and prints ms/step.
-Development aid for the strand / part / GEMM-overlap knobs:  python tools/exp_matrix.py OUT.json NAME=K1:V1,K2:V2 ..."""
+Development aid for any environment knob:  python tools/exp_matrix.py OUT.json NAME=K1:V1,K2:V2 ..."""
 import json
 import os
 import subprocess
