@@ -138,55 +138,6 @@ def test_gru_seq_fwd_bwd(dev, reverse, use_mask):
         assert_close(t.grad, r.grad, 1e-4, n)
 
 
-@pytest.mark.parametrize("reverse", [False, True])
-def test_gru_seq_cached_runner_replays_its_graphs(dev, reverse):
-    """Round 5: unmasked scans of a recurring shape (T >= 16) keep their runner -- fixed buffers, its own copies of the weights,
-    hipGraphs captured once and replayed.  Three windows of the same shape with DIFFERENT weights / inputs / states must each
-    match the oracle (forward and every gradient); a second forward issued while the first one's backward is still pending
-    must not disturb it (it gets a runner of its own); a forward under no_grad must not hold the runner."""
-    from oracle import parrot_ref as R
-    from parrot_amd import ops
-    T, B, H = 24, 32, 64
-    ops._GRU_RUNNERS.clear()
-
-    def make(seed):
-        ts = [_rand((T, B, H), dev, seed), _rand((T, B, 2 * H), dev, seed + 1), _rand((B, H), dev, seed + 2),
-              _rand((H, H), dev, seed + 3, 1 / math.sqrt(H)), _rand((H, 2 * H), dev, seed + 4, 1 / math.sqrt(H))]
-        return [t.clone().requires_grad_() for t in ts], _rand((T, B, H), dev, seed + 5)
-
-    def check(ts, gout, hs, what):
-        rs = [t.detach().double().cpu().requires_grad_() for t in ts]
-        if reverse:
-            ref = R.gru_scan(rs[0].flip(0), rs[1].flip(0), rs[2], rs[3], rs[4], None).flip(0)
-        else:
-            ref = R.gru_scan(rs[0], rs[1], rs[2], rs[3], rs[4], None)
-        (ref * gout.double().cpu()).sum().backward()
-        assert_close(hs, ref, 2e-5, what + ": forward")
-        for t, r, n in zip(ts, rs, ("d_inputs", "d_gate_inputs", "dh0", "dWc", "dWg")):
-            assert_close(t.grad, r.grad, 1e-4, what + ": " + n)
-
-    for w in range(3):  # window after window on the cached runner
-        ts, gout = make(10 * w + 1)
-        hs = ops.gru_seq(*ts, None, reverse)
-        (hs * gout).sum().backward()
-        check(ts, gout, hs, f"window {w}")
-    assert len(ops._GRU_RUNNERS) == 1 and not next(iter(ops._GRU_RUNNERS.values())).busy
-    # two forwards before either backward: the second one must not overwrite what the first one's backward reads
-    ts_a, g_a = make(101)
-    ts_b, g_b = make(201)
-    hs_a = ops.gru_seq(*ts_a, None, reverse)
-    assert next(iter(ops._GRU_RUNNERS.values())).busy
-    hs_b = ops.gru_seq(*ts_b, None, reverse)
-    (hs_b * g_b).sum().backward()
-    (hs_a * g_a).sum().backward()
-    check(ts_a, g_a, hs_a, "first of two pending")
-    check(ts_b, g_b, hs_b, "second of two pending")
-    with torch.no_grad():
-        ops.gru_seq(*[t.detach() for t in ts_a], None, reverse)
-    assert not next(iter(ops._GRU_RUNNERS.values())).busy
-    ops._GRU_RUNNERS.clear()
-
-
 @pytest.mark.parametrize("T,B,H,reverse,use_mask", [(6, 37, 128, False, True), (5, 20, 256, True, False),
                                                    (64, 200, 128, True, True), (7, 16, 16, False, False)])
 def test_gru_seq_rowwise_vs_step_launches(dev, monkeypatch, T, B, H, reverse, use_mask):
