@@ -5,8 +5,6 @@ runs in libparrot_hip.so.  All functions require float32 CUDA(HIP) tensors and r
 """
 from __future__ import annotations
 
-import collections
-
 import torch
 
 from . import _lib
@@ -502,52 +500,17 @@ class GruSeqRunner:
             pass
 
 
-# Round 5: unmasked scans of a recurring shape (the SampleRNN tiers' 50- and 400-step scans of every training window) keep
-# their runner: its buffers and its own copies of the two weight matrices have fixed addresses, so the plan's hipGraphs --
-# ~900 kernel nodes forward, as many backward -- are captured once and REPLAYED per window instead of being enqueued launch
-# by launch from Python.  A runner whose backward is still pending is never handed out twice (a fresh, eager one is).
-_GRU_RUNNERS = collections.OrderedDict()
-_GRU_RUNNER_CAP = 4
-
-
-def _cached_gru_runner(T, B, H, reverse, device):
-    key = (T, B, H, bool(reverse), str(device))
-    run = _GRU_RUNNERS.get(key)
-    if run is not None:
-        _GRU_RUNNERS.move_to_end(key)
-        return None if run.busy else run
-    run = GruSeqRunner(T, B, H, 1, [reverse], device, use_graph=True)
-    f = dict(device=device, dtype=torch.float32)
-    run.own_Wg, run.own_Wc = torch.empty(H, 2 * H, **f), torch.empty(H, H, **f)
-    run.busy = False
-    _GRU_RUNNERS[key] = run
-    while len(_GRU_RUNNERS) > _GRU_RUNNER_CAP:
-        _, old = _GRU_RUNNERS.popitem(last=False)
-        if not old.busy:
-            old.close()
-    return run
-
-
 class _GruSeqFn(torch.autograd.Function):
     """GatedRecurrent.apply over a sequence: inputs [T,B,H], gate_inputs [T,B,2H], h0 [B,H]."""
 
     @staticmethod
     def forward(ctx, inputs, gate_inputs, h0, Wc, Wg, mask, reverse):
         T, B, H = inputs.shape
-        run = _cached_gru_runner(T, B, H, reverse, inputs.device) if (mask is None and T >= 16) else None
-        ctx.cached = run is not None
-        if run is None:
-            run = GruSeqRunner(T, B, H, 1, [reverse], inputs.device, use_graph=False)
+        run = GruSeqRunner(T, B, H, 1, [reverse], inputs.device, use_graph=False)
         run.inputs[0].copy_(inputs)
         run.gate_inputs[0].copy_(gate_inputs)
         run.h[0][0].copy_(h0)
-        if ctx.cached:
-            run.busy = any(ctx.needs_input_grad)  # (a forward nobody differentiates does not hold the runner)
-            run.own_Wg.copy_(Wg)
-            run.own_Wc.copy_(Wc)
-            run.bind([run.own_Wg], [run.own_Wc], None)  # (same pointers every window: the plan and its graphs are kept)
-        else:
-            run.bind([Wg], [Wc], mask.contiguous() if mask is not None else None)
+        run.bind([Wg], [Wc], mask.contiguous() if mask is not None else None)
         run.forward()
         ctx.run = run
         ctx.reverse = reverse
@@ -570,9 +533,6 @@ class _GruSeqFn(torch.autograd.Function):
             hprev = hprev.flip(0)  # step s handled time T-1-s
         dWc = gemm(run.rh[0].reshape(T * B, H).t(), dC.reshape(T * B, H)) if ctx.needs_input_grad[3] else None
         dWg = gemm(hprev.reshape(T * B, H).t(), dG.reshape(T * B, 2 * H)) if ctx.needs_input_grad[4] else None
-        if ctx.cached:  # the runner goes back to the cache: hand out copies, not views of its buffers
-            dC, dG = dC.clone(), dG.clone()
-            run.busy = False
         return dC, dG, run.dh[0][0].clone(), dWc, dWg, None, None
 
 
