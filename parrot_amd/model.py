@@ -521,9 +521,11 @@ class Parrot(Brick):
             ws.update(cst=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
                       gate4=[torch.empty(T, B, 4 * H, **f) for _ in range(L)],
                       dcell=[torch.zeros(B, H, **f) for _ in range(L)])
-            if self.compute_bf16:
+            if self.compute_bf16 and B <= 64 and H % 32 == 0:
                 # second accumulators of the backward scan (ParrotDecoderDesc::dh_b ...): the transposed products of a
-                # tick run as two K halves; zero-filled once (the scan stores into every slot it later reads)
+                # tick run as two K halves; zero-filled once (the scan stores into every slot it later reads).  (Only
+                # where the C plan can take them -- B <= 64, the wide kernel's widths: ADVICE r04 -- so that nothing is
+                # allocated, zeroed per window and added back for a plan that declines the split.)
                 ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
                           dhup_b=[torch.zeros(T + 1, B, H, **f) if l < L - 1 else None for l in range(L)],
                           dw_b=torch.zeros(T + 1, B, E, **f), dw0_b=torch.zeros(T + 1, B, E, **f))
@@ -536,7 +538,7 @@ class Parrot(Brick):
             # layers >= 2 always get the buffer: the plan batches the lower layers' projections into it
             ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker or l >= 2)
                                 else None for l in range(1, L + 1)]
-        if (not lstm and L == 2 and not self.compute_bf16 and not self.layer_norm
+        if (not lstm and L == 2 and not self.compute_bf16 and not self.layer_norm and B <= 64 and H % 16 == 0 and E % 16 == 0
                 and os.environ.get('PARROT_BWD_HETERO', '1') != '0'):
             # second / third accumulators of the K-balanced backward tick (ParrotDecoderDesc::dh_b ... dw0_c, plans.hip bwd8)
             ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
