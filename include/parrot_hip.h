@@ -321,7 +321,7 @@ int parrot_decoder_schedule(void* plan);
  * descriptor's buffers the job reads / writes.  Records are 5 x int64: launch index, job id (0..8 step-GEMM jobs, 100 the
  * attention (+ the state backward fused behind it), 200 + c state-backward chain c), kind (0 read, 1 write, 2 read +
  * write, 3 read behind an in-launch flag), lo, hi (byte addresses).  Returns the number of records (fills min(n, cap)
- * of them into `out`), or -(error code); launch schedules 0, 5 and 6 only.  PARROT_TRACE_ONLY=1 lets schedule 6 be
+ * of them into `out`), or -(error code); launch schedules 0, 5 and 7 only.  PARROT_TRACE_ONLY=1 lets schedule 7 be
  * created on a box without a GPU. */
 long long parrot_decoder_trace(void* plan, int which, long long* out, long long cap);
 /* The same dry run, one record per job: 6 x int64 = launch index, job id, M (rows), N (output columns), K (sum over the

@@ -197,8 +197,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const BgArgs a, int vecA, int v
 
 
 // ---- 8-wave variant (512 threads, same 128x128x16 tile): waves as 2 x 4, each 64 x 32 (2 MFMA blocks, 32
-// accumulator VGPRs), twice the waves per CU for the same LDS: the default (PARROT_GEMM_W8=0 selects the 4-wave
-// kernel above).  PMC on the 4-wave kernel: MFMA pipe 56 % busy, waves parked at s_waitcnt/barriers 45 % of
+// accumulator VGPRs), twice the waves per CU for the same LDS: the kernel that runs (the 4-wave
+// kernel above is kept for reference).  PMC on the 4-wave kernel: MFMA pipe 56 % busy, waves parked at s_waitcnt/barriers 45 % of
 // their cycles, no LDS bank conflicts -- more resident waves hide those waits.
 template <bool XC>
 __device__ __forceinline__ void bg_load8(const float* __restrict__ p, int x0, int X, int k0, int kend,

@@ -646,7 +646,7 @@ struct DecoderPlan : PlanBase {
     // The pre-activation of an upper layer is now (recurrent sum) + (input sum) instead of one running sum over the
     // concatenated K: same terms, other rounding (not bit-identical to schedule 0; the oracle tests cover both).
     int esplit5 = 1;
-    bool s5_split = true;  // PARROT_S5_SPLIT=0: LSTM input projections of l >= 2 as one job
+    bool s5_split = true;  // LSTM input projections of l >= 2 as two K-balanced jobs (false: one job; measured slower)
     int lag5(int l) const { return l == 0 ? 0 : l + 1; }
     int nticks5() const { return d.T + lag5(d.L - 1); }
     // part 0: the whole projection; 1: the rows of w and h_0 .. h_{l-2} (ready a tick earlier); 2: the rows of h_{l-1},
@@ -725,7 +725,7 @@ struct DecoderPlan : PlanBase {
     // The attention of step q-1 only feeds the LAST K = E rows of layer 0's product at step q (and the upper layers a
     // tick later), and an LSTM launch is three times as long as the attention chain.  So the attention rides at the head
     // of the next tick's launch: its blocks are dispatched first and publish w write-through plus an arrival count
-    // (att_fwd_body.h, as in schedule 6); layer 0's workgroups -- the shortest K of the launch -- come LAST in the grid,
+    // (att_fwd_body.h; the hand-off first built for round 3's schedule 6); layer 0's workgroups -- the shortest K of the launch -- come LAST in the grid,
     // start on the CUs the attention blocks free, walk their h rows and take the w rows behind the flag (wk_body's tail;
     // sk_body's for f32 operands).  The upper layers lag one tick more than in schedule 0 so that the w they read was
     // published by an EARLIER launch:  tick q:  attention(q-1) || lstm(l0, q) [w rows flagged], lstm(l, q - lag7(l)),
@@ -770,7 +770,7 @@ struct DecoderPlan : PlanBase {
     // Gradient contributions that cross layers land in separate buffers (dhup[l] for the state, dw0
     // for layer 0's share of dw), so no two jobs of a launch update the same element: no atomics, and
     // the result is deterministic.  The consumers add the parts when they read.
-    bool bwd_split = true;  // PARROT_BWD_SPLIT=0: the dC products stay in the Y launch (K = 3H jobs), as before round 3
+    bool bwd_split = true;  // false: the dC products stay in the Y launch (K = 3H jobs), as before round 3
     // schedule 7 with bf16 operands: the backward tick of LSTM layers as ONE launch (skinny.hip wkb_kernel); bwd_flags =
     // [ticks x 4 chains] arrival counters, plan-owned, zeroed at the head of the backward scan
     unsigned* att_flags = nullptr;  // [T + 2] arrival counters, one per tick (plan-owned, zeroed at the head of the scan)
@@ -779,7 +779,7 @@ struct DecoderPlan : PlanBase {
     unsigned* bwd_flags = nullptr;
     // LSTM layers, bf16 operands, second accumulators given (ParrotDecoderDesc::dh_b ...): the backward products in two K
     // halves.  A wide workgroup streams its whole [B, 4H] operand: 156 workgroups of ~40 us each at cfg4, whatever
-    // their width, and 100 idle CUs; two K halves = 312 workgroups of ~20 us (PARROT_BWD_KSPLIT=0: one part).
+    // their width, and 100 idle CUs; two K halves = 312 workgroups of ~20 us.
     bool bwd_ksplit = false;
     // (Layer 0's products in FOUR K parts were built and measured in round 4: cfg4 94.6 vs 91.4 ms -- 112 narrow workgroups
     // with a ring fill each cost more than the shorter stream returns; removed in round 5.)
@@ -1433,7 +1433,7 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
             p->flags_fake = true;
         }
         if (p->schedule == 7 && desc->bf16) {
-            // the backward tick as one launch too (wkb_kernel); PARROT_BWD_FUSED=0 keeps the two launches of schedule 0
+            // the backward tick as one launch too (wkb_kernel)
             const size_t words = (size_t)4 * (desc->T + desc->L);
             if (p->flags_fake) p->bwd_flags = reinterpret_cast<unsigned*>((uintptr_t)0x100000);
             else if (hipMalloc(&p->bwd_flags, sizeof(unsigned) * words) != hipSuccess) { delete p; return PARROT_ERR_BADARG; }
