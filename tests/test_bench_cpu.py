@@ -43,7 +43,9 @@ def test_repo_has_no_stale_traffic_figure():
     import bench
     value, note = bench.pmc_traffic_figure()
     if value is not None:
-        blob = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")))
+        import re
+        name = re.search(r"profiles/(\S+\.json)", note).group(1)  # the file the note says the figure comes from
+        blob = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert blob["source_digest"] == bench.kernel_source_digest()
     else:
         assert note is None or "stale" in note or "unreadable" in note
