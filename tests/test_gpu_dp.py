@@ -67,3 +67,47 @@ def test_two_rank_trainer_step_equals_single_process(dev):
         err = float((flat - flat1).abs().max() / flat1.abs().max())
         assert err <= 1e-5, f"rank {r}: parameters after two clip+Adam steps differ by {err:.2e}"
     assert torch.equal(ret[0][0], ret[1][0]), "replicas stay bit-identical"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(which_cost='GMM', k_gmm=3), dict(layer_norm=True), dict(use_speaker=True, num_speakers=4),
+                                dict(cell_type='lstm', num_layers=3), dict(num_layers=1, weak_feedback=False)])
+def test_early_gradient_bucket_is_final_when_the_hook_fires(dev, kw):
+    """dist.GradientExchange starts the all-reduce of `Parrot.early_gradient_range()` the moment the backward pass calls
+    `on_early_gradients` -- before the backward scan.  What it promises: nothing in the rest of the backward pass writes that
+    slice of the flat gradient again.  Checked here for every head / variant: the slice captured inside the hook equals the
+    slice after the whole backward, bit for bit; it is not empty, holds non-zero gradients, starts at the readout matrix and
+    ends with the output layer; everything outside it is still changing when the hook fires (the split is worth something)."""
+    from oracle import parrot_ref as R
+    from parrot_amd.model import Parrot
+    full = dict(KW, **kw)
+    cfg = R.default_config(**full)
+    p = R.init_params(cfg, seed=11, scale_by_fan_in=True)
+    m = Parrot(device=dev, use_graph=True, **full).allocate()
+    m.set_parameter_values(p)
+    feat, fm, lab, lm, spk = make_batch(cfg, T, B, U, seed=5, ragged=True, speaker=cfg['use_speaker'])
+    rng = m.early_gradient_range()
+    assert rng is not None
+    lo, hi = rng
+    names = list(m.store._entries)
+    assert lo == m.store.offsets['dec.Wr'][0] and 0 <= lo < hi <= m.flat_gradients.numel()
+    seen = []
+    m.on_early_gradients = lambda: seen.append((m.flat_gradients[lo:hi].clone(), m.flat_gradients.clone()))
+    m.zero_grad()
+    cost, _, _, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev),
+                                   None if spk is None else spk.to(dev), 1, B)
+    cost.backward()
+    m.on_early_gradients = None
+    assert len(seen) == 1, "the hook fires exactly once per backward pass"
+    early_then, all_then = seen[0]
+    final = m.flat_gradients
+    assert torch.equal(early_then, final[lo:hi]), "the early bucket was written again after the hook"
+    assert float(early_then.abs().max()) > 0.0
+    outside_then = torch.cat([all_then[:lo], all_then[hi:]])
+    outside_final = torch.cat([final[:lo], final[hi:]])
+    assert not torch.equal(outside_then, outside_final), "nothing was left to do after the hook: the split buys nothing"
+    # the output layer's parameters are inside the bucket
+    for wn, bn, _ in m._out_names:
+        for n in (wn, bn):
+            o, k = m.store.offsets[n]
+            assert lo <= o and o + k <= hi, n
+    m.close()
