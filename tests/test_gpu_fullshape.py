@@ -130,6 +130,59 @@ def test_cfg2_benchmarked_window_T800_matches_oracle(dev, capsys):
     m.close()
 
 
+@pytest.mark.timeout(2400)
+def test_reference_literal_3gru_window_T800_matches_oracle(dev, capsys):
+    """The reference's OWN decoder depth -- three GatedRecurrent layers, h = 1024 (model.py:312-347), literal batch-axis encoder
+    -- at the benchmarked window (B = 64, T_enc = 200, T_dec = 800, fp32), as `bench.py`'s `secondary.ref_literal_3gru` runs it
+    (round 5): cost, frames, kappa, w, phi at 1e-4 and every parameter gradient at 1e-3 norm-wise against the fp64 oracle with
+    checkpointed BPTT.  Three layers run schedule 5 forward and the three-launch backward tick (bwd8 covers two layers only)."""
+    from oracle import parrot_ref as R
+    from parrot_amd import _lib
+    from parrot_amd.model import Parrot
+    kw = dict(num_layers=3, encoder_type='bidirectional', rnn_h_dim=1024, readouts_dim=1024)
+    T, B, U = 800, 64, 200
+    cfg = R.default_config(**kw)
+    assert cfg['encoder_literal']
+    p = R.init_params(cfg, seed=1234)
+    p['/parrot/h1_to_att/fork_kappa.b'].fill_(-1.5)
+    m = Parrot(device=dev, use_graph=True, **kw).allocate()
+    m.set_parameter_values(p)
+    feat, fm, lab, lm, _ = make_batch(cfg, T, B, U, seed=77)
+    m.zero_grad()
+    cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
+    cost.backward()
+    assert int(_lib.load().parrot_decoder_schedule(next(iter(m._train_ws.values()))['plan'])) == 5
+    grads = {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()}
+    av = [x.detach().cpu().double() for x in av]
+    cost = float(cost)
+    m.close()
+    for v in p.values():
+        v.requires_grad_()
+    rc, rav = R.cost_and_grads_checkpointed(p, cfg, feat, fm, lab, lm, None, chunk=100)
+    report = [f"cost: hip {cost:.8f} oracle {float(rc):.8f} rel {abs(cost - float(rc)) / abs(float(rc)):.2e}"]
+    assert abs(cost - float(rc)) <= 1e-4 * abs(float(rc))
+    assert float(rav[1][-1].min()) > 100.0, "kappa must have moved through the text for the window to mean anything"
+    for i, n in ((0, "predicted frames"), (1, "kappa"), (2, "w"), (4, "phi")):
+        e = assert_close(av[i], rav[i], 1e-4, n)
+        report.append(f"{n}: norm-wise {e:.2e}, element-wise {rel_err_elem(av[i], rav[i]):.2e}")
+    worst, n_checked = ("", 0.0), 0
+    for name, ref in p.items():
+        if ref.grad is None:
+            continue
+        if float(ref.grad.abs().max()) < 1e-12:
+            assert float(grads[name].abs().max()) < 1e-6, name
+            continue
+        e = rel_err(grads[name], ref.grad)
+        assert e <= 1e-3, f"grad {name}: rel err {e:.3e}"
+        if e > worst[1]:
+            worst = (name, e)
+        n_checked += 1
+    assert n_checked >= 15
+    report.append(f"{n_checked} parameter gradients within 1e-3; worst {worst[0]}: {worst[1]:.2e}")
+    with capsys.disabled():
+        print("\n[ref-literal 3xGRU T800 parity] " + "\n[ref-literal 3xGRU T800 parity] ".join(report))
+
+
 # SURVEY 8d variants of the benchmarked windows (VERDICT r03 item 2): (decoder kwargs, init kwargs, kappa bias, B, U, ragged)
 VARIANTS = {
     # configs[1] with the N(0, 1/fan_in) parameter set (gates and attention leave their linear regime), ragged lengths
