@@ -600,3 +600,64 @@ def test_cfg5_generator_full_width_greedy(dev, capsys):
     finally:
         lib.delete_all_params()
         tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+
+
+def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
+    """BASELINE configs[4] widths in TRAINING (three-tier GRU, DIM = 1024, EMB_SIZE = 256, Q = 256; three_tier.py:534-636) on the
+    round-5 operators -- gather-sum / segmented-sum embedding, ReLU MLP with gated dx products, softmax-CE kernels, 1024-wide
+    tier GEMMs and scans: cost, ip_cost, the carried states and EVERY parameter gradient vs the fp64 oracle, on mu-law-like
+    (peaked) sample codes with a ragged mask, a fresh window (reset) and a carried one.  B = 4, 320 samples: 1280 rows of the
+    sample-level tier, ten 128-position chunks per embedding position in the segmented sum, most of the 256 codes unused."""
+    from oracle import samplernn_ref as S
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+    try:
+        c = S.config()
+        p = S.init_params(c, seed=8, perturb=0.1)
+        lib.set_params(p)
+        g = torch.Generator().manual_seed(3)
+        B, S_len = 4, 320
+        seq = (torch.randn(B, S_len + 80, generator=g) * 12 + 128).round().clamp(0, 255).long()
+        seq[:, ::9] = 128
+        feats = torch.randn(B, S_len // 80, 63, generator=g, dtype=torch.float64)
+        mask = torch.ones(B, S_len + 80, dtype=torch.float64)
+        mask[1, 250:] = 0
+        mask[3, 333:] = 0
+        rep = []
+        for reset in (1, 0):
+            h0 = torch.randn(B, 1, 1024, generator=g, dtype=torch.float64) * 0.3
+            bh0 = torch.randn(B, 1, 1024, generator=g, dtype=torch.float64) * 0.3
+            ref_p = {k: v.clone().requires_grad_() for k, v in p.items()}
+            rc, rip, rh0, rbh0 = S.compute_cost(ref_p, c, seq, feats, h0, bh0, reset, mask)
+            (rc + rip).backward()
+            for t in lib.named_params().values():
+                t.grad = None
+            cost, ip_cost, allp, ipp, otherp, nh0, nbh0 = tt.compute_cost(
+                seq.to(dev), feats.float().to(dev), h0.float().to(dev), bh0.float().to(dev), reset, mask.float().to(dev))
+            (cost + ip_cost).backward()
+            assert_close(cost, rc, 1e-4, "cost")
+            assert_close(ip_cost, rip, 1e-4, "ip_cost")
+            assert_close(nh0, rh0, 1e-4, "new_h0")
+            assert_close(nbh0, rbh0, 1e-4, "new_big_h0")
+            worst, n = ("", 0.0), 0
+            for name, t in lib.named_params().items():
+                rg = ref_p[name].grad
+                if rg is None or float(rg.abs().max()) < 1e-12:
+                    continue
+                assert t.grad is not None, name
+                e = rel_err(t.grad, rg)
+                assert e < 2e-3, (name, e)
+                if e > worst[1]:
+                    worst = (name, e)
+                n += 1
+            assert n >= 20
+            rep.append(f"reset={reset}: cost {float(cost.detach()):.5f} (oracle {float(rc.detach()):.5f}), ip_cost {float(ip_cost.detach()):.5f}; {n} gradients, "
+                       f"worst {worst[0]}: {worst[1]:.2e}")
+        with capsys.disabled():
+            print("\n[cfg5 training parity] " + "\n[cfg5 training parity] ".join(rep))
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
