@@ -141,7 +141,11 @@ struct SrPlan {
     struct Tiled { float* U = nullptr; float* Wg = nullptr; float* Wc = nullptr; float* Wout = nullptr; };
     Tiled t_big, t_frm;
     float* tiled_slab = nullptr;
-    float* t2 = nullptr;  // [Q, D] = emb_tbl[FS-1] . W2 (persistent sample kernel)
+    // Persistent sample kernel (round 5): everything in front of L2's ReLU is linear, so it is composed through W2 once --
+    //   t2tbl[pos] = emb_tbl[pos] . W2  [FS, Q, D],   Pout_i = Wout_i . W2  [D, FS*D],   cb_i = bout_i . W2 + b2  [FS*D]
+    // -- the frame tier's projection launch makes h . Pout + cb (same shape and cost as h . Wout + bout) and the sample
+    // kernel's L2 pre-activation is a gather-sum: one product and one hand-off fewer per audio sample.
+    float* t2tbl = nullptr; float* Pout = nullptr; float* cb = nullptr;
     // Round 5 (single-GRU tiers): the frame tier's input xf . Win + bin + big_out only enters the step through x . U, so
     //   x . U + bU = xf . (Win . U) + [(bin + big_out) . U + bU].
     // winu = Win . U [FS, 3D] and pbias = bin . U + bU [3D] are composed once (the weights are fixed for the plan's life);
@@ -170,12 +174,23 @@ struct SrPlan {
         if (rc != 0) { (void)hipFree(winu); winu = nullptr; }
         return 0;
     }
-    int make_t2() {
-        if (hipMalloc(&t2, (size_t)d.Q * d.D * sizeof(float)) != hipSuccess) { t2 = nullptr; return 1; }
-        BgPrecisionScope f32_only(0);  // whatever the process-wide GEMM precision is: this table feeds an f32 path
-        int rc = parrot_gemm(d.emb_tbl + (size_t)(d.FS - 1) * d.Q * d.D, d.D, 0, d.W2, d.D, 0, t2, d.D, d.Q, d.D, d.D, nullptr, 1.f,
-                             0, 0, 1, 0, 0, 0, 1, nullptr);
+    int make_composed() {
+        const size_t D = d.D, Q = d.Q, FS = d.FS;
+        if (hipMalloc(&t2tbl, (FS * Q * D + D * FS * D + FS * D) * sizeof(float)) != hipSuccess) { t2tbl = nullptr; return 1; }
+        Pout = t2tbl + FS * Q * D;
+        cb = Pout + D * FS * D;
+        BgPrecisionScope f32_only(0);  // whatever the process-wide GEMM precision is: these tables feed an f32 path
+        int rc = parrot_gemm(d.emb_tbl, (int)D, 0, d.W2, (int)D, 0, t2tbl, (int)D, (int)(FS * Q), (int)D, (int)D, nullptr, 1.f, 0, 0, 1,
+                             0, 0, 0, 1, nullptr);
+        for (size_t i = 0; i < FS && rc == 0; ++i) {
+            rc = parrot_gemm(d.frm_Wout + i * D, (int)(FS * D), 0, d.W2, (int)D, 0, Pout + i * D, (int)(FS * D), (int)D, (int)D, (int)D,
+                             nullptr, 1.f, 0, 0, 1, 0, 0, 0, 1, nullptr);
+            if (rc == 0)
+                rc = parrot_gemm(d.frm_bout + i * D, (int)D, 0, d.W2, (int)D, 0, cb + i * D, (int)D, 1, (int)D, (int)D, d.b2, 1.f, 0, 0,
+                                 1, 0, 0, 0, 1, nullptr);
+        }
         if (rc == 0) rc = (int)hipDeviceSynchronize();
+        if (rc != 0) { (void)hipFree(t2tbl); t2tbl = nullptr; Pout = cb = nullptr; }
         return rc;
     }
     int make_tiled() {
@@ -194,7 +209,7 @@ struct SrPlan {
         rc |= tile(d.big_U, d.D, 3 * d.D, t_big.U); rc |= tile(d.big_Wg, d.D, 2 * d.D, t_big.Wg);
         rc |= tile(d.big_Wc, d.D, d.D, t_big.Wc); rc |= tile(d.big_Wout, d.D, (int)nfr * d.D, t_big.Wout);
         rc |= tile(d.frm_U, d.D, 3 * d.D, t_frm.U); rc |= tile(d.frm_Wg, d.D, 2 * d.D, t_frm.Wg);
-        rc |= tile(d.frm_Wc, d.D, d.D, t_frm.Wc); rc |= tile(d.frm_Wout, d.D, d.FS * d.D, t_frm.Wout);
+        rc |= tile(d.frm_Wc, d.D, d.D, t_frm.Wc); rc |= tile(persist ? Pout : d.frm_Wout, d.D, d.FS * d.D, t_frm.Wout);
         if (rc != 0 || hipDeviceSynchronize() != hipSuccess) {
             (void)hipFree(tiled_slab);
             tiled_slab = nullptr;
@@ -209,7 +224,7 @@ struct SrPlan {
         if (exec) hipGraphExecDestroy(exec);
         if (cap) hipStreamDestroy(cap);
         if (tiled_slab) (void)hipFree(tiled_slab);
-        if (t2) (void)hipFree(t2);
+        if (t2tbl) (void)hipFree(t2tbl);
         if (winu) (void)hipFree(winu);
     }
 
@@ -375,15 +390,15 @@ struct SrPlan {
                                        toff, FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
                 SR_TRY(stack_step(false, d.gru_in, &ftop, st));
             }
-            SR_TRY(linear(ftop, D, d.frm_Wout, FS * D, D, FS * D, d.frm_bout, nullptr, 0, d.frame_out, FS * D, 0, st,
-                          nullptr, 0, nullptr, 0, t_frm.Wout));
+            SR_TRY(linear(ftop, D, persist ? Pout : d.frm_Wout, FS * D, D, FS * D, persist ? cb : d.frm_bout, nullptr, 0, d.frame_out,
+                          FS * D, 0, st, nullptr, 0, nullptr, 0, t_frm.Wout));
             if (persist) {
                 // ---- all FS sample steps of this frame in one launch: XCD-local persistent-thread kernel
                 SrpArgs sa{};
                 sa.tbase = d.tbase; sa.toff = toff; sa.samples = d.samples; sa.len = len;
                 sa.B = B; sa.D = D; sa.Q = d.Q; sa.FS = FS; sa.nsteps = FS;
-                sa.emb_tbl = d.emb_tbl; sa.t2 = t2; sa.frame_out = d.frame_out; sa.ldf = FS * D;
-                sa.W2 = d.W2; sa.b2 = d.b2; sa.W3 = d.W3; sa.b3 = d.b3; sa.W4 = d.W4; sa.b4 = d.b4;
+                sa.t2tbl = t2tbl; sa.frame_out = d.frame_out; sa.ldf = FS * D;
+                sa.W3 = d.W3; sa.b3 = d.b3; sa.W4 = d.W4; sa.b4 = d.b4;
                 sa.logits = d.logits; sa.ws = d.persist_ws; sa.temperature = d.temperature; sa.seed = d.seed;
                 if (f + 1 < nfr && winu) {  // the next frame of this period: its big-tier share is already known
                     sa.next_in = pin; sa.next_Win = winu; sa.next_bias = nullptr;
@@ -469,11 +484,11 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_EN
     SrPlan* p = new (std::nothrow) SrPlan();
     if (!p) return PARROT_ERR_BADARG;
     p->d = *desc;
-    p->make_tiled();
-    p->make_winu();
     p->persist = desc->persist_ws && srp_eligible(desc->B, desc->D, desc->Q, desc->FS) &&
                  desc->persist_ws_floats >= srp_ws_floats(desc->D, desc->Q) && srp_prepare(desc->D) == 0 &&
-                 srp_init_ws(desc->persist_ws, desc->D, desc->Q) == 0 && p->make_t2() == 0;
+                 srp_init_ws(desc->persist_ws, desc->D, desc->Q) == 0 && p->make_composed() == 0;
+    p->make_tiled();  // (after the decision: the persistent path tiles the composed projection)
+    p->make_winu();
     *plan = p;
     return 0;
 }

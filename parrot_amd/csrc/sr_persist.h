@@ -7,11 +7,11 @@ struct SrpArgs {
     const int* tbase; int toff;        // first sample index of this launch: tbase[0] + toff
     int* samples; int len;             // [B][len] sample history (read: the FS samples before t0; written: t0 .. t0+nsteps-1)
     int B, D, Q, FS, nsteps;
-    const float* emb_tbl;              // [FS][Q][D]  (Embedding folded with L1_PrevSamples)
-    const float* t2;                   // [Q][D] = emb_tbl[FS-1] . W2: the newest sample's share of the L2 pre-activation
-    const float* frame_out; int ldf;   // [B][ldf]; step i adds columns [i*D, (i+1)*D)
-    const float* W2; const float* b2; const float* W3; const float* b3;   // [D][D], [D]
-    const float* W4; const float* b4;                                      // [D][Q], [Q]
+    // Everything in front of L2's ReLU composed through W2 by the plan (samplernn.hip, SrPlan::make_composed):
+    const float* t2tbl;                // [FS][Q][D] = emb_tbl[pos] . W2 (Embedding folded with L1_PrevSamples, then with L2)
+    const float* frame_out; int ldf;   // [B][ldf]; step i adds columns [i*D, (i+1)*D) of h . (Wout . W2) + bout . W2 + b2
+    const float* W3; const float* b3;  // [D][D], [D]
+    const float* W4; const float* b4;  // [D][Q], [Q]
     float* logits;                     // [B][Q]: logits of the launch's last step (or null)
     // Optional: the frame tier's input for the NEXT frame (three_tier.py:398-411), computed by every team for its own
     // streams from the samples it has just produced: next_in[b][d] = next_bias[d] + next_add[b][d] + sum_i xf_i * next_Win[i][d],

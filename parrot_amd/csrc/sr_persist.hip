@@ -3,12 +3,16 @@
 // The loop body of three_tier.py:809-832 is a chain of four dependent [B,D] products per audio sample
 // (embedding gather-sum -> L2 -> L3 -> Output -> argmax -> next sample).  As separate launches each link costs a
 // launch (~6 us: 31.7 us per sample at B = 32, D = 1024); as phases of a chip-wide persistent kernel each link costs a
-// cross-XCD hand-off (~4.7 us).  But the streams are independent and the whole sample-level MLP is only 9.4 MB, so the
+// cross-XCD hand-off (~4.7 us).  But the streams are independent and the sample-level MLP is small, so the
 // chip is split along its XCDs instead: XCD x (32 CUs, one workgroup each, private L2) runs streams 4x .. 4x+3 through
 // the complete MLP, and nothing ever crosses an XCD boundary:
-//   * every CU owns D/32 output columns of L2 / L3 and Q/32 of the output layer and keeps those weight slices on chip
-//     for the whole launch -- L2's in LDS (128 KB at D = 1024), L3's and the output layer's in VGPRs (64 + 16 per
-//     thread): no weight traffic per sample;
+//   * the first product of the chain is gone (round 5): everything in front of L2's ReLU is linear, so the caller
+//     composes it through W2 -- the embedding tables (t2tbl[pos] = emb_tbl[pos] . W2) and the frame tier's output
+//     projection (frame_out = h . (Wout_i . W2) + bout_i . W2 + b2) -- and L2's pre-activation is a ten-row gather-sum:
+//     nine rows known a step early (summed in the shadow of the previous step), the newest sample's row from this CU's
+//     slice of t2tbl[FS-1] in LDS (32 KB).  Per sample: three hand-offs and two products instead of four and three;
+//   * every CU owns D/32 output columns of L3 and Q/32 of the output layer and keeps those weight slices in VGPRs
+//     (64 + 16 per thread) for the whole launch: no weight traffic per sample;
 //   * a hand-off = 16-byte stores of the CU's [4 streams x columns] slice (write-through into the XCD's L2) and sc1
 //     loads (TCP miss, L2 hit) on the consumer side that re-read a slot until it is no longer EMPTY (a NaN payload):
 //     one store-to-load latency per link.  The counted variant (store, s_waitcnt, L2 atomic, poll, load) measured
@@ -113,12 +117,12 @@ __device__ __forceinline__ f32x4 srp_dpp_add(const f32x4& v) {
 
 // out[4 rows][CC columns of this CU] = sum_k a[k][row] * W[k][col].  Thread (sl = tid & 7, g = (tid >> 3) % GG,
 // sh = tid / (8 GG)) owns K-slice s = 8 sh + sl, i.e. k = kk * SS + s, and columns 4g .. 4g+3 of the CU's slice; its
-// weights w(kk) are W[k][4g .. 4g+3] (VGPRs or the LDS image wl[kk * 512 + tid]).  The 8 slices of neighbouring lanes
+// weights w(kk) are W[k][4g .. 4g+3] (VGPRs).  The 8 slices of neighbouring lanes
 // are added with DPP (quad swaps, then half-row mirror: a fixed tree), the 64 / GG lane groups through LDS in group
 // order.  Result: threads tid < CC return the finished f32x4 (4 rows) of CU column 4 * (tid % GG) + tid / GG.
-template <int KPP, int GG, bool WLDS>
-__device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f32x4 (&w)[KPP], const f32x4* __restrict__ wl,
-                                          f32x4* __restrict__ red, f32x4& out) {
+template <int KPP, int GG>
+__device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f32x4 (&w)[KPP], f32x4* __restrict__ red,
+                                          f32x4& out) {
     constexpr int CC = 4 * GG, SS = SRP_THREADS / GG, GROUPS = 64 / GG;
     const int tid = threadIdx.x, sl = tid & 7, g = (tid >> 3) % GG, shi = tid / (8 * GG), s = 8 * shi + sl;
     f32x4 acc[4];
@@ -127,7 +131,7 @@ __device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f
 #pragma unroll
     for (int kk = 0; kk < KPP; ++kk) {
         const f32x4 a = act[kk * SS + s];
-        const f32x4 wv = WLDS ? wl[kk * SRP_THREADS + tid] : w[WLDS ? 0 : kk];
+        const f32x4 wv = w[kk];
         // acc[r] = the 4 columns of stream r.  The scalar operand is the (transient) activation: broadcasting the
         // loop-invariant weights instead makes the compiler keep a 4-register splat of every weight alive.
 #pragma unroll
@@ -165,8 +169,8 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     f32x4* lg = red + 256;                                  // [Q]   team logits (4 streams per vector)
     float* ev = reinterpret_cast<float*>(lg + Q);           // [4][Q] exp values of the temperature draw
     float* tmp = ev + 4 * Q;                                // [4 * DC] transposition scratch of the gather phase
-    f32x4* w2l = reinterpret_cast<f32x4*>(tmp + 4 * DC);    // [KP * 512] L2 weight slice (the registers hold L3 + Output)
-    SrpShared* sh = reinterpret_cast<SrpShared*>(w2l + KP * SRP_THREADS);
+    float* t2l = tmp + 4 * DC;                              // [Q][DC] this CU's columns of t2tbl[FS-1] (the newest sample's row)
+    SrpShared* sh = reinterpret_cast<SrpShared*>(t2l + Q * DC);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned* sync = reinterpret_cast<unsigned*>(a.ws);
@@ -181,15 +185,17 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     __syncthreads();
     const int cu = sh->rank;
 
-    // ---- weight slices: L2 -> LDS, L3 and Output -> registers
+    // ---- weight slices: L3 and Output -> registers; this CU's columns of the newest sample's table -> LDS
     const int g = (tid >> 3) % G, s = 8 * (tid / (8 * G)) + (tid & 7);
     const int gq = (tid >> 3) % GQ, sq = 8 * (tid / (8 * GQ)) + (tid & 7);
     f32x4 w3[KP], w4[KQ];
 #pragma unroll
-    for (int kk = 0; kk < KP; ++kk) {
-        const size_t off = (size_t)(kk * S + s) * D + cu * DC + 4 * g;
-        w2l[kk * SRP_THREADS + tid] = *reinterpret_cast<const f32x4*>(a.W2 + off);
-        w3[kk] = *reinterpret_cast<const f32x4*>(a.W3 + off);
+    for (int kk = 0; kk < KP; ++kk)
+        w3[kk] = *reinterpret_cast<const f32x4*>(a.W3 + (size_t)(kk * S + s) * D + cu * DC + 4 * g);
+    for (int idx = tid; idx < Q * (DC / 4); idx += SRP_THREADS) {
+        const int q = idx / (DC / 4), c4 = idx % (DC / 4);
+        reinterpret_cast<f32x4*>(t2l)[idx] =
+            *reinterpret_cast<const f32x4*>(a.t2tbl + ((size_t)(a.FS - 1) * Q + q) * D + cu * DC + 4 * c4);
     }
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk)
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     // column this thread finishes in the reductions (threads tid < DC / tid < QC)
     const int fin_h = cu * DC + 4 * (tid % G) + tid / G;
     const int fin_q = cu * QC + 4 * (tid % GQ) + tid / GQ;
-    const float bias2 = tid < DC ? a.b2[fin_h] : 0.f, bias3 = tid < DC ? a.b3[fin_h] : 0.f;
+    const float bias3 = tid < DC ? a.b3[fin_h] : 0.f;
     const float bias4 = tid < QC ? a.b4[fin_q] : 0.f;
 
     const int t0 = a.tbase[0] + a.toff;
@@ -206,12 +212,10 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         const int b = min(team * SRP_ROWS + r, a.B - 1);
         sh->hist[r][pos] = a.samples[(size_t)b * a.len + t0 - a.FS + pos];
     }
-    // team exchange buffers ([D] f32x4 each, 4 streams per vector): xb[2] (embedding base of the even / odd steps), x1, x2,
-    // and the logits ([Q] f32x4)
-    float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * (4 * D + Q) * 4;
+    // team exchange buffers ([D] f32x4 each, 4 streams per vector): x1, x2, and the logits ([Q] f32x4)
+    float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * (2 * D + Q) * 4;
     const __amdgpu_buffer_rsrc_t xr = srp_rsrc(xbase);
-    f32x4* xb = reinterpret_cast<f32x4*>(xbase);
-    f32x4* x1 = xb + 2 * D;
+    f32x4* x1 = reinterpret_cast<f32x4*>(xbase);
     f32x4* x2 = x1 + D;
     f32x4* lb = x2 + D;
     __syncthreads();
@@ -224,26 +228,25 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     // s_waitcnt vmcnt(0), something the readers take before they look at the emptied buffer again.  No counted barrier.
     if (tid < QC) lb[fin_q] = srp_empty();
 
-    // base_i = frame_out[:, i] + sum_{pos < FS-1} tbl[pos][sample[t - FS + pos]] for this CU's DC columns: everything of
-    // step i's embedding sum that is known one step early (the newest sample's row is added when it is known)
-    auto publish_base = [&](int i) {
+    // part_i = frame_out[:, i] + sum_{pos < FS-1} t2tbl[pos][sample[t - FS + pos]] for this CU's DC columns: everything of
+    // step i's L2 pre-activation that is known one step early (frame_out carries the composed projection and both
+    // biases); threads tid < DC keep it as one f32x4 (4 streams) of column fin_h
+    f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto make_part = [&](int i) {
         if (tid < SRP_ROWS * DC) {
             const int r = tid / DC, c = tid % DC, col = cu * DC + c;
             const int b = min(team * SRP_ROWS + r, a.B - 1);
             float acc = a.frame_out[(size_t)b * a.ldf + (size_t)i * D + col];
             for (int pos = 0; pos < a.FS - 1; ++pos) {
                 const int q = sh->hist[r][i + pos];
-                acc += a.emb_tbl[((size_t)pos * Q + q) * D + col];
+                acc += a.t2tbl[((size_t)pos * Q + q) * D + col];
             }
             tmp[c * SRP_ROWS + r] = acc;
         }
         __syncthreads();
-        if (tid < DC) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            xb[(i & 1) * D + fin_h] = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC];
-        }
+        if (tid < DC) part = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC];
     };
-    publish_base(0);
+    make_part(0);
 
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sync + 600);
     const bool timing = a.pad && team == 0 && cu == 0 && tid == 0;
@@ -251,49 +254,36 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     for (int i = 0; i < a.nsteps; ++i) {
         const bool more = i + 1 < a.nsteps;
         stamp(i, 0);
-        // ---- L2 on base_i; the newest sample's share of the pre-activation, t2[sample] = (tbl[FS-1][sample]) . W2, is a
-        //      precomputed row whose gather (this CU's columns only) flies while the product runs: nothing between the
-        //      pick and the L2 product but the load of the base
-        {
-            float tq[SRP_ROWS] = {0.f, 0.f, 0.f, 0.f};
-            if (tid < DC) {
+        // ---- x1 = relu(part_i + the newest sample's row): no product, the owner publishes its columns right away
+        if (tid < DC) {
+            const int c = fin_h - cu * DC;
+            f32x4 v = part;
 #pragma unroll
-                for (int r = 0; r < SRP_ROWS; ++r) tq[r] = a.t2[(size_t)sh->hist[r][i + a.FS - 1] * D + fin_h];
-            }
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)(((i & 1) * D + k) * 16), abort_, sh);
-            __syncthreads();
-            if (!sh->ok) return;
-            stamp(i, 1);
-            f32x4 v;
-            srp_layer<KP, G, true>(act, w3, w2l, red, v);
-            if (tid < DC) {
-                v += bias2;
-                v += (f32x4){tq[0], tq[1], tq[2], tq[3]};
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                x1[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-            }
-            stamp(i, 2);
-            stamp(i, 3);
+            for (int r = 0; r < SRP_ROWS; ++r) v[r] += t2l[sh->hist[r][i + a.FS - 1] * DC + c];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x1[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         }
+        stamp(i, 1);
         {
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((2 * D + k) * 16), abort_, sh);
+            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)(k * 16), abort_, sh);
             __syncthreads();
             if (!sh->ok) return;
-            stamp(i, 4);
-            // x1(i) complete => every CU is done with base_i and with the logits of step i-1
-            if (tid < DC) xb[(i & 1) * D + fin_h] = srp_empty();
+            stamp(i, 2);
+            // x1(i) complete => every CU is done with the logits of step i-1
             if (i > 0 && tid < QC) lb[fin_q] = srp_empty();
             f32x4 v;
-            srp_layer<KP, G, false>(act, w3, nullptr, red, v);
+            srp_layer<KP, G>(act, w3, red, v);
             if (tid < DC) {
                 v += bias3;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 x2[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
-            if (more) publish_base(i + 1);  // needs nothing from the other workgroups: runs while their x2 slices arrive
+            stamp(i, 3);
+            if (more) make_part(i + 1);  // needs nothing from the other workgroups: runs while their x2 slices arrive
+            stamp(i, 4);
         }
         {
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((3 * D + k) * 16), abort_, sh);
+            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
             __syncthreads();
             if (!sh->ok) return;
             stamp(i, 5);
@@ -302,7 +292,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
                 for (int q = 0; q < DC / QC; ++q) x1[cu * DC + tid * (DC / QC) + q] = srp_empty();
             }
             f32x4 v;
-            srp_layer<KQ, GQ, false>(act, w4, nullptr, red, v);
+            srp_layer<KQ, GQ>(act, w4, red, v);
             if (tid < QC) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lb[fin_q] = v + bias4;
@@ -310,7 +300,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         }
 
         // ---- pick (every CU of the team, identical result): argmax with lowest-index ties, or the seeded draw
-        if (tid < Q) lg[tid] = srp_take(xr, (unsigned)((4 * D + tid) * 16), abort_, sh);
+        if (tid < Q) lg[tid] = srp_take(xr, (unsigned)((2 * D + tid) * 16), abort_, sh);
         __syncthreads();
         if (!sh->ok) return;
         stamp(i, 6);
@@ -388,8 +378,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
 }
 
 size_t srp_lds_bytes(int D) {
-    const int KP = D * (D / 128) / SRP_THREADS;  // K rows per thread slice
-    return (size_t)(D + 256 + SRP_Q + KP * SRP_THREADS) * 16 + (size_t)(4 * SRP_Q + 4 * (D / 32)) * 4 + sizeof(SrpShared) + 64;
+    return (size_t)(D + 256 + SRP_Q) * 16 + (size_t)(4 * SRP_Q + 4 * (D / 32) + SRP_Q * (D / 32)) * 4 + sizeof(SrpShared) + 64;
 }
 
 }  // namespace
@@ -408,13 +397,13 @@ bool srp_eligible(int B, int D, int Q, int FS) {
     return D == 256 || D == 512 || D == 1024;
 }
 
-long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * (4 * D + Q) * 4; }
+long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * (2 * D + Q) * 4; }
 
 int srp_init_ws(float* ws, int D, int Q) {
     // barrier / census / abort words zero, every hand-off slot EMPTY
     PH_CHECK(hipMemset(ws, 0, SRP_SYNC_WORDS * sizeof(float)));
     PH_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ws + SRP_SYNC_WORDS), (int)SRP_EMPTY,
-                          (size_t)SRP_NTEAMS * (4 * D + Q) * 4));
+                          (size_t)SRP_NTEAMS * (2 * D + Q) * 4));
     return (int)hipDeviceSynchronize();
 }
 

@@ -1,6 +1,7 @@
 """Phase timers of the persistent SampleRNN sample kernel (PARROT_SR_TIMING=1): workgroup 0 of team 0 stamps, per step,
-0 step start | 1 o1 assembled (base + newest row) | 2 x1 published | 3 next base published | 4 x1 taken |
-5 x2 taken | 6 logits taken | 7 pick done.  Prints the median interval of each stage over the last launch's steps."""
+0 step start | 1 x1 published (part + newest row, no product) | 2 x1 taken | 3 L3 product done, x2 published |
+4 next step's part summed | 5 x2 taken | 6 logits taken | 7 pick done.  Prints the median interval of each stage over the
+last launch's steps."""
 import os, sys
 import numpy as np
 import torch
@@ -21,8 +22,8 @@ feats = np.random.RandomState(0).randn(T, B, 63).astype('float32')
 gen.generate(feats); torch.cuda.synchronize()
 w = gen.ws['persist_ws'][:1024].cpu().view(torch.int32).numpy()
 st = w[600:600 + 160].view(np.int64).reshape(10, 8).astype(np.float64) / 100.0  # us
-names = ["assemble o1 (take base + gather newest row)", "L2 product + publish x1", "publish next base", "take x1",
-         "L3 product + publish x2, take x2", "output product + publish logits, take logits", "pick"]
+names = ["publish x1 (part + newest row)", "take x1", "L3 product + publish x2", "next step's part (gather-sum)",
+         "take x2", "output product + publish logits, take logits", "pick"]
 d = np.diff(st, axis=1)
 for q, n in enumerate(names):
     print(f"{n:55s} median {np.median(d[1:9, q]):6.2f} us   (min {d[1:9, q].min():.2f}, max {d[1:9, q].max():.2f})")
