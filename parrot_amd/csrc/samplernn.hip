@@ -136,6 +136,7 @@ __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
 struct SrPlan {
     SampleRnnGenDesc d;
     bool persist = false;  // sample steps on the persistent-thread kernel (sr_persist.hip)
+    bool resident = false; // ... and the frame tier inside it: one launch per big frame (sr_resident.hip)
     // Fragment-major copies (sk_tile_weights, mode 0) of the single-GRU tiers' matrices, owned by the plan and made once
     // at create time: the step kernel then reads its weights as contiguous 1 KB wave loads instead of 64-byte row pieces.
     struct Tiled { float* U = nullptr; float* Wg = nullptr; float* Wc = nullptr; float* Wout = nullptr; };
@@ -154,16 +155,18 @@ struct SrPlan {
     // their additive input -- written by the previous frame's sample kernel (SrpArgs::next_n) or, for the first frame of a
     // period, by sr_frame_in_kernel at width 3D.
     float* winu = nullptr; float* pbias = nullptr; float* pbig = nullptr; float* pin = nullptr;
+    float* gpre = nullptr;  // [B, 2D] h . Wg of the next frame, made beside the projection (persistent path)
     int make_winu() {
         const size_t D = d.D, nfr = d.BFS / d.FS;
         if (d.n_rnn != 0) return 0;
-        if (hipMalloc(&winu, ((size_t)d.FS * 3 * D + 3 * D + (size_t)d.B * nfr * 3 * D + (size_t)d.B * 3 * D) * sizeof(float)) != hipSuccess) {
+        if (hipMalloc(&winu, ((size_t)d.FS * 3 * D + 3 * D + (size_t)d.B * nfr * 3 * D + (size_t)d.B * 3 * D + (size_t)d.B * 2 * D) * sizeof(float)) != hipSuccess) {
             winu = nullptr;
             return 0;
         }
         pbias = winu + (size_t)d.FS * 3 * D;
         pbig = pbias + 3 * D;
         pin = pbig + (size_t)d.B * nfr * 3 * D;
+        gpre = pin + (size_t)d.B * 3 * D;
         BgPrecisionScope f32_only(0);
         int rc = parrot_gemm(d.frm_Win, (int)D, 0, d.frm_U, 3 * (int)D, 0, winu, 3 * (int)D, d.FS, 3 * (int)D, (int)D, nullptr, 1.f, 0, 0,
                              1, 0, 0, 0, 1, nullptr);
@@ -247,7 +250,7 @@ struct SrPlan {
     // GRU step of a tier (ops.py:356-393): gates = sigm(h.Wg + x.U[:, :2D] + b[:2D]); cand = tanh((r*h).Wc + x.U[:, 2D:] +
     // b[2D:]); in-place h.  The Input linear rides in the step GEMMs as a second K segment: two launches, not three.
     int gru(const float* x, const float* U, const float* bU, const float* Wg, const float* Wc, float* h, hipStream_t st,
-            const Tiled* t = nullptr, const float* pre = nullptr) {
+            const Tiled* t = nullptr, const float* pre = nullptr, bool gates_done = false) {
         const int D = d.D;
         const int blk = (D >> 4) * 256;  // floats per column tile of a [D, *] fragment-major copy
         const bool tl = t && t->U;
@@ -255,14 +258,16 @@ struct SrPlan {
         SkLaunch L;
         sk_job_init(j);
         if (pre) {  // x . U + bU arrives precomputed ([B, 3D]: gates | candidate): only the recurrent product is left
-            j.nseg = 1;
-            j.seg[0] = tl ? sk_seg(h, D, t->Wg, blk, D, 2) : sk_seg(h, D, Wg, 2 * D, D, 0);
-            j.M = d.B; j.N = 2 * D; j.H = D; j.epi = SK_EPI_GRU_GATES;
-            j.add = pre; j.ld_add = 3 * D;
-            j.e0 = h; j.lde0 = D;
-            j.o1 = d.z; j.ldo1 = D; j.o2 = d.r; j.ldo2 = D; j.out = d.rh; j.ldo = D;
-            SR_TRY(sk_make_launch(L, &j, 1));
-            SR_TRY(sk_launch(L, st));
+            if (!gates_done) {  // (gates_done: the previous frame's sample kernel has left z and r*h already)
+                j.nseg = 1;
+                j.seg[0] = tl ? sk_seg(h, D, t->Wg, blk, D, 2) : sk_seg(h, D, Wg, 2 * D, D, 0);
+                j.M = d.B; j.N = 2 * D; j.H = D; j.epi = SK_EPI_GRU_GATES;
+                j.add = pre; j.ld_add = 3 * D;
+                j.e0 = h; j.lde0 = D;
+                j.o1 = d.z; j.ldo1 = D; j.o2 = d.r; j.ldo2 = D; j.out = d.rh; j.ldo = D;
+                SR_TRY(sk_make_launch(L, &j, 1));
+                SR_TRY(sk_launch(L, st));
+            }
             sk_job_init(j);
             j.nseg = 1;
             j.seg[0] = tl ? sk_seg(d.rh, D, t->Wc, blk, D, 2) : sk_seg(d.rh, D, Wc, D, D, 0);
@@ -372,6 +377,23 @@ struct SrPlan {
                 }
             }
         }
+        if (resident) {  // the period's nfr frame-tier steps and BFS sample steps in ONE launch
+            SrqArgs qa{};
+            qa.tbase = d.tbase; qa.samples = d.samples; qa.len = len;
+            qa.B = B; qa.D = D; qa.Q = d.Q; qa.FS = FS; qa.nfr = nfr;
+            qa.t2tbl = t2tbl; qa.Pout = Pout; qa.cb = cb;
+            qa.W3 = d.W3; qa.b3 = d.b3; qa.W4 = d.W4; qa.b4 = d.b4;
+            qa.Wg = d.frm_Wg; qa.Wc = d.frm_Wc; qa.winu = winu; qa.pbig = pbig; qa.ld_pbig = nfr * 3 * D;
+            qa.frm_h = d.frm_h; qa.logits = d.logits; qa.ws = d.persist_ws;
+            qa.temperature = d.temperature; qa.seed = d.seed;
+            {
+                static const int timing = getenv("PARROT_SR_TIMING") ? atoi(getenv("PARROT_SR_TIMING")) : 0;
+                qa.timing = timing;
+            }
+            SR_TRY(srq_launch(qa, st));
+            hipLaunchKernelGGL(sr_tick_kernel, dim3(1), dim3(64), 0, st, d.tbase, BFS, 0);
+            return (int)hipGetLastError();
+        }
         for (int f = 0; f < nfr; ++f) {
             // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
             const int toff = f * FS;
@@ -382,7 +404,7 @@ struct SrPlan {
                     hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(3 * D, 256), B), dim3(256), 0, st, d.samples, len,
                                        d.tbase, toff, FS, half_q, winu, (const float*)nullptr, pbig + (size_t)f * 3 * D,
                                        nfr * 3 * D, pin, 3 * D);
-                SR_TRY(gru(nullptr, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st, &t_frm, pin));
+                SR_TRY(gru(nullptr, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st, &t_frm, pin, persist && f > 0));
                 ftop = d.frm_h;
             } else {
                 if (!persist || f == 0)
@@ -390,8 +412,28 @@ struct SrPlan {
                                        toff, FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
                 SR_TRY(stack_step(false, d.gru_in, &ftop, st));
             }
-            SR_TRY(linear(ftop, D, persist ? Pout : d.frm_Wout, FS * D, D, FS * D, persist ? cb : d.frm_bout, nullptr, 0, d.frame_out,
-                          FS * D, 0, st, nullptr, 0, nullptr, 0, t_frm.Wout));
+            if (persist && winu && f + 1 < nfr) {
+                // the projection and, beside it, the recurrent product of the NEXT frame's gates (h' . Wg: it does not wait for
+                // the frame's samples); the sample kernel finishes those gates at its end
+                SkJob jobs[2];
+                const int blk = (D >> 4) * 256;
+                sk_job_init(jobs[0]);
+                jobs[0].nseg = 1;
+                jobs[0].seg[0] = t_frm.Wout ? sk_seg(ftop, D, t_frm.Wout, blk, D, 2) : sk_seg(ftop, D, Pout, FS * D, D, 0);
+                jobs[0].M = B; jobs[0].N = FS * D; jobs[0].H = FS * D; jobs[0].epi = SK_EPI_LINEAR;
+                jobs[0].bias = cb; jobs[0].out = d.frame_out; jobs[0].ldo = FS * D;
+                sk_job_init(jobs[1]);
+                jobs[1].nseg = 1;
+                jobs[1].seg[0] = t_frm.Wg ? sk_seg(ftop, D, t_frm.Wg, blk, D, 2) : sk_seg(ftop, D, d.frm_Wg, 2 * D, D, 0);
+                jobs[1].M = B; jobs[1].N = 2 * D; jobs[1].H = 2 * D; jobs[1].epi = SK_EPI_LINEAR;
+                jobs[1].out = gpre; jobs[1].ldo = 2 * D;
+                SkLaunch L;
+                SR_TRY(sk_make_launch(L, jobs, 2));
+                SR_TRY(sk_launch(L, st));
+            } else {
+                SR_TRY(linear(ftop, D, persist ? Pout : d.frm_Wout, FS * D, D, FS * D, persist ? cb : d.frm_bout, nullptr, 0,
+                              d.frame_out, FS * D, 0, st, nullptr, 0, nullptr, 0, t_frm.Wout));
+            }
             if (persist) {
                 // ---- all FS sample steps of this frame in one launch: XCD-local persistent-thread kernel
                 SrpArgs sa{};
@@ -403,6 +445,7 @@ struct SrPlan {
                 if (f + 1 < nfr && winu) {  // the next frame of this period: its big-tier share is already known
                     sa.next_in = pin; sa.next_Win = winu; sa.next_bias = nullptr;
                     sa.next_add = pbig + (size_t)(f + 1) * 3 * D; sa.next_ld_add = nfr * 3 * D; sa.next_n = 3 * D;
+                    sa.next_gpre = gpre; sa.next_h = d.frm_h; sa.next_z = d.z; sa.next_rh = d.rh;
                 } else if (f + 1 < nfr) {
                     sa.next_in = d.gru_in; sa.next_Win = d.frm_Win; sa.next_bias = d.frm_bin;
                     sa.next_add = d.big_out + (size_t)(f + 1) * D; sa.next_ld_add = nfr * D;
@@ -489,6 +532,8 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_EN
                  srp_init_ws(desc->persist_ws, desc->D, desc->Q) == 0 && p->make_composed() == 0;
     p->make_tiled();  // (after the decision: the persistent path tiles the composed projection)
     p->make_winu();
+    p->resident = p->persist && p->winu && desc->n_rnn == 0 &&
+                  srq_eligible(desc->B, desc->D, desc->Q, desc->FS, desc->BFS / desc->FS) && srq_prepare(desc->D, desc->FS) == 0;
     *plan = p;
     return 0;
 }
@@ -499,7 +544,8 @@ long long samplernn_persist_floats(const SampleRnnGenDesc* desc) { PH_ENTRY();
 }
 
 int samplernn_generate_is_persistent(void* plan) { PH_ENTRY();
-    return plan && static_cast<SrPlan*>(plan)->persist ? 1 : 0;
+    const SrPlan* p = static_cast<SrPlan*>(plan);
+    return p && p->persist ? (p->resident ? 2 : 1) : 0;
 }
 
 int samplernn_generate_status(void* plan) { PH_ENTRY();

@@ -1,0 +1,273 @@
+// Device helpers shared by the two SampleRNN persistent-thread kernels (sr_persist.hip: one launch per frame of FS sample
+// steps; sr_resident.hip: one launch per big frame with the frame tier inside): XCD teams, EMPTY-slot hand-offs that stay
+// in the XCD's L2, the register-resident [4 streams x CU columns] product.  See sr_persist.hip for the protocol.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int SRP_THREADS = 512, SRP_TEAM = 32, SRP_NTEAMS = 8, SRP_ROWS = 4, SRP_Q = 256;
+constexpr int SRP_SYNC_WORDS = 1024;  // [0..255] arrive (32 words per team), [256..511] census, [512] abort, [513] fault code
+constexpr int SRP_MAXHIST = 112;      // FS + nsteps (the resident kernel: FS + BFS)
+// f32x4 hand-off slots per team in the workspace: sr_persist.hip uses x1, x2 [D] and the logits [Q]; sr_resident.hip x1, x2,
+// r*h, two h' [D each] and the logits
+__host__ __device__ constexpr int srp_team_vecs(int D, int Q) { return 5 * D + Q; }
+
+__device__ __forceinline__ int srp_xcc() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 7);
+}
+// RMW executed in the issuing XCD's L2 (no sc1: the line never leaves this XCD), returns the previous value
+__device__ __forceinline__ unsigned srp_l2_add(unsigned* p, unsigned v) {
+    unsigned old;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
+    return old;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srp_rsrc(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
+}
+// sc1 load: misses in the CU's vector cache, served by the XCD's L2 (where the team's stores have landed)
+__device__ __forceinline__ f32x4 srp_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
+}
+
+// Plain 16-byte store / 4-byte load through a buffer descriptor: the address is four SGPRs and one 32-bit VGPR offset, where
+// a pointer costs two VGPRs that the optimiser hoists out of the sample loop and keeps alive across it.
+__device__ __forceinline__ void srp_st(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ float srp_ldf(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+// Hand-off slots are 16 bytes = one value for each of the team's 4 streams.  An empty slot holds a NaN with a payload
+// arithmetic never produces; a 16-byte store replaces it atomically in the L2, so a consumer simply re-reads a slot
+// until it is full: no store acknowledgement, arrival counter or flag poll sits between producer and consumer.
+constexpr unsigned SRP_EMPTY = 0x7FC0DEADu;
+__device__ __forceinline__ f32x4 srp_empty() {
+    const float e = __uint_as_float(SRP_EMPTY);
+    return (f32x4){e, e, e, e};
+}
+__device__ __forceinline__ bool srp_is_empty(const f32x4& v) {
+    return __float_as_uint(v[0]) == SRP_EMPTY || __float_as_uint(v[3]) == SRP_EMPTY;
+}
+
+// 100 MHz wall clock (timing aid, PARROT_SR_TIMING=1: workgroup 0 of team 0 stamps the phase boundaries of every step
+// into sync words 600..)
+__device__ __forceinline__ unsigned long long srp_clock() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
+struct SrpShared {
+    int rank, ok, gen;
+    int hist[SRP_ROWS][SRP_MAXHIST];
+    float mx[SRP_ROWS];
+};
+
+// Load a hand-off slot, re-reading until it is full (bounded: ~1 s, then the abort word is raised).
+__device__ __forceinline__ f32x4 srp_take(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned* abort_, SrpShared* sh) {
+    f32x4 v = srp_ld(r, byte_off);
+    unsigned n = 0;
+    while (srp_is_empty(v)) {
+        if ((++n & 1023u) == 0u) {
+            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh->ok = 0; break; }
+            if (n > (1u << 21)) {
+                __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(abort_ + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = srp_ld(r, byte_off);
+    }
+    return v;
+}
+
+// N slots per thread at once: every round issues the loads of all slots that are still EMPTY before looking at any, so a
+// take costs one L2 round trip per round whatever N is (one slot after the other costs N round trips).  Slot j of the
+// thread is vector k0 + j * stride of the buffer that starts at byte offset base; values go to dst[k0 + j * stride].
+template <int N>
+__device__ __forceinline__ void srp_take_n(__amdgpu_buffer_rsrc_t r, unsigned base, int k0, int stride, int limit,
+                                           f32x4* __restrict__ dst, unsigned* abort_, SrpShared* sh) {
+    f32x4 v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = k0 + j * stride < limit ? srp_ld(r, base + (unsigned)(k0 + j * stride) * 16u) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned n = 0;
+    for (;;) {
+        bool e = false;
+#pragma unroll
+        for (int j = 0; j < N; ++j) e |= srp_is_empty(v[j]);
+        if (!e) break;
+        if ((++n & 1023u) == 0u) {
+            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh->ok = 0; break; }
+            if (n > (1u << 21)) {
+                __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(abort_ + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh->ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (srp_is_empty(v[j])) v[j] = srp_ld(r, base + (unsigned)(k0 + j * stride) * 16u);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if (k0 + j * stride < limit) dst[k0 + j * stride] = v[j];
+}
+
+// f32x4 += the same vector of the lane selected by a DPP control (all four components)
+template <int CTRL>
+__device__ __forceinline__ f32x4 srp_dpp_add(const f32x4& v) {
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        r[c] = v[c] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c]), CTRL, 0xf, 0xf, true));
+    return r;
+}
+
+// out[4 rows][CC columns of this CU] = sum_k a[k][row] * W[k][col].  Thread (sl = tid & 7, g = (tid >> 3) % GG,
+// sh = tid / (8 GG)) owns K-slice s = 8 sh + sl, i.e. k = kk * SS + s, and columns 4g .. 4g+3 of the CU's slice; its
+// weights w(kk) are W[k][4g .. 4g+3] (VGPRs).  The 8 slices of neighbouring lanes
+// are added with DPP (quad swaps, then half-row mirror: a fixed tree), the 64 / GG lane groups through LDS in group
+// order.  Result: threads tid < CC return the finished f32x4 (4 rows) of CU column 4 * (tid % GG) + tid / GG.
+// Wave-wide max / min with every lane receiving the result: quad swaps, half-row and row mirrors on the DPP path (no LDS
+// crossbar as __shfl_xor would use: ~100 clocks instead of ~1200 for the six levels), the four row results through
+// v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float srp_dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int srp_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ float srp_wave_max(float v) {
+    v = fmaxf(v, srp_dpp_f<0xB1>(v));
+    v = fmaxf(v, srp_dpp_f<0x4E>(v));
+    v = fmaxf(v, srp_dpp_f<0x141>(v));
+    v = fmaxf(v, srp_dpp_f<0x140>(v));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ int srp_wave_min(int v) {
+    v = min(v, srp_dpp_i<0xB1>(v));
+    v = min(v, srp_dpp_i<0x4E>(v));
+    v = min(v, srp_dpp_i<0x141>(v));
+    v = min(v, srp_dpp_i<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// argmax of row r of the team's logits lg[Q] (4 streams per vector), lowest index on ties (numpy / Theano argmax):
+// every lane returns the index and, through best, the maximum.
+template <int Q>
+__device__ __forceinline__ int srp_argmax_row(const f32x4* __restrict__ lg, int r, int lane, float& best) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int m = 0; m < Q / 64; ++m) {
+        const float v = lg[lane + 64 * m][r];
+        if (v > bv) { bv = v; bi = lane + 64 * m; }
+    }
+    best = srp_wave_max(bv);
+    return srp_wave_min(bv == best ? bi : 0x7fffffff);
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
+// wave (s_waitcnt vmcnt(0)), which would pin table gathers and LDS-DMA streams that are meant to fly across it.
+__device__ __forceinline__ void srp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The thread index as a value the optimiser cannot see through.  Everything a sample step derives from it (column and
+// slot offsets, LDS addresses) would otherwise be hoisted out of the step loop as a loop invariant and kept alive across
+// it -- a hundred-odd VGPRs next to 80 of resident weights; derived from this inside the loop they are temporaries.
+__device__ __forceinline__ int srp_opaque_tid() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
+// Fold of a product's per-thread partial sums acc[r] (stream r, the thread's 4 columns): the 8 K-slices of neighbouring
+// lanes with DPP (quad swaps, then half-row mirror: a fixed tree), the 64 / GG lane groups through LDS in group order.
+// Threads tid < 4 GG return the finished f32x4 (4 streams) of CU column 4 * (tid % GG) + tid / GG.
+template <int GG>
+__device__ __forceinline__ void srp_reduce(f32x4 (&acc)[4], f32x4* __restrict__ red, f32x4& out, int tid) {
+    constexpr int CC = 4 * GG, GROUPS = 64 / GG;
+    const int sl = tid & 7, g = (tid >> 3) % GG, shi = tid / (8 * GG);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        acc[r] = srp_dpp_add<0xB1>(acc[r]);   // quad_perm [1,0,3,2]
+        acc[r] = srp_dpp_add<0x4E>(acc[r]);   // quad_perm [2,3,0,1]
+        acc[r] = srp_dpp_add<0x141>(acc[r]);  // row_half_mirror
+    }
+    if (sl == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[shi * CC + j * GG + g] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+    }
+    srp_barrier();
+    if (tid < CC) {
+        f32x4 v = red[tid];
+#pragma unroll 4
+        for (int p = 1; p < GROUPS; ++p) v += red[p * CC + tid];
+        out = v;
+    }
+}
+
+template <int KPP, int GG>
+__device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f32x4 (&w)[KPP], f32x4* __restrict__ red,
+                                          f32x4& out, int tid) {
+    constexpr int SS = SRP_THREADS / GG;
+    const int s = 8 * (tid / (8 * GG)) + (tid & 7);
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KPP; ++kk) {
+        const f32x4 a = act[kk * SS + s];
+        const f32x4 wv = w[kk];
+        // acc[r] = the 4 columns of stream r.  The scalar operand is the (transient) activation: broadcasting the
+        // loop-invariant weights instead makes the compiler keep a 4-register splat of every weight alive.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += a[r] * wv;
+        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // do not hoist all KPP operand reads: registers are tight
+    }
+    srp_reduce<GG>(acc, red, out, tid);
+}
+
+// The same product with the weights STREAMED from memory (W: this CU's first column of the slice, row-major with leading
+// dimension ld): blocks of up to 4 K-rows per thread in flight (16 registers), every wave load a whole 128-byte line per row.
+template <int KPP, int GG>
+__device__ __forceinline__ void srp_stream_layer(const float* __restrict__ W, int ld, const f32x4* __restrict__ act,
+                                                 f32x4* __restrict__ red, f32x4& out, int tid) {
+    constexpr int SS = SRP_THREADS / GG, BLK = KPP < 4 ? KPP : 4;
+    const int g = (tid >> 3) % GG, s = 8 * (tid / (8 * GG)) + (tid & 7);
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wp = W + (size_t)s * ld + 4 * g;
+#pragma unroll 1
+    for (int k0 = 0; k0 < KPP; k0 += BLK) {
+        f32x4 w[BLK];
+#pragma unroll
+        for (int j = 0; j < BLK; ++j)
+            w[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)(k0 + j) * SS * ld));
+#pragma unroll
+        for (int j = 0; j < BLK; ++j) {
+            const f32x4 a = act[(k0 + j) * SS + s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += a[r] * w[j];
+        }
+    }
+    srp_reduce<GG>(acc, red, out, tid);
+}
+
+}  // namespace

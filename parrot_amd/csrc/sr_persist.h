@@ -20,6 +20,10 @@ struct SrpArgs {
     // next_add = the big-tier share of the pre-activations, the kernel leaves the frame tier's additive gate / candidate
     // inputs themselves ([B, 3D]) and the tier's two step GEMMs walk K = D instead of 2 D.  next_bias may be null.
     float* next_in; const float* next_Win; const float* next_bias; const float* next_add; int next_ld_add, next_n;
+    // With next_n = 3 D and next_gpre = h . Wg of the next frame ([B, 2D], update | reset: made beside the output projection,
+    // it does not depend on the new samples) the kernel also finishes that frame's gates: next_z = sigm(gpre_z + in_z),
+    // next_rh = sigm(gpre_r + in_r) * next_h; only the candidate's third of next_in is written.  Null: not computed.
+    const float* next_gpre; const float* next_h; float* next_z; float* next_rh;
     float* ws;                         // srp_ws_floats() floats, prepared once by srp_init_ws
     float temperature; int pad;
     unsigned long long seed;
@@ -32,3 +36,25 @@ int srp_prepare(int D);  // once per process and width, outside stream capture (
 int srp_launch(const SrpArgs& a, hipStream_t stream);
 // 0 when no launch on this workspace has timed out / mis-teamed so far
 int srp_status(const float* ws);
+
+// ---- resident variant (sr_resident.hip): ONE launch per big frame (nfr frames of FS sample steps) with the frame tier's
+// GRU step and output projection inside the kernel, XCD-local like the sample steps.  Single-GRU frame tier only.
+struct SrqArgs {
+    const int* tbase;                  // first sample index of the period: tbase[0]
+    int* samples; int len;             // [B][len]
+    int B, D, Q, FS, nfr;
+    const float* t2tbl;                // [FS][Q][D]      emb_tbl[pos] . W2
+    const float* Pout; const float* cb;  // [D][FS*D] = Wout_i . W2,  [FS*D] = bout_i . W2 + b2
+    const float* W3; const float* b3; const float* W4; const float* b4;
+    const float* Wg; const float* Wc;  // frame tier: Recurrent_Gates [D][2D] (update | reset), Recurrent_Candidate [D][D]
+    const float* winu;                 // [FS][3D] = Win . U: the samples' share of the step's additive inputs
+    const float* pbig; int ld_pbig;    // [B][nfr][3D]: big_out[b, f] . U + bin . U + bU (the period's launches make it)
+    float* frm_h;                      // [B][D] frame-tier state: read at entry, written at exit
+    float* logits;                     // [B][Q] logits of the period's last step (or null)
+    float* ws;                         // srp_ws_floats() floats, prepared once by srp_init_ws
+    float temperature; int timing;
+    unsigned long long seed;
+};
+bool srq_eligible(int B, int D, int Q, int FS, int nfr);
+int srq_prepare(int D, int FS);
+int srq_launch(const SrqArgs& a, hipStream_t stream);

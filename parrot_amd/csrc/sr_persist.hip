@@ -30,132 +30,9 @@
 
 #include <stdlib.h>
 
+#include "sr_common.h"
+
 namespace {
-
-constexpr int SRP_THREADS = 512, SRP_TEAM = 32, SRP_NTEAMS = 8, SRP_ROWS = 4, SRP_Q = 256;
-constexpr int SRP_SYNC_WORDS = 1024;  // [0..255] arrive (32 words per team), [256..511] census, [512] abort, [513] fault code
-constexpr int SRP_MAXHIST = 64;       // FS + nsteps
-
-__device__ __forceinline__ int srp_xcc() {
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return (int)(v & 7);
-}
-// RMW executed in the issuing XCD's L2 (no sc1: the line never leaves this XCD), returns the previous value
-__device__ __forceinline__ unsigned srp_l2_add(unsigned* p, unsigned v) {
-    unsigned old;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
-    return old;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t srp_rsrc(const void* p) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    void* q = (void*)(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
-}
-// sc1 load: misses in the CU's vector cache, served by the XCD's L2 (where the team's stores have landed)
-__device__ __forceinline__ f32x4 srp_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
-}
-
-// Hand-off slots are 16 bytes = one value for each of the team's 4 streams.  An empty slot holds a NaN with a payload
-// arithmetic never produces; a 16-byte store replaces it atomically in the L2, so a consumer simply re-reads a slot
-// until it is full: no store acknowledgement, arrival counter or flag poll sits between producer and consumer.
-constexpr unsigned SRP_EMPTY = 0x7FC0DEADu;
-__device__ __forceinline__ f32x4 srp_empty() {
-    const float e = __uint_as_float(SRP_EMPTY);
-    return (f32x4){e, e, e, e};
-}
-__device__ __forceinline__ bool srp_is_empty(const f32x4& v) {
-    return __float_as_uint(v[0]) == SRP_EMPTY || __float_as_uint(v[3]) == SRP_EMPTY;
-}
-
-// 100 MHz wall clock (timing aid, PARROT_SR_TIMING=1: workgroup 0 of team 0 stamps the phase boundaries of every step
-// into sync words 600..)
-__device__ __forceinline__ unsigned long long srp_clock() {
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-
-struct SrpShared {
-    int rank, ok, gen;
-    int hist[SRP_ROWS][SRP_MAXHIST];
-    float mx[SRP_ROWS];
-};
-
-// Load a hand-off slot, re-reading until it is full (bounded: ~1 s, then the abort word is raised).
-__device__ __forceinline__ f32x4 srp_take(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned* abort_, SrpShared* sh) {
-    f32x4 v = srp_ld(r, byte_off);
-    unsigned n = 0;
-    while (srp_is_empty(v)) {
-        if ((++n & 1023u) == 0u) {
-            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh->ok = 0; break; }
-            if (n > (1u << 21)) {
-                __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(abort_ + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->ok = 0;
-                break;
-            }
-        }
-        __builtin_amdgcn_s_sleep(1);
-        v = srp_ld(r, byte_off);
-    }
-    return v;
-}
-
-// f32x4 += the same vector of the lane selected by a DPP control (all four components)
-template <int CTRL>
-__device__ __forceinline__ f32x4 srp_dpp_add(const f32x4& v) {
-    f32x4 r;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        r[c] = v[c] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c]), CTRL, 0xf, 0xf, true));
-    return r;
-}
-
-// out[4 rows][CC columns of this CU] = sum_k a[k][row] * W[k][col].  Thread (sl = tid & 7, g = (tid >> 3) % GG,
-// sh = tid / (8 GG)) owns K-slice s = 8 sh + sl, i.e. k = kk * SS + s, and columns 4g .. 4g+3 of the CU's slice; its
-// weights w(kk) are W[k][4g .. 4g+3] (VGPRs).  The 8 slices of neighbouring lanes
-// are added with DPP (quad swaps, then half-row mirror: a fixed tree), the 64 / GG lane groups through LDS in group
-// order.  Result: threads tid < CC return the finished f32x4 (4 rows) of CU column 4 * (tid % GG) + tid / GG.
-template <int KPP, int GG>
-__device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f32x4 (&w)[KPP], f32x4* __restrict__ red,
-                                          f32x4& out) {
-    constexpr int CC = 4 * GG, SS = SRP_THREADS / GG, GROUPS = 64 / GG;
-    const int tid = threadIdx.x, sl = tid & 7, g = (tid >> 3) % GG, shi = tid / (8 * GG), s = 8 * shi + sl;
-    f32x4 acc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KPP; ++kk) {
-        const f32x4 a = act[kk * SS + s];
-        const f32x4 wv = w[kk];
-        // acc[r] = the 4 columns of stream r.  The scalar operand is the (transient) activation: broadcasting the
-        // loop-invariant weights instead makes the compiler keep a 4-register splat of every weight alive.
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += a[r] * wv;
-        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // do not hoist all KPP operand reads: registers are tight
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        acc[r] = srp_dpp_add<0xB1>(acc[r]);   // quad_perm [1,0,3,2]
-        acc[r] = srp_dpp_add<0x4E>(acc[r]);   // quad_perm [2,3,0,1]
-        acc[r] = srp_dpp_add<0x141>(acc[r]);  // row_half_mirror
-    }
-    if (sl == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) red[shi * CC + j * GG + g] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-    }
-    __syncthreads();
-    if (tid < CC) {
-        f32x4 v = red[tid];
-#pragma unroll 4
-        for (int p = 1; p < GROUPS; ++p) v += red[p * CC + tid];
-        out = v;
-    }
-}
 
 template <int D>
 __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
@@ -213,7 +90,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         sh->hist[r][pos] = a.samples[(size_t)b * a.len + t0 - a.FS + pos];
     }
     // team exchange buffers ([D] f32x4 each, 4 streams per vector): x1, x2, and the logits ([Q] f32x4)
-    float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * (2 * D + Q) * 4;
+    float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * srp_team_vecs(D, Q) * 4;
     const __amdgpu_buffer_rsrc_t xr = srp_rsrc(xbase);
     f32x4* x1 = reinterpret_cast<f32x4*>(xbase);
     f32x4* x2 = x1 + D;
@@ -232,9 +109,11 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     // step i's L2 pre-activation that is known one step early (frame_out carries the composed projection and both
     // biases); threads tid < DC keep it as one f32x4 (4 streams) of column fin_h
     f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto make_part = [&](int i) {
-        if (tid < SRP_ROWS * DC) {
-            const int r = tid / DC, c = tid % DC, col = cu * DC + c;
+    // the gather itself (threads u < 4 DC of whichever half of the workgroup is free), result transposed through tmp;
+    // threads tid < DC pick it up behind the caller's next workgroup barrier
+    auto gather_part = [&](int i, int u) {
+        if (u < SRP_ROWS * DC) {
+            const int r = u / DC, c = u % DC, col = cu * DC + c;
             const int b = min(team * SRP_ROWS + r, a.B - 1);
             float acc = a.frame_out[(size_t)b * a.ldf + (size_t)i * D + col];
             for (int pos = 0; pos < a.FS - 1; ++pos) {
@@ -243,10 +122,11 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
             }
             tmp[c * SRP_ROWS + r] = acc;
         }
-        __syncthreads();
-        if (tid < DC) part = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC];
     };
-    make_part(0);
+    auto take_part = [&]() { if (tid < DC) part = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC]; };
+    gather_part(0, tid);
+    __syncthreads();
+    take_part();
 
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sync + 600);
     const bool timing = a.pad && team == 0 && cu == 0 && tid == 0;
@@ -272,27 +152,33 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
             // x1(i) complete => every CU is done with the logits of step i-1
             if (i > 0 && tid < QC) lb[fin_q] = srp_empty();
             f32x4 v;
-            srp_layer<KP, G>(act, w3, red, v);
+            srp_layer<KP, G>(act, w3, red, v, tid);
             if (tid < DC) {
                 v += bias3;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 x2[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
             stamp(i, 3);
-            if (more) make_part(i + 1);  // needs nothing from the other workgroups: runs while their x2 slices arrive
             stamp(i, 4);
         }
         {
-            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
+            // waves 0-3 take x2; waves 4-7 sum the next step's part meanwhile (it needs nothing from the other workgroups;
+            // a wave's loads return in order, so a wave with table rows in flight could not poll)
+            if (tid < SRP_THREADS / 2) {
+                for (int k = tid; k < D; k += SRP_THREADS / 2) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
+            } else if (more) {
+                gather_part(i + 1, tid - SRP_THREADS / 2);
+            }
             __syncthreads();
             if (!sh->ok) return;
+            if (more) take_part();
             stamp(i, 5);
             if (tid < QC) {  // x2(i) complete => every CU is done with x1(i); emptied by the threads that publish lb
 #pragma unroll
                 for (int q = 0; q < DC / QC; ++q) x1[cu * DC + tid * (DC / QC) + q] = srp_empty();
             }
             f32x4 v;
-            srp_layer<KQ, GQ>(act, w4, red, v);
+            srp_layer<KQ, GQ>(act, w4, red, v, tid);
             if (tid < QC) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lb[fin_q] = v + bias4;
@@ -308,19 +194,8 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         const int t = t0 + i;
         if (wave < SRP_ROWS) {
             const int r = wave;
-            float best = -INFINITY;
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int m = 0; m < Q / 64; ++m) {
-                const float v = lg[lane + 64 * m][r];
-                if (v > best) { best = v; bi = lane + 64 * m; }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(best, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-            }
+            float best;
+            const int bi = srp_argmax_row<Q>(lg, r, lane, best);
             int pick = bi;
             if (a.temperature > 0.f) {
 #pragma unroll
@@ -372,7 +247,16 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
                 const float xf = ((float)sh->hist[r][a.nsteps + p] / half_q - 1.0f) * 2.0f;
                 acc = fmaf(xf, a.next_Win[(size_t)p * NN + col], acc);
             }
-            a.next_in[(size_t)b * NN + col] = acc + (a.next_bias ? a.next_bias[col] : 0.f) + a.next_add[(size_t)b * a.next_ld_add + col];
+            acc += (a.next_bias ? a.next_bias[col] : 0.f) + a.next_add[(size_t)b * a.next_ld_add + col];
+            if (a.next_gpre && col < 2 * D) {
+                // the recurrent product h . Wg of the NEXT frame's gates is already there (it does not depend on the new
+                // samples: the projection launch made it): finish the gates here -- one launch fewer per frame
+                const float gt = ph_sigmoid(a.next_gpre[(size_t)b * 2 * D + col] + acc);
+                if (col < D) a.next_z[(size_t)b * D + col] = gt;                                         // update gate
+                else a.next_rh[(size_t)b * D + col - D] = gt * a.next_h[(size_t)b * D + col - D];        // reset gate * h
+            } else {
+                a.next_in[(size_t)b * NN + col] = acc;
+            }
         }
     }
 }
@@ -397,13 +281,13 @@ bool srp_eligible(int B, int D, int Q, int FS) {
     return D == 256 || D == 512 || D == 1024;
 }
 
-long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * (2 * D + Q) * 4; }
+long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * srp_team_vecs(D, Q) * 4; }
 
 int srp_init_ws(float* ws, int D, int Q) {
     // barrier / census / abort words zero, every hand-off slot EMPTY
     PH_CHECK(hipMemset(ws, 0, SRP_SYNC_WORDS * sizeof(float)));
     PH_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ws + SRP_SYNC_WORDS), (int)SRP_EMPTY,
-                          (size_t)SRP_NTEAMS * (2 * D + Q) * 4));
+                          (size_t)SRP_NTEAMS * srp_team_vecs(D, Q) * 4));
     return (int)hipDeviceSynchronize();
 }
 
