@@ -589,8 +589,7 @@ typedef struct SampleRnnGenDesc {
 long long samplernn_persist_floats(const SampleRnnGenDesc* desc);
 int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan);
 int samplernn_generate_run(void* plan, void* stream);
-/* 1 when the plan's sample steps run on the persistent-thread kernel (one launch per frame), 2 when the frame tier runs
- * inside it as well (one launch per big frame; single-GRU tiers), 0 on the launch path. */
+/* 1 when the plan's sample steps run on the persistent-thread kernel. */
 int samplernn_generate_is_persistent(void* plan);
 /* Waits for the device and returns 0, or a non-zero fault code when a persistent sample kernel gave up (a team of
  * workgroups was incomplete or timed out): the samples of that run are invalid.  Always 0 on the launch path. */

@@ -18,7 +18,7 @@ OBJDIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 
 SOURCES = ["skinny.hip", "biggemm.hip", "attention.hip", "elementwise.hip", "quantize.hip",
-           "plans.hip", "plans_decode.hip", "capi.hip", "samplernn.hip", "persist.hip", "sr_persist.hip", "sr_resident.hip", "rowgru.hip", "trainops.hip"]
+           "plans.hip", "plans_decode.hip", "capi.hip", "samplernn.hip", "persist.hip", "sr_persist.hip", "rowgru.hip", "trainops.hip"]
 EXTRA_FLAGS = {"quantize.hip": ["-ffp-contract=off"]}
 if os.environ.get("PARROT_PM_DEPTH"):  # development: ring depth of the persistent machine's K loop
     EXTRA_FLAGS["persist.hip"] = ["-DPM_DEPTH=" + os.environ["PARROT_PM_DEPTH"]]

@@ -136,7 +136,6 @@ __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
 struct SrPlan {
     SampleRnnGenDesc d;
     bool persist = false;  // sample steps on the persistent-thread kernel (sr_persist.hip)
-    bool resident = false; // ... and the frame tier inside it: one launch per big frame (sr_resident.hip)
     // Fragment-major copies (sk_tile_weights, mode 0) of the single-GRU tiers' matrices, owned by the plan and made once
     // at create time: the step kernel then reads its weights as contiguous 1 KB wave loads instead of 64-byte row pieces.
     struct Tiled { float* U = nullptr; float* Wg = nullptr; float* Wc = nullptr; float* Wout = nullptr; };
@@ -377,23 +376,6 @@ struct SrPlan {
                 }
             }
         }
-        if (resident) {  // the period's nfr frame-tier steps and BFS sample steps in ONE launch
-            SrqArgs qa{};
-            qa.tbase = d.tbase; qa.samples = d.samples; qa.len = len;
-            qa.B = B; qa.D = D; qa.Q = d.Q; qa.FS = FS; qa.nfr = nfr;
-            qa.t2tbl = t2tbl; qa.Pout = Pout; qa.cb = cb;
-            qa.W3 = d.W3; qa.b3 = d.b3; qa.W4 = d.W4; qa.b4 = d.b4;
-            qa.Wg = d.frm_Wg; qa.Wc = d.frm_Wc; qa.winu = winu; qa.pbig = pbig; qa.ld_pbig = nfr * 3 * D;
-            qa.frm_h = d.frm_h; qa.logits = d.logits; qa.ws = d.persist_ws;
-            qa.temperature = d.temperature; qa.seed = d.seed;
-            {
-                static const int timing = getenv("PARROT_SR_TIMING") ? atoi(getenv("PARROT_SR_TIMING")) : 0;
-                qa.timing = timing;
-            }
-            SR_TRY(srq_launch(qa, st));
-            hipLaunchKernelGGL(sr_tick_kernel, dim3(1), dim3(64), 0, st, d.tbase, BFS, 0);
-            return (int)hipGetLastError();
-        }
         for (int f = 0; f < nfr; ++f) {
             // ---- frame tier (three_tier.py:382-450), consumes samples[t-10:t] and big_out[:, (t/10)%8]
             const int toff = f * FS;
@@ -532,8 +514,6 @@ int samplernn_generate_create(const SampleRnnGenDesc* desc, void** plan) { PH_EN
                  srp_init_ws(desc->persist_ws, desc->D, desc->Q) == 0 && p->make_composed() == 0;
     p->make_tiled();  // (after the decision: the persistent path tiles the composed projection)
     p->make_winu();
-    p->resident = p->persist && p->winu && desc->n_rnn == 0 &&
-                  srq_eligible(desc->B, desc->D, desc->Q, desc->FS, desc->BFS / desc->FS) && srq_prepare(desc->D, desc->FS) == 0;
     *plan = p;
     return 0;
 }
@@ -544,8 +524,7 @@ long long samplernn_persist_floats(const SampleRnnGenDesc* desc) { PH_ENTRY();
 }
 
 int samplernn_generate_is_persistent(void* plan) { PH_ENTRY();
-    const SrPlan* p = static_cast<SrPlan*>(plan);
-    return p && p->persist ? (p->resident ? 2 : 1) : 0;
+    return plan && static_cast<SrPlan*>(plan)->persist ? 1 : 0;
 }
 
 int samplernn_generate_status(void* plan) { PH_ENTRY();

@@ -1,6 +1,5 @@
-// Device helpers shared by the two SampleRNN persistent-thread kernels (sr_persist.hip: one launch per frame of FS sample
-// steps; sr_resident.hip: one launch per big frame with the frame tier inside): XCD teams, EMPTY-slot hand-offs that stay
-// in the XCD's L2, the register-resident [4 streams x CU columns] product.  See sr_persist.hip for the protocol.
+// Device helpers of the SampleRNN persistent-thread sample kernel (sr_persist.hip): XCD teams, EMPTY-slot hand-offs that
+// stay in the XCD's L2, the register-resident [4 streams x CU columns] product, DPP wave reductions.
 #pragma once
 #include "common.h"
 
@@ -8,10 +7,9 @@ namespace {
 
 constexpr int SRP_THREADS = 512, SRP_TEAM = 32, SRP_NTEAMS = 8, SRP_ROWS = 4, SRP_Q = 256;
 constexpr int SRP_SYNC_WORDS = 1024;  // [0..255] arrive (32 words per team), [256..511] census, [512] abort, [513] fault code
-constexpr int SRP_MAXHIST = 112;      // FS + nsteps (the resident kernel: FS + BFS)
-// f32x4 hand-off slots per team in the workspace: sr_persist.hip uses x1, x2 [D] and the logits [Q]; sr_resident.hip x1, x2,
-// r*h, two h' [D each] and the logits
-__host__ __device__ constexpr int srp_team_vecs(int D, int Q) { return 5 * D + Q; }
+constexpr int SRP_MAXHIST = 64;       // FS + nsteps
+// f32x4 hand-off slots per team in the workspace: x1, x2 [D] and the logits [Q]
+__host__ __device__ constexpr int srp_team_vecs(int D, int Q) { return 2 * D + Q; }
 
 __device__ __forceinline__ int srp_xcc() {
     unsigned v;
@@ -34,15 +32,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t srp_rsrc(const void* p) {
 // sc1 load: misses in the CU's vector cache, served by the XCD's L2 (where the team's stores have landed)
 __device__ __forceinline__ f32x4 srp_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16));
-}
-
-// Plain 16-byte store / 4-byte load through a buffer descriptor: the address is four SGPRs and one 32-bit VGPR offset, where
-// a pointer costs two VGPRs that the optimiser hoists out of the sample loop and keeps alive across it.
-__device__ __forceinline__ void srp_st(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, byte_off, 0, 0);
-}
-__device__ __forceinline__ float srp_ldf(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
 }
 
 // Hand-off slots are 16 bytes = one value for each of the team's 4 streams.  An empty slot holds a NaN with a payload
@@ -89,40 +78,6 @@ __device__ __forceinline__ f32x4 srp_take(__amdgpu_buffer_rsrc_t r, unsigned byt
         v = srp_ld(r, byte_off);
     }
     return v;
-}
-
-// N slots per thread at once: every round issues the loads of all slots that are still EMPTY before looking at any, so a
-// take costs one L2 round trip per round whatever N is (one slot after the other costs N round trips).  Slot j of the
-// thread is vector k0 + j * stride of the buffer that starts at byte offset base; values go to dst[k0 + j * stride].
-template <int N>
-__device__ __forceinline__ void srp_take_n(__amdgpu_buffer_rsrc_t r, unsigned base, int k0, int stride, int limit,
-                                           f32x4* __restrict__ dst, unsigned* abort_, SrpShared* sh) {
-    f32x4 v[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) v[j] = k0 + j * stride < limit ? srp_ld(r, base + (unsigned)(k0 + j * stride) * 16u) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    unsigned n = 0;
-    for (;;) {
-        bool e = false;
-#pragma unroll
-        for (int j = 0; j < N; ++j) e |= srp_is_empty(v[j]);
-        if (!e) break;
-        if ((++n & 1023u) == 0u) {
-            if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { sh->ok = 0; break; }
-            if (n > (1u << 21)) {
-                __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(abort_ + 1, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh->ok = 0;
-                break;
-            }
-        }
-        __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (srp_is_empty(v[j])) v[j] = srp_ld(r, base + (unsigned)(k0 + j * stride) * 16u);
-    }
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if (k0 + j * stride < limit) dst[k0 + j * stride] = v[j];
 }
 
 // f32x4 += the same vector of the lane selected by a DPP control (all four components)
@@ -183,19 +138,6 @@ __device__ __forceinline__ int srp_argmax_row(const f32x4* __restrict__ lg, int 
     return srp_wave_min(bv == best ? bi : 0x7fffffff);
 }
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
-// wave (s_waitcnt vmcnt(0)), which would pin table gathers and LDS-DMA streams that are meant to fly across it.
-__device__ __forceinline__ void srp_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// The thread index as a value the optimiser cannot see through.  Everything a sample step derives from it (column and
-// slot offsets, LDS addresses) would otherwise be hoisted out of the step loop as a loop invariant and kept alive across
-// it -- a hundred-odd VGPRs next to 80 of resident weights; derived from this inside the loop they are temporaries.
-__device__ __forceinline__ int srp_opaque_tid() {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
-    return t;
-}
-
 // Fold of a product's per-thread partial sums acc[r] (stream r, the thread's 4 columns): the 8 K-slices of neighbouring
 // lanes with DPP (quad swaps, then half-row mirror: a fixed tree), the 64 / GG lane groups through LDS in group order.
 // Threads tid < 4 GG return the finished f32x4 (4 streams) of CU column 4 * (tid % GG) + tid / GG.
@@ -213,7 +155,7 @@ __device__ __forceinline__ void srp_reduce(f32x4 (&acc)[4], f32x4* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[shi * CC + j * GG + g] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
     }
-    srp_barrier();
+    __syncthreads();
     if (tid < CC) {
         f32x4 v = red[tid];
 #pragma unroll 4
@@ -239,33 +181,6 @@ __device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += a[r] * wv;
         if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // do not hoist all KPP operand reads: registers are tight
-    }
-    srp_reduce<GG>(acc, red, out, tid);
-}
-
-// The same product with the weights STREAMED from memory (W: this CU's first column of the slice, row-major with leading
-// dimension ld): blocks of up to 4 K-rows per thread in flight (16 registers), every wave load a whole 128-byte line per row.
-template <int KPP, int GG>
-__device__ __forceinline__ void srp_stream_layer(const float* __restrict__ W, int ld, const f32x4* __restrict__ act,
-                                                 f32x4* __restrict__ red, f32x4& out, int tid) {
-    constexpr int SS = SRP_THREADS / GG, BLK = KPP < 4 ? KPP : 4;
-    const int g = (tid >> 3) % GG, s = 8 * (tid / (8 * GG)) + (tid & 7);
-    f32x4 acc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* wp = W + (size_t)s * ld + 4 * g;
-#pragma unroll 1
-    for (int k0 = 0; k0 < KPP; k0 += BLK) {
-        f32x4 w[BLK];
-#pragma unroll
-        for (int j = 0; j < BLK; ++j)
-            w[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)(k0 + j) * SS * ld));
-#pragma unroll
-        for (int j = 0; j < BLK; ++j) {
-            const f32x4 a = act[(k0 + j) * SS + s];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += a[r] * w[j];
-        }
     }
     srp_reduce<GG>(acc, red, out, tid);
 }

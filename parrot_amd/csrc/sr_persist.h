@@ -36,25 +36,3 @@ int srp_prepare(int D);  // once per process and width, outside stream capture (
 int srp_launch(const SrpArgs& a, hipStream_t stream);
 // 0 when no launch on this workspace has timed out / mis-teamed so far
 int srp_status(const float* ws);
-
-// ---- resident variant (sr_resident.hip): ONE launch per big frame (nfr frames of FS sample steps) with the frame tier's
-// GRU step and output projection inside the kernel, XCD-local like the sample steps.  Single-GRU frame tier only.
-struct SrqArgs {
-    const int* tbase;                  // first sample index of the period: tbase[0]
-    int* samples; int len;             // [B][len]
-    int B, D, Q, FS, nfr;
-    const float* t2tbl;                // [FS][Q][D]      emb_tbl[pos] . W2
-    const float* Pout; const float* cb;  // [D][FS*D] = Wout_i . W2,  [FS*D] = bout_i . W2 + b2
-    const float* W3; const float* b3; const float* W4; const float* b4;
-    const float* Wg; const float* Wc;  // frame tier: Recurrent_Gates [D][2D] (update | reset), Recurrent_Candidate [D][D]
-    const float* winu;                 // [FS][3D] = Win . U: the samples' share of the step's additive inputs
-    const float* pbig; int ld_pbig;    // [B][nfr][3D]: big_out[b, f] . U + bin . U + bU (the period's launches make it)
-    float* frm_h;                      // [B][D] frame-tier state: read at entry, written at exit
-    float* logits;                     // [B][Q] logits of the period's last step (or null)
-    float* ws;                         // srp_ws_floats() floats, prepared once by srp_init_ws
-    float temperature; int timing;
-    unsigned long long seed;
-};
-bool srq_eligible(int B, int D, int Q, int FS, int nfr);
-int srq_prepare(int D, int FS);
-int srq_launch(const SrqArgs& a, hipStream_t stream);

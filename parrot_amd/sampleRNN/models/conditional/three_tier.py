@@ -284,9 +284,7 @@ class DeviceGenerator:
         self.desc = d
         self.plan = C.c_void_p()
         _lib.call('samplernn_generate_create', C.byref(d), C.byref(self.plan))
-        kind = int(_lib.load().samplernn_generate_is_persistent(self.plan))
-        self.persistent = kind > 0   # sample steps on the persistent-thread kernel
-        self.resident = kind == 2    # ... with the frame tier inside: one launch per big frame (sr_resident.hip)
+        self.persistent = bool(_lib.load().samplernn_generate_is_persistent(self.plan))
 
     def generate(self, features):
         """features [T, B, 63] time-major (what generate_and_save_samples receives) -> samples [B, 80*T] int32."""

@@ -21,25 +21,6 @@ gen = tt.DeviceGenerator(B, T, temperature=0.0, use_graph=False)
 feats = np.random.RandomState(0).randn(T, B, 63).astype('float32')
 gen.generate(feats); torch.cuda.synchronize()
 w = gen.ws['persist_ws'][:1024].cpu().view(torch.int32).numpy()
-if getattr(gen, 'resident', False):
-    # sr_resident.hip stamps frame 1 of the last period: 0..4 the boundary (start | r*h taken | candidate product done, h' published |
-    # h' taken | first projection slice done), then 8 stamps per sample step as below
-    st = w[600:600 + 192].view(np.int64).astype(np.float64) / 100.0
-    b = st[:5]
-    for n, d in zip(["r, z, publish r*h, take r*h", "candidate product (streamed slice) + publish h'", "take h'",
-                     "first projection slice (streamed) + barrier"], np.diff(b)):
-        print(f"boundary: {n:55s} {d:6.2f} us")
-    print(f"boundary total {b[4] - b[0]:6.2f} us")
-    st = st[8:88].reshape(10, 8)
-    names = ["publish x1 (part + projection + newest row)", "take x1 | background: finish", "L3 product + publish x2",
-             "window 1: part, take x2 | background: consume + issue", "output product + publish logits",
-             "window 2: take logits | background: consume + issue", "pick | background: finish"]
-    d = np.diff(st, axis=1)
-    for q, n in enumerate(names):
-        print(f"{n:60s} median {np.median(d[:, q]):6.2f} us   (min {d[:, q].min():.2f}, max {d[:, q].max():.2f})")
-    print(f"{'step total':60s} median {np.median(st[1:, 0] - st[:-1, 0]):6.2f} us")
-    print("frame span (boundary + 10 steps): %.2f us" % (st[9, 7] - b[0]))
-    sys.exit(0)
 st = w[600:600 + 160].view(np.int64).reshape(10, 8).astype(np.float64) / 100.0  # us
 names = ["publish x1 (part + newest row)", "take x1", "L3 product + publish x2", "next step's part (gather-sum)",
          "take x2", "output product + publish logits, take logits", "pick"]
