@@ -373,7 +373,10 @@ def secondary_leg(a):
                              "samples_per_s": round(B * nsamp / best, 1),
                              "x_realtime_per_stream": round(nsamp / best / 16000.0, 3),
                              "alg_bytes_per_sample_step": int(alg), "alg_GBps": round(alg * nsamp / best * 1e-9, 1),
-                             "frac": round(alg * nsamp / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000}
+                             "frac": round(alg * nsamp / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000,
+                             "note": "alg bytes = the weights one sample step of the reference's formulation touches (SURVEY 8d: three "
+                                     "sample-MLP products per sample, the tiers' share per frame / big frame); since round 5 the first product "
+                                     "is composed away (tables and frame projection through W2), so the kernel reads less than this"}
     # ---- SampleRNN TRAINING (three_tier.py:534-636): one truncated-BPTT window, forward + backward of cost + ip_cost
     try:
         S = 4000
