@@ -237,6 +237,40 @@ def test_persistent_sample_kernel_matches_oracle_and_launch_path(dev, dim, B, T,
         tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
 
 
+@pytest.mark.parametrize("rnn_type,n_rnn", [("GRU", 2), ("LSTM", 1), ("LSTM", 2)])
+def test_persistent_sample_kernel_under_stacked_and_lstm_tiers(dev, rnn_type, n_rnn):
+    """Stacked / LSTM tiers keep their frame tier on launches, but the sample steps still run on the persistent kernel and
+    so on the COMPOSED projection (frame_out = top . (Wout . W2) + bout . W2 + b2, sr_persist.hip): greedy indices and the
+    last step's logits vs the fp64 oracle at a width the kernel takes (DIM 256), partial team (B = 5)."""
+    from oracle import samplernn_ref as S
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.models.conditional import three_tier as tt
+    lib.delete_all_params()
+    lib.set_device(dev)
+    tt.configure(DIM=256, EMB_SIZE=32, RNN_TYPE=rnn_type, N_RNN=n_rnn)
+    try:
+        c = S.config(DIM=256, EMB_SIZE=32, RNN_TYPE=rnn_type, N_RNN=n_rnn)
+        p = S.init_params(c, seed=13, perturb=0.25)
+        lib.set_params(p)
+        g = torch.Generator().manual_seed(8)
+        T, B = 3, 5
+        feats = torch.randn(T, B, 63, generator=g, dtype=torch.float64)
+        with torch.no_grad():
+            ref, ref_logits = S.generate(p, c, feats, return_logits=True)
+        ref = ref.numpy()
+        gen = tt.DeviceGenerator(B, T, temperature=0.0, use_graph=True)
+        assert gen.persistent, "the persistent sample kernel did not engage"
+        for rep in range(2):
+            out = gen.generate(feats.float().numpy()).cpu().numpy()
+            exact = _greedy_follows_oracle(out, ref, ref_logits, B, slack_rows=1)
+            last = gen.ws['logits'].detach().cpu().double()
+            assert_close(last[exact], ref_logits[exact, -1], 1e-4, "last-step logits")
+        gen.close()
+    finally:
+        lib.delete_all_params()
+        tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+
+
 def test_persistent_sample_kernel_seeded_draws(dev):
     from oracle import samplernn_ref as S
     from parrot_amd.sampleRNN import lib
