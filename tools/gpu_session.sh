@@ -8,6 +8,7 @@
 #   cfg4stats | secstats      the same for `bench.py --config cfg4` / `bench.py --secondary-only`
 #   pmc | pmc4                FETCH_SIZE / WRITE_SIZE / SQ passes over tools/pmc_probe.py (cfg2 / cfg4) -> pmc_traffic*.json
 #   pmcdecode                 the three counter passes over the configs[2] decode (tools/pm_timing.py) -> pmc_decode_summary.txt
+#   pmcsr                     the same over the configs[4] SampleRNN generation (tools/sr_timing.py) -> pmc_sr_summary.txt
 #   run:<command>             anything else, logged to run_<n>.log
 tag=$1; shift
 cd $GRAFT_REPO_ROOT
@@ -61,6 +62,7 @@ for step in "$@"; do
     pmc)     pmc "" cfg2 ;;
     pmc4)    pmc _cfg4 cfg4 ;;
     pmcdecode) MODE=decode pmcx decode python tools/pm_timing.py ;;
+    pmcsr)   pmcx sr python tools/sr_timing.py ;;
     run:*)   n=$((n+1)); ( eval "${step#run:}" ) > $out/run_$n.log 2>&1; tail -30 $out/run_$n.log ;;
     *) echo "unknown step $step" ;;
   esac
