@@ -541,7 +541,9 @@ int parrot_relu_gate(const float* dy, const float* gate, float* out, long long n
  * temperature > 0 -> multinomial draw from a seeded counter-based generator (not Theano's MRG stream).
  * samples: [B, BFS*T] int32, first BFS entries = Q/2 set by the caller; big_h / frm_h hold the
  * initial states (learned h0) on entry and the final states on return.  The weight buffers must not change during a
- * plan's life: create makes fragment-major copies of the tiers' matrices for the step kernel (single-GRU tiers).
+ * plan's life: create makes fragment-major copies of the tiers' matrices for the step kernel (single-GRU tiers) and, on the
+ * persistent path, composes everything in front of L2's ReLU through W2 once (emb_tbl[pos] . W2, frm_Wout_i . W2,
+ * frm_bout_i . W2 + b2; round 5) -- the sample kernel then has no L2 product.
  * ------------------------------------------------------------------------------------------ */
 typedef struct SampleRnnGenDesc {
     int B, D, T, Q, FS, BFS, feat_dim, use_graph;
