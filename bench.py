@@ -56,6 +56,8 @@ def parse():
                          "kappa advances ~1 per frame and leaves the text after ~210 frames, after which no context row "
                          "is read at all -- a favourable, unrealistic case)")
     ap.add_argument("--no-dense", action="store_true", help="skip the second timed run that reads all context rows")
+    ap.add_argument("--no-f32-gemm", action="store_true",
+                    help="skip the extra timed run with the batched products on the f32-input MFMA kernel (value_f32_mfma)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` object (decode configs[2], SampleRNN configs[4], configs[3] bf16 step), "
                          "measured after the headline region in child processes")
@@ -440,7 +442,7 @@ def child_json(a, flag, extra=(), timeout=420):
 def secondary_subprocess(a):
     sec = child_json(a, "--secondary-only", timeout=300)
     if a.config == "cfg2":  # BASELINE configs[3] per GPU (the 8-GPU line's workload), bf16 operands
-        d = child_json(a, "--no-secondary", ["--config", "cfg4", "--no-cpu-baseline", "--no-dense", "--no-parity",
+        d = child_json(a, "--no-secondary", ["--config", "cfg4", "--no-cpu-baseline", "--no-dense", "--no-f32-gemm", "--no-parity",
                                               "--steps", "3", "--warmup", "1", "--L", "3", "--H", "1536",
                                               "--cell", "lstm", "--dtype", "bf16"], timeout=420)
         sec["cfg4_bf16"] = ({"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"],
@@ -449,7 +451,7 @@ def secondary_subprocess(a):
         # the reference's own decoder depth (model.py:312-347: three GatedRecurrent layers, h = 1024), literal batch-axis
         # encoder, fp32: the one instance where "the reference's model" is literally defined
         d = child_json(a, "--no-secondary", ["--L", "3", "--H", "1024", "--cell", "gru", "--dtype", "f32", "--no-cpu-baseline",
-                                              "--no-dense", "--no-parity", "--steps", "3", "--warmup", "1"], timeout=420)
+                                              "--no-dense", "--no-f32-gemm", "--no-parity", "--steps", "3", "--warmup", "1"], timeout=420)
         if "ms_per_step" in d:
             fwd_bytes = 99.9e6  # 21.26 M weights per decoder timestep, forward
             sec["ref_literal_3gru"] = {
@@ -609,6 +611,20 @@ def main():
                    6: "6 (attention inside the gate launch, in-launch hand-off)",
                    7: "7 (LSTM: one launch per tick, the attention at its head, layer 0's w rows behind an in-launch flag)"}
     kappa_end = float(model._carry[a.B]['k'].mean()) if a.B in model._carry else None
+    # extra timed run, outside the headline region: the batched products (readouts, deferred weight gradients) on the
+    # f32-input matrix instructions instead of the split-bf16 kernel (the same f32 operands, f32-grade results either way)
+    from parrot_amd import ops as pops
+    gemm_mode = {pops.PRECISION_F32: "f32 (v_mfma_f32_32x32x2_f32)",
+                 pops.PRECISION_BF16X3: "bf16x3 (f32 operands split into three bf16 terms in-kernel, six "
+                                        "v_mfma_f32_32x32x16_bf16 per block, f32 accumulate: f32-grade results)"}[pops.full_precision()]
+    if a.dtype == "bf16":
+        gemm_mode = "bf16 operands (bf16-in kernels)"
+    f32run = None
+    if not a.no_f32_gemm and a.dtype == "f32" and pops.full_precision() == pops.PRECISION_BF16X3:
+        prev_mode = pops.set_full_precision(pops.PRECISION_F32)
+        el_f, _ = timed(a.steps, 1)
+        pops.set_full_precision(prev_mode)
+        f32run = {"value": round(world * a.B * a.T * a.steps / el_f, 1), "ms_per_step": round(1e3 * el_f / a.steps, 3)}
     # second timed run, outside the headline region: the attention kernels read ALL context rows (no window support)
     dense = None
     if not a.no_dense and os.environ.get("PARROT_ATT_DENSE", "0") in ("", "0"):
@@ -662,6 +678,8 @@ def main():
                                           "(bit-identical results); `dense` = the same step reading all rows"),
                        "scan_schedule": sched_names.get(sched_id, str(sched_id))},
             "dense": dense,
+            "gemm_mode": gemm_mode,
+            "value_f32_mfma": f32run and f32run["value"], "ms_per_step_f32_mfma": f32run and f32run["ms_per_step"],
             "final_cost": round(final_cost, 5),
             "roofline": roof, "cpu_baseline": cpu, "parity_check": parity, "secondary": secondary,
         }

@@ -59,6 +59,7 @@ long long parrot_profile_end2(double* total_us, double* flops, double* bytes, do
  * ------------------------------------------------------------------------------------------ */
 #define PARROT_PRECISION_F32 0
 #define PARROT_PRECISION_BF16 1
+#define PARROT_PRECISION_BF16X3 2
 /* Operand precision of the batched path of parrot_gemm (M > 64, or transA / batched / split-K calls), process-wide:
  * PARROT_PRECISION_F32 (default; the reference computes in floatX = float32, model.py:21) or PARROT_PRECISION_BF16:
  * A and B are read as f32 and rounded to bf16 (nearest even) on their way into the matrix cores, products are

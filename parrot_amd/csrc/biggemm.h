@@ -25,6 +25,8 @@ struct BgArgs {
     int ldg;            // ReLU backward through the saved activation, fused into the dx product (nbatch == 1 only)
     int bf16;        // 1: operands rounded to bf16 on their way into LDS, v_mfma_f32_32x32x16_bf16, f32 accumulation
                      // 2: A and B point at bf16 data (strides in bf16 elements), any "one stride is 1" layout: bgh_kernel
+                     // 3: f32 operands split into three bf16 terms each inside the kernel, six bf16 MFMAs per block,
+                     //    f32-grade result (bgs_kernel; set by gemm_impl for PARROT_PRECISION_BF16X3)
 };
 
 int bg_launch(const BgArgs& a, hipStream_t stream);
@@ -35,7 +37,7 @@ int bg_reduce_launch(const BgArgs& a, hipStream_t stream);  // second pass of th
 // Operand precision of parrot_gemm's batched path: the process-wide mode (parrot_set_gemm_precision) unless a scan
 // plan running on this thread pins its own (a plan built for bf16 operands keeps them whatever the caller's mode is).
 struct BgPrecisionScope {
-    explicit BgPrecisionScope(int bf16);
+    explicit BgPrecisionScope(int bf16);  // 1 / 0: pin bf16 / f32 operands; < 0: keep what is in force
     ~BgPrecisionScope();
     int saved;
 };

@@ -653,6 +653,221 @@ __global__ __launch_bounds__(512) void bgh_kernel(const BgArgs a, int tiles_m, i
         }
 }
 
+// ---- split-bf16 variant (BgArgs::bf16 == 3, round 6): f32 operands, f32-grade results, bf16 matrix pipe --------------
+// On gfx950 the f32-input MFMA runs at 1/16 of the bf16 rate and there is no xf32.  An f32 value is EXACTLY the sum of
+// three bf16 values (x1 = rn(x), x2 = rn(x - x1), x3 = x - x1 - x2: 8 + 8 + 8 significand bits, the residuals are exact
+// in f32 and the last one fits bf16), so a * b = sum of nine bf16 products, each exact in f32.  The six with i + j <= 4
+// are kept -- (1,1) (1,2) (2,1) (1,3) (3,1) (2,2); the dropped ones are below 2^-26 |a b|, a quarter of the rounding of
+// one f32 product -- and accumulated in f32 by six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block: 192 matrix-pipe
+// cycles where v_mfma_f32_32x32x2_f32 needs 512.  The operands stay f32 in HBM (no copies): each thread splits the
+// values it fetched (5.5 VALU per element, hidden beside the MFMAs of the SIMD's other wave) and writes three bf16
+// planes per operand into LDS; 256 x 256 x 16 macro tile, a wave owns 128 x 64: 18 fragment reads feed 48 MFMAs
+// (0.375 per MFMA; bgh_kernel: 0.75).  Inf operands give NaN (inf - inf in the residual); finite data only.
+// Split-K slices are mapped to XCDs (z % 8 == XCC): the workgroups that run side by side on one XCD's 32 CUs walk the
+// same K range, so each XCD streams its own rows of both operands from HBM exactly once.
+constexpr int SBK = 16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bgs_split(const f32x4& v, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+    p0 = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(p0, f32x4);
+    p1 = __builtin_convertvector(r1, bf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(p1, f32x4);
+    p2 = __builtin_convertvector(r2, bf16x4);
+}
+
+template <bool XC>
+struct BgsOperand {
+    static constexpr int PK = SBK + 8;                                  // [x][k] row pitch (bf16): 48 B
+    static constexpr int PLANE = XC ? SBK * HPITCH : 256 * PK;          // bf16 per plane
+    static constexpr int SZ = 3 * PLANE;                                // bf16 per stage
+    // 256 x 16 f32 per K tile = two 16-byte vectors per thread.  XC: vector id -> (k = id / 64, x = 4 (id % 64)): a wave
+    // load is one whole 1 KB row.  KC: id -> (x = id / 4, k = 4 (id % 4)): 16 rows x 64 B per wave load.
+    static __device__ __forceinline__ void load(const float* __restrict__ p, long long ld, int x0, int X, int k0, int kend,
+                                                bool vec, int t, f32x4 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = t + 512 * i;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (XC) {
+                const int k = k0 + (id >> 6), x = x0 + 4 * (id & 63);
+                if (k < kend && x < X) {
+                    const float* q = p + (long long)k * ld + x;
+                    if (vec && x + 3 < X) v[i] = *reinterpret_cast<const f32x4*>(q);
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (x + u < X) v[i][u] = q[u];
+                    }
+                }
+            } else {
+                const int x = x0 + (id >> 2), k = k0 + 4 * (id & 3);
+                if (x < X && k < kend) {
+                    const float* q = p + (long long)x * ld + k;
+                    if (vec && k + 3 < kend) v[i] = *reinterpret_cast<const f32x4*>(q);
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (k + u < kend) v[i][u] = q[u];
+                    }
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(__bf16* __restrict__ s, int t, const f32x4 (&v)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = t + 512 * i;
+            bf16x4 p0, p1, p2;
+            bgs_split(v[i], p0, p1, p2);
+            __bf16* d = XC ? s + (id >> 6) * HPITCH + 4 * (id & 63) : s + (id >> 2) * PK + 4 * (id & 3);
+            *reinterpret_cast<bf16x4*>(d) = p0;
+            *reinterpret_cast<bf16x4*>(d + PLANE) = p1;
+            *reinterpret_cast<bf16x4*>(d + 2 * PLANE) = p2;
+        }
+    }
+    // MFMA 32x32x16 operand of lane (kk, li): row xb + li, k = 8 kk .. +7 of the tile
+    static __device__ __forceinline__ bf16x8 frag(const __bf16* __restrict__ img, int xb, int kk, int li) {
+        if (XC) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            typedef __attribute__((address_space(3))) s16x4* lds4;
+            const int q = (li >> 2) & 3, xg = xb + (li & 16) + 4 * (li & 3);
+            const __bf16* p = img + (8 * kk + q) * HPITCH + xg;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(p + 4 * HPITCH));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            return *reinterpret_cast<const bf16x8*>(img + (xb + li) * PK + 8 * kk);
+        }
+    }
+};
+
+template <bool AXC, bool BXC, int ROLES>
+__global__ __launch_bounds__(512) void bgs_kernel(const BgArgs a, int vecA, int vecB, int tiles_m, int tiles_n, int zmap) {
+    typedef BgsOperand<AXC> OA;
+    typedef BgsOperand<BXC> OB;
+    extern __shared__ __attribute__((aligned(16))) __bf16 bgs_smem[];
+    __bf16* As = bgs_smem;                 // [2][OA::SZ]
+    __bf16* Bs = bgs_smem + 2 * OA::SZ;    // [2][OB::SZ]
+    int tm, tn, z;
+    if (zmap) {  // 1-d grid, slices dealt to XCDs: block b runs on XCD b % 8 and takes slice 8 * (idx / tiles) + b % 8
+        const int tiles = tiles_m * tiles_n, idx = blockIdx.x >> 3;
+        z = 8 * (idx / tiles) + (blockIdx.x & 7);
+        const int tl = idx % tiles;
+        tm = tl / tiles_n;
+        tn = tl % tiles_n;
+    } else {
+        bg_tile_of_block(blockIdx.x, tiles_m, tiles_n, tm, tn);
+        z = blockIdx.y;
+    }
+    const int m0 = tm * HBMT, n0 = tn * HBNT;
+    const int batch = z / a.splitk, ks = z % a.splitk;
+    int kchunk = (a.K + a.splitk - 1) / a.splitk;
+    kchunk = (kchunk + SBK - 1) / SBK * SBK;
+    const int kbeg = ks * kchunk;
+    const int kend = min(a.K, kbeg + kchunk);
+    const float* A = a.A + (long long)batch * a.batchA;
+    const float* B = a.B + (long long)batch * a.batchB;
+    float* C = a.C + (long long)batch * a.batchC;
+    const long long lda = AXC ? a.sak : a.sam, ldb = BXC ? a.sbk : a.sbn;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int kk = lane >> 5, li = lane & 31;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    f32x4 ra[2], rb[2];
+    const int nk = (kend - kbeg + SBK - 1) / SBK;
+    if (nk > 0) {
+        OA::load(A, lda, m0, a.M, kbeg, kend, vecA, t, ra);
+        OB::load(B, ldb, n0, a.N, kbeg, kend, vecB, t, rb);
+        OA::store(As, t, ra);
+        OB::store(Bs, t, rb);
+        if (nk > 1) {
+            OA::load(A, lda, m0, a.M, kbeg + SBK, kend, vecA, t, ra);
+            OB::load(B, ldb, n0, a.N, kbeg + SBK, kend, vecB, t, rb);
+        }
+    }
+    __syncthreads();
+    // Waves w and w + 4 share a SIMD (a workgroup's waves are dealt to the SIMDs cyclically).  ROLES: the upper four
+    // split and store the next tile BEFORE their MFMAs, the lower four after, so that on every SIMD one wave's vector /
+    // LDS-store work runs beside the other's matrix work instead of all eight meeting in the same phase.
+    const bool early = ROLES && (wave >= 4);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const __bf16* as = As + cur * OA::SZ;
+        const __bf16* bs = Bs + cur * OB::SZ;
+        if (early && kt + 1 < nk) {
+            OA::store(As + (cur ^ 1) * OA::SZ, t, ra);
+            OB::store(Bs + (cur ^ 1) * OB::SZ, t, rb);
+            if (kt + 2 < nk) {
+                OA::load(A, lda, m0, a.M, kbeg + (kt + 2) * SBK, kend, vecA, t, ra);
+                OB::load(B, ldb, n0, a.N, kbeg + (kt + 2) * SBK, kend, vecB, t, rb);
+            }
+        }
+        bf16x8 fb[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fb[j][p] = OB::frag(bs + p * OB::PLANE, wn * 64 + 32 * j, kk, li);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 fa[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) fa[p] = OA::frag(as + p * OA::PLANE, wm * 128 + 32 * i, kk, li);
+            // smallest terms first; the two accumulators alternate so that no MFMA waits for its predecessor
+#define BGS_MM(pa, pb)                                                                                    \
+    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[0][pb], acc[i][0], 0, 0, 0);          \
+    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa], fb[1][pb], acc[i][1], 0, 0, 0)
+            BGS_MM(2, 0);
+            BGS_MM(0, 2);
+            BGS_MM(1, 1);
+            BGS_MM(1, 0);
+            BGS_MM(0, 1);
+            BGS_MM(0, 0);
+#undef BGS_MM
+        }
+        if (!early && kt + 1 < nk) {
+            OA::store(As + (cur ^ 1) * OA::SZ, t, ra);
+            OB::store(Bs + (cur ^ 1) * OB::SZ, t, rb);
+            if (kt + 2 < nk) {
+                OA::load(A, lda, m0, a.M, kbeg + (kt + 2) * SBK, kend, vecA, t, ra);
+                OB::load(B, ldb, n0, a.N, kbeg + (kt + 2) * SBK, kend, vecB, t, rb);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            if (n >= a.N) continue;
+            const float bias = (a.bias && ks == 0) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+                if (m >= a.M) continue;
+                const float v = a.alpha * acc[i][j][q];
+                if (a.splitk > 1) {
+                    a.ws[((long long)z * a.M + m) * a.N + n] = v;  // summed in slice order by the reducer (which adds the bias)
+                } else {
+                    float* c = C + (long long)m * a.ldc + n;
+                    float r = a.accumulate ? *c + v + bias : v + bias;
+                    if (a.act == 1) r = fmaxf(r, 0.f);  // (tanh / sigmoid epilogues stay on the f32 kernel: bg_launch)
+                    if (a.gate && !(a.gate[(long long)m * a.ldg + n] > 0.f)) r = 0.f;
+                    *c = r;
+                }
+            }
+        }
+}
+
 // f32 -> bf16 (round to nearest even), 8 elements per thread: the operand copies bgh_kernel reads.
 __global__ __launch_bounds__(256) void bg_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, long long n8) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -692,7 +907,48 @@ int bg_reduce_launch(const BgArgs& a, hipStream_t stream) {
 
 void bg_tile_shape(int bf16, int& bm, int& bn) {
     bm = bn = 128;
-    if (bf16 == 2) { bm = HBMT; bn = HBNT; return; }
+    if (bf16 == 2 || bf16 == 3) { bm = HBMT; bn = HBNT; return; }
+}
+
+// One "dynamic LDS above 64 KB" attribute call per kernel instantiation (a function template has one static per
+// instantiation; the generic lambda this replaces had ONE flag for all bgh_kernel variants: ADVICE r05).
+template <typename K>
+static void bg_big_lds_once(K kern, bool& done) {
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done = true;
+    }
+}
+
+template <int BKT, bool AX, bool BX>
+static void bgh_go(const BgArgs& a, dim3 grid, int tm, int tn, hipStream_t stream) {
+    static bool done = false;
+    bg_big_lds_once(bgh_kernel<BKT, AX, BX>, done);
+    const size_t lds = (size_t)4 * (BghOperand<BKT, AX>::SZ + BghOperand<BKT, BX>::SZ);
+    hipLaunchKernelGGL((bgh_kernel<BKT, AX, BX>), grid, dim3(512), lds, stream, a, tm, tn);
+}
+
+static int bgs_roles() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PARROT_GEMM_SPLIT_ROLES");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+template <bool AX, bool BX, int ROLES>
+static void bgs_go2(const BgArgs& a, dim3 grid, int vecA, int vecB, int tm, int tn, int zmap, hipStream_t stream) {
+    static bool done = false;
+    bg_big_lds_once(bgs_kernel<AX, BX, ROLES>, done);
+    const size_t lds = (size_t)4 * (BgsOperand<AX>::SZ + BgsOperand<BX>::SZ);
+    hipLaunchKernelGGL((bgs_kernel<AX, BX, ROLES>), grid, dim3(512), lds, stream, a, vecA, vecB, tm, tn, zmap);
+}
+
+template <bool AX, bool BX>
+static void bgs_go(const BgArgs& a, dim3 grid, int vecA, int vecB, int tm, int tn, int zmap, hipStream_t stream) {
+    if (bgs_roles()) bgs_go2<AX, BX, 1>(a, grid, vecA, vecB, tm, tn, zmap, stream);
+    else bgs_go2<AX, BX, 0>(a, grid, vecA, vecB, tm, tn, zmap, stream);
 }
 
 int bg_to_bf16_launch(const float* x, void* y, long long n, hipStream_t stream) {
@@ -733,25 +989,27 @@ int bg_launch(const BgArgs& a, hipStream_t stream) {
         // cache lines, which the CU's vector-memory path moves at a quarter of the rate of whole lines (first
         // r05 build: 310 TFLOP/s); with 64 a wave load is 8 rows x one whole 128-byte line.
         const int bkt = (axc && bxc) ? 32 : 64;
-        const dim3 g2(tm * tn, a.nbatch * a.splitk), b8(512);
-        auto go = [&](auto kern, size_t lds) {
-            static bool attr_done = false;  // (one flag per kernel instantiation: the lambda's call operator is a template)
-            if (!attr_done) {
-                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(kern, g2, b8, lds + pad, stream, a, tm, tn);
-        };
-#define BGH_GO(BKT, AX, BX) go(bgh_kernel<BKT, AX, BX>, (size_t)4 * (BghOperand<BKT, AX>::SZ + BghOperand<BKT, BX>::SZ))
+        const dim3 g2(tm * tn, a.nbatch * a.splitk);
         if (bkt == 64) {
-            if (axc && bxc) BGH_GO(64, true, true);
-            else if (axc) BGH_GO(64, true, false);
-            else if (bxc) BGH_GO(64, false, true);
-            else BGH_GO(64, false, false);
+            if (axc && bxc) bgh_go<64, true, true>(a, g2, tm, tn, stream);
+            else if (axc) bgh_go<64, true, false>(a, g2, tm, tn, stream);
+            else if (bxc) bgh_go<64, false, true>(a, g2, tm, tn, stream);
+            else bgh_go<64, false, false>(a, g2, tm, tn, stream);
         } else {
-            BGH_GO(32, true, true);
+            bgh_go<32, true, true>(a, g2, tm, tn, stream);
         }
-#undef BGH_GO
+        return (int)hipGetLastError();
+    }
+    if (a.bf16 == 3) {  // f32 operands split into three bf16 terms each, six bf16 MFMAs per block: bgs_kernel
+        if (a.act > 1) return PH_ERR_UNSUPPORTED;
+        const int tm = ceil_div(a.M, HBMT), tn = ceil_div(a.N, HBNT);
+        const int Z = a.nbatch * a.splitk;
+        const int zmap = (Z % 8 == 0) ? 1 : 0;
+        const dim3 g = zmap ? dim3(tm * tn * Z) : dim3(tm * tn, Z);
+        if (axc && bxc) bgs_go<true, true>(a, g, vecA, vecB, tm, tn, zmap, stream);
+        else if (axc) bgs_go<true, false>(a, g, vecA, vecB, tm, tn, zmap, stream);
+        else if (bxc) bgs_go<false, true>(a, g, vecA, vecB, tm, tn, zmap, stream);
+        else bgs_go<false, false>(a, g, vecA, vecB, tm, tn, zmap, stream);
         return (int)hipGetLastError();
     }
     if (a.bf16) {

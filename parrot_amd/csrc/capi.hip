@@ -8,6 +8,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <map>
@@ -17,15 +18,24 @@ static int gemm_target_wgs() {
     return 1024;  // 8-wave kernel: 1024..4096 measure the same; fewer slices = less partial-sum traffic
 }
 
-static std::atomic<int> g_gemm_bf16{0};      // parrot_set_gemm_precision (process-wide; plans override per thread)
+// parrot_set_gemm_precision (process-wide; plans override per thread).  Default since round 6: the split-bf16 products
+// (PARROT_PRECISION_BF16X3: f32 operands, f32-grade results, 1.7-1.9 x the f32-input MFMA kernel's rate);
+// PARROT_GEMM_PRECISION=f32 in the environment restores the f32-input matrix instructions for everything.
+static int gemm_default_mode() {
+    const char* e = getenv("PARROT_GEMM_PRECISION");
+    if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) return PARROT_PRECISION_F32;
+    if (e && (!strcmp(e, "bf16") || !strcmp(e, "1"))) return PARROT_PRECISION_BF16;
+    return PARROT_PRECISION_BF16X3;
+}
+static std::atomic<int> g_gemm_bf16{gemm_default_mode()};
 static thread_local int t_gemm_bf16 = -1;   // BgPrecisionScope (-1: follow the process-wide mode)
-BgPrecisionScope::BgPrecisionScope(int bf16) : saved(t_gemm_bf16) { t_gemm_bf16 = bf16 ? 1 : 0; }
+BgPrecisionScope::BgPrecisionScope(int bf16) : saved(t_gemm_bf16) { t_gemm_bf16 = bf16 < 0 ? saved : (bf16 ? 1 : 0); }
 BgPrecisionScope::~BgPrecisionScope() { t_gemm_bf16 = saved; }
 
 extern "C" {
 
 int parrot_set_gemm_precision(int mode) { PH_ENTRY();
-    if (mode != PARROT_PRECISION_F32 && mode != PARROT_PRECISION_BF16) return PARROT_ERR_BADARG;
+    if (mode != PARROT_PRECISION_F32 && mode != PARROT_PRECISION_BF16 && mode != PARROT_PRECISION_BF16X3) return PARROT_ERR_BADARG;
     g_gemm_bf16.store(mode, std::memory_order_relaxed);
     return 0;
 }
@@ -86,7 +96,19 @@ static int bg_run(BgArgs a, int split_k, hipStream_t st) {
         bg_tile_shape(a.bf16, bm, bn);
         const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn) * nbatch;
         split = 1;
-        if (a.bf16 == 2 && K >= 512) {
+        if (a.bf16 == 3) {
+            // 256 x 256 tiles, one workgroup per CU, slices dealt to XCDs: a multiple of 8 slices whose workgroups fill
+            // whole rounds of 256 best, at least 512 K rows per slice
+            if (act == 0 && tiles < 256 && K >= 4096) {
+                double best = -1.0;
+                for (int sp = 8; sp <= 64 && K / sp >= 512; sp += 8) {
+                    const long long wgs = tiles * sp;
+                    const double eff = (double)wgs / (double)((wgs + 255) / 256 * 256);
+                    const double score = eff - 0.001 * sp;
+                    if (score > best) { best = score; split = sp; }
+                }
+            }
+        } else if (a.bf16 == 2 && K >= 512) {
             // 256 x 256 tiles, one workgroup per CU: the slice count whose workgroups fill whole rounds of 256 best
             // (at least two rounds, at most 16 slices, at least 1024 K rows per slice)
             double best = -1.0;
@@ -156,6 +178,15 @@ static int gemm_impl(const float* A, int lda, int transA, const float* B, int ld
     a.accumulate = accumulate; a.alpha = alpha; a.act = act;
     a.gate = gate; a.ldg = ldg;
     a.bf16 = t_gemm_bf16 >= 0 ? t_gemm_bf16 : g_gemm_bf16.load(std::memory_order_relaxed);
+    if (a.bf16 == PARROT_PRECISION_BF16X3) {
+        // split-bf16 products (bgs_kernel): f32 operands and f32-grade results on the bf16 matrix pipe.  Taken where the
+        // 256 x 256 tile pays: both operands fetched as aligned 16-byte vectors, enough work; the rest stays on the
+        // f32-input MFMA kernel.
+        auto al = [](const float* p, long long ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); };
+        const bool ok = act <= 1 && al(A, lda) && al(B, ldb) && (strideA % 4 == 0) && (strideB % 4 == 0) && M >= 128 && N >= 128 &&
+                        K >= 64 && (!transA || M % 4 == 0) && (transA || K % 4 == 0) && (transB || N % 4 == 0) && (!transB || K % 4 == 0);
+        a.bf16 = ok ? 3 : 0;
+    }
     return bg_run(a, split_k, st);
 }
 

@@ -218,7 +218,7 @@ struct DecoderPlan : PlanBase {
     }
 
     int enqueue(int which, hipStream_t s) override {
-        BgPrecisionScope precision(d.bf16);  // the hoisted projections follow the plan's operand mode
+        BgPrecisionScope precision(d.bf16 ? 1 : -1);  // the hoisted projections follow the plan's operand mode (f32 plans: the process-wide one)
         if (which == 0 && persist_ok) return pm_launch(pm_prog, s);  // schedule 4: the persistent phase machine
         if (schedule == 3) return which == 0 ? fwd_skew(s) : bwd_skew(s);
         if (which == 1 && bwd_hetero && (schedule == 0 || schedule == 5)) return bwd8(s);
@@ -1340,7 +1340,7 @@ struct DecoderPlan : PlanBase {
 
 
     int run(int which, hipStream_t s) override {
-        BgPrecisionScope precision(d.bf16);
+        BgPrecisionScope precision(d.bf16 ? 1 : -1);
         return PlanBase::run(which, s);
     }
 

@@ -681,11 +681,11 @@ class Parrot(Brick):
     # ------------------------------------------------------------------ compute_cost
     def compute_cost(self, *args, **kwargs):
         """Parrot.compute_cost (model.py:551-824); see _compute_cost.  Runs under the model's operand precision."""
-        with ops.gemm_precision(ops.PRECISION_BF16 if self.compute_bf16 else ops.PRECISION_F32):
+        with ops.gemm_precision(ops.PRECISION_BF16 if self.compute_bf16 else ops.full_precision()):
             return self._compute_cost(*args, **kwargs)
 
     def _backward(self, token, gscale):
-        with ops.gemm_precision(ops.PRECISION_BF16 if self.compute_bf16 else ops.PRECISION_F32):
+        with ops.gemm_precision(ops.PRECISION_BF16 if self.compute_bf16 else ops.full_precision()):
             return self._backward_f(token, gscale)
 
     def _compute_cost(self, features, features_mask, labels, labels_mask, speaker, start_flag,

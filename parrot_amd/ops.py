@@ -133,7 +133,33 @@ def _mat16(t: torch.Tensor, name: str):
     raise ValueError(f"{name}: unsupported strides {t.stride()}")
 
 
-PRECISION_F32, PRECISION_BF16 = 0, 1
+PRECISION_F32, PRECISION_BF16, PRECISION_BF16X3 = 0, 1, 2
+
+
+def _default_full_precision() -> int:
+    import os
+    return PRECISION_F32 if os.environ.get("PARROT_GEMM_PRECISION", "") in ("f32", "0") else PRECISION_BF16X3
+
+
+_FULL_PRECISION = _default_full_precision()
+
+
+def full_precision() -> int:
+    """The mode f32 models run their batched products in: PRECISION_BF16X3 (f32 operands split into three bf16 terms
+    inside the kernel, six bf16 MFMAs per block, f32-grade result; default) or PRECISION_F32 (the f32-input matrix
+    instructions; PARROT_GEMM_PRECISION=f32 or set_full_precision)."""
+    return _FULL_PRECISION
+
+
+def set_full_precision(mode: int) -> int:
+    """Selects the f32-grade mode (PRECISION_F32 / PRECISION_BF16X3) for this process, library default included;
+    returns the previous one."""
+    global _FULL_PRECISION
+    if mode not in (PRECISION_F32, PRECISION_BF16X3):
+        raise ValueError("set_full_precision: PRECISION_F32 or PRECISION_BF16X3")
+    prev, _FULL_PRECISION = _FULL_PRECISION, int(mode)
+    _lib.call("parrot_set_gemm_precision", int(mode))
+    return prev
 
 
 class gemm_precision:

@@ -71,6 +71,92 @@ def test_big_gemm_splitk_bias_batched(dev):
     assert_close(ops.colsum(tall), tall.double().cpu().sum(0), 2e-5, "colsum tall")
 
 
+# ---- split-bf16 products (PARROT_PRECISION_BF16X3, bgs_kernel): f32 operands, six bf16 MFMAs per block ---------------
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (128, 132, 100), (300, 260, 516), (1024, 1024, 1024), (1000, 520, 72),
+                                   (260, 4096, 2052)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_split_gemm_layouts(dev, M, N, K, ta, tb):
+    """Every operand layout, ragged edges in all three dimensions: the split kernel holds the tolerance of the f32 kernel."""
+    from parrot_amd import ops
+    a = _rand((K, M) if ta else (M, K), dev, 4)
+    b = _rand((N, K) if tb else (K, N), dev, 5)
+    aa = a.t() if ta else a
+    bb = b.t() if tb else b
+    with ops.gemm_precision(ops.PRECISION_BF16X3):
+        out = ops.gemm(aa, bb)
+    ref = aa.double().cpu() @ bb.double().cpu()
+    assert_close(out, ref, 3e-6, "split gemm")
+
+
+def test_split_gemm_splitk_bias_accumulate_relu_gate(dev):
+    from parrot_amd import ops
+    a = _rand((12000, 512), dev, 6)
+    b = _rand((12000, 384), dev, 7)
+    ref = a.double().cpu().t() @ b.double().cpu()
+    acc = _rand((512, 384), dev, 8)
+    bias = _rand((384,), dev, 9)
+    with ops.gemm_precision(ops.PRECISION_BF16X3):
+        o_auto = ops.gemm(a.t(), b)                      # automatic split (slices dealt to XCDs)
+        o_8 = ops.gemm(a.t(), b, split_k=8)
+        o_3 = ops.gemm(a.t(), b, split_k=3)              # not a multiple of 8: the 2-d grid path
+        o_acc = ops.gemm(a.t(), b, out=acc.clone(), accumulate=True, bias=bias, split_k=8)
+        o_acc1 = ops.gemm(a.t(), b, out=acc.clone(), accumulate=True, bias=bias, split_k=1)
+        x = _rand((700, 300), dev, 10, 1.0 / math.sqrt(300))
+        w = _rand((300, 260), dev, 11)
+        o_relu = ops.gemm(x, w, bias=_rand((260,), dev, 12), act=ops.ACT_RELU)
+        gate = _rand((700, 260), dev, 13)
+        o_gate = ops.gemm_gated(x, w, gate)
+        o_tanh = ops.gemm(x, w, act=ops.ACT_TANH)        # tanh epilogues stay on the f32 kernel
+        assert torch.equal(ops.gemm(a.t(), b, split_k=8), o_8), "split-K result depends on scheduling"
+    for o, what in ((o_auto, "auto"), (o_8, "8 slices"), (o_3, "3 slices")):
+        assert_close(o, ref, 5e-6, "split gemm split-k " + what)
+    full = acc.double().cpu() + ref + bias.double().cpu()
+    assert_close(o_acc, full, 5e-6, "split gemm accumulate + bias, split-k")
+    assert_close(o_acc1, full, 5e-6, "split gemm accumulate + bias, one slice")
+    r2 = x.double().cpu() @ w.double().cpu()
+    assert_close(o_relu, torch.relu(r2 + _rand((260,), dev, 12).double().cpu()), 3e-6, "split gemm relu")
+    assert_close(o_gate, r2 * (gate.double().cpu() > 0), 3e-6, "split gemm gated")
+    assert_close(o_tanh, torch.tanh(r2), 5e-6, "tanh epilogue (f32 kernel)")
+
+
+def test_split_gemm_error_gate_vs_f32_mfma(dev):
+    """The gate of VERDICT r05 item 1c: on the K = T*B weight-gradient product and on same-sign, wide-range operands
+    (nothing cancels, every element has a meaningful relative error) the element-wise error of the split kernel against
+    float64 is at most 2 x the f32-input MFMA kernel's on the same operands."""
+    from parrot_amd import ops
+    from tests.util import rel_err_elem
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(51200, 512, generator=g).to(dev)
+    dy = torch.randn(51200, 256, generator=g).to(dev)
+    ref = x.double().t() @ dy.double()
+    a2 = ((torch.rand(512, 8192, generator=g) + 0.5) * torch.exp2(torch.randint(-12, 12, (512, 8192), generator=g).float())).to(dev)
+    b2 = (torch.rand(8192, 384, generator=g) + 0.5).to(dev)
+    ref2 = a2.double() @ b2.double()
+    errs = {}
+    for mode in (ops.PRECISION_F32, ops.PRECISION_BF16X3):
+        with ops.gemm_precision(mode):
+            o1 = ops.gemm(x.t(), dy)
+            o2 = ops.gemm(a2, b2)
+        errs[mode] = (rel_err_elem(o1, ref), float(((o2.double() - ref2).abs() / ref2.abs()).max()), rel_err(o1, ref))
+    f, s = errs[ops.PRECISION_F32], errs[ops.PRECISION_BF16X3]
+    print("element-wise error vs fp64 (K = 51200 product, same-sign product, norm-wise): f32 MFMA", f, "split bf16", s)
+    assert s[0] <= 2 * f[0] and s[1] <= 2 * f[1] and s[2] <= 2 * f[2], (f, s)
+    assert s[1] < 2e-6
+
+
+def test_split_gemm_terms_are_exact(dev):
+    """x = x1 + x2 + x3 exactly (three bf16 terms): a product with the identity returns its operand bit for bit, and a
+    one-hot gather-sum adds exactly the selected rows -- for normal floats of any magnitude and sign."""
+    from parrot_amd import ops
+    g = torch.Generator().manual_seed(5)
+    v = (torch.randn(384, 256, generator=g) * torch.exp2(torch.randint(-60, 60, (384, 256), generator=g).float())).to(dev)
+    eye = torch.eye(256, device=dev)
+    with ops.gemm_precision(ops.PRECISION_BF16X3):
+        assert torch.equal(ops.gemm(v, eye), v)
+        assert torch.equal(ops.gemm(eye, v.t().contiguous()), v.t().contiguous())
+        assert torch.equal(ops.gemm(v.t().contiguous().t(), eye), v)
+
+
 def test_linear_autograd(dev):
     from parrot_amd import ops
     x = _rand((7, 20, 33), dev, 1).requires_grad_()

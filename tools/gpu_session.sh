@@ -56,7 +56,7 @@ for step in "$@"; do
     tests:*) timeout 2700 python -m pytest tests -q -m gpu --timeout 600 -k "${step#tests:}" 2>&1 | tail -40 | tee -a $out/tests_k.log ;;
     bench)   ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err ) 2> $out/bench.time
              tail -c 3000 $out/bench.json; tail -3 $out/bench.time ;;
-    stats)   stats bench 600 python bench.py --no-cpu-baseline --no-parity --no-secondary ;;
+    stats)   stats bench 600 python bench.py --no-cpu-baseline --no-parity --no-secondary --no-f32-gemm ;;
     cfg4stats) stats cfg4 600 python bench.py --config cfg4 --no-cpu-baseline --no-dense --no-parity --no-secondary --steps 3 --warmup 1 ;;
     secstats) stats secondary 600 python bench.py --secondary-only ;;
     pmc)     pmc "" cfg2 ;;
