@@ -213,19 +213,35 @@ def frame_level_rnn(p, c, input_sequences, other_input, h0, reset):
     return output, last_hidden
 
 
-def sample_level_predictor(p, c, frame_level_outputs, prev_samples):
-    """three_tier.py:452-515."""
+def _relu_at_ties(pre, tie_mask, tie_tol, report):
+    """relu(pre), except that an element within tie_tol * max|pre| of the kink takes the branch `tie_mask` names
+    (the implementation under test's own mask): at pre = 0 +- rounding the branch -- and one whole term of every upstream
+    gradient -- is decided by the last bit of an f32 product, so a checker that insists on its own float64 sign there
+    tests luck, not arithmetic (the same policy as the arg-max ties of the greedy generation check)."""
+    own = pre > 0
+    if tie_mask is None:
+        return torch.relu(pre)
+    near = pre.detach().abs() < tie_tol * pre.detach().abs().max()
+    use = torch.where(near, tie_mask.to(own.device), own)
+    if report is not None:
+        report.append((int(near.sum()), int((use != own).sum())))
+    return pre * use.to(pre.dtype)
+
+
+def sample_level_predictor(p, c, frame_level_outputs, prev_samples, relu_ties=None, tie_tol=1e-6, tie_report=None):
+    """three_tier.py:452-515.  relu_ties: optional [mask of L2, mask of L3] (bool, the tested implementation's relu
+    outputs > 0), consulted only for pre-activations within tie_tol of 0 (see _relu_at_ties)."""
     FS, EMB = c['FRAME_SIZE'], c['EMB_SIZE']
     emb = p['SampleLevel.Embedding'][prev_samples.reshape(-1).long()].reshape(-1, FS * EMB)
     out = linear(p, c, 'SampleLevel.L1_PrevSamples', emb, biases=False) + frame_level_outputs
-    out = torch.relu(linear(p, c, 'SampleLevel.L2', out))
-    out = torch.relu(linear(p, c, 'SampleLevel.L3', out))
+    out = _relu_at_ties(linear(p, c, 'SampleLevel.L2', out), relu_ties and relu_ties[0], tie_tol, tie_report)
+    out = _relu_at_ties(linear(p, c, 'SampleLevel.L3', out), relu_ties and relu_ties[1], tie_tol, tie_report)
     return linear(p, c, 'SampleLevel.Output', out)
 
 
-def compute_cost(p, c, sequences, features, h0, big_h0, reset, mask):
+def compute_cost(p, c, sequences, features, h0, big_h0, reset, mask, relu_ties=None, tie_tol=1e-6, tie_report=None):
     """three_tier.py:534-636.  sequences [B, S+80] int, features [B, S/80, 63], mask [B, S+80].
-    Returns (cost_bits, ip_cost_bits, new_h0, new_big_h0)."""
+    Returns (cost_bits, ip_cost_bits, new_h0, new_big_h0).  relu_ties / tie_tol / tie_report: see sample_level_predictor."""
     BFS, FS, D, Q = c['BIG_FRAME_SIZE'], c['FRAME_SIZE'], c['DIM'], c['Q_LEVELS']
     big_in = sequences[:, :-BFS]
     inp = sequences[:, BFS - FS:-FS]
@@ -235,7 +251,7 @@ def compute_cost(p, c, sequences, features, h0, big_h0, reset, mask):
     frame_out, new_h0 = frame_level_rnn(p, c, inp, big_out, h0, reset)
     prev = sequences[:, BFS - FS:-1]
     prev = prev.unfold(1, FS, 1).reshape(-1, FS)  # images2neibs, stride 1 (three_tier.py:555-558)
-    logits = sample_level_predictor(p, c, frame_out.reshape(-1, D), prev)
+    logits = sample_level_predictor(p, c, frame_out.reshape(-1, D), prev, relu_ties, tie_tol, tie_report)
     lse = torch.logsumexp(logits, -1)
     ce = (lse - logits.gather(1, target.reshape(-1, 1).long())[:, 0]).reshape(target.shape)
     log2e = math.log2(math.e)

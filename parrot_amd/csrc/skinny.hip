@@ -233,6 +233,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const void* p) {  // r
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, 0x7fffffff, 0x00020000);
 }
 
+// Development: -DSK_TIMERS stamps every wave's phases (100 MHz wall clock) into sk_timer_buf (tools/sktimers.hip):
+// [0] entry  [1] operands requested, K loop starts  [2] K loop done  [3] past the LDS meeting point  [4] epilogue stores issued
+#ifdef SK_TIMERS
+__constant__ unsigned long long* sk_timer_buf = nullptr;  // (constant address space: a scalar load, no vmcnt wait at a stamp)
+#define SK_STAMP(i)                                                                                                  \
+    do {                                                                                                             \
+        if (sk_timer_buf && (threadIdx.x & 63) == 0) {                                                               \
+            const size_t wg_ = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);       \
+            sk_timer_buf[(wg_ * 16 + (threadIdx.x >> 6)) * 8 + (i)] = wall_clock64();                                \
+        }                                                                                                            \
+    } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
+
+// Element offset m * ld + c of an epilogue operand: rows and leading dimensions are below 2^24 (sk_make_launch checks), so
+// one full-rate v_mad_u32_u24 instead of the quarter-rate 64-bit multiply-add `(size_t)m * ld + c` compiles to; the
+// epilogue's ~30 addresses per wave sit on the critical path in front of the K loop and behind the LDS meeting point.
+__device__ __forceinline__ unsigned sk_off(int m, int ld, int c) { return __umul24((unsigned)m, (unsigned)ld) + (unsigned)c; }
+
 // One workgroup: (16*MB rows) x (16*NB columns) output tile, K split over the SK_NW waves.
 template <int MB, int NB, bool FAST>
 __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red) {
@@ -242,6 +262,7 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
     const int kk = lane >> 4, i = lane & 15;
     const int m0 = blockIdx.y * (16 * MB);  // the launch picks MB / NB
     const int M = job.M, N = job.N;
+    SK_STAMP(0);
     if (m0 >= M) return;
 
     f32x4 acc[MB][NB];
@@ -253,44 +274,57 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
     // Epilogue operands (bias, additive input, previous state / gates, accumulate targets) are requested now by
     // the waves that will run the epilogue: nothing in this launch writes them, and their latency then hides
     // behind the K loop instead of adding a dependent memory round trip after the reduction.
-    float p_bias = 0.f, p_add[4] = {0.f, 0.f, 0.f, 0.f}, p_e0[4] = {0.f, 0.f, 0.f, 0.f}, p_e1[4] = {0.f, 0.f, 0.f, 0.f},
-          p_oc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < MB * NB * 64) {
-        const int blk_ = tid >> 6;
-        const int rb_ = blk_ / NB, tile_ = tile0 + blk_ % NB;
-        const int g_ = lane >> 4, jj_ = lane & 15;
-        const int n_ = sk_jcol(job, tile_, jj_);
-        const bool n_ok_ = n_ < N;
-        if (job.bias && n_ok_) p_bias = job.bias[n_];
+    // Branch-free and unconditional: one uniform choice of four source pointers (a slot that is off reads element 0 of a
+    // buffer that always exists), clamped indices, 17 loads issued back to back -- nothing here waits for anything.
+    // (Rounds 1-5 requested them under `if (job.add)` / `switch (job.epi)`: the compiler closed every conditional block
+    // with s_waitcnt vmcnt(0), four dependent round trips = 1.4 - 2.1 us during which the epilogue waves had not started
+    // their K loop and for which the other waves then waited at the LDS meeting point: tools/sktimers.hip,
+    // profiles/r06_sk_phase_timers.txt.)  Values of slots that are off, or of rows / columns outside the job, are never used.
+    // Round 6: the reduction + epilogue is dealt to ALL waves where the tile allows it -- EG row groups per 16 x 16 block, a
+    // wave takes RPW = 4 / EG of a lane's four accumulator rows -- instead of MB * NB waves doing four rows each while the
+    // rest exit: half the instructions on the tail's critical path (1.1 us from the LDS meeting point to the last store
+    // at 32 x 32 tiles, one wave per SIMD), half the request instructions in front of every wave's K loop, all waves alike.
+    constexpr int NBLK = MB * NB;
+    constexpr int EG = (SK_NW % NBLK == 0) ? (SK_NW / NBLK > 4 ? 4 : SK_NW / NBLK) : 1;
+    constexpr int RPW = 4 / EG, EWAVES = NBLK * EG;
+    const int eblk = wave % NBLK, er0 = (wave / NBLK) * RPW;  // this wave's block and first row (of a lane's four)
+    float p_bias = 0.f, p_add[RPW], p_e0[RPW], p_e1[RPW], p_oc[RPW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + rb_ * 16 + 4 * g_ + r;
-            if (m >= M || !n_ok_) continue;
-            if (job.add) p_add[r] = job.add[(size_t)m * job.ld_add + n_];
-            switch (job.epi) {
-                case SK_EPI_LINEAR:
-                    if (job.accumulate == 1) p_oc[r] = job.out[(size_t)m * job.ldo + n_];
-                    break;
-                case SK_EPI_GRU_GATES:
-                    if (n_ >= job.H) p_e0[r] = job.e0[(size_t)m * job.lde0 + n_ - job.H];
-                    break;
-                case SK_EPI_GRU_CAND:
-                    p_e0[r] = job.e0[(size_t)m * job.lde0 + n_];
-                    p_e1[r] = job.e1[(size_t)m * job.lde1 + n_];
-                    break;
-                case SK_EPI_BWD_RH:
-                    p_e0[r] = job.e0[(size_t)m * job.lde0 + n_];
-                    p_e1[r] = job.e1[(size_t)m * job.lde1 + n_];
-                    p_oc[r] = job.o1[(size_t)m * job.ldo1 + n_];
-                    break;
-                case SK_EPI_LSTM:
-                    if ((jj_ >> 2) == 0) p_e1[r] = job.e1[(size_t)m * job.lde1 + n_];
-                    break;
-                default: break;
-            }
+    for (int r = 0; r < RPW; ++r) p_add[r] = p_e0[r] = p_e1[r] = p_oc[r] = 0.f;
+    const bool has_add = job.add != nullptr;
+    if (wave < EWAVES) {
+        const int rb_ = eblk / NB, tile_ = tile0 + eblk % NB;
+        const int g_ = lane >> 4, jj_ = lane & 15;
+        const int epi_ = job.epi, H_ = job.H;
+        const int n_ = min(sk_jcol(job, tile_, jj_), N - 1);
+        const float* dummy = epi_ == SK_EPI_BWD_RH ? job.o1 : job.out;  // (always a live buffer of this job)
+        const float* q_add = has_add ? job.add : dummy;
+        const int l_add = has_add ? job.ld_add : 0, c_add = has_add ? n_ : 0;
+        const bool on0 = epi_ == SK_EPI_GRU_GATES || epi_ == SK_EPI_GRU_CAND || epi_ == SK_EPI_BWD_RH;
+        const float* q_e0 = on0 ? job.e0 : dummy;
+        const int l_e0 = on0 ? job.lde0 : 0;
+        const int c_e0 = !on0 ? 0 : (epi_ == SK_EPI_GRU_GATES ? max(n_ - H_, 0) : n_);
+        const bool on1 = epi_ == SK_EPI_GRU_CAND || epi_ == SK_EPI_BWD_RH || epi_ == SK_EPI_LSTM;
+        const float* q_e1 = on1 ? job.e1 : dummy;
+        const int l_e1 = on1 ? job.lde1 : 0;
+        const int c_e1 = !on1 ? 0 : (epi_ == SK_EPI_LSTM ? ((jj_ >> 2) == 0 ? min(n_, H_ - 1) : 0) : n_);
+        const bool onc = (epi_ == SK_EPI_LINEAR && job.accumulate == 1) || epi_ == SK_EPI_BWD_RH;
+        const float* q_oc = !onc ? dummy : (epi_ == SK_EPI_BWD_RH ? job.o1 : job.out);
+        const int l_oc = !onc ? 0 : (epi_ == SK_EPI_BWD_RH ? job.ldo1 : job.ldo);
+        const int c_oc = onc ? n_ : 0;
+        const float* q_b = job.bias ? job.bias : dummy;
+        p_bias = q_b[job.bias ? n_ : 0];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int m = min(m0 + rb_ * 16 + 4 * g_ + er0 + r, M - 1);
+            p_add[r] = q_add[sk_off(m, l_add, c_add)];
+            p_e0[r] = q_e0[sk_off(m, l_e0, c_e0)];
+            p_e1[r] = q_e1[sk_off(m, l_e1, c_e1)];
+            p_oc[r] = q_oc[sk_off(m, l_oc, c_oc)];
         }
     }
 
+    SK_STAMP(6);
     if (FAST) {
         // One flat sequence of 16-deep chunks over all segments, dealt round-robin to the waves.  The
         // loop body is straight-line code: segment descriptors sit in scalar registers and are picked
@@ -438,6 +472,10 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
             for (int dd = 0; dd < SK_DEPTH - 1; ++dd)
                 if (dd < rem) sk_mma_bf16<MB, NB>(ra[dd], rb_[dd], acc);
         };
+        SK_STAMP(1);
+#if SK_PRIO_YOUNG
+        if (wave >= SK_NW / 2) __builtin_amdgcn_s_setprio(1);  // the second-dispatched half loses every arbitration otherwise
+#endif
         if (mine > 0) {
             if (job.seg[0].b_kcontig == 3) run_bf16();
             else if (job.seg[0].b_kcontig == 2) run(std::integral_constant<int, 2>{});
@@ -503,37 +541,53 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
     }
 
     // Intra-workgroup split-K reduction through LDS.
+#if SK_PRIO_YOUNG
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    SK_STAMP(2);
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) red[((wave * MB + rb) * NB + nb) * 64 + lane] = acc[rb][nb];
     __syncthreads();
-    if (tid >= MB * NB * 64) return;
-    const int blk = tid >> 6;
+    SK_STAMP(3);
+    if (wave >= EWAVES) return;
+    const int blk = eblk;
     const int rb = blk / NB, nbi = blk % NB;
     const int tile = tile0 + nbi;
-    f32x4 v = red[blk * 64 + lane];
+    float v[RPW];  // rows er0 .. er0 + RPW - 1 of this lane's four, summed over the waves in wave order (as ever)
+    {
+        const float* rp = reinterpret_cast<const float*>(red) + er0;
 #pragma unroll
-    for (int w = 1; w < SK_NW; ++w) v += red[(w * MB * NB + blk) * 64 + lane];
+        for (int r = 0; r < RPW; ++r) v[r] = rp[(blk * 64 + lane) * 4 + r];
+#pragma unroll
+        for (int w = 1; w < SK_NW; ++w)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) v[r] += rp[((w * NBLK + blk) * 64 + lane) * 4 + r];
+    }
 
     // Fused epilogue.  MFMA C/D layout (16x16): column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int g = lane >> 4, jj = lane & 15;
     const int n = sk_jcol(job, tile, jj);
     const bool n_ok = n < N;
-    const float bias = p_bias;
+    const float bias = job.bias ? p_bias : 0.f;
     const int H = job.H;
+    if (!has_add) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) p_add[r] = 0.f;
+    }
 
     if (job.epi == SK_EPI_LSTM) {
         // Gates of hidden unit j live in lanes jj = q*4 + (j&3), q = 0..3 (i, f, o, g order,
         // ops.py:523-541).  Gather them with wave shuffles; lanes with q == 0 do the cell update.
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + rb * 16 + 4 * g + r;
+        for (int r = 0; r < RPW; ++r) {
+            const int m = m0 + rb * 16 + 4 * g + er0 + r;
             const bool ok = (m < M) && n_ok;
             const float pre = v[r] + bias + p_add[r];
             const int q = jj >> 2;
             const float gate = (q == 3) ? tanhf(pre) : ph_sigmoid(pre);
-            if (job.o2 && ok) job.o2[(size_t)m * job.ldo2 + n] = gate;  // saved activations [M,4H]
+            if (job.o2 && ok) job.o2[sk_off(m, job.ldo2, n)] = gate;  // saved activations [M,4H]
             const int src = (lane & ~12);
             const float gi = __shfl(gate, src | 0, 64);
             const float gf = __shfl(gate, src | 4, 64);
@@ -543,16 +597,17 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 const int j = n;  // q == 0 -> n = hidden index
                 const float cp = p_e1[r];
                 const float cn = cp * gf + gg * gi;
-                job.o1[(size_t)m * job.ldo1 + j] = cn;
-                job.out[(size_t)m * job.ldo + j] = tanhf(cn) * go;
+                job.o1[sk_off(m, job.ldo1, j)] = cn;
+                job.out[sk_off(m, job.ldo, j)] = tanhf(cn) * go;
             }
         }
+        SK_STAMP(4);
         return;
     }
 
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + rb * 16 + 4 * g + r;
+    for (int r = 0; r < RPW; ++r) {
+        const int m = m0 + rb * 16 + 4 * g + er0 + r;
         if (m >= M || !n_ok) continue;
         float x = v[r];
         switch (job.epi) {
@@ -561,19 +616,19 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                 if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
-                float* o = job.out + (size_t)m * job.ldo + n;
-                if (job.accumulate) x += p_oc[r];  // exclusive owner of the tile: no two jobs of a launch share one
+                float* o = job.out + sk_off(m, job.ldo, n);
+                if (job.accumulate == 1) x += p_oc[r];  // exclusive owner of the tile: no two jobs of a launch share one
                 *o = x;
             } break;
             case SK_EPI_GRU_GATES: {
                 x += bias + p_add[r];
                 const float gt = ph_sigmoid(x);
                 if (n < H) {
-                    job.o1[(size_t)m * job.ldo1 + n] = gt;  // update gate z
+                    job.o1[sk_off(m, job.ldo1, n)] = gt;  // update gate z
                 } else {
                     const int j = n - H;
-                    job.o2[(size_t)m * job.ldo2 + j] = gt;  // reset gate r
-                    job.out[(size_t)m * job.ldo + j] = gt * p_e0[r];
+                    job.o2[sk_off(m, job.ldo2, j)] = gt;  // reset gate r
+                    job.out[sk_off(m, job.ldo, j)] = gt * p_e0[r];
                 }
             } break;
             case SK_EPI_GRU_CAND: {
@@ -586,19 +641,24 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
                     const float mk = job.mask[m];
                     hn = mk * hn + (1.f - mk) * hp;
                 }
-                if (job.o1) job.o1[(size_t)m * job.ldo1 + n] = c;
-                job.out[(size_t)m * job.ldo + n] = hn;
+                if (job.o1) job.o1[sk_off(m, job.ldo1, n)] = c;
+                job.out[sk_off(m, job.ldo, n)] = hn;
             } break;
             case SK_EPI_BWD_RH: {
                 // x = d(r*h_prev)[m][n]
                 const float r_ = p_e1[r];
                 const float hp = p_e0[r];
-                job.out[(size_t)m * job.ldo + n] = x * hp * r_ * (1.f - r_);  // dG_r
-                job.o1[(size_t)m * job.ldo1 + n] = p_oc[r] + x * r_;          // dh_prev +=
+                job.out[sk_off(m, job.ldo, n)] = x * hp * r_ * (1.f - r_);  // dG_r
+                job.o1[sk_off(m, job.ldo1, n)] = p_oc[r] + x * r_;          // dh_prev +=
             } break;
             default: break;
         }
     }
+    SK_STAMP(4);
+#ifdef SK_TIMERS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // [5] the epilogue's stores acknowledged
+    SK_STAMP(5);
+#endif
 }
 
 template <int MB, int NB>
@@ -727,6 +787,13 @@ void sk_finalize_job(SkJob& j) {
 
 int sk_make_launch(SkLaunch& L, const SkJob* jobs, int njobs) {
     if (njobs < 1 || njobs > SK_MAXJOB) return PH_ERR_BADARG;
+    for (int q = 0; q < njobs; ++q) {  // sk_off: 24-bit rows and leading dimensions
+        const SkJob& j = jobs[q];
+        const int lim = 1 << 24;
+        if (j.M >= lim || j.ld_add >= lim || j.ldo >= lim || j.lde0 >= lim || j.lde1 >= lim || j.ldo1 >= lim || j.ldo2 >= lim ||
+            j.ld_add < 0 || j.ldo < 0 || j.lde0 < 0 || j.lde1 < 0 || j.ldo1 < 0 || j.ldo2 < 0)
+            return PH_ERR_BADARG;
+    }
     memset(&L, 0, sizeof(L));
     int t = 0;
     for (int q = 0; q < njobs; ++q) {

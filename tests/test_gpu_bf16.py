@@ -63,7 +63,7 @@ def test_gemm_bf16_matches_rounded_operands(dev, ta, tb, M, N, K):
         out = ops.gemm(av, bv, bias=bias)
         acc = ops.gemm(av, bv, out=out.clone(), accumulate=True)
         relu = ops.gemm(av, bv, bias=bias, act=ops.ACT_RELU, split_k=1)
-    assert ops._lib.load().parrot_get_gemm_precision() == 0  # restored
+    assert ops._lib.load().parrot_get_gemm_precision() == ops.full_precision()  # restored (the f32-grade default)
     assert_close(out, ref, 2e-5, "bf16 gemm vs rounded-operand product")
     assert_close(acc, 2 * ref - bias.cpu().double(), 2e-5, "accumulate")
     assert_close(relu, ref.clamp_min(0), 2e-5, "relu epilogue")

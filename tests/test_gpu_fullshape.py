@@ -614,6 +614,23 @@ def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
     lib.delete_all_params()
     lib.set_device(dev)
     tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
+    # A ReLU pre-activation within rounding of 0 makes the GRADIENT ill-posed for any f32 implementation: the mask bit of
+    # that element -- and with it one whole term of every upstream gradient -- follows the last bit of the product
+    # (round 6: exactly one of 2.6 M pre-activations sits at 1.6e-6 of a layer whose largest is 11.4; the f32-input MFMA
+    # kernel lands above 0, the split-bf16 kernel below, both within 1e-7 of the float64 value; tools/x3_debug.py: every
+    # gradient then moves by 1e-3).  The oracle therefore takes the HIP run's own branch for elements within 1e-6 of the
+    # kink (oracle/samplernn_ref.py _relu_at_ties) and its own float64 sign everywhere else; the test asserts that at
+    # most a handful of elements are that close and reports how many branches were actually taken over.
+    from parrot_amd import ops as hops
+    masks = []
+    orig_gemm = hops.gemm
+
+    def spy(a, b, bias=None, out=None, accumulate=False, act=hops.ACT_NONE, alpha=1.0, split_k=0):
+        r = orig_gemm(a, b, bias=bias, out=out, accumulate=accumulate, act=act, alpha=alpha, split_k=split_k)
+        if act == hops.ACT_RELU:
+            masks.append((r.detach() > 0).cpu())
+        return r
+    hops.gemm = spy
     try:
         c = S.config()
         p = S.init_params(c, seed=8, perturb=0.1)
@@ -630,14 +647,20 @@ def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
         for reset in (1, 0):
             h0 = torch.randn(B, 1, 1024, generator=g, dtype=torch.float64) * 0.3
             bh0 = torch.randn(B, 1, 1024, generator=g, dtype=torch.float64) * 0.3
-            ref_p = {k: v.clone().requires_grad_() for k, v in p.items()}
-            rc, rip, rh0, rbh0 = S.compute_cost(ref_p, c, seq, feats, h0, bh0, reset, mask)
-            (rc + rip).backward()
             for t in lib.named_params().values():
                 t.grad = None
+            masks.clear()
             cost, ip_cost, allp, ipp, otherp, nh0, nbh0 = tt.compute_cost(
                 seq.to(dev), feats.float().to(dev), h0.float().to(dev), bh0.float().to(dev), reset, mask.float().to(dev))
             (cost + ip_cost).backward()
+            assert len(masks) == 2, "the two ReLU layers of sample_level_predictor"
+            ref_p = {k: v.clone().requires_grad_() for k, v in p.items()}
+            ties = []
+            rc, rip, rh0, rbh0 = S.compute_cost(ref_p, c, seq, feats, h0, bh0, reset, mask, relu_ties=list(masks),
+                                                tie_tol=1e-6, tie_report=ties)
+            (rc + rip).backward()
+            near, taken = sum(t_[0] for t_ in ties), sum(t_[1] for t_ in ties)
+            assert near <= 64, f"{near} pre-activations within 1e-6 of the kink: not a handful"
             assert_close(cost, rc, 1e-4, "cost")
             assert_close(ip_cost, rip, 1e-4, "ip_cost")
             assert_close(nh0, rh0, 1e-4, "new_h0")
@@ -655,9 +678,10 @@ def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
                 n += 1
             assert n >= 20
             rep.append(f"reset={reset}: cost {float(cost.detach()):.5f} (oracle {float(rc.detach()):.5f}), ip_cost {float(ip_cost.detach()):.5f}; {n} gradients, "
-                       f"worst {worst[0]}: {worst[1]:.2e}")
+                       f"worst {worst[0]}: {worst[1]:.2e}; ReLU pre-activations within 1e-6 of 0: {near} of 2.6 M, branch taken from the HIP run: {taken}")
         with capsys.disabled():
             print("\n[cfg5 training parity] " + "\n[cfg5 training parity] ".join(rep))
     finally:
+        hops.gemm = orig_gemm
         lib.delete_all_params()
         tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
