@@ -40,7 +40,13 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, timers: bool = False) -> str:
+    """timers=True: the development build with in-kernel phase stamps (-DSK_TIMERS) -> libparrot_hip_timers.so, loaded
+    instead of the product library when PARROT_LIB points at it (tools/att_timing.py)."""
+    global OUT, OBJDIR
+    if timers:
+        OUT = os.path.join(HERE, "libparrot_hip_timers.so")
+        OBJDIR = os.path.join(CSRC, "build_timers")
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "parrot_hip.h"))
@@ -50,7 +56,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"]
+    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + (["-DSK_TIMERS"] if timers else [])
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
@@ -74,4 +80,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, timers="--timers" in sys.argv)

@@ -31,6 +31,7 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const float* ctx = g.ctx + (size_t)b * U * E;
+    ATT_STAMP(1, b, 0);
 
     // Everything that does not depend on the incoming gradient is requested first: this wave's context rows
     // (for dphi) and this thread's column of the projection matrix (for dh1).  One round trip instead of a
@@ -45,40 +46,63 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
         u_lo = g.sup[2 * b];
         u_hi = g.sup[2 * b + 1];
     }
+    // Round 6: every request below is unconditional and branch-free (indices clamped into what exists, absent gradient
+    // shares re-read the first one and are dropped by a select later): under `cond ? p[i] : 0` / `if (g.dw3) v += ...`
+    // the compiler ended each conditional load with s_waitcnt vmcnt(0) -- the six shares of dw alone were six dependent
+    // round trips, 4.3 us from entry to the first barrier (tools/att_timing.py).  The sums keep their order.
     float cpre[RPW][SEG];
     if (use_pre) {
+        const int hi_c = u_hi >= u_lo ? u_hi : u_lo;  // (empty support: u_lo = U, u_hi = -1 -> everything clamps to row U - 1 / 0)
 #pragma unroll
         for (int q = 0; q < RPW; ++q) {
-            const int u = wave + q * NWB;
+            int u = wave + q * NWB;
+            u = u < u_lo ? u_lo : u;
+            u = u > hi_c ? hi_c : u;
+            u = u > U - 1 ? U - 1 : (u < 0 ? 0 : u);  // rows outside the support re-read a row that is fetched anyway
 #pragma unroll
             for (int sg = 0; sg < SEG; ++sg) {
                 const int e = lane + 64 * sg;
-                cpre[q][sg] = (u >= u_lo && u <= u_hi && e < E) ? ctx[(size_t)u * E + e] : 0.f;
+                cpre[q][sg] = ctx[(size_t)u * E + (e < E ? e : E - 1)];  // (their sums are discarded below)
             }
         }
     }
     constexpr int WPRE = 32;
     const bool use_wpre = (H <= ATTB_THREADS) && (3 * A <= WPRE);
     float wpre[WPRE];
-
-    for (int e = t; e < E; e += ATTB_THREADS) {
-        float v = g.dw[(size_t)b * g.lddw + e];
-        if (g.dw2) {
-            v += g.dw2[(size_t)b * g.lddw + e];
-            if (g.dw3) v += g.dw3[(size_t)b * g.lddw + e];
-            if (g.dw4) v += g.dw4[(size_t)b * g.lddw + e];
-            if (g.dw5) v += g.dw5[(size_t)b * g.lddw + e];
-            if (g.dw6) v += g.dw6[(size_t)b * g.lddw + e];
-            g.dw[(size_t)b * g.lddw + e] = v;  // total, needed later for the deferred d(ctx) GEMM
+    // the carry of kappa's gradient and kappa_{t-1}: needed four phases later, requested now
+    const int ta = t < A ? t : A - 1;
+    const float pre_dkappa = g.dkappa[(size_t)b * A + ta], pre_kprev = g.kappa_prev[(size_t)b * A + ta];
+    const float pre_a = g.a[(size_t)b * A + ta], pre_b = g.b[(size_t)b * A + ta], pre_k = g.kappa[(size_t)b * A + ta];
+    {
+        const bool on2 = g.dw2 != nullptr, on3 = on2 && g.dw3, on4 = on2 && g.dw4, on5 = on2 && g.dw5, on6 = on2 && g.dw6;
+        const float* p2 = on2 ? g.dw2 : g.dw;
+        const float* p3 = on3 ? g.dw3 : g.dw;
+        const float* p4 = on4 ? g.dw4 : g.dw;
+        const float* p5 = on5 ? g.dw5 : g.dw;
+        const float* p6 = on6 ? g.dw6 : g.dw;
+        for (int e = t; e < E; e += ATTB_THREADS) {
+            const size_t i = (size_t)b * g.lddw + e;
+            const float x1 = g.dw[i], x2 = p2[i], x3 = p3[i], x4 = p4[i], x5 = p5[i], x6 = p6[i];
+            float v = x1;
+            if (on2) {
+                v += x2;
+                v += on3 ? x3 : 0.f;
+                v += on4 ? x4 : 0.f;
+                v += on5 ? x5 : 0.f;
+                v += on6 ? x6 : 0.f;
+                g.dw[i] = v;  // total, needed later for the deferred d(ctx) GEMM
+            }
+            s_dw[e] = v;
         }
-        s_dw[e] = v;
     }
     if (t < A) {
-        s_a[t] = g.a[(size_t)b * A + t];
-        s_b[t] = g.b[(size_t)b * A + t];
-        s_k[t] = g.kappa[(size_t)b * A + t];
+        s_a[t] = pre_a;
+        s_b[t] = pre_b;
+        s_k[t] = pre_k;
     }
+    ATT_STAMP(1, b, 1);  // dw total, window parameters in LDS (this wave)
     __syncthreads();
+    ATT_STAMP(1, b, 2);
 
     // dphi[u] = sum_e dw[e] ctx[u][e]: one wave per u, lanes over e (coalesced row reads).
     if (use_pre) {
@@ -113,13 +137,16 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
             if (lane == 0 && u0 + q < U) s_dphi[u0 + q] = r;
         }
     }
+    ATT_STAMP(1, b, 3);  // dphi of this wave's rows
     __syncthreads();
+    ATT_STAMP(1, b, 4);
 
     // The context registers are dead now: request this thread's column of the projection matrix (used by the
     // last phase) so that its latency hides behind the reductions below.
-    if (use_wpre && t < H) {
+    if (use_wpre) {
+        const int tc = t < H ? t : H - 1, jmax = 3 * A - 1;
 #pragma unroll
-        for (int j = 0; j < WPRE; ++j) wpre[j] = (j < 3 * A) ? g.WattT[(size_t)j * H + t] : 0.f;
+        for (int j = 0; j < WPRE; ++j) wpre[j] = g.WattT[(size_t)(j < jmax ? j : jmax) * H + tc];  // (rows >= 3A: never used)
     }
 
     // da, db, dkappa: reduce over the support of the window for every mixture j, one wave per mixture
@@ -157,6 +184,7 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
         }
     }
     __syncthreads();
+    ATT_STAMP(1, b, 5);  // mixture reductions done
 
     // chain through the window parameterisation.
     if (g.att_type == 1) {
@@ -174,8 +202,8 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
         if (g.att_type == 1) dpa = sa * (s_dp[t] - s_red[20]);
         else dpa = s_dp[t] * sa;
         dpb = s_dp[A + t] * (s_b[t] - g.eps);
-        const float dkt = s_dp[2 * A + t] + g.dkappa[(size_t)b * A + t];  // + carry from step t+1
-        dpk = dkt * (s_k[t] - g.kappa_prev[(size_t)b * A + t]);
+        const float dkt = s_dp[2 * A + t] + pre_dkappa;  // + carry from step t+1
+        dpk = dkt * (s_k[t] - pre_kprev);
         g.dkappa[(size_t)b * A + t] = dkt;  // kappa_t = kappa_{t-1} + ... : carry to step t-1
     }
     __syncthreads();
@@ -188,6 +216,7 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
         g.dp_out[(size_t)b * 3 * A + 2 * A + t] = dpk;
     }
     __syncthreads();
+    ATT_STAMP(1, b, 6);  // dp in LDS
 
     // dh1[b][k] += sum_j dp[j] Watt[k][j]
     float* dh = g.dh1 + (size_t)b * g.lddh;
@@ -205,6 +234,7 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
                 dh[t] += acc;
             }
         }
+        ATT_STAMP(1, b, 7);  // dh1 updated
         return true;
     }
     for (int k = t; k < H; k += ATTB_THREADS) {
@@ -226,6 +256,12 @@ __device__ __forceinline__ void state_bwd_row(const GruStateBwdChain& c, int m, 
 __device__ __forceinline__ void state_bwd_row(const LstmStateBwdChain& c, int m, int H, int tid, int nthr) {
     lstm_state_bwd_row(c, m, H, tid, nthr);
 }
+__device__ __forceinline__ void state_bwd_rows(const GruStateBwdChain& c, int m0, int nrows, int H, int tid, int nthr) {
+    for (; nrows > 0; m0 += 4, nrows -= 4) gru_state_bwd_rows4(c, m0, nrows < 4 ? nrows : 4, H, tid, nthr);
+}
+__device__ __forceinline__ void state_bwd_rows(const LstmStateBwdChain& c, int m0, int nrows, int H, int tid, int nthr) {
+    for (int m = m0; m < m0 + nrows; ++m) lstm_state_bwd_row(c, m, H, tid, nthr);
+}
 
 // rpb: batch rows per block of the chains that are NOT fused behind the attention (1 in the stand-alone kernel; the
 // heterogeneous backward launch packs 4 so that the upper layers' elementwise rows take 16 CUs instead of 64 and every
@@ -242,19 +278,24 @@ __device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const S
             if (l0_chain >= 0 && H <= ATTB_THREADS && 3 * g.A <= 32) {
                 const GruStateBwdChain& c = sa.chain[l0_chain];
                 const size_t i = (size_t)bx * H + t;
-                float dh = 0.f, dh2 = 0.f, hp = 0.f, z = 0.f, cc = 0.f, dhp = 0.f, mk = 1.f;
-                if (t < H) {
-                    dh = c.dh[i];  // (= g.dh1[b][t]: the attention backward's accumulation target)
-                    if (c.dh2) dh2 = c.dh2[i];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        if (c.dhx[q]) dh2 += c.dhx[q][i];  // (further shares from above: added to the same late term)
-                    hp = c.hprev[i]; z = c.z[i]; cc = c.c[i]; dhp = c.dhprev[i];
-                    if (c.mask) mk = c.mask[bx];
-                }
+                // (all requested back to back, unconditionally: a share that is absent re-reads dh and is dropped by a select)
+                const size_t ic = (size_t)bx * H + (t < H ? t : 0);
+                const float* q2 = c.dh2 ? c.dh2 : c.dh;
+                const float* q3 = c.dhx[0] ? c.dhx[0] : c.dh;
+                const float* q4 = c.dhx[1] ? c.dhx[1] : c.dh;
+                const float* q5 = c.dhx[2] ? c.dhx[2] : c.dh;
+                const float* qm = c.mask ? c.mask + bx : c.z;
+                float dh = c.dh[ic];  // (= g.dh1[b][t]: the attention backward's accumulation target)
+                const float y2 = q2[ic], y3 = q3[ic], y4 = q4[ic], y5 = q5[ic];
+                const float hp = c.hprev[ic], z = c.z[ic], cc = c.c[ic], dhp = c.dhprev[ic], mkl = *qm;
                 const bool got = att_bwd_row(g, bx, sm, &dh);
                 if (got) {
                     if (t < H) {
+                        float dh2 = c.dh2 ? y2 : 0.f;
+                        dh2 += c.dhx[0] ? y3 : 0.f;  // (further shares from above: added to the same late term)
+                        dh2 += c.dhx[1] ? y4 : 0.f;
+                        dh2 += c.dhx[2] ? y5 : 0.f;
+                        const float mk = c.mask ? mkl : 1.f;
                         dh += dh2;  // same order as gru_state_bwd_row: (dh1 + attention share) + share from above
                         float dhp_direct = 0.f;
                         if (c.mask) { dhp_direct = dh * (1.f - mk); dh *= mk; }
@@ -262,6 +303,7 @@ __device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const S
                         c.dG[(size_t)bx * 2 * H + t] = dh * (cc - hp) * z * (1.f - z);
                         c.dhprev[i] = dhp + (dh * (1.f - z) + dhp_direct);
                     }
+                    ATT_STAMP(1, bx, 8);  // layer 0's state backward stored (issued)
                     return;
                 }
                 state_bwd_row(c, bx, H, t, ATTB_THREADS);
@@ -277,6 +319,6 @@ __device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const S
     int ch = idx / bpc;
     const int m0 = (idx % bpc) * rpb;
     if (att_rows > 0 && l0_chain >= 0 && ch >= l0_chain) ++ch;  // skip the chain fused above
-    if (ch < sa.nchain)
-        for (int m = m0; m < m0 + rpb && m < sa.B; ++m) state_bwd_row(sa.chain[ch], m, sa.H, threadIdx.x, ATTB_THREADS);
+    if (ch < sa.nchain && m0 < sa.B)
+        state_bwd_rows(sa.chain[ch], m0, (m0 + rpb <= sa.B ? rpb : sa.B - m0), sa.H, threadIdx.x, ATTB_THREADS);
 }

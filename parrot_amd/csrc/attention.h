@@ -2,6 +2,19 @@
 #pragma once
 #include "common.h"
 
+// Development (-DSK_TIMERS, `python -m parrot_amd.build --timers`, tools/att_timing.py): every wave of an attention row block
+// stamps its phases (100 MHz wall clock) into att_timer_buf[dir][row][wave][16]; dir 0 = forward, 1 = backward.
+#ifdef SK_TIMERS
+static __constant__ unsigned long long* att_timer_buf = nullptr;  // one copy per translation unit (set by sk_debug_set_timers)
+#define ATT_STAMP(dir, row, i)                                                                                       \
+    do {                                                                                                             \
+        if (att_timer_buf && (threadIdx.x & 63) == 0 && (row) < 64)                                                  \
+            att_timer_buf[((((dir) * 64 + (row)) * 16) + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64();           \
+    } while (0)
+#else
+#define ATT_STAMP(dir, row, i) do { } while (0)
+#endif
+
 struct AttFwdArgs {
     const float* h1;  int ldh;     // [B,H] layer-1 state of this step
     const float* WattT;            // [3A,H] (alpha | beta | kappa rows): h1_to_att weights, transposed

@@ -21,26 +21,73 @@ struct GruStateBwdArgs {
 
 // Elementwise half of the GRU backward step for row m of one chain (h_t = z*c + (1-z)*h_prev):
 // dC = dh*z*(1-c^2), dG_z = dh*(c-h_prev)*z*(1-z), dh_prev += dh*(1-z).  Threads tid, tid+nthr, ... of the caller.
+// Every operand is requested before anything is used, unconditionally (an optional share that is absent reads the first
+// one again and is dropped by a select): written as `if (c.dh2) dh += c.dh2[i]` the compiler closed each conditional
+// load with s_waitcnt vmcnt(0), one dependent round trip per share (round 6, tools/att_timing.py).  The sums keep their order.
 __device__ __forceinline__ void gru_state_bwd_row(const GruStateBwdChain& c, int m, int H, int tid, int nthr) {
+    const bool on2 = c.dh2 != nullptr, on3 = c.dhx[0] != nullptr, on4 = c.dhx[1] != nullptr, on5 = c.dhx[2] != nullptr;
+    const float* p2 = on2 ? c.dh2 : c.dh;
+    const float* p3 = on3 ? c.dhx[0] : c.dh;
+    const float* p4 = on4 ? c.dhx[1] : c.dh;
+    const float* p5 = on5 ? c.dhx[2] : c.dh;
+    const float* pm = c.mask ? c.mask + m : c.z;  // (c.z: any live word)
     for (int k = tid; k < H; k += nthr) {
         const size_t i = (size_t)m * H + k;
-        float dh = c.dh[i];
-        if (c.dh2) dh += c.dh2[i];
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (c.dhx[q]) dh += c.dhx[q][i];
-        const float hp = c.hprev[i];
+        const float x1 = c.dh[i], x2 = p2[i], x3 = p3[i], x4 = p4[i], x5 = p5[i];
+        const float hp = c.hprev[i], z = c.z[i], cc = c.c[i], dhp = c.dhprev[i], mkv = *pm;
+        float dh = x1;
+        dh += on2 ? x2 : 0.f;
+        dh += on3 ? x3 : 0.f;
+        dh += on4 ? x4 : 0.f;
+        dh += on5 ? x5 : 0.f;
         float dhp_direct = 0.f;
         if (c.mask) {
-            const float mk = c.mask[m];
-            dhp_direct = dh * (1.f - mk);
-            dh *= mk;
+            dhp_direct = dh * (1.f - mkv);
+            dh *= mkv;
         }
-        const float z = c.z[i];
-        const float cc = c.c[i];
         c.dC[i] = dh * z * (1.f - cc * cc);
         c.dG[(size_t)m * 2 * H + k] = dh * (cc - hp) * z * (1.f - z);
-        c.dhprev[i] += dh * (1.f - z) + dhp_direct;
+        c.dhprev[i] = dhp + (dh * (1.f - z) + dhp_direct);
+    }
+}
+
+// Up to four consecutive rows m0 .. m0 + nrows - 1 of one chain: the operands of ALL rows are in flight before the first
+// row's results are stored (row after row, the stores of one row fence the loads of the next: four round trips).
+__device__ __forceinline__ void gru_state_bwd_rows4(const GruStateBwdChain& c, int m0, int nrows, int H, int tid, int nthr) {
+    const bool on2 = c.dh2 != nullptr, on3 = c.dhx[0] != nullptr, on4 = c.dhx[1] != nullptr, on5 = c.dhx[2] != nullptr;
+    const float* p2 = on2 ? c.dh2 : c.dh;
+    const float* p3 = on3 ? c.dhx[0] : c.dh;
+    const float* p4 = on4 ? c.dhx[1] : c.dh;
+    const float* p5 = on5 ? c.dhx[2] : c.dh;
+    for (int k = tid; k < H; k += nthr) {
+        float x1[4], x2[4], x3[4], x4[4], x5[4], hp[4], z[4], cc[4], dhp[4], mkv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (r < nrows ? r : 0);
+            const size_t i = (size_t)m * H + k;
+            x1[r] = c.dh[i]; x2[r] = p2[i]; x3[r] = p3[i]; x4[r] = p4[i]; x5[r] = p5[i];
+            hp[r] = c.hprev[i]; z[r] = c.z[i]; cc[r] = c.c[i]; dhp[r] = c.dhprev[i];
+            mkv[r] = c.mask ? c.mask[m] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nrows) break;
+            const int m = m0 + r;
+            const size_t i = (size_t)m * H + k;
+            float dh = x1[r];
+            dh += on2 ? x2[r] : 0.f;
+            dh += on3 ? x3[r] : 0.f;
+            dh += on4 ? x4[r] : 0.f;
+            dh += on5 ? x5[r] : 0.f;
+            float dhp_direct = 0.f;
+            if (c.mask) {
+                dhp_direct = dh * (1.f - mkv[r]);
+                dh *= mkv[r];
+            }
+            c.dC[i] = dh * z[r] * (1.f - cc[r] * cc[r]);
+            c.dG[(size_t)m * 2 * H + k] = dh * (cc[r] - hp[r]) * z[r] * (1.f - z[r]);
+            c.dhprev[i] = dhp[r] + (dh * (1.f - z[r]) + dhp_direct);
+        }
     }
 }
 

@@ -933,6 +933,15 @@ void sk_account(const SkLaunch& L, double& flops, double& bytes) {
 }
 }  // namespace
 
+#ifdef SK_TIMERS
+// Development builds only (python -m parrot_amd.build --timers): where the step kernels / attention row blocks stamp.
+extern "C" int parrot_debug_set_timers(void* sk_buf, void* att_buf) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(sk_timer_buf), &sk_buf, sizeof(sk_buf));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(att_timer_buf), &att_buf, sizeof(att_buf));
+}
+#endif
+
 void sk_profile_begin() {
     for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.recs.clear();
