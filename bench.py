@@ -88,6 +88,13 @@ def host_cores():
     return max(1, n)
 
 
+def gemm_mode_name():
+    from parrot_amd import ops as pops
+    return {pops.PRECISION_F32: "f32 (v_mfma_f32_32x32x2_f32)",
+            pops.PRECISION_BF16X3: "bf16x3 (f32 operands split into three bf16 terms in-kernel, six "
+                                   "v_mfma_f32_32x32x16_bf16 per block, f32 accumulate: f32-grade results)"}[pops.full_precision()]
+
+
 def make_batch(a, dev, seed):
     g = torch.Generator().manual_seed(seed)
     feat = torch.randn(a.T + 1, a.B, 63, generator=g).to(dev)
@@ -120,7 +127,57 @@ def kernel_source_digest(root=ROOT):
     return hd.hexdigest()
 
 
-def pmc_traffic_figure(root=ROOT, names=("r05_pmc_traffic.json", "r04_pmc_traffic.json"), key="hbm_bytes_per_launch"):
+def secondary_source_digest(root=ROOT):
+    """sha256 over the sources of the decode machine and the SampleRNN sample kernel: what profiles/rNN_pmc_secondary.json
+    is valid for."""
+    import hashlib
+    hd = hashlib.sha256()
+    for name in ("persist.hip", "persist.h", "plans_decode.hip", "sr_persist.hip", "sr_persist.h", "sr_common.h", "samplernn.hip"):
+        hd.update(open(os.path.join(root, "parrot_amd", "csrc", name), "rb").read())
+    return hd.hexdigest()
+
+
+def pmc_secondary_figure(which, root=ROOT, names=("r06_pmc_secondary.json",)):
+    """(counter bytes per step | None, note): HBM-side bytes per decode step / per SampleRNN sample step from the committed
+    counter passes (tools/pmc_secondary.py), refused when the kernels' sources changed after they were measured."""
+    for name in names:
+        path = os.path.join(root, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            blob = json.load(open(path))
+        except Exception:
+            return None, f"profiles/{name} is unreadable"
+        if blob.get("source_digest") != secondary_source_digest(root):
+            return None, f"profiles/{name} is stale: the kernel sources changed after it was measured"
+        rec = blob.get(which)
+        if not rec:
+            return None, f"profiles/{name} has no {which} record"
+        return rec["bytes_per_step"], f"profiles/{name} ({blob.get('session', '?')}; tools/pmc_secondary.py; separate --pmc passes)"
+    return None, "no committed counter passes"
+
+
+def trace_launch_figure(root=ROOT, names=("r06_bench_kernel_stats.csv",), kernels=("sk_kernel<",)):
+    """(average launch duration in us | None, note) of the plain step-GEMM launches in the committed rocprofv3 --kernel-trace
+    --stats summary of the headline command: the figure the HIP-event leg of this run should agree with."""
+    import csv
+    for name in names:
+        path = os.path.join(root, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        tot_ns, calls = 0.0, 0
+        try:
+            for r in csv.DictReader(open(path)):
+                if any(k in r["Name"] for k in kernels) and "ska_kernel" not in r["Name"] and "skb_kernel" not in r["Name"]:
+                    tot_ns += float(r["TotalDurationNs"]); calls += int(r["Calls"])
+        except Exception:
+            return None, f"profiles/{name} is unreadable"
+        if calls:
+            return round(tot_ns / calls * 1e-3, 3), f"profiles/{name} ({calls} launches in the trace)"
+    return None, "no committed kernel trace"
+
+
+def pmc_traffic_figure(root=ROOT, names=("r06_pmc_traffic.json", "r05_pmc_traffic.json"), key="hbm_bytes_per_launch"):
     """(bytes per launch | None, source note).  HBM-side bytes per step-kernel launch come from separate rocprofv3 --pmc
     passes (FETCH_SIZE / WRITE_SIZE cannot share a pass with the timed run), so the number is a committed measurement,
     not one of this run -- and it is only reported while the kernel sources it was measured on are unchanged (digest
@@ -180,7 +237,7 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
         # bf16 operands: 16 x the f32 matrix rate, half the weight bytes -- the step GEMMs (M = 64 rows per weight
         # element) are bound by how fast the weights and the f32 activations arrive, so the roof is HBM / L2 bandwidth
         gbps = by.value / us.value * 1e-3
-        traffic4, traffic4_src = pmc_traffic_figure(names=("r05_pmc_traffic_cfg4.json", "r04_pmc_traffic_cfg4.json"))
+        traffic4, traffic4_src = pmc_traffic_figure(names=("r06_pmc_traffic_cfg4.json", "r05_pmc_traffic_cfg4.json"))
         return {
             "kernel": "wk_kernel family (fused LSTM step GEMM, bf16 operands, fwd + bwd ticks as one launch each)",
             "bound": "hbm", "achieved": round(gbps, 1), "peak": 8000, "unit": "GB/s", "frac": round(gbps / 8000, 4),
@@ -199,6 +256,7 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
     else:
         us_d, fl_d, by_d, n_d = us.value, fl.value, by.value, float(n)
     ach_d = fl_d / us_d * 1e-6
+    trace_us, trace_src = trace_launch_figure()
     return {
         "kernel": "sk_kernel (fused GRU gate/candidate/backward step GEMM: the plain launches, fwd + bwd)",
         "bound": "mfma", "achieved": round(ach_d, 2), "peak": peak, "unit": "TFLOP/s",
@@ -208,6 +266,8 @@ def _roofline_leg(a, dev, flat_params, _lib, Parrot, Trainer):
                      "whose flops do not (the reading of rounds 1-3)",
         "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_step": int(n_d), "avg_launch_us": round(us_d / n_d, 3),
+        "trace_avg_launch_us": trace_us, "trace_source": trace_src,
+        "frac_trace": (round(fl_d / n_d / trace_us * 1e-6 / peak, 4) if trace_us else None),
         "alg_flops_per_launch": round(fl_d / n_d), "alg_bytes_per_launch": round(by_d / n_d),
         "alg_GBps": round(by_d / us_d * 1e-3, 1), "hbm_peak_GBps": 8000,
         "kernel_time_ms_per_step": round(us_d * 1e-3, 3),
@@ -340,10 +400,17 @@ def secondary_leg(a):
     kind = int(_plib.load().parrot_sample_is_persistent(next(iter(m._sample_ws.values()))['plan']))
     m.close()
     alg = 58.5e6
+    cb, cb_src = pmc_secondary_figure("decode_cfg3")
     out["decode_cfg3"] = {"workload": "BASELINE configs[2]: greedy decode, batch 16, 1000 frames, 2-layer GRU h=1024, feedback on",
                           "us_per_step": round(1e6 * best / S, 2), "frames_per_s": round(N * S / best, 1),
-                          "alg_bytes_per_step": int(alg), "alg_GBps": round(alg * S / best * 1e-9, 1),
-                          "frac": round(alg * S / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000,
+                          "counter_bytes_per_step": cb, "counter_source": cb_src,
+                          "frac_counter": (round(cb * S / best / 8e12, 4) if cb else None),
+                          "frac": (round(cb * S / best / 8e12, 4) if cb else None),
+                          "frac_note": "frac = frac_counter: HBM-side bytes the resident kernel actually moves per step (committed "
+                                       "counter passes) / time / 8 TB/s; frac_ref_formulation divides SURVEY 8d's 58.5 MB of the "
+                                       "reference's formulation, which the plan no longer reads (composed weights, stationary slabs)",
+                          "alg_bytes_per_step_ref_formulation": int(alg), "alg_GBps_ref_formulation": round(alg * S / best * 1e-9, 1),
+                          "frac_ref_formulation": round(alg * S / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000,
                           "plan": {3: "resident kernel, 5 phases per step (products cut along K by operand age, "
                                       "readout.output composed, the fed-back frame out of the chain: x = x_pre + h_last.A)",
                                    2: "resident kernel, 6 phases per step (products cut along K by operand age, "
@@ -370,15 +437,21 @@ def secondary_leg(a):
     gen.close()
     nsamp = (T - 1) * 80
     alg = 27.4e6
+    cb, cb_src = pmc_secondary_figure("samplernn_cfg5")
     out["samplernn_cfg5"] = {"workload": "BASELINE configs[4]: 3-tier GRU h=1024, batch 32, greedy, 2000 samples per stream",
                              "us_per_sample_step": round(1e6 * best / nsamp, 2),
                              "samples_per_s": round(B * nsamp / best, 1),
                              "x_realtime_per_stream": round(nsamp / best / 16000.0, 3),
-                             "alg_bytes_per_sample_step": int(alg), "alg_GBps": round(alg * nsamp / best * 1e-9, 1),
-                             "frac": round(alg * nsamp / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000,
-                             "note": "alg bytes = the weights one sample step of the reference's formulation touches (SURVEY 8d: three "
-                                     "sample-MLP products per sample, the tiers' share per frame / big frame); since round 5 the first product "
-                                     "is composed away (tables and frame projection through W2), so the kernel reads less than this"}
+                             "counter_bytes_per_sample_step": cb, "counter_source": cb_src,
+                             "frac_counter": (round(cb * nsamp / best / 8e12, 4) if cb else None),
+                             "frac": (round(cb * nsamp / best / 8e12, 4) if cb else None),
+                             "frac_note": "frac = frac_counter: HBM-side bytes the sample kernel moves per sample step (weights live in "
+                                          "VGPRs / LDS: polls, hand-offs and the per-frame weight prologue) / time / 8 TB/s -- a latency "
+                                          "chain, not a bandwidth figure; frac_ref_formulation divides SURVEY 8d's 27.4 MB of the reference's "
+                                          "formulation (three sample-MLP products per sample + the tiers' share), which the kernel no longer reads",
+                             "alg_bytes_per_sample_step_ref_formulation": int(alg),
+                             "alg_GBps_ref_formulation": round(alg * nsamp / best * 1e-9, 1),
+                             "frac_ref_formulation": round(alg * nsamp / best / 8e12, 4), "bound": "hbm", "peak_GBps": 8000}
     # ---- SampleRNN TRAINING (three_tier.py:534-636): one truncated-BPTT window, forward + backward of cost + ip_cost
     try:
         S = 4000
@@ -409,14 +482,17 @@ def secondary_leg(a):
                                   "ms_per_window": round(1e3 * best, 2), "samples_per_s": round(rows / best, 1),
                                   "cost_bits": round(c_, 4),
                                   "mlp_fwd_TFLOP": round(mlp * 1e-12, 3),
-                                  "alg_TFLOPs": round(3.0 * (mlp + ip) / best * 1e-12, 1),
                                   "executed_TFLOPs": round(3.0 * (mlp - 2.0 * rows * 2560 * 1024 + ip) / best * 1e-12, 1),
-                                  "note": "alg_TFLOPs = 3 x (sample-MLP + IndependentPreds forward flops of the "
-                                          "reference's formulation, three_tier.py:452-515) / time, against the f32 MFMA "
-                                          "roof (157.3); since round 5 the K = 2560 product behind the Embedding is a "
-                                          "gather-sum / segmented sum over the folded table (parrot_gather_sum_*), so "
-                                          "executed_TFLOPs counts only the products that still run",
-                                  "frac": round(3.0 * (mlp + ip) / best * 1e-12 / 157.3, 4), "bound": "mfma",
+                                  "ref_formulation_TFLOPs": round(3.0 * (mlp + ip) / best * 1e-12, 1),
+                                  "gemm_mode": gemm_mode_name(),
+                                  "note": "frac = executed_TFLOPs / 157.3 (the f32-input MFMA roof; in bf16x3 mode the products "
+                                          "run on the bf16 pipe at six MFMAs per block, so the same roof is the honest "
+                                          "f32-equivalent yardstick): 3 x the forward flops of the products that still run "
+                                          "(sample-MLP L2 / L3 / Output + IndependentPreds).  frac_ref_formulation also counts the "
+                                          "K = 2560 product behind the Embedding (three_tier.py:452-515), which since round 5 is a "
+                                          "gather-sum / segmented sum over the folded table (parrot_gather_sum_*) and no longer runs",
+                                  "frac": round(3.0 * (mlp - 2.0 * rows * 2560 * 1024 + ip) / best * 1e-12 / 157.3, 4),
+                                  "frac_ref_formulation": round(3.0 * (mlp + ip) / best * 1e-12 / 157.3, 4), "bound": "mfma",
                                   "peak_TFLOPs": 157.3}
     except Exception as e:  # a secondary figure must never take the headline line down with it
         out["samplernn_train"] = {"error": repr(e)[:300]}
@@ -614,9 +690,7 @@ def main():
     # extra timed run, outside the headline region: the batched products (readouts, deferred weight gradients) on the
     # f32-input matrix instructions instead of the split-bf16 kernel (the same f32 operands, f32-grade results either way)
     from parrot_amd import ops as pops
-    gemm_mode = {pops.PRECISION_F32: "f32 (v_mfma_f32_32x32x2_f32)",
-                 pops.PRECISION_BF16X3: "bf16x3 (f32 operands split into three bf16 terms in-kernel, six "
-                                        "v_mfma_f32_32x32x16_bf16 per block, f32 accumulate: f32-grade results)"}[pops.full_precision()]
+    gemm_mode = gemm_mode_name()
     if a.dtype == "bf16":
         gemm_mode = "bf16 operands (bf16-in kernels)"
     f32run = None

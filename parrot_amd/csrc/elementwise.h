@@ -123,22 +123,51 @@ struct LstmStateBwdArgs {
     int nchain, B, H;
 };
 
-// Row m of one chain of the LSTM state backward (same arithmetic as lstm_state_bwd_kernel).
+// Operands of column k of row m, all requested before any is used and unconditionally (a gradient share that is absent
+// re-reads dh and is dropped by a select; written as `c.dh2 ? c.dh2[idx] : 0.f` every optional share was a dependent round
+// trip of its own: round 6).  The sums keep their order.
+struct LstmSbVals { float gi, gf, go, gg, cn, cp, dc, x1, x2, x3, x4, x5, x6; };
+__device__ __forceinline__ LstmSbVals lstm_sb_load(const LstmStateBwdChain& c, int m, int H, int k) {
+    const size_t idx = (size_t)m * H + k;
+    const float* g = c.gates + (size_t)m * 4 * H;
+    const float* p2 = c.dh2 ? c.dh2 : c.dh;
+    const float* p3 = c.dh3 ? c.dh3 : c.dh;
+    const float* p4 = c.dh4 ? c.dh4 : c.dh;
+    const float* p5 = c.dh5 ? c.dh5 : c.dh;
+    const float* p6 = c.dh6 ? c.dh6 : c.dh;
+    LstmSbVals v;
+    v.gi = g[k]; v.gf = g[H + k]; v.go = g[2 * H + k]; v.gg = g[3 * H + k];
+    v.cn = c.c_new[idx]; v.cp = c.c_prev[idx]; v.dc = c.dc[idx];
+    v.x1 = c.dh[idx]; v.x2 = p2[idx]; v.x3 = p3[idx]; v.x4 = p4[idx]; v.x5 = p5[idx]; v.x6 = p6[idx];
+    return v;
+}
+// dP (i | f | o | g) and the carried dc of one column: out[0..3], returns dc_{t-1}
+__device__ __forceinline__ float lstm_sb_math(const LstmStateBwdChain& c, const LstmSbVals& v, float (&out)[4]) {
+    const float tc = tanhf(v.cn);
+    const float dhv = v.x1 + (c.dh2 ? v.x2 : 0.f) + (c.dh3 ? v.x3 : 0.f) + (c.dh4 ? v.x4 : 0.f) + (c.dh5 ? v.x5 : 0.f) +
+                      (c.dh6 ? v.x6 : 0.f);
+    const float dcv = dhv * v.go * (1.f - tc * tc) + v.dc;
+    out[0] = dcv * v.gg * v.gi * (1.f - v.gi);
+    out[1] = dcv * v.cp * v.gf * (1.f - v.gf);
+    out[2] = dhv * tc * v.go * (1.f - v.go);
+    out[3] = dcv * v.gi * (1.f - v.gg * v.gg);
+    return dcv * v.gf;
+}
+
+// Row m of one chain of the LSTM state backward (same arithmetic as lstm_state_bwd_kernel); two columns per thread in flight.
 __device__ __forceinline__ void lstm_state_bwd_row(const LstmStateBwdChain& c, int m, int H, int tid, int nthr) {
-    for (int k = tid; k < H; k += nthr) {
-        const size_t idx = (size_t)m * H + k;
-        const float* g = c.gates + (size_t)m * 4 * H;
-        const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
-        const float tc = tanhf(c.c_new[idx]);
-        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f) + (c.dh3 ? c.dh3[idx] : 0.f) + (c.dh4 ? c.dh4[idx] : 0.f) +
-                          (c.dh5 ? c.dh5[idx] : 0.f) + (c.dh6 ? c.dh6[idx] : 0.f);
-        const float dcv = dhv * go * (1.f - tc * tc) + c.dc[idx];
-        float* o = c.dP + (size_t)m * 4 * H;
-        o[k] = dcv * gg * gi * (1.f - gi);
-        o[H + k] = dcv * c.c_prev[idx] * gf * (1.f - gf);
-        o[2 * H + k] = dhv * tc * go * (1.f - go);
-        o[3 * H + k] = dcv * gi * (1.f - gg * gg);
-        c.dc[idx] = dcv * gf;
+    float* o = c.dP + (size_t)m * 4 * H;
+    for (int k = tid; k < H; k += 2 * nthr) {
+        const int k2 = k + nthr < H ? k + nthr : k;
+        const LstmSbVals va = lstm_sb_load(c, m, H, k), vb = lstm_sb_load(c, m, H, k2);
+        float ra[4], rb[4];
+        const float da = lstm_sb_math(c, va, ra), db = lstm_sb_math(c, vb, rb);
+        o[k] = ra[0]; o[H + k] = ra[1]; o[2 * H + k] = ra[2]; o[3 * H + k] = ra[3];
+        c.dc[(size_t)m * H + k] = da;
+        if (k2 != k) {
+            o[k2] = rb[0]; o[H + k2] = rb[1]; o[2 * H + k2] = rb[2]; o[3 * H + k2] = rb[3];
+            c.dc[(size_t)m * H + k2] = db;
+        }
     }
 }
 
@@ -146,19 +175,17 @@ __device__ __forceinline__ void lstm_state_bwd_row(const LstmStateBwdChain& c, i
 // the dP row is staged in LDS (`row`, 4H floats) and leaves as 16-byte write-through stores (a 4-byte sc1 store is one
 // fabric write each); the caller drains them (s_waitcnt vmcnt(0) + barrier) before it arrives on the chain's flag.
 __device__ __forceinline__ void lstm_state_bwd_row_pub(const LstmStateBwdChain& c, int m, int H, int tid, int nthr, float* row) {
-    for (int k = tid; k < H; k += nthr) {
-        const size_t idx = (size_t)m * H + k;
-        const float* g = c.gates + (size_t)m * 4 * H;
-        const float gi = g[k], gf = g[H + k], go = g[2 * H + k], gg = g[3 * H + k];
-        const float tc = tanhf(c.c_new[idx]);
-        const float dhv = c.dh[idx] + (c.dh2 ? c.dh2[idx] : 0.f) + (c.dh3 ? c.dh3[idx] : 0.f) + (c.dh4 ? c.dh4[idx] : 0.f) +
-                          (c.dh5 ? c.dh5[idx] : 0.f) + (c.dh6 ? c.dh6[idx] : 0.f);
-        const float dcv = dhv * go * (1.f - tc * tc) + c.dc[idx];
-        row[k] = dcv * gg * gi * (1.f - gi);
-        row[H + k] = dcv * c.c_prev[idx] * gf * (1.f - gf);
-        row[2 * H + k] = dhv * tc * go * (1.f - go);
-        row[3 * H + k] = dcv * gi * (1.f - gg * gg);
-        c.dc[idx] = dcv * gf;
+    for (int k = tid; k < H; k += 2 * nthr) {
+        const int k2 = k + nthr < H ? k + nthr : k;
+        const LstmSbVals va = lstm_sb_load(c, m, H, k), vb = lstm_sb_load(c, m, H, k2);
+        float ra[4], rb[4];
+        const float da = lstm_sb_math(c, va, ra), db = lstm_sb_math(c, vb, rb);
+        row[k] = ra[0]; row[H + k] = ra[1]; row[2 * H + k] = ra[2]; row[3 * H + k] = ra[3];
+        c.dc[(size_t)m * H + k] = da;
+        if (k2 != k) {
+            row[k2] = rb[0]; row[H + k2] = rb[1]; row[2 * H + k2] = rb[2]; row[3 * H + k2] = rb[3];
+            c.dc[(size_t)m * H + k2] = db;
+        }
     }
     __syncthreads();
     float* o = c.dP + (size_t)m * 4 * H;

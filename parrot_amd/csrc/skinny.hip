@@ -1193,30 +1193,55 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
     const int g = lane >> 4, jj = lane & 15;
     const int n = sk_jcol(job, tile, jj);
     const bool n_ok = n < N;
-    const float bias = (job.bias && n_ok) ? job.bias[n] : 0.f;
+    // Round 6: every epilogue operand of the wave (additive input, previous cell, the sums a split part adds to) is requested
+    // up front, unconditionally, before the first is used: read where needed -- `if (job.add && ok) pre += job.add[..]`, then
+    // `cp = job.e1[..]` behind the gate shuffles, `x += *o` -- each conditional load ended in s_waitcnt vmcnt(0): up to two
+    // dependent round trips per accumulator row, sixteen rows per lane.
+    const bool lstm = job.epi == SK_EPI_LSTM;
+    const bool has_add = job.add != nullptr && (lstm || !kpart);
+    const bool acc_on = !lstm && (kpart == 0 ? job.accumulate != 0 : (kpart == 1 && job.ldo2 != 0));
+    const int nc = min(n, N - 1);
+    const float* q_add = has_add ? job.add : kbase;
+    const int l_add = has_add ? job.ld_add : kld;
+    const float* q_e1 = lstm ? job.e1 : kbase;
+    const int l_e1 = lstm ? job.lde1 : kld;
+    const int c_e1 = lstm ? ((jj >> 2) == 0 ? nc : 0) : nc;
+    const float* q_b = job.bias ? job.bias : kbase;
+    const float bias_raw = q_b[job.bias ? nc : 0];
+    float v_add[MB][4], v_e1[MB][4], v_old[MB][4];
+#pragma unroll
+    for (int rb = 0; rb < MB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mc = min(16 * (rh * MB + rb) + 4 * g + r, M - 1);
+            v_add[rb][r] = q_add[sk_off(mc, l_add, nc)];
+            v_e1[rb][r] = q_e1[sk_off(mc, l_e1, c_e1)];
+            v_old[rb][r] = kbase[sk_off(mc, kld, nc)];
+        }
+    const float bias = (job.bias && n_ok) ? bias_raw : 0.f;
 #pragma unroll
     for (int rb = 0; rb < MB; ++rb) {
         const int mb0 = 16 * (rh * MB + rb) + 4 * g;
-        if (job.epi == SK_EPI_LSTM) {
+        if (lstm) {
             const int q = jj >> 2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mb0 + r;
                 const bool ok = m < M && n_ok;
                 float pre = acc[rb][r] + bias;
-                if (job.add && ok) pre += job.add[(size_t)m * job.ld_add + n];
+                if (has_add && ok) pre += v_add[rb][r];
                 const float gate = (q == 3) ? tanhf(pre) : ph_sigmoid(pre);
-                if (job.o2 && ok) job.o2[(size_t)m * job.ldo2 + n] = gate;
+                if (job.o2 && ok) job.o2[sk_off(m, job.ldo2, n)] = gate;
                 const int src = lane & ~12;
                 const float gi = __shfl(gate, src | 0, 64);
                 const float gf = __shfl(gate, src | 4, 64);
                 const float go = __shfl(gate, src | 8, 64);
                 const float gg = __shfl(gate, src | 12, 64);
                 if (q == 0 && ok) {
-                    const float cp = job.e1[(size_t)m * job.lde1 + n];
+                    const float cp = v_e1[rb][r];
                     const float cn = cp * gf + gg * gi;
-                    job.o1[(size_t)m * job.ldo1 + n] = cn;
-                    job.out[(size_t)m * job.ldo + n] = tanhf(cn) * go;
+                    job.o1[sk_off(m, job.ldo1, n)] = cn;
+                    job.out[sk_off(m, job.ldo, n)] = tanhf(cn) * go;
                 }
             }
         } else {
@@ -1225,13 +1250,13 @@ __device__ __forceinline__ void wk_body(const SkJob& job, int wg_in, int wgh, ch
                 const int m = mb0 + r;
                 if (m >= M || !n_ok) continue;
                 float x = acc[rb][r] + (kpart ? 0.f : bias);
-                if (job.add && !kpart) x += job.add[(size_t)m * job.ld_add + n];
+                if (has_add) x += v_add[rb][r];
                 if (job.act == SK_ACT_RELU) x = fmaxf(x, 0.f);
                 else if (job.act == SK_ACT_TANH) x = tanhf(x);
                 else if (job.act == SK_ACT_SIGMOID) x = ph_sigmoid(x);
-                float* o = kbase + (size_t)m * kld + n;
+                float* o = kbase + sk_off(m, kld, n);
                 // part 0 follows `accumulate`, part 1 the flag in ldo2 (split LINEAR jobs), parts 2 and 3 are stored
-                if (kpart == 0 ? job.accumulate != 0 : (kpart == 1 && job.ldo2 != 0)) x += *o;
+                if (acc_on) x += v_old[rb][r];
                 *o = x;
             }
         }

