@@ -317,6 +317,10 @@ int parrot_decoder_is_persistent(void* plan);
  * not cover): 0 merged wavefront, 2 / 3 chunked pipelines, 5 balanced wavefront (attention beside the upper layers'
  * input projections), 6 two launches per tick (attention inside the gate launch). */
 int parrot_decoder_schedule(void* plan);
+/* Which backward tick the plan runs: 8 = the K-balanced tick with the downward products of the upper layers inside the
+ * attention launch (GRU stacks of 2 or 3 layers, f32: reference depth model.py:312-347), 7 = the fused LSTM tick of
+ * bf16-operand decoders, 0 = three launches per tick (attention + state backward, X, Y). */
+int parrot_decoder_backward_tick(void* plan);
 /* Schedule tracing (test infrastructure of the library itself; runs without a GPU): instead of launching, the plan
  * records for every launch of direction `which` (0 forward, 1 backward) and every job in it the byte ranges of the
  * descriptor's buffers the job reads / writes.  Records are 5 x int64: launch index, job id (0..8 step-GEMM jobs, 100 the

@@ -165,6 +165,7 @@ SIGNATURES = {
     "parrot_decoder_persist_floats": (C.c_longlong, [C.POINTER(DecoderDesc)]),
     "parrot_decoder_is_persistent": (_i, [_vp]),
     "parrot_decoder_schedule": (_i, [_vp]),
+    "parrot_decoder_backward_tick": (_i, [_vp]),
     "parrot_decoder_writes_bf16_grads": (_i, [_vp]),
     "parrot_decoder_trace": (C.c_longlong, [_vp, _i, C.POINTER(C.c_longlong), C.c_longlong]),
     "parrot_decoder_trace_jobs": (C.c_longlong, [_vp, _i, C.POINTER(C.c_longlong), C.c_longlong]),

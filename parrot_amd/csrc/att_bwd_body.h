@@ -18,7 +18,12 @@ static inline size_t att_bwd_lds(int U, int E) {
 // Backward of one step for batch row b (one workgroup per row).
 // dh_io (optional, used when every thread owns one column of dh1, H <= ATTB_THREADS): on entry the caller's prefetched
 // dh1[b][t], on exit the updated value; returns whether that path was taken (else dh1 was updated in memory only).
-__device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* sm, float* dh_io = nullptr) {
+struct AttBwdNoLate { __device__ __forceinline__ void operator()() const {} };
+// late(): called once the context registers are dead (after the dphi phase): the caller requests what it needs behind the
+// attention backward there (layer 0's state-backward operands), where 64 VGPRs have just been freed -- requested at entry
+// they pushed the 1024-thread block over its 128 registers (84 bytes of scratch per lane).
+template <class LATE = AttBwdNoLate>
+__device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* sm, float* dh_io = nullptr, LATE late = LATE()) {
     const int A = g.A, U = g.U, E = g.E, H = g.H;
     float* s_a = sm;                  // [A]
     float* s_b = s_a + ATT_MAXA;
@@ -143,6 +148,7 @@ __device__ __forceinline__ bool att_bwd_row(const AttBwdArgs& g, int b, float* s
 
     // The context registers are dead now: request this thread's column of the projection matrix (used by the
     // last phase) so that its latency hides behind the reductions below.
+    late();
     if (use_wpre) {
         const int tc = t < H ? t : H - 1, jmax = 3 * A - 1;
 #pragma unroll
@@ -278,17 +284,22 @@ __device__ __forceinline__ void att_state_bwd_block(const AttBwdArgs& g, const S
             if (l0_chain >= 0 && H <= ATTB_THREADS && 3 * g.A <= 32) {
                 const GruStateBwdChain& c = sa.chain[l0_chain];
                 const size_t i = (size_t)bx * H + t;
-                // (all requested back to back, unconditionally: a share that is absent re-reads dh and is dropped by a select)
+                // (all requested back to back, unconditionally: a share that is absent re-reads dh and is dropped by a select;
+                // integer address selects: see gru_state_bwd_row)
                 const size_t ic = (size_t)bx * H + (t < H ? t : 0);
-                const float* q2 = c.dh2 ? c.dh2 : c.dh;
-                const float* q3 = c.dhx[0] ? c.dhx[0] : c.dh;
-                const float* q4 = c.dhx[1] ? c.dhx[1] : c.dh;
-                const float* q5 = c.dhx[2] ? c.dhx[2] : c.dh;
-                const float* qm = c.mask ? c.mask + bx : c.z;
-                float dh = c.dh[ic];  // (= g.dh1[b][t]: the attention backward's accumulation target)
-                const float y2 = q2[ic], y3 = q3[ic], y4 = q4[ic], y5 = q5[ic];
-                const float hp = c.hprev[ic], z = c.z[ic], cc = c.c[ic], dhp = c.dhprev[ic], mkl = *qm;
-                const bool got = att_bwd_row(g, bx, sm, &dh);
+                const unsigned long long a1 = (unsigned long long)c.dh, a2 = (unsigned long long)c.dh2, a3 = (unsigned long long)c.dhx[0],
+                                         a4 = (unsigned long long)c.dhx[1], a5 = (unsigned long long)c.dhx[2], am = (unsigned long long)c.mask;
+                const float* q2 = reinterpret_cast<const float*>(a2 ? a2 : a1);
+                const float* q3 = reinterpret_cast<const float*>(a3 ? a3 : a1);
+                const float* q4 = reinterpret_cast<const float*>(a4 ? a4 : a1);
+                const float* q5 = reinterpret_cast<const float*>(a5 ? a5 : a1);
+                const float* qm = reinterpret_cast<const float*>(am ? am + 4ull * (unsigned)bx : (unsigned long long)c.z);
+                float dh = 0.f, y2 = 0.f, y3 = 0.f, y4 = 0.f, y5 = 0.f, hp = 0.f, z = 0.f, cc = 0.f, dhp = 0.f, mkl = 1.f;
+                const bool got = att_bwd_row(g, bx, sm, &dh, [&]() {
+                    dh = c.dh[ic];  // (= g.dh1[b][t]: the attention backward's accumulation target)
+                    y2 = q2[ic]; y3 = q3[ic]; y4 = q4[ic]; y5 = q5[ic];
+                    hp = c.hprev[ic]; z = c.z[ic]; cc = c.c[ic]; dhp = c.dhprev[ic]; mkl = *qm;
+                });
                 if (got) {
                     if (t < H) {
                         float dh2 = c.dh2 ? y2 : 0.f;

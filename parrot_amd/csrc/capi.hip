@@ -108,7 +108,9 @@ static int bg_run(BgArgs a, int split_k, hipStream_t st) {
                     if (score > best) { best = score; split = sp; }
                 }
             }
-        } else if (a.bf16 == 2 && K >= 512) {
+        } else if (a.bf16 == 2 && K >= 512 && tiles < 256) {
+            // (tiles >= 256: the output tiles fill the chip by themselves -- the M = T*B readout products -- and a split
+            // would only add a partial-sum pass larger than the operands: ADVICE r05)
             // 256 x 256 tiles, one workgroup per CU: the slice count whose workgroups fill whole rounds of 256 best
             // (at least two rounds, at most 16 slices, at least 1024 K rows per slice)
             double best = -1.0;

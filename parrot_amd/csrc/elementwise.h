@@ -25,12 +25,17 @@ struct GruStateBwdArgs {
 // one again and is dropped by a select): written as `if (c.dh2) dh += c.dh2[i]` the compiler closed each conditional
 // load with s_waitcnt vmcnt(0), one dependent round trip per share (round 6, tools/att_timing.py).  The sums keep their order.
 __device__ __forceinline__ void gru_state_bwd_row(const GruStateBwdChain& c, int m, int H, int tid, int nthr) {
-    const bool on2 = c.dh2 != nullptr, on3 = c.dhx[0] != nullptr, on4 = c.dhx[1] != nullptr, on5 = c.dhx[2] != nullptr;
-    const float* p2 = on2 ? c.dh2 : c.dh;
-    const float* p3 = on3 ? c.dhx[0] : c.dh;
-    const float* p4 = on4 ? c.dhx[1] : c.dh;
-    const float* p5 = on5 ? c.dhx[2] : c.dh;
-    const float* pm = c.mask ? c.mask + m : c.z;  // (c.z: any live word)
+    // (addresses picked as INTEGERS: a select of pointers loaded from a dynamically indexed kernel-argument struct makes the
+    // compiler copy the struct to scratch -- the wk_body lesson of round 4, tests/test_build_cpu.py)
+    const unsigned long long a1 = (unsigned long long)c.dh, a2 = (unsigned long long)c.dh2, a3 = (unsigned long long)c.dhx[0],
+                             a4 = (unsigned long long)c.dhx[1], a5 = (unsigned long long)c.dhx[2];
+    const bool on2 = a2 != 0, on3 = a3 != 0, on4 = a4 != 0, on5 = a5 != 0;
+    const float* p2 = reinterpret_cast<const float*>(on2 ? a2 : a1);
+    const float* p3 = reinterpret_cast<const float*>(on3 ? a3 : a1);
+    const float* p4 = reinterpret_cast<const float*>(on4 ? a4 : a1);
+    const float* p5 = reinterpret_cast<const float*>(on5 ? a5 : a1);
+    const unsigned long long am = (unsigned long long)c.mask;
+    const float* pm = reinterpret_cast<const float*>(am ? am + 4ull * (unsigned)m : (unsigned long long)c.z);  // (c.z: any live word)
     for (int k = tid; k < H; k += nthr) {
         const size_t i = (size_t)m * H + k;
         const float x1 = c.dh[i], x2 = p2[i], x3 = p3[i], x4 = p4[i], x5 = p5[i];
@@ -54,17 +59,21 @@ __device__ __forceinline__ void gru_state_bwd_row(const GruStateBwdChain& c, int
 // Up to four consecutive rows m0 .. m0 + nrows - 1 of one chain: the operands of ALL rows are in flight before the first
 // row's results are stored (row after row, the stores of one row fence the loads of the next: four round trips).
 __device__ __forceinline__ void gru_state_bwd_rows4(const GruStateBwdChain& c, int m0, int nrows, int H, int tid, int nthr) {
-    const bool on2 = c.dh2 != nullptr, on3 = c.dhx[0] != nullptr, on4 = c.dhx[1] != nullptr, on5 = c.dhx[2] != nullptr;
-    const float* p2 = on2 ? c.dh2 : c.dh;
-    const float* p3 = on3 ? c.dhx[0] : c.dh;
-    const float* p4 = on4 ? c.dhx[1] : c.dh;
-    const float* p5 = on5 ? c.dhx[2] : c.dh;
+    // (addresses picked as INTEGERS: a select of pointers loaded from a dynamically indexed kernel-argument struct makes the
+    // compiler copy the struct to scratch -- the wk_body lesson of round 4, tests/test_build_cpu.py)
+    const unsigned long long a1 = (unsigned long long)c.dh, a2 = (unsigned long long)c.dh2, a3 = (unsigned long long)c.dhx[0],
+                             a4 = (unsigned long long)c.dhx[1], a5 = (unsigned long long)c.dhx[2];
+    const bool on2 = a2 != 0, on3 = a3 != 0, on4 = a4 != 0, on5 = a5 != 0;
+    const float* p2 = reinterpret_cast<const float*>(on2 ? a2 : a1);
+    const float* p3 = reinterpret_cast<const float*>(on3 ? a3 : a1);
+    const float* p4 = reinterpret_cast<const float*>(on4 ? a4 : a1);
+    const float* p5 = reinterpret_cast<const float*>(on5 ? a5 : a1);
     for (int k = tid; k < H; k += nthr) {
         float x1[4], x2[4], x3[4], x4[4], x5[4], hp[4], z[4], cc[4], dhp[4], mkv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + (r < nrows ? r : 0);
-            const size_t i = (size_t)m * H + k;
+            const unsigned i = (unsigned)m * (unsigned)H + (unsigned)k;  // (32-bit offsets from uniform bases: no 64-bit VGPR addresses)
             x1[r] = c.dh[i]; x2[r] = p2[i]; x3[r] = p3[i]; x4[r] = p4[i]; x5[r] = p5[i];
             hp[r] = c.hprev[i]; z[r] = c.z[i]; cc[r] = c.c[i]; dhp[r] = c.dhprev[i];
             mkv[r] = c.mask ? c.mask[m] : 1.f;
@@ -73,7 +82,7 @@ __device__ __forceinline__ void gru_state_bwd_rows4(const GruStateBwdChain& c, i
         for (int r = 0; r < 4; ++r) {
             if (r >= nrows) break;
             const int m = m0 + r;
-            const size_t i = (size_t)m * H + k;
+            const unsigned i = (unsigned)m * (unsigned)H + (unsigned)k;
             float dh = x1[r];
             dh += on2 ? x2[r] : 0.f;
             dh += on3 ? x3[r] : 0.f;
@@ -85,7 +94,7 @@ __device__ __forceinline__ void gru_state_bwd_rows4(const GruStateBwdChain& c, i
                 dh *= mkv[r];
             }
             c.dC[i] = dh * z[r] * (1.f - cc[r] * cc[r]);
-            c.dG[(size_t)m * 2 * H + k] = dh * (cc[r] - hp[r]) * z[r] * (1.f - z[r]);
+            c.dG[2u * (unsigned)m * (unsigned)H + (unsigned)k] = dh * (cc[r] - hp[r]) * z[r] * (1.f - z[r]);
             c.dhprev[i] = dhp[r] + (dh * (1.f - z[r]) + dhp_direct);
         }
     }

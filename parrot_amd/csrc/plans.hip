@@ -878,6 +878,12 @@ struct DecoderPlan : PlanBase {
                     for (int q2 = 0; q2 < nl; ++q2) { jl[q2].wait_flag = nullptr; jl[q2].wait_target = 0; jl[q2].wait_all = 0; }
                 }
                 if (la.nchain > 0) PL_TRY(traced_att_state_bwd_launch(att_on ? &g : nullptr, la, l0c, st));
+                // Only the fused tick's row blocks write the bf16 copies of the pre-activation gradients (dG16): on this
+                // fall-back path they are made here, so that parrot_decoder_writes_bf16_grads() stays true for every tick
+                // (the weight-gradient products would otherwise read rows nobody wrote).
+                for (int c2 = 0; c2 < la.nchain; ++c2)
+                    if (la.chain[c2].dP16)
+                        PL_TRY(bg_to_bf16_launch(la.chain[c2].dP, la.chain[c2].dP16, (long long)d.B * 4 * H, st));
                 if (nl > 0) PL_TRY(launch_jobs(jl, nl, st, full_wgs, 0, bwd_ksplit ? 1 : 0));
                 continue;
             }
@@ -1035,7 +1041,13 @@ struct DecoderPlan : PlanBase {
                 c.dG = d.dG[l] + t * 2 * BH;
                 c.dhprev = d.dh[l] + t * BH;
             }
-            SkJob js[SK_MAXJOB], jx[SK_MAXJOB], jy[SK_MAXJOB];
+            // (round 6, L = 3: a tick has 10 / 6 / 11 jobs for S' / X / Y and a launch carries SK_MAXJOB = 9 -- its
+            // descriptors travel by value in the 4 KB kernel-argument block --, so the lists are built generously and
+            // the overflow is moved: S' -> Y (everything S' multiplies is a tick old), Y -> X for the jobs that do not
+            // read what X writes: the dC products and the update-gate halves, `ymov`.)
+            constexpr int JCAP = 2 * SK_MAXJOB;
+            SkJob js[JCAP], jx[JCAP], jy[JCAP];
+            bool ymov[JCAP];
             int ns = 0, nx = 0, ny = 0;
             for (int l = d.L - 1; l >= 1; --l) {  // the dG halves of the step layer l handled one tick ago
                 const int s = tl[l] + 1;
@@ -1065,17 +1077,26 @@ struct DecoderPlan : PlanBase {
                 x.out = d.dG[l] + t * 2 * BH + H; x.ldo = 2 * H;
                 x.o1 = d.dh[l] + t * BH; x.ldo1 = H;
                 lin_job(jx[nx++], rseg_k(dG, l, 0, 0, 2 * H, 0, H), d.B, H, H, d.dh_b[l] + t * BH, H, 0);
-                lin_job(jy[ny++], rseg_k(dG, l, 0, 0, 2 * H, H, H), d.B, H, H, d.dh[l] + t * BH, H, 1);
+                ymov[ny] = false; lin_job(jy[ny++], rseg_k(dG, l, 0, 0, 2 * H, H, H), d.B, H, H, d.dh[l] + t * BH, H, 1);
                 if (l == 0) {
-                    lin_job(jy[ny++], rseg(dC, 0, 1, H, H), d.B, E, H, d.dw0 + (size_t)t * BE, E, 1);
-                    lin_job(jy[ny++], rseg_k(dG, 0, 0, H, 2 * H, 0, H), d.B, E, H, d.dw0_b + (size_t)t * BE, E, 0);
-                    lin_job(jy[ny++], rseg_k(dG, 0, 0, H, 2 * H, H, H), d.B, E, H, d.dw0_c + (size_t)t * BE, E, 0);
+                    ymov[ny] = true;  lin_job(jy[ny++], rseg(dC, 0, 1, H, H), d.B, E, H, d.dw0 + (size_t)t * BE, E, 1);
+                    ymov[ny] = true;  lin_job(jy[ny++], rseg_k(dG, 0, 0, H, 2 * H, 0, H), d.B, E, H, d.dw0_b + (size_t)t * BE, E, 0);
+                    ymov[ny] = false; lin_job(jy[ny++], rseg_k(dG, 0, 0, H, 2 * H, H, H), d.B, E, H, d.dw0_c + (size_t)t * BE, E, 0);
                 } else {
-                    lin_job(jy[ny++], rseg(dC, l, 1, H, H), d.B, E, H, d.dw + (size_t)(t + 1) * BE, E, 1);
-                    for (int p = 0; p < l; ++p)
+                    ymov[ny] = true;  lin_job(jy[ny++], rseg(dC, l, 1, H, H), d.B, E, H, d.dw + (size_t)(t + 1) * BE, E, 1);
+                    for (int p = 0; p < l; ++p) {
+                        ymov[ny] = true;
                         lin_job(jy[ny++], rseg(dC, l, 1, H + E + p * H, H), d.B, H, H, d.dhup[p] + (t + 1) * BH, H, 1);
+                    }
                 }
             }
+            while (ns > SK_MAXJOB) { ymov[ny] = true; jy[ny++] = js[--ns]; }  // (a tick old: movable further, too)
+            for (int i = ny - 1; i >= 0 && ny > SK_MAXJOB && nx < SK_MAXJOB; --i)
+                if (ymov[i]) {
+                    jx[nx++] = jy[i];
+                    for (int k2 = i; k2 + 1 < ny; ++k2) { jy[k2] = jy[k2 + 1]; ymov[k2] = ymov[k2 + 1]; }
+                    --ny;
+                }
             if (ns > SK_MAXJOB || nx > SK_MAXJOB || ny > SK_MAXJOB) return PARROT_ERR_BADARG;
             if (ga.nchain > 0) {
                 const int l0c = att_on ? ga.nchain - 1 : -1;
@@ -1450,11 +1471,10 @@ int parrot_decoder_create(const ParrotDecoderDesc* desc, void** plan) { PH_ENTRY
     if (p->try_persist) p->build_persist();  // persist_ok stays false when the shape / workspace does not qualify
     {   // the K-balanced backward tick (bwd8): 2-layer f32 GRU decoders with fragment-major weights and all accumulators
         const char* e = getenv("PARROT_BWD_HETERO");
-        bool ok = desc->cell == 0 && desc->L == 2 && !desc->bf16 && !desc->layer_norm && p->tiled && desc->B <= 64 &&
-                  desc->dw_b && desc->dw_c && desc->dw0_b && desc->dw0_c &&
-                  desc->dhup_b[0] && desc->dhup_c[0] && (e ? atoi(e) != 0 : true);
+        bool ok = desc->cell == 0 && (desc->L == 2 || desc->L == 3) && !desc->bf16 && !desc->layer_norm && p->tiled && desc->B <= 64 &&
+                  desc->dw_b && desc->dw_c && desc->dw0_b && desc->dw0_c && (e ? atoi(e) != 0 : true);
         for (int l = 0; l < desc->L; ++l)
-            if (!desc->dh_b[l]) ok = false;
+            if (!desc->dh_b[l] || (l + 1 < desc->L && (!desc->dhup_b[l] || !desc->dhup_c[l]))) ok = false;
         p->bwd_hetero = ok;
     }
     if (desc->layer_norm && desc->L >= 2) {
@@ -1481,6 +1501,7 @@ int parrot_decoder_status(void* plan) { PH_ENTRY(); return plan ? static_cast<De
 
 int parrot_decoder_is_persistent(void* plan) { return static_cast<DecoderPlan*>(plan)->persist_ok ? 1 : 0; }
 int parrot_decoder_schedule(void* plan) { return plan ? static_cast<DecoderPlan*>(plan)->schedule : -1; }
+int parrot_decoder_backward_tick(void* plan) { return plan ? (static_cast<DecoderPlan*>(plan)->bwd_hetero ? 8 : (static_cast<DecoderPlan*>(plan)->bwd_fused ? 7 : 0)) : -1; }
 int parrot_decoder_writes_bf16_grads(void* plan) {
     const DecoderPlan* p = static_cast<const DecoderPlan*>(plan);
     if (!p || !p->bwd_fused) return 0;

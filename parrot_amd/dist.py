@@ -120,6 +120,7 @@ class GradientExchange:
                 early = (lo, hi)
         self.early = early
         self._pending = []   # (work, wire tensor or None, destination view)
+        self._ready = []     # [lo, hi) ranges handed over this step
         self._early_done = False
 
     def _issue(self, view, async_op):
@@ -137,29 +138,50 @@ class GradientExchange:
         else:
             view.copy_(t)
 
+    def mark_ready(self, lo, hi):
+        """flat[lo:hi] is final for this step: its all-reduce is issued now, asynchronously (round 6: the deferred weight-
+        gradient products report their outputs one by one, so each bucket travels beside the products that follow it and
+        only the last one's bytes are exposed).  Ranges must not overlap within a step; a no-op outside a process group.
+
+        Contract: ONE backward pass per `finish()`.  A slice that has been handed over is being summed in place -- writing
+        to it again before `finish()` (a second backward under gradient accumulation, a parameter that receives a later
+        contribution) is lost or double-counted; an overlapping range raises."""
+        if not is_distributed():
+            return
+        lo, hi = int(lo), int(hi)
+        if not (0 <= lo < hi <= self.flat.numel()):
+            raise ValueError(f"mark_ready: [{lo}, {hi}) outside the buffer")
+        for a, b in self._ready:
+            if lo < b and a < hi:
+                raise RuntimeError(f"mark_ready: [{lo}, {hi}) overlaps [{a}, {b}), already handed over this step")
+        self._ready.append((lo, hi))
+        self._issue(self.flat[lo:hi], async_op=True)
+
     def start_early(self):
-        """Call when flat[lo:hi] is final for this step (at most once per step; a no-op outside a process group)."""
+        """Call when flat[early] is final for this step (at most once per step; a no-op outside a process group)."""
         if not is_distributed() or self.early is None or self._early_done:
             return
         self._early_done = True
-        self._issue(self.flat[self.early[0]:self.early[1]], async_op=True)
+        self.mark_ready(*self.early)
 
     def finish(self):
-        """Reduces whatever `start_early` did not take and waits for everything; the buffer then holds the global sum."""
+        """Reduces whatever was not handed over by `mark_ready` / `start_early` (the gaps between the ready ranges, in
+        address order) and waits for everything; the buffer then holds the global sum."""
         if not is_distributed():
             self._early_done = False
+            self._ready = []
             return
-        if self._early_done:
-            lo, hi = self.early
-            self._issue(self.flat[:lo], async_op=False)
-            self._issue(self.flat[hi:], async_op=False)
-        else:
-            self._issue(self.flat, async_op=False)
+        pos = 0
+        for a, b in sorted(self._ready):
+            self._issue(self.flat[pos:a], async_op=False)
+            pos = b
+        self._issue(self.flat[pos:], async_op=False)
         for w, t, view in self._pending:
             w.wait()
             if t is not None:
                 view.copy_(t)
         self._pending = []
+        self._ready = []
         self._early_done = False
 
 

@@ -538,7 +538,7 @@ class Parrot(Brick):
             # layers >= 2 always get the buffer: the plan batches the lower layers' projections into it
             ws['seq_' + key] = [torch.zeros(T, B, wd, **f) if (l in self._fb_layers or self.use_speaker or l >= 2)
                                 else None for l in range(1, L + 1)]
-        if (not lstm and L == 2 and not self.compute_bf16 and not self.layer_norm and B <= 64 and H % 16 == 0 and E % 16 == 0
+        if (not lstm and L in (2, 3) and not self.compute_bf16 and not self.layer_norm and B <= 64 and H % 16 == 0 and E % 16 == 0
                 and os.environ.get('PARROT_BWD_HETERO', '1') != '0'):
             # second / third accumulators of the K-balanced backward tick (ParrotDecoderDesc::dh_b ... dw0_c, plans.hip bwd8)
             ws.update(dh_b=[torch.zeros(T + 1, B, H, **f) for _ in range(L)],
@@ -1057,6 +1057,8 @@ class Parrot(Brick):
                     if self.layer_norm:  # seq_bwd left the gradient wrt the pre-norm projection in ln_y
                         dPj = ws['ln_y' + key][(l, j)][t0:t1].view(R, wd)
                     ops.gemm(ws['h'][j][t0 + 1:t1 + 1].view(R, H).t(), dPj, out=gW[r0:r0 + H], accumulate=True)
+                if t0 == 0 and t1 == T:
+                    self._gradient_ready(f'{mat}{ll}')  # data-parallel: this matrix's all-reduce starts beside the next products
         # (Measured in round 4: all of these as ONE grouped grid -- 74.47 vs 74.43 ms per cfg2 step, no gain: the
         # products are long enough that the chip's drain between them does not show; the grouped launch was removed.)
         # attention projection (h1_to_att Fork)
@@ -1064,6 +1066,14 @@ class Parrot(Brick):
         with ops.gemm_precision(ops.PRECISION_F32):  # the attention window stays f32 in every operand mode
             ops.gemm(ws['dp'][t0:t1].view(R, 3 * A).t(), ws['h'][0][t0 + 1:t1 + 1].view(R, H),
                      out=sg_['dec.WattT'], accumulate=True)
+
+    def _gradient_ready(self, storage_name):
+        """Reports a storage entry whose gradient is final for this step to `on_gradient_ready(lo, hi)` (flat-buffer range;
+        set by the trainer in data-parallel runs: dist.GradientExchange.mark_ready)."""
+        hook = getattr(self, 'on_gradient_ready', None)
+        if hook is not None:
+            o, n = self.store.offsets[storage_name]
+            hook(o, o + (n + 3) // 4 * 4)
 
     def _bf16_weight_grads(self, t0, t1, T):
         """bf16-operand decoders take the whole window's weight gradients from bf16 COPIES of the saved activations and

@@ -270,10 +270,22 @@ def gemm_gated(a: torch.Tensor, b: torch.Tensor, gate: torch.Tensor, out=None) -
     return out
 
 
-def _int32(t: torch.Tensor, name: str) -> torch.Tensor:
+def _int32(t: torch.Tensor, name: str, bound=None) -> torch.Tensor:
+    """int32 copy of an index tensor; with `bound`, every value must lie in [0, bound): the gather / cross-entropy kernels
+    index their tables with these values unchecked, where the reference's Embedding / one-hot (and torch's) raise on a bad
+    sample code.  The check costs two reductions and a host read per call (PARROT_SKIP_INDEX_CHECK=1 turns it off)."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.HipCallError(f"{name}: the parrot_amd product path needs a GPU tensor; there is no CPU fallback")
-    return t.to(torch.int32).contiguous()
+    t32 = t.to(torch.int32).contiguous()
+    if bound is not None and t32.numel() and not _SKIP_INDEX_CHECK:
+        lo, hi = int(t32.min()), int(t32.max())
+        if lo < 0 or hi >= bound:
+            raise IndexError(f"{name}: values in [{lo}, {hi}] outside [0, {bound})")
+    return t32
+
+
+import os as _os
+_SKIP_INDEX_CHECK = _os.environ.get("PARROT_SKIP_INDEX_CHECK", "0") not in ("", "0")
 
 
 class _EmbedSumFn(torch.autograd.Function):
@@ -289,7 +301,7 @@ class _EmbedSumFn(torch.autograd.Function):
         if W1.shape[0] != J * EMB:
             raise ValueError("embed_sum: W1 must be [J * EMB, D]")
         E_, W1_ = E.contiguous(), W1.contiguous()
-        idx32 = _int32(idx, "idx")
+        idx32 = _int32(idx, "idx", bound=Q)
         tbl = torch.empty(J, Q, D, device=E.device, dtype=torch.float32)
         with gemm_precision(PRECISION_F32):  # (a table of 2.6 M entries: nothing to gain from bf16 operands)
             gemm_batched(E_.unsqueeze(0).expand(J, -1, -1), W1_.view(J, EMB, D), tbl)
@@ -389,7 +401,7 @@ class _SoftmaxCeFn(torch.autograd.Function):
         if x.stride(1) != 1:
             x = x.contiguous()
         rows, Q = x.shape
-        t32 = _int32(target.reshape(-1), "target")
+        t32 = _int32(target.reshape(-1), "target", bound=Q)
         if t32.numel() != rows:
             raise ValueError("softmax_ce: one target per row expected")
         lse = torch.empty(rows, device=x.device, dtype=torch.float32)

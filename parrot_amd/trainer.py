@@ -62,10 +62,12 @@ class Trainer:
         if pdist.is_distributed():
             scale, den_global = pdist.global_cost_scale(den_local)
             p.on_early_gradients = self.exchanges[0].start_early  # fired by the backward pass (model.py side)
+            p.on_gradient_ready = self.exchanges[0].mark_ready    # every deferred weight-gradient matrix as it completes
             try:
                 cost.backward(gradient=scale.to(cost.dtype))
             finally:
                 p.on_early_gradients = None
+                p.on_gradient_ready = None
             for ex in self.exchanges:
                 ex.finish()
             gcost = pdist.allreduce_cost(cost.detach() * (den_local + pdist.COST_EPS), den_global)

@@ -23,10 +23,10 @@ def test_traffic_figure_fresh_stale_absent(tmp_path):
     root = _fake_tree(tmp_path)
     assert bench.pmc_traffic_figure(root) == (None, None)  # nothing measured: null, no note
     blob = {"hbm_bytes_per_launch": 12345678, "session": "unit test", "source_digest": bench.kernel_source_digest(root)}
-    path = os.path.join(root, "profiles", "r04_pmc_traffic.json")
+    path = os.path.join(root, "profiles", "r06_pmc_traffic.json")
     json.dump(blob, open(path, "w"))
     value, note = bench.pmc_traffic_figure(root)
-    assert value == 12345678 and "unit test" in note and "r04_pmc_traffic.json" in note
+    assert value == 12345678 and "unit test" in note and "r06_pmc_traffic.json" in note
     # a kernel source changes -> the figure is refused and the note says why
     with open(os.path.join(root, "parrot_amd", "csrc", "plans.hip"), "a") as f:
         f.write("// edited\n")

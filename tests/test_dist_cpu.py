@@ -137,6 +137,20 @@ def _worker_buckets(rank, world, port, ret):
             ex.start_early()
         ex.finish()
         out[name + "_again"] = bool(torch.equal(buf2, flat))
+    # readiness order (round 6): the early bucket, then several ranges reported one by one in no particular address order
+    # ("each deferred weight-gradient matrix as its product completes"), the gaps at the end -- still bit for bit
+    buf = grad.clone()
+    ex = pdist.GradientExchange(buf, (lo, hi))
+    ex.start_early()
+    for a_, b_ in ((8000, 9000), (0, 12), (6504, 7000), (9000, 10007)):
+        ex.mark_ready(a_, b_)
+    try:
+        ex.mark_ready(8500, 8600)                     # handed over already: must raise, not double-sum
+        out["overlap_raises"] = False
+    except RuntimeError:
+        out["overlap_raises"] = True
+    ex.finish()
+    out["ready_ranges"] = bool(torch.equal(buf, flat))
     # bf16 on the wire: each rank's gradient rounded once, summed, widened; compare with that arithmetic done by hand
     others = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(others, grad)

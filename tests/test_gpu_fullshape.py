@@ -152,6 +152,7 @@ def test_reference_literal_3gru_window_T800_matches_oracle(dev, capsys):
     cost, _, av, _ = m.compute_cost(feat.float().to(dev), fm.float().to(dev), lab.to(dev), lm.float().to(dev), None, 1, B)
     cost.backward()
     assert int(_lib.load().parrot_decoder_schedule(next(iter(m._train_ws.values()))['plan'])) == 5
+    assert int(_lib.load().parrot_decoder_backward_tick(next(iter(m._train_ws.values()))['plan'])) == 8  # bwd8 at L = 3 (round 6)
     grads = {k: v.detach().cpu().double().clone() for k, v in m.get_gradient_dict().items()}
     av = [x.detach().cpu().double() for x in av]
     cost = float(cost)

@@ -100,3 +100,19 @@ def test_softmax_ce_matches_torch(dev, rows, Q):
     (ce * w.float().to(dev)).sum().backward()
     assert_close(ce, ref, 2e-6, "cross-entropy")
     assert_close(xh.grad, xr.grad, 1e-5, "d logits")
+
+
+def test_bad_sample_codes_raise(dev):
+    """A sample code outside [0, Q) raises (as the reference's Embedding / one-hot do) instead of indexing out of bounds."""
+    from parrot_amd import ops
+    E = torch.randn(16, 8, device=dev)
+    W1 = torch.randn(3 * 8, 32, device=dev)
+    idx = torch.randint(0, 16, (40, 3), device=dev)
+    ops.embed_sum(E, W1, idx)
+    bad = idx.clone()
+    bad[7, 1] = 16
+    with pytest.raises(IndexError):
+        ops.embed_sum(E, W1, bad)
+    logits = torch.randn(40, 16, device=dev)
+    with pytest.raises(IndexError):
+        ops.softmax_ce(logits, torch.full((40,), -1, device=dev))

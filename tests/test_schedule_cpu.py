@@ -291,21 +291,24 @@ def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
         lib.parrot_decoder_destroy(plan)
 
 
+@pytest.mark.parametrize("nl", [2, 3])
 @pytest.mark.parametrize("sched", [5, 0])
-def test_k_balanced_backward_tick_keeps_the_scan_orderings(monkeypatch, sched):
+def test_k_balanced_backward_tick_keeps_the_scan_orderings(monkeypatch, sched, nl):
     """bwd8 (2-layer f32 GRU decoders with all accumulators given): every K = 2H product of a backward tick in two K = H
     halves with their own buffers, layer 1 two ticks ahead of layer 0, its dG-fed downward products in the NEXT tick's
     heterogeneous attention launch.  Same ordering rules as every other schedule; plus: three launches per tick, no job
     walks more than K = H, and the attention launch carries step-GEMM jobs."""
     L, lib = _lib()
     T, B, H, E, A, U = 6, 20, 32, 16, 4, 7
-    plan, ar, d = _make_plan(L, lib, sched, 0, 2, 0, monkeypatch, T, B, H, E, A, U, hetero=True)
+    plan, ar, d = _make_plan(L, lib, sched, 0, nl, 0, monkeypatch, T, B, H, E, A, U, hetero=True)
     try:
+        assert lib.parrot_decoder_backward_tick(plan) == 8  # (round 6: also the reference's own depth, three layers)
         recs = _trace(lib, plan, 1)
-        bwd_once = {"dp", "dG0", "dG1", "dC0", "dC1"}
-        acc = {"dw", "dw0", "dw_b", "dw0_b", "dw_c", "dw0_c", "dh0", "dh1", "dhup0", "dh_b0", "dh_b1", "dhup_b0", "dhup_c0"}
+        bwd_once = {"dp"} | {f"dG{l}" for l in range(nl)} | {f"dC{l}" for l in range(nl)}
+        acc = {"dw", "dw0", "dw_b", "dw0_b", "dw_c", "dw0_c"} | {f"dh{l}" for l in range(nl)} | {f"dh_b{l}" for l in range(nl)}
+        acc |= {f"dhup{l}" for l in range(nl - 1)} | {f"dhup_b{l}" for l in range(nl - 1)} | {f"dhup_c{l}" for l in range(nl - 1)}
         n_bwd = _check(recs, ar, bwd_once, acc, T, {})
-        assert n_bwd == 3 * (T + 2), n_bwd  # three launches per tick, T + 2 ticks
+        assert n_bwd == 3 * (T + 2 * (nl - 1)), n_bwd  # three launches per tick, T + 2 (L - 1) ticks
         n = lib.parrot_decoder_trace_jobs(plan, 1, None, 0)
         buf = (C.c_longlong * (6 * n))()
         lib.parrot_decoder_trace_jobs(plan, 1, buf, n)
@@ -313,14 +316,16 @@ def test_k_balanced_backward_tick_keeps_the_scan_orderings(monkeypatch, sched):
         assert max(j[4] for j in jobs if j[5] >= 0) == H  # no step-GEMM job walks more than K = H
         att_launches = {j[0] for j in jobs if j[5] == -2}
         assert any(j[0] in att_launches and j[5] >= 0 for j in jobs)  # GEMM work rides beside the attention backward
-        for name in ("dh_b0", "dh_b1", "dhup_b0", "dhup_c0", "dw_b", "dw_c", "dw0_b", "dw0_c"):
+        for name in ["dw_b", "dw_c", "dw0_b", "dw0_c"] + [f"dh_b{l}" for l in range(nl)] + \
+                [f"dhup_{x}{l}" for x in "bc" for l in range(nl - 1)]:
             kinds = {r[2] for r in recs if _owner(ar, r[3]) == name}
             assert (1 in kinds or 2 in kinds) and 0 in kinds, (name, kinds)
     finally:
         lib.parrot_decoder_destroy(plan)
     monkeypatch.setenv("PARROT_BWD_HETERO", "0")  # opt-out: the three-launch tick of bwd()
-    plan, ar, d = _make_plan(L, lib, sched, 0, 2, 0, monkeypatch, T, B, H, E, A, U, hetero=True)
+    plan, ar, d = _make_plan(L, lib, sched, 0, nl, 0, monkeypatch, T, B, H, E, A, U, hetero=True)
     try:
+        assert lib.parrot_decoder_backward_tick(plan) == 0
         n = lib.parrot_decoder_trace_jobs(plan, 1, None, 0)
         buf = (C.c_longlong * (6 * n))()
         lib.parrot_decoder_trace_jobs(plan, 1, buf, n)
