@@ -535,14 +535,13 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
         g.b[(size_t)t * BA + (size_t)b * A + tid] = bv;
         pm_stf(g.kappa + (size_t)(t + 1) * BA + (size_t)b * A + tid, kv);
     }
-    if (tid == 0) {
-        reinterpret_cast<int*>(s_red)[6] = U;
-        reinterpret_cast<int*>(s_red)[7] = -1;
-    }
     __syncthreads();
-    // 3) phi
+    // 3) phi.  Round 6 (as att_fwd_body.h): the support [lo, hi] = positions whose phi is not exactly zero from wave ballots
+    // and one LDS word per wave instead of two LDS atomics per position on one address.
     float* phi_out = g.phi + ((size_t)t * g.B + b) * U;
-    for (int u = tid; u < U; u += PM_THREADS) {
+    int w_lo = U, w_hi = -1;  // this wave's support (wave-uniform)
+    for (int base = 0; base < U; base += PM_THREADS) {
+        const int u = base + tid;
         float ph = 0.f;
         const float uf = (float)u;
         if (g.att_type == 1) {
@@ -557,18 +556,33 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
                 ph += s_a[j] * expf(-s_b[j] * d * d);
             }
         }
-        s_phi[u] = ph;
-        if (ph != 0.f) {
-            atomicMin(&reinterpret_cast<int*>(s_red)[6], u);
-            atomicMax(&reinterpret_cast<int*>(s_red)[7], u);
+        if (u < U) {
+            s_phi[u] = ph;
+            phi_out[u] = ph;
         }
-        phi_out[u] = ph;
+        const unsigned long long nz = __ballot(u < U && ph != 0.f);
+        if (nz) {
+            w_lo = min(w_lo, base + wave * 64 + __ffsll((long long)nz) - 1);
+            w_hi = max(w_hi, base + wave * 64 + 63 - __clzll((long long)nz));
+        }
+    }
+    if (lane == 0) {
+        reinterpret_cast<int*>(s_acc)[wave] = w_lo;
+        reinterpret_cast<int*>(s_acc)[PM_THREADS / 64 + wave] = w_hi;
     }
     __syncthreads();
     int u_lo = 0, u_hi = U - 1;
-    if (!g.dense) {
-        u_lo = reinterpret_cast<int*>(s_red)[6];
-        u_hi = reinterpret_cast<int*>(s_red)[7];
+    {
+        int s_lo = U, s_hi = -1;
+#pragma unroll
+        for (int q = 0; q < PM_THREADS / 64; ++q) {
+            s_lo = min(s_lo, reinterpret_cast<const int*>(s_acc)[q]);
+            s_hi = max(s_hi, reinterpret_cast<const int*>(s_acc)[PM_THREADS / 64 + q]);
+        }
+        if (!g.dense) {
+            u_lo = s_lo;
+            u_hi = s_hi;
+        }
     }
     if (g.sup && tid == 0) {
         g.sup[((size_t)t * g.B + b) * 2] = u_lo;
@@ -595,14 +609,15 @@ __device__ __forceinline__ void pm_att_row(const PmAtt& g, int b, int t, float* 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
             }
-            for (; u + 3 * G <= u_hi; u += 4 * G) {
-                float v[4];
+            {   // the remaining (< 8) rows in ONE batch of clamped, unconditional loads (row after row each was a dependent
+                // round trip): same terms, same order
+                float v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ctx[(size_t)(u + q * G) * E + e];
+                for (int q = 0; q < 8; ++q) v[q] = ctx[(size_t)min(u + q * G, u_hi) * E + e];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
+                for (int q = 0; q < 8; ++q)
+                    if (u + q * G <= u_hi) acc = __builtin_fmaf(s_phi[u + q * G], v[q], acc);
             }
-            for (; u <= u_hi; u += G) acc = __builtin_fmaf(s_phi[u], ctx[(size_t)u * E + e], acc);
         }
         __syncthreads();
         s_acc[tid] = acc;

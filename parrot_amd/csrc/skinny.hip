@@ -88,6 +88,9 @@ __device__ __forceinline__ void sk_fetch(const SkSeg& sg, int kc, int m0, int M,
 // Register-buffer ring depth of the fast path (chunks in flight per wave).  Measured on MI355X, cfg2 training
 // step fwd/bwd ms: depth 2: 55.9/79.9, 4: 57.4/80.0, 6: 61.9/82.5, 8: 60.7/87.9 -- more loads in flight do
 // not help (the clamped tail refills add traffic), so the ping-pong pair stays.
+#ifndef SK_EARLY_DESC
+#define SK_EARLY_DESC 1
+#endif
 #ifndef SK_DEPTH
 #define SK_DEPTH 2
 #endif
@@ -263,6 +266,16 @@ __device__ __forceinline__ void sk_body(const SkJob& job, int tile0, f32x4* red)
     const int m0 = blockIdx.y * (16 * MB);  // the launch picks MB / NB
     const int M = job.M, N = job.N;
     SK_STAMP(0);
+#if SK_EARLY_DESC  // (default 1: 20.2 -> 19.3 us per gate / candidate launch pair, tools/sktimers.hip)
+    // The descriptor fields the prologue needs, pulled into scalar registers in one batch: read where the code first
+    // needs them they arrive through five or six dependent s_load / s_waitcnt rounds (a cold kernel-argument line
+    // each time) spread over the branches in front of the K loop.  (Invariant loads: the later reads reuse these.)
+    asm volatile("" ::"s"(job.M), "s"(job.N), "s"(job.epi), "s"(job.H), "s"(job.nseg), "s"(job.accumulate), "s"(job.colmode),
+                 "s"(job.bias), "s"(job.add), "s"(job.out), "s"(job.e0), "s"(job.e1), "s"(job.o1), "s"(job.ld_add),
+                 "s"(job.ldo), "s"(job.lde0), "s"(job.lde1), "s"(job.ldo1), "s"(job.wait_flag), "s"(job.seg[0].A),
+                 "s"(job.seg[0].B), "s"(job.seg[0].lda), "s"(job.seg[0].ldb), "s"(job.seg[0].K), "s"(job.seg[0].b_kcontig),
+                 "s"(job.seg[1].A), "s"(job.seg[1].B), "s"(job.seg[1].lda), "s"(job.seg[1].ldb), "s"(job.seg[1].K));
+#endif
     if (m0 >= M) return;
 
     f32x4 acc[MB][NB];
@@ -670,6 +683,10 @@ __global__ __launch_bounds__(SK_THREADS) void sk_kernel(const SkLaunch L) {
     // workgroups of the jobs are laid out back to back along x and the job is found in the prefix table
     // (a z-grid sized for the largest job was measured slower there: 59 -> 65 ms backward at cfg2).
     int j = blockIdx.z, bx = blockIdx.x;
+#if SK_EARLY_DESC  // the launch header in one batch of scalar loads (zmode, njobs and the prefix table sit in one line)
+    asm volatile("" ::"s"(L.zmode), "s"(L.njobs), "s"(L.tile_end[0]), "s"(L.tile_end[1]), "s"(L.tile_end[2]), "s"(L.tile_end[3]),
+                 "s"(L.tile_end[4]), "s"(L.tile_end[5]), "s"(L.tile_end[6]), "s"(L.tile_end[7]));
+#endif
     if (!L.zmode) {
         j = 0;
 #pragma unroll
