@@ -1141,7 +1141,7 @@ class Parrot(Brick):
     def _scan_bwd_and_weight_grads(self, ws, save, T, B, before=None):
         """`before()` (the readout weight gradients: operands ready before the scan starts), the backward scan, then the
         deferred weight-gradient GEMMs that only read what the scan leaves behind.  (Rounds 2-4 could also run those GEMMs
-        part by part BESIDE the scan on a second stream: measured slower every time -- DESIGN.md 3.2 -- and removed.)"""
+        part by part BESIDE the scan on a second stream: measured slower every time -- docs/DESIGN_rounds_1_5.md 3.2 -- and removed.)"""
         if before is not None:
             before()
         hook = getattr(self, 'on_early_gradients', None)

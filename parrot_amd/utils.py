@@ -24,7 +24,7 @@ def _common_extras(parser):
     parser.add_argument('--cell_type', type=str, default='gru', choices=('gru', 'lstm'),
                         help="decoder layers: 'gru' (the reference's GatedRecurrent) or 'lstm' (BASELINE configs[3])")
     parser.add_argument('--compute_dtype', type=str, default='float32', choices=('float32', 'bf16'),
-                        help='bf16: bf16 MFMA operands, f32 accumulation / states / master weights (DESIGN.md 3.7)')
+                        help='bf16: bf16 MFMA operands, f32 accumulation / states / master weights (DESIGN.md 3.4)')
     parser.add_argument('--encoder_literal', type=int, default=1,
                         help='1: scan the encoder over the batch axis like the reference does')
     parser.add_argument('--device', type=str, default='cuda')
