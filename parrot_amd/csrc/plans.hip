@@ -668,11 +668,20 @@ struct DecoderPlan : PlanBase {
         j.out = sq; j.ldo = wd;
         j.accumulate = part == 2 ? 1 : ((d.seq_init >> l) & 1);  // caller data (feedback / speaker terms) already there
     }
+    // Round 6, GRU layers l >= 2 (the reference's own depth: model.py:312-347): the input projection walks K = E + l H
+    // (2304 at l = 2) -- the longest K of its launch by far, in a launch that already holds 1.75 rounds of workgroups
+    // (25.8 us at three layers).  It is cut like the LSTM one: part 1 = the rows of w and h_0 .. h_{l-2}, ready two ticks
+    // before the rows of h_{l-1}, rides in the gate launch (the gate block) and the candidate launch (the candidate block) of
+    // the tick in between -- both are 1.5 rounds there and take the extra half round for nothing --, part 2 = the rows of
+    // h_{l-1} stays in the attention launch and accumulates.  No job of a tick walks more than K = H + E.
+    bool s5_gru_split = true;
     int fwd5(hipStream_t st) {
         const int Q = nticks5();
         const int cfull = 160;  // workgroup count at which the heterogeneous launch keeps 32 x 32 tiles (measured)
-        // launches of a tick: <= L gate jobs, <= L candidate jobs, <= 3 input-projection jobs per upper layer
-        static_assert(3 * (PARROT_MAX_LAYERS - 1) <= SK_MAXJOB && PARROT_MAX_LAYERS <= SK_MAXJOB, "fwd5: jobs[] too short");
+        // launches of a tick: <= L gate jobs (+ part 1 of the upper layers' gate projections), <= L candidate jobs (+ part 1
+        // of the candidate projections), <= 3 input-projection jobs per upper layer
+        static_assert(3 * (PARROT_MAX_LAYERS - 1) <= SK_MAXJOB && 2 * PARROT_MAX_LAYERS - 2 <= SK_MAXJOB, "fwd5: jobs[] too short");
+        const bool gsplit = d.cell == 0 && s5_gru_split && d.L >= 3;
         for (int q = 0; q < Q; ++q) {
             SkJob jobs[SK_MAXJOB];
             int n = 0;
@@ -684,6 +693,11 @@ struct DecoderPlan : PlanBase {
                 else gates_job(j, l, t);
                 if (l > 0) j.nseg = 1;  // recurrent block only; the rest arrives through seq_g (has_seq)
             }
+            if (gsplit)
+                for (int l = 2; l < d.L; ++l) {  // part 1 of the step whose part 2 the attention launch of THIS tick adds
+                    const int tp = q - lag5(l) + 1;
+                    if (tp >= 0 && tp < d.T) input_job(jobs[n++], l, tp, 0, 1);
+                }
             if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             n = 0;
             if (d.cell == 0) {
@@ -694,15 +708,21 @@ struct DecoderPlan : PlanBase {
                     cand_job(j, l, t);
                     if (l > 0) j.nseg = 1;
                 }
+                if (gsplit)
+                    for (int l = 2; l < d.L; ++l) {
+                        const int tp = q - lag5(l) + 1;
+                        if (tp >= 0 && tp < d.T) input_job(jobs[n++], l, tp, 1, 1);
+                    }
                 if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             }
             n = 0;
             for (int l = 1; l < d.L; ++l) {
                 const int t = q - lag5(l) + 1;
                 const bool split = d.cell == 1 && l >= 2 && s5_split;
+                const bool gs = gsplit && l >= 2;  // (part 1 was written by the gate / candidate launches of this tick)
                 if (t >= 0 && t < d.T) {
-                    input_job(jobs[n++], l, t, 0, split ? 2 : 0);
-                    if (d.cell == 0) input_job(jobs[n++], l, t, 1);
+                    input_job(jobs[n++], l, t, 0, (split || gs) ? 2 : 0);
+                    if (d.cell == 0) input_job(jobs[n++], l, t, 1, gs ? 2 : 0);
                 }
                 if (split) {  // the rows that were ready a tick earlier
                     const int ta = t + 1;
