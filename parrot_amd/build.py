@@ -47,6 +47,10 @@ def build(force: bool = False, verbose: bool = True, timers: bool = False) -> st
     if timers:
         OUT = os.path.join(HERE, "libparrot_hip_timers.so")
         OBJDIR = os.path.join(CSRC, "build_timers")
+    tag, extra = os.environ.get("PARROT_BUILD_TAG"), os.environ.get("PARROT_BUILD_FLAGS", "").split()
+    if tag:  # development: a variant library (compile-time knobs, e.g. -DWK_PB_DEPTH=4), loaded through PARROT_HIP_LIB
+        OUT = os.path.join(HERE, f"libparrot_hip_{tag}.so")
+        OBJDIR = os.path.join(CSRC, f"build_{tag}")
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "parrot_hip.h"))
@@ -56,7 +60,7 @@ def build(force: bool = False, verbose: bool = True, timers: bool = False) -> st
         return OUT
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + (["-DSK_TIMERS"] if timers else [])
+    common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + (["-DSK_TIMERS"] if timers else []) + (extra if tag else [])
 
     def compile_one(src):
         obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
