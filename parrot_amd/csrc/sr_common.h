@@ -8,6 +8,7 @@ namespace {
 constexpr int SRP_THREADS = 512, SRP_TEAM = 32, SRP_NTEAMS = 8, SRP_ROWS = 4, SRP_Q = 256;
 constexpr int SRP_SYNC_WORDS = 1024;  // [0..255] arrive (32 words per team), [256..511] census, [512] abort, [513] fault code
 constexpr int SRP_MAXHIST = 64;       // FS + nsteps
+constexpr int SRP_GMAX = 12;          // table rows of the gather requested in one batch (FS - 1 <= SRP_GMAX; else a loop)
 // f32x4 hand-off slots per team in the workspace: x1, x2 [D] and the logits [Q]
 __host__ __device__ constexpr int srp_team_vecs(int D, int Q) { return 2 * D + Q; }
 
@@ -80,6 +81,24 @@ __device__ __forceinline__ f32x4 srp_take(__amdgpu_buffer_rsrc_t r, unsigned byt
     return v;
 }
 
+// The same for the NK slots k = tid + j * SRP_THREADS < n of a thread: every slot requested once up front (one L2 round
+// trip for the slots that are already full), then the empty ones re-read one after the other.
+template <int NK>
+__device__ __forceinline__ void srp_take_all(__amdgpu_buffer_rsrc_t r, unsigned base_vec, int n, int tid, f32x4* __restrict__ dst,
+                                             unsigned* abort_, SrpShared* sh) {
+    f32x4 v[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) v[j] = srp_ld(r, (base_vec + (unsigned)min(tid + j * SRP_THREADS, n - 1)) * 16u);
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = tid + j * SRP_THREADS;
+        if (k < n) {
+            if (srp_is_empty(v[j])) v[j] = srp_take(r, (base_vec + (unsigned)k) * 16u, abort_, sh);
+            dst[k] = v[j];
+        }
+    }
+}
+
 // f32x4 += the same vector of the lane selected by a DPP control (all four components)
 template <int CTRL>
 __device__ __forceinline__ f32x4 srp_dpp_add(const f32x4& v) {
@@ -138,11 +157,30 @@ __device__ __forceinline__ int srp_argmax_row(const f32x4* __restrict__ lg, int 
     return srp_wave_min(bv == best ? bi : 0x7fffffff);
 }
 
+// v + the same vector of the lane 16 (ROWS = 16: neighbouring row) or 32 (other half of the wave) lanes away
+template <int ROWS>
+__device__ __forceinline__ f32x4 srp_swap_add(const f32x4& v) {
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned u = __float_as_uint(v[c]);
+        if (ROWS == 16) {
+            const auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            r[c] = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+        } else {
+            const auto q = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            r[c] = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+        }
+    }
+    return r;
+}
+
 // Fold of a product's per-thread partial sums acc[r] (stream r, the thread's 4 columns): the 8 K-slices of neighbouring
 // lanes with DPP (quad swaps, then half-row mirror: a fixed tree), the 64 / GG lane groups through LDS in group order.
 // Threads tid < 4 GG return the finished f32x4 (4 streams) of CU column 4 * (tid % GG) + tid / GG.
 template <int GG>
-__device__ __forceinline__ void srp_reduce(f32x4 (&acc)[4], f32x4* __restrict__ red, f32x4& out, int tid) {
+__device__ __forceinline__ void srp_reduce(f32x4 (&acc)[4], f32x4* __restrict__ red, f32x4& out, int tid,
+                                           unsigned long long* tp = nullptr) {
     constexpr int CC = 4 * GG, GROUPS = 64 / GG;
     const int sl = tid & 7, g = (tid >> 3) % GG, shi = tid / (8 * GG);
 #pragma unroll
@@ -151,38 +189,60 @@ __device__ __forceinline__ void srp_reduce(f32x4 (&acc)[4], f32x4* __restrict__ 
         acc[r] = srp_dpp_add<0x4E>(acc[r]);   // quad_perm [2,3,0,1]
         acc[r] = srp_dpp_add<0x141>(acc[r]);  // row_half_mirror
     }
+    if (tp) tp[1] = srp_clock();
     if (sl == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[shi * CC + j * GG + g] = (f32x4){acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
     }
     __syncthreads();
-    if (tid < CC) {
-        f32x4 v = red[tid];
-#pragma unroll 4
-        for (int p = 1; p < GROUPS; ++p) v += red[p * CC + tid];
-        out = v;
+    if (tp) tp[2] = srp_clock();
+    // The GROUPS partial sums of each of the CC column vectors: wave 0 takes four of them per lane in ONE batch of LDS
+    // reads (lane = part * CC + column) and adds the 64 / CC parts across lanes on the VALU -- row rotate, then the
+    // gfx950 row / half-wave swaps.  (Round 5 had threads tid < CC walk the GROUPS partials four at a time: eight
+    // dependent LDS round trips for the output layer, 1.1 us of the step.)
+    if (tid < 64) {
+        static_assert(GROUPS * CC == 256, "64 lanes x 4 partials");
+        const int c = tid % CC, part = tid / CC;
+        const f32x4 p0 = red[(4 * part + 0) * CC + c], p1 = red[(4 * part + 1) * CC + c];
+        const f32x4 p2 = red[(4 * part + 2) * CC + c], p3 = red[(4 * part + 3) * CC + c];
+        f32x4 v = (p0 + p1) + (p2 + p3);
+        if (CC <= 8) v = srp_dpp_add<0x128>(v);  // row_ror:8
+        if (CC <= 16) v = srp_swap_add<16>(v);
+        out = srp_swap_add<32>(v);
     }
+    if (tp) tp[3] = srp_clock();
 }
 
 template <int KPP, int GG>
 __device__ __forceinline__ void srp_layer(const f32x4* __restrict__ act, const f32x4 (&w)[KPP], f32x4* __restrict__ red,
-                                          f32x4& out, int tid) {
+                                          f32x4& out, int tid, unsigned long long* tp = nullptr) {
     constexpr int SS = SRP_THREADS / GG;
     const int s = 8 * (tid / (8 * GG)) + (tid & 7);
     f32x4 acc[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Activation reads run PF iterations ahead of the FMAs that use them, pinned by scheduling barriers: left alone the
+    // scheduler (register pressure near the limit) emits read, wait, 8 FMAs, read, wait ... -- an LDS latency per step of K.
+    constexpr int PF = KPP < 4 ? KPP : 4;
+    f32x4 buf[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) buf[j] = act[j * SS + s];
 #pragma unroll
     for (int kk = 0; kk < KPP; ++kk) {
-        const f32x4 a = act[kk * SS + s];
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 a = buf[kk % PF];
         const f32x4 wv = w[kk];
         // acc[r] = the 4 columns of stream r.  The scalar operand is the (transient) activation: broadcasting the
         // loop-invariant weights instead makes the compiler keep a 4-register splat of every weight alive.
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += a[r] * wv;
-        if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // do not hoist all KPP operand reads: registers are tight
+        if (kk + PF < KPP) {
+            __builtin_amdgcn_sched_barrier(0);
+            buf[kk % PF] = act[(kk + PF) * SS + s];
+        }
     }
-    srp_reduce<GG>(acc, red, out, tid);
+    if (tp) tp[0] = srp_clock();
+    srp_reduce<GG>(acc, red, out, tid, tp);
 }
 
 }  // namespace

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     constexpr int Q = SRP_Q;
     constexpr int DC = D / 32, G = DC / 4, S = SRP_THREADS / G, KP = D / S;
     constexpr int QC = Q / 32, GQ = QC / 4, SQ = SRP_THREADS / GQ, KQ = D / SQ;
+    constexpr int NKD = (D + SRP_THREADS - 1) / SRP_THREADS;  // hand-off slots of x1 / x2 per thread
     static_assert(KP >= 1 && KQ >= 1 && S * G == SRP_THREADS && S * KP == D, "unsupported width");
     extern __shared__ __attribute__((aligned(16))) char srp_smem[];
     f32x4* act = reinterpret_cast<f32x4*>(srp_smem);       // [D]
@@ -52,43 +53,53 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned* sync = reinterpret_cast<unsigned*>(a.ws);
     unsigned* abort_ = sync + 512;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sync + 600);
+    // Team = the XCD this workgroup runs on; rank = its place among the XCD's 32 workgroups.  The dispatcher deals
+    // workgroups to the XCDs round-robin, so blockIdx / 8 numbers the workgroups of one XCD 0 .. 31 without the census
+    // atomic (a cold L2 round trip in front of every load of the prologue); the census word is still counted, without
+    // waiting for it.  A placement that breaks the rule leaves a team incomplete: its polls time out and raise abort.
     const int team = srp_xcc();
+    const int cu = (int)(blockIdx.x / SRP_NTEAMS);
+    const bool timing = a.pad && blockIdx.x == 0 && tid == 0;
+    if (timing) stamps[80] = srp_clock();
     if (tid == 0) {
-        const unsigned old = srp_l2_add(sync + 256 + team * 32, 1u);
-        sh->rank = (int)(old % SRP_TEAM);
-        sh->gen = (int)(old / SRP_TEAM);
+        __hip_atomic_fetch_add(sync + 256 + team * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sh->rank = cu;
         sh->ok = 1;
     }
-    __syncthreads();
-    const int cu = sh->rank;
 
-    // ---- weight slices: L3 and Output -> registers; this CU's columns of the newest sample's table -> LDS
+    // ---- the weight slices: L3 and Output -> registers; this CU's columns of the newest sample's table -> LDS; the
+    // sample history (the gather of step 0 waits for it).  Every load is requested before the first wait.
+    const int t0 = a.tbase[0] + a.toff;
     const int g = (tid >> 3) % G, s = 8 * (tid / (8 * G)) + (tid & 7);
     const int gq = (tid >> 3) % GQ, sq = 8 * (tid / (8 * GQ)) + (tid & 7);
     f32x4 w3[KP], w4[KQ];
 #pragma unroll
     for (int kk = 0; kk < KP; ++kk)
         w3[kk] = *reinterpret_cast<const f32x4*>(a.W3 + (size_t)(kk * S + s) * D + cu * DC + 4 * g);
-    for (int idx = tid; idx < Q * (DC / 4); idx += SRP_THREADS) {
-        const int q = idx / (DC / 4), c4 = idx % (DC / 4);
-        reinterpret_cast<f32x4*>(t2l)[idx] =
-            *reinterpret_cast<const f32x4*>(a.t2tbl + ((size_t)(a.FS - 1) * Q + q) * D + cu * DC + 4 * c4);
+    constexpr int T2V = Q * (DC / 4) / SRP_THREADS;  // f32x4 of the table slice per thread
+    static_assert(T2V * SRP_THREADS == Q * (DC / 4), "table slice not a multiple of the workgroup");
+    f32x4 tv[T2V];
+#pragma unroll
+    for (int j = 0; j < T2V; ++j) {
+        const int idx = tid + j * SRP_THREADS, q = idx / (DC / 4), c4 = idx % (DC / 4);
+        tv[j] = *reinterpret_cast<const f32x4*>(a.t2tbl + ((size_t)(a.FS - 1) * Q + q) * D + cu * DC + 4 * c4);
     }
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk)
         w4[kk] = *reinterpret_cast<const f32x4*>(a.W4 + (size_t)(kk * SQ + sq) * Q + cu * QC + 4 * gq);
+    // the history's address waits for tbase: requested behind the weights, which do not
+    __builtin_amdgcn_sched_barrier(0);
+    // (threads past SRP_ROWS * FS repeat the last slot: same address, same value, same LDS word -- no divergent block the
+    // compiler could sink the request into)
+    const int hu = min(tid, SRP_ROWS * a.FS - 1), hr = hu / a.FS, hpos = hu % a.FS;
+    const int hv = a.samples[(size_t)min(team * SRP_ROWS + hr, a.B - 1) * a.len + t0 - a.FS + hpos];
     // column this thread finishes in the reductions (threads tid < DC / tid < QC)
     const int fin_h = cu * DC + 4 * (tid % G) + tid / G;
     const int fin_q = cu * QC + 4 * (tid % GQ) + tid / GQ;
-    const float bias3 = tid < DC ? a.b3[fin_h] : 0.f;
-    const float bias4 = tid < QC ? a.b4[fin_q] : 0.f;
-
-    const int t0 = a.tbase[0] + a.toff;
-    if (tid < SRP_ROWS * a.FS) {
-        const int r = tid / a.FS, pos = tid % a.FS;
-        const int b = min(team * SRP_ROWS + r, a.B - 1);
-        sh->hist[r][pos] = a.samples[(size_t)b * a.len + t0 - a.FS + pos];
-    }
+    const float bias3 = a.b3[min(fin_h, D - 1)];
+    const float bias4 = a.b4[min(fin_q, Q - 1)];
+    sh->hist[hr][hpos] = hv;
     // team exchange buffers ([D] f32x4 each, 4 streams per vector): x1, x2, and the logits ([Q] f32x4)
     float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * srp_team_vecs(D, Q) * 4;
     const __amdgpu_buffer_rsrc_t xr = srp_rsrc(xbase);
@@ -107,29 +118,54 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
 
     // part_i = frame_out[:, i] + sum_{pos < FS-1} t2tbl[pos][sample[t - FS + pos]] for this CU's DC columns: everything of
     // step i's L2 pre-activation that is known one step early (frame_out carries the composed projection and both
-    // biases); threads tid < DC keep it as one f32x4 (4 streams) of column fin_h
+    // biases); threads tid < DC keep it as one f32x4 (4 streams) of column fin_h.
+    // The gather: SRP_ROWS * DC sums of FS rows each, by the last waves of the workgroup (the first one publishes and
+    // finishes the reductions).  Its rows are REQUESTED right after x1 has been taken and SUMMED behind the L3 product --
+    // a memory latency in the product's shadow; requests are unconditional (clamped indices, selected sums): a load
+    // inside a divergent block is closed by the compiler with s_waitcnt vmcnt(0).  The sum keeps the order of the
+    // positions.  Result transposed through tmp; threads tid < DC pick it up behind the next workgroup barrier.
     f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the gather itself (threads u < 4 DC of whichever half of the workgroup is free), result transposed through tmp;
-    // threads tid < DC pick it up behind the caller's next workgroup barrier
-    auto gather_part = [&](int i, int u) {
-        if (u < SRP_ROWS * DC) {
-            const int r = u / DC, c = u % DC, col = cu * DC + c;
-            const int b = min(team * SRP_ROWS + r, a.B - 1);
-            float acc = a.frame_out[(size_t)b * a.ldf + (size_t)i * D + col];
-            for (int pos = 0; pos < a.FS - 1; ++pos) {
-                const int q = sh->hist[r][i + pos];
-                acc += a.t2tbl[((size_t)pos * Q + q) * D + col];
-            }
-            tmp[c * SRP_ROWS + r] = acc;
+    constexpr int GU = SRP_ROWS * DC, GW0 = (SRP_THREADS - GU) / 64;  // first gathering wave (GU <= 128: waves 6-7 at D = 1024)
+    const int gu = min(max(tid - GW0 * 64, 0), GU - 1), gr = gu / DC, gc = gu % DC;
+    const int gb = min(team * SRP_ROWS + gr, a.B - 1);
+    const bool gwave = __builtin_amdgcn_readfirstlane(wave) >= GW0, gfast = a.FS - 1 <= SRP_GMAX;
+    float gf = 0.f, gv[SRP_GMAX];
+    const __amdgpu_buffer_rsrc_t tr = srp_rsrc(a.t2tbl);
+    auto gather_request = [&](int i) {
+        gf = a.frame_out[(size_t)gb * a.ldf + (size_t)i * D + cu * DC + gc];
+        int hq[SRP_GMAX];  // the history in one LDS round trip (left to itself the compiler reads, waits, requests: x 12)
+#pragma unroll
+        for (int pos = 0; pos < SRP_GMAX; ++pos) hq[pos] = sh->hist[gr][i + max(min(pos, a.FS - 2), 0)];
+        __builtin_amdgcn_sched_barrier(0);
+        // (buffer loads: table base in scalar registers, the position's table as the scalar offset -- no 64-bit address
+        // per position kept alive across the sample loop)
+#pragma unroll
+        for (int pos = 0; pos < SRP_GMAX; ++pos) {
+            const int pp = max(min(pos, a.FS - 2), 0);
+            gv[pos] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                tr, (unsigned)(hq[pos] * D + cu * DC + gc) * 4u, (unsigned)(pp * Q * D) * 4u, 0));
         }
     };
+    auto gather_sum = [&](int i) {
+        float acc = gf;
+        if (gfast) {
+#pragma unroll
+            for (int pos = 0; pos < SRP_GMAX; ++pos) acc = pos < a.FS - 1 ? acc + gv[pos] : acc;
+        } else {
+            for (int pos = 0; pos < a.FS - 1; ++pos)
+                acc += a.t2tbl[((size_t)pos * Q + sh->hist[gr][i + pos]) * D + cu * DC + gc];
+        }
+        if (tid - GW0 * 64 >= 0 && tid - GW0 * 64 < GU) tmp[gc * SRP_ROWS + gr] = acc;
+    };
     auto take_part = [&]() { if (tid < DC) part = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC]; };
-    gather_part(0, tid);
+    if (gwave) gather_request(0);
+#pragma unroll
+    for (int j = 0; j < T2V; ++j) reinterpret_cast<f32x4*>(t2l)[tid + j * SRP_THREADS] = tv[j];
+    if (gwave) gather_sum(0);
     __syncthreads();
     take_part();
+    if (timing) stamps[81] = srp_clock();
 
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sync + 600);
-    const bool timing = a.pad && team == 0 && cu == 0 && tid == 0;
     auto stamp = [&](int i, int q) { if (timing && i < 10) stamps[i * 8 + q] = srp_clock(); };
     for (int i = 0; i < a.nsteps; ++i) {
         const bool more = i + 1 < a.nsteps;
@@ -145,30 +181,46 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         }
         stamp(i, 1);
         {
+#ifdef SRP_TAKE_BATCH
+            srp_take_all<NKD>(xr, 0u, D, tid, act, abort_, sh);
+#else
             for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)(k * 16), abort_, sh);
+#endif
             __syncthreads();
             if (!sh->ok) return;
             stamp(i, 2);
             // x1(i) complete => every CU is done with the logits of step i-1
             if (i > 0 && tid < QC) lb[fin_q] = srp_empty();
+#ifndef SRP_GATHER_BESIDE
+            if (more && gwave) gather_request(i + 1);
+#endif
             f32x4 v;
-            srp_layer<KP, G>(act, w3, red, v, tid);
+            srp_layer<KP, G>(act, w3, red, v, tid, timing && i == 5 ? stamps + 84 : nullptr);
             if (tid < DC) {
                 v += bias3;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 x2[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
             stamp(i, 3);
+#ifndef SRP_GATHER_BESIDE
+            if (more && gwave) gather_sum(i + 1);
+#endif
             stamp(i, 4);
         }
         {
-            // waves 0-3 take x2; waves 4-7 sum the next step's part meanwhile (it needs nothing from the other workgroups;
-            // a wave's loads return in order, so a wave with table rows in flight could not poll)
+#ifdef SRP_GATHER_BESIDE
+            // waves 0-3 take x2; the gathering waves request and sum the next step's part meanwhile
             if (tid < SRP_THREADS / 2) {
                 for (int k = tid; k < D; k += SRP_THREADS / 2) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
-            } else if (more) {
-                gather_part(i + 1, tid - SRP_THREADS / 2);
+            } else if (more && gwave) {
+                gather_request(i + 1);
+                gather_sum(i + 1);
             }
+#elif defined(SRP_TAKE_BATCH)
+            srp_take_all<NKD>(xr, (unsigned)D, D, tid, act, abort_, sh);
+#else
+            for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
+#endif
             __syncthreads();
             if (!sh->ok) return;
             if (more) take_part();
@@ -178,11 +230,12 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
                 for (int q = 0; q < DC / QC; ++q) x1[cu * DC + tid * (DC / QC) + q] = srp_empty();
             }
             f32x4 v;
-            srp_layer<KQ, GQ>(act, w4, red, v, tid);
+            srp_layer<KQ, GQ>(act, w4, red, v, tid, timing && i == 5 ? stamps + 88 : nullptr);
             if (tid < QC) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lb[fin_q] = v + bias4;
             }
+            if (timing && i == 5) stamps[92] = srp_clock();
         }
 
         // ---- pick (every CU of the team, identical result): argmax with lowest-index ties, or the seeded draw
@@ -234,31 +287,62 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         __syncthreads();
         stamp(i, 7);
     }
-    // ---- the next frame's frame-tier input for this team's streams (saves the launch that would compute it)
+    // ---- the next frame's frame-tier input for this team's streams (saves the launch that would compute it).  All
+    // operands of an item are requested in one batch (unconditional loads, dummy addresses where an operand is absent).
+    if (timing) stamps[82] = srp_clock();
     if (a.next_in) {
+        constexpr int TW = SRP_GMAX + 1;
         const float half_q = (float)(Q / 2);
         const int NN = a.next_n > 0 ? a.next_n : D, NC = NN / 32;  // this CU's share: NC of the NN columns
-        for (int idx = tid; idx < SRP_ROWS * NC; idx += SRP_THREADS) {
+        const bool gates = a.next_gpre != nullptr, wfast = a.FS <= TW;
+        const float* bias_p = a.next_bias ? a.next_bias : a.next_Win;
+        const float* gpre_p = gates ? a.next_gpre : a.next_Win;
+        const float* h_p = gates ? a.next_h : a.next_Win;
+        for (int idx0 = 0; idx0 < SRP_ROWS * NC; idx0 += SRP_THREADS) {
+            const int idx = min(idx0 + tid, SRP_ROWS * NC - 1);
             const int r = idx / NC, col = cu * NC + idx % NC;
-            const int b = team * SRP_ROWS + r;
-            if (b >= a.B) continue;
+            const int b = team * SRP_ROWS + r, bb = min(b, a.B - 1);
+            const bool live = idx0 + tid < SRP_ROWS * NC && b < a.B;
+            const bool gcol = gates && col < 2 * D;
+            const int hc = col < D ? col : min(col - D, D - 1);
+            float wv[TW];
+#pragma unroll
+            for (int p = 0; p < TW; ++p) wv[p] = a.next_Win[(size_t)min(p, a.FS - 1) * NN + col];
+            const float bv = bias_p[col];
+            const float av = a.next_add[(size_t)bb * a.next_ld_add + col];
+            const float gp = gpre_p[gcol ? (size_t)bb * 2 * D + col : 0];
+            const float hv2 = h_p[gcol ? (size_t)bb * D + hc : 0];
             float acc = 0.f;
-            for (int p = 0; p < a.FS; ++p) {
-                const float xf = ((float)sh->hist[r][a.nsteps + p] / half_q - 1.0f) * 2.0f;
-                acc = fmaf(xf, a.next_Win[(size_t)p * NN + col], acc);
+            if (wfast) {
+                int hq[TW];
+#pragma unroll
+                for (int p = 0; p < TW; ++p) hq[p] = sh->hist[r][a.nsteps + min(p, a.FS - 1)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int p = 0; p < TW; ++p) {
+                    const float xf = ((float)hq[p] / half_q - 1.0f) * 2.0f;
+                    acc = p < a.FS ? fmaf(xf, wv[p], acc) : acc;
+                }
+            } else {
+                for (int p = 0; p < a.FS; ++p) {
+                    const float xf = ((float)sh->hist[r][a.nsteps + p] / half_q - 1.0f) * 2.0f;
+                    acc = fmaf(xf, a.next_Win[(size_t)p * NN + col], acc);
+                }
             }
-            acc += (a.next_bias ? a.next_bias[col] : 0.f) + a.next_add[(size_t)b * a.next_ld_add + col];
-            if (a.next_gpre && col < 2 * D) {
+            acc += (a.next_bias ? bv : 0.f) + av;
+            if (!live) continue;
+            if (gcol) {
                 // the recurrent product h . Wg of the NEXT frame's gates is already there (it does not depend on the new
                 // samples: the projection launch made it): finish the gates here -- one launch fewer per frame
-                const float gt = ph_sigmoid(a.next_gpre[(size_t)b * 2 * D + col] + acc);
-                if (col < D) a.next_z[(size_t)b * D + col] = gt;                                         // update gate
-                else a.next_rh[(size_t)b * D + col - D] = gt * a.next_h[(size_t)b * D + col - D];        // reset gate * h
+                const float gt = ph_sigmoid(gp + acc);
+                if (col < D) a.next_z[(size_t)b * D + col] = gt;          // update gate
+                else a.next_rh[(size_t)b * D + col - D] = gt * hv2;       // reset gate * h
             } else {
                 a.next_in[(size_t)b * NN + col] = acc;
             }
         }
     }
+    if (timing) stamps[83] = srp_clock();
 }
 
 size_t srp_lds_bytes(int D) {

@@ -29,3 +29,25 @@ for q, n in enumerate(names):
     print(f"{n:55s} median {np.median(d[1:9, q]):6.2f} us   (min {d[1:9, q].min():.2f}, max {d[1:9, q].max():.2f})")
 print(f"{'step total':55s} median {np.median(st[2:9, 0] - st[1:8, 0]):6.2f} us")
 print("launch span (10 steps, without prologue): %.2f us" % (st[9, 7] - st[0, 0]))
+ex = w[600 + 160:600 + 168].view(np.int64).astype(np.float64) / 100.0  # kernel entry | prologue done | steps done | tail done
+print("prologue (entry -> first step): %.2f us   tail (next frame's tier input): %.2f us   entry -> tail done: %.2f us"
+      % (ex[1] - ex[0], ex[3] - ex[2], ex[3] - ex[0]))
+fx = w[600 + 168:600 + 186].view(np.int64).astype(np.float64) / 100.0
+if fx[0] > 0:
+    b2, b5 = st[5, 2], st[5, 5]
+    print("step 5, L3 product (from x1 taken): FMAs %.2f | DPP fold %.2f | barrier %.2f | final sums %.2f | published (stamp 3) %.2f"
+          % (fx[0] - b2, fx[1] - fx[0], fx[2] - fx[1], fx[3] - fx[2], st[5, 3] - fx[3]))
+    print("step 5, output product (from x2 taken): FMAs %.2f | DPP fold %.2f | barrier %.2f | final sums %.2f | published %.2f | logits taken %.2f"
+          % (fx[4] - b5, fx[5] - fx[4], fx[6] - fx[5], fx[7] - fx[6], fx[8] - fx[7], st[5, 6] - fx[8]))
+# end-to-end: a longer utterance through the graph path
+T2 = 25
+gen2 = tt.DeviceGenerator(B, T2, temperature=0.0)
+feats2 = np.random.RandomState(1).randn(T2, B, 63).astype('float32')
+gen2.generate(feats2); torch.cuda.synchronize()
+import time
+ts = []
+for _ in range(7):
+    t = time.perf_counter(); out = gen2.generate(feats2); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+ns = T2 * 80
+print("generation, %d samples x %d streams: %.2f us per sample step (min of 7; median %.2f)"
+      % (ns, B, min(ts) * 1e6 / ns, float(np.median(ts)) * 1e6 / ns))
