@@ -11,6 +11,13 @@ constexpr int SRP_MAXHIST = 64;       // FS + nsteps
 constexpr int SRP_GMAX = 12;          // table rows of the gather requested in one batch (FS - 1 <= SRP_GMAX; else a loop)
 // f32x4 hand-off slots per team in the workspace: x1, x2 [D] and the logits [Q]
 __host__ __device__ constexpr int srp_team_vecs(int D, int Q) { return 2 * D + Q; }
+// Carry between consecutive launches, per team, behind the hand-off slots: [0] the sample index it is for (-1: none),
+// [16 ..) the team's last FS samples [4][SRP_CARRY_HIST], then per CU the table part of the next first gather [32][4][DC <= 32]
+constexpr int SRP_CARRY_HIST = 32;
+constexpr int SRP_CARRY_WORDS = 16 + SRP_ROWS * SRP_CARRY_HIST + SRP_TEAM * SRP_ROWS * 32;
+__host__ __device__ constexpr long long srp_carry_base(int D, int Q) {
+    return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * srp_team_vecs(D, Q) * 4;
+}
 
 __device__ __forceinline__ int srp_xcc() {
     unsigned v;
@@ -79,24 +86,6 @@ __device__ __forceinline__ f32x4 srp_take(__amdgpu_buffer_rsrc_t r, unsigned byt
         v = srp_ld(r, byte_off);
     }
     return v;
-}
-
-// The same for the NK slots k = tid + j * SRP_THREADS < n of a thread: every slot requested once up front (one L2 round
-// trip for the slots that are already full), then the empty ones re-read one after the other.
-template <int NK>
-__device__ __forceinline__ void srp_take_all(__amdgpu_buffer_rsrc_t r, unsigned base_vec, int n, int tid, f32x4* __restrict__ dst,
-                                             unsigned* abort_, SrpShared* sh) {
-    f32x4 v[NK];
-#pragma unroll
-    for (int j = 0; j < NK; ++j) v[j] = srp_ld(r, (base_vec + (unsigned)min(tid + j * SRP_THREADS, n - 1)) * 16u);
-#pragma unroll
-    for (int j = 0; j < NK; ++j) {
-        const int k = tid + j * SRP_THREADS;
-        if (k < n) {
-            if (srp_is_empty(v[j])) v[j] = srp_take(r, (base_vec + (unsigned)k) * 16u, abort_, sh);
-            dst[k] = v[j];
-        }
-    }
 }
 
 // f32x4 += the same vector of the lane selected by a DPP control (all four components)

@@ -34,12 +34,18 @@
 
 namespace {
 
+// -DSRP_FINE_TIMERS: step 5 of a timed launch also stamps the inside of its two products (tools/sr_timing.py)
+#ifdef SRP_FINE_TIMERS
+#define SRP_FINE(slot) (timing && i == 5 ? stamps + (slot) : nullptr)
+#else
+#define SRP_FINE(slot) nullptr
+#endif
+
 template <int D>
 __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     constexpr int Q = SRP_Q;
     constexpr int DC = D / 32, G = DC / 4, S = SRP_THREADS / G, KP = D / S;
     constexpr int QC = Q / 32, GQ = QC / 4, SQ = SRP_THREADS / GQ, KQ = D / SQ;
-    constexpr int NKD = (D + SRP_THREADS - 1) / SRP_THREADS;  // hand-off slots of x1 / x2 per thread
     static_assert(KP >= 1 && KQ >= 1 && S * G == SRP_THREADS && S * KP == D, "unsupported width");
     extern __shared__ __attribute__((aligned(16))) char srp_smem[];
     f32x4* act = reinterpret_cast<f32x4*>(srp_smem);       // [D]
@@ -62,21 +68,35 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     const int cu = (int)(blockIdx.x / SRP_NTEAMS);
     const bool timing = a.pad && blockIdx.x == 0 && tid == 0;
     if (timing) stamps[80] = srp_clock();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(sync + 256 + team * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        sh->rank = cu;
-        sh->ok = 1;
-    }
+    if (tid == 0) __hip_atomic_fetch_add(sync + 256 + team * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 
-    // ---- the weight slices: L3 and Output -> registers; this CU's columns of the newest sample's table -> LDS; the
-    // sample history (the gather of step 0 waits for it).  Every load is requested before the first wait.
-    const int t0 = a.tbase[0] + a.toff;
+    // ---- Prologue.  Everything the first step needs is requested before the first wait, in the order of need: the
+    // carry of the previous launch (below), the newest sample's table slice (-> LDS), then the weight slices of L3 and
+    // Output (-> registers), which the first step's products wait for where they use them.
+    //
+    // Carry: the sample history of this team and the table part of step 0's gather depend on the samples the PREVIOUS
+    // launch produced -- through tbase -> samples -> table rows, three dependent cold round trips.  The previous launch
+    // knows all of it when it ends, so its tail leaves both in the workspace (history [4][FS]; per CU the sums
+    // [4][DC]) together with the sample index they are for; a launch whose t0 matches takes them from fixed
+    // addresses (one round trip beside everything else), any other launch (the first of an utterance) walks the chain.
+    // (tbase and the carry's sample index through the scalar cache: not in the queue of the vector loads, whose results
+    // return in order -- the weight requests need not wait for them)
+    typedef const int __attribute__((address_space(4))) * srp_cint;
+    const int t0 = *(srp_cint)(unsigned long long)a.tbase + a.toff;
+    int* carry = reinterpret_cast<int*>(a.ws + srp_carry_base(D, Q)) + (size_t)team * SRP_CARRY_WORDS;
+    float* carry_sum = reinterpret_cast<float*>(carry + 16 + SRP_ROWS * SRP_CARRY_HIST) + (size_t)cu * SRP_ROWS * DC;
+    const int carry_t = *(srp_cint)(unsigned long long)carry;
+    // (threads past SRP_ROWS * FS repeat the last slot: same address, same value, same LDS word -- no divergent block the
+    // compiler could sink the request into)
+    const int hu = min(tid, SRP_ROWS * a.FS - 1), hr = hu / a.FS, hpos = hu % a.FS;
+    const int hc = carry[16 + hr * SRP_CARRY_HIST + min(hpos, SRP_CARRY_HIST - 1)];
+    constexpr int GU = SRP_ROWS * DC, GW0 = (SRP_THREADS - GU) / 64;  // first gathering wave (GU <= 128: waves 6-7 at D = 1024)
+    const int gu = min(max(tid - GW0 * 64, 0), GU - 1), gr = gu / DC, gc = gu % DC;
+    const int gb = min(team * SRP_ROWS + gr, a.B - 1);
+    const float cs = carry_sum[gu];
+    const float f0 = a.frame_out[(size_t)gb * a.ldf + cu * DC + gc];
     const int g = (tid >> 3) % G, s = 8 * (tid / (8 * G)) + (tid & 7);
     const int gq = (tid >> 3) % GQ, sq = 8 * (tid / (8 * GQ)) + (tid & 7);
-    f32x4 w3[KP], w4[KQ];
-#pragma unroll
-    for (int kk = 0; kk < KP; ++kk)
-        w3[kk] = *reinterpret_cast<const f32x4*>(a.W3 + (size_t)(kk * S + s) * D + cu * DC + 4 * g);
     constexpr int T2V = Q * (DC / 4) / SRP_THREADS;  // f32x4 of the table slice per thread
     static_assert(T2V * SRP_THREADS == Q * (DC / 4), "table slice not a multiple of the workgroup");
     f32x4 tv[T2V];
@@ -85,36 +105,33 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         const int idx = tid + j * SRP_THREADS, q = idx / (DC / 4), c4 = idx % (DC / 4);
         tv[j] = *reinterpret_cast<const f32x4*>(a.t2tbl + ((size_t)(a.FS - 1) * Q + q) * D + cu * DC + 4 * c4);
     }
-#pragma unroll
-    for (int kk = 0; kk < KQ; ++kk)
-        w4[kk] = *reinterpret_cast<const f32x4*>(a.W4 + (size_t)(kk * SQ + sq) * Q + cu * QC + 4 * gq);
-    // the history's address waits for tbase: requested behind the weights, which do not
-    __builtin_amdgcn_sched_barrier(0);
-    // (threads past SRP_ROWS * FS repeat the last slot: same address, same value, same LDS word -- no divergent block the
-    // compiler could sink the request into)
-    const int hu = min(tid, SRP_ROWS * a.FS - 1), hr = hu / a.FS, hpos = hu % a.FS;
-    const int hv = a.samples[(size_t)min(team * SRP_ROWS + hr, a.B - 1) * a.len + t0 - a.FS + hpos];
     // column this thread finishes in the reductions (threads tid < DC / tid < QC)
     const int fin_h = cu * DC + 4 * (tid % G) + tid / G;
     const int fin_q = cu * QC + 4 * (tid % GQ) + tid / GQ;
     const float bias3 = a.b3[min(fin_h, D - 1)];
     const float bias4 = a.b4[min(fin_q, Q - 1)];
-    sh->hist[hr][hpos] = hv;
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 w3[KP], w4[KQ];
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)
+        w3[kk] = *reinterpret_cast<const f32x4*>(a.W3 + (size_t)(kk * S + s) * D + cu * DC + 4 * g);
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk)
+        w4[kk] = *reinterpret_cast<const f32x4*>(a.W4 + (size_t)(kk * SQ + sq) * Q + cu * QC + 4 * gq);
+    __builtin_amdgcn_sched_barrier(0);
     // team exchange buffers ([D] f32x4 each, 4 streams per vector): x1, x2, and the logits ([Q] f32x4)
     float* xbase = a.ws + SRP_SYNC_WORDS + (size_t)team * srp_team_vecs(D, Q) * 4;
     const __amdgpu_buffer_rsrc_t xr = srp_rsrc(xbase);
     f32x4* x1 = reinterpret_cast<f32x4*>(xbase);
     f32x4* x2 = x1 + D;
     f32x4* lb = x2 + D;
-    __syncthreads();
 
     // Slot life cycle.  All slots are EMPTY when a plan is created (srp_init_ws) and every launch leaves them EMPTY again,
-    // except the logits of its last step, which their new owners empty right here (nobody looks at the logits before
-    // having taken a complete x2, and the emptying threads publish part of x1 -- after s_waitcnt vmcnt(0) -- before that).
-    // During the launch a buffer is emptied by its owner as soon as the owner has taken the NEXT buffer of the chain from
-    // all 32 CUs (which proves that all of them are done with this one), always by threads that later publish, behind an
+    // except the logits of its last step: their owners empty them once they hold the complete x1 of the NEXT launch's
+    // first step (every CU that published into it has left the previous launch), like the logits of any other step.
+    // A buffer is emptied by its owner as soon as the owner has taken the NEXT buffer of the chain from all 32 CUs (which
+    // proves that all of them are done with this one), always by threads that later publish, behind an
     // s_waitcnt vmcnt(0), something the readers take before they look at the emptied buffer again.  No counted barrier.
-    if (tid < QC) lb[fin_q] = srp_empty();
 
     // part_i = frame_out[:, i] + sum_{pos < FS-1} t2tbl[pos][sample[t - FS + pos]] for this CU's DC columns: everything of
     // step i's L2 pre-activation that is known one step early (frame_out carries the composed projection and both
@@ -125,14 +142,11 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     // inside a divergent block is closed by the compiler with s_waitcnt vmcnt(0).  The sum keeps the order of the
     // positions.  Result transposed through tmp; threads tid < DC pick it up behind the next workgroup barrier.
     f32x4 part = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int GU = SRP_ROWS * DC, GW0 = (SRP_THREADS - GU) / 64;  // first gathering wave (GU <= 128: waves 6-7 at D = 1024)
-    const int gu = min(max(tid - GW0 * 64, 0), GU - 1), gr = gu / DC, gc = gu % DC;
-    const int gb = min(team * SRP_ROWS + gr, a.B - 1);
     const bool gwave = __builtin_amdgcn_readfirstlane(wave) >= GW0, gfast = a.FS - 1 <= SRP_GMAX;
+    const bool glane = tid - GW0 * 64 >= 0 && tid - GW0 * 64 < GU;
     float gf = 0.f, gv[SRP_GMAX];
     const __amdgpu_buffer_rsrc_t tr = srp_rsrc(a.t2tbl);
-    auto gather_request = [&](int i) {
-        gf = a.frame_out[(size_t)gb * a.ldf + (size_t)i * D + cu * DC + gc];
+    auto gather_rows = [&](int i) {
         int hq[SRP_GMAX];  // the history in one LDS round trip (left to itself the compiler reads, waits, requests: x 12)
 #pragma unroll
         for (int pos = 0; pos < SRP_GMAX; ++pos) hq[pos] = sh->hist[gr][i + max(min(pos, a.FS - 2), 0)];
@@ -146,8 +160,11 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
                 tr, (unsigned)(hq[pos] * D + cu * DC + gc) * 4u, (unsigned)(pp * Q * D) * 4u, 0));
         }
     };
-    auto gather_sum = [&](int i) {
-        float acc = gf;
+    auto gather_request = [&](int i) {
+        gf = a.frame_out[(size_t)gb * a.ldf + (size_t)i * D + cu * DC + gc];
+        gather_rows(i);
+    };
+    auto rows_sum = [&](int i, float acc) {
         if (gfast) {
 #pragma unroll
             for (int pos = 0; pos < SRP_GMAX; ++pos) acc = pos < a.FS - 1 ? acc + gv[pos] : acc;
@@ -155,13 +172,28 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
             for (int pos = 0; pos < a.FS - 1; ++pos)
                 acc += a.t2tbl[((size_t)pos * Q + sh->hist[gr][i + pos]) * D + cu * DC + gc];
         }
-        if (tid - GW0 * 64 >= 0 && tid - GW0 * 64 < GU) tmp[gc * SRP_ROWS + gr] = acc;
+        return acc;
+    };
+    auto gather_sum = [&](int i) {
+        const float acc = rows_sum(i, gf);
+        if (glane) tmp[gc * SRP_ROWS + gr] = acc;
     };
     auto take_part = [&]() { if (tid < DC) part = reinterpret_cast<const f32x4*>(tmp)[fin_h - cu * DC]; };
-    if (gwave) gather_request(0);
+    if (tid == 0) sh->ok = 1;
 #pragma unroll
     for (int j = 0; j < T2V; ++j) reinterpret_cast<f32x4*>(t2l)[tid + j * SRP_THREADS] = tv[j];
-    if (gwave) gather_sum(0);
+    if (carry_t == t0) {
+        sh->hist[hr][hpos] = hc;
+        if (glane) tmp[gc * SRP_ROWS + gr] = f0 + cs;
+    } else {
+        const int hv = a.samples[(size_t)min(team * SRP_ROWS + hr, a.B - 1) * a.len + t0 - a.FS + hpos];
+        sh->hist[hr][hpos] = hv;
+        __syncthreads();
+        if (gwave) {
+            gather_request(0);
+            gather_sum(0);
+        }
+    }
     __syncthreads();
     take_part();
     if (timing) stamps[81] = srp_clock();
@@ -176,51 +208,32 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
             f32x4 v = part;
 #pragma unroll
             for (int r = 0; r < SRP_ROWS; ++r) v[r] += t2l[sh->hist[r][i + a.FS - 1] * DC + c];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (behind the stores that emptied x2: none in front of step 0, whose wait would be for the weight slices)
+            if (i > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             x1[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         }
         stamp(i, 1);
         {
-#ifdef SRP_TAKE_BATCH
-            srp_take_all<NKD>(xr, 0u, D, tid, act, abort_, sh);
-#else
             for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)(k * 16), abort_, sh);
-#endif
             __syncthreads();
             if (!sh->ok) return;
             stamp(i, 2);
-            // x1(i) complete => every CU is done with the logits of step i-1
-            if (i > 0 && tid < QC) lb[fin_q] = srp_empty();
-#ifndef SRP_GATHER_BESIDE
+            // x1(i) complete => every CU is done with the logits of step i-1 (i = 0: of the previous launch's last step)
+            if (tid < QC) lb[fin_q] = srp_empty();
             if (more && gwave) gather_request(i + 1);
-#endif
             f32x4 v;
-            srp_layer<KP, G>(act, w3, red, v, tid, timing && i == 5 ? stamps + 84 : nullptr);
+            srp_layer<KP, G>(act, w3, red, v, tid, SRP_FINE(84));
             if (tid < DC) {
                 v += bias3;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 x2[fin_h] = (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             }
             stamp(i, 3);
-#ifndef SRP_GATHER_BESIDE
             if (more && gwave) gather_sum(i + 1);
-#endif
             stamp(i, 4);
         }
         {
-#ifdef SRP_GATHER_BESIDE
-            // waves 0-3 take x2; the gathering waves request and sum the next step's part meanwhile
-            if (tid < SRP_THREADS / 2) {
-                for (int k = tid; k < D; k += SRP_THREADS / 2) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
-            } else if (more && gwave) {
-                gather_request(i + 1);
-                gather_sum(i + 1);
-            }
-#elif defined(SRP_TAKE_BATCH)
-            srp_take_all<NKD>(xr, (unsigned)D, D, tid, act, abort_, sh);
-#else
             for (int k = tid; k < D; k += SRP_THREADS) act[k] = srp_take(xr, (unsigned)((D + k) * 16), abort_, sh);
-#endif
             __syncthreads();
             if (!sh->ok) return;
             if (more) take_part();
@@ -230,12 +243,14 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
                 for (int q = 0; q < DC / QC; ++q) x1[cu * DC + tid * (DC / QC) + q] = srp_empty();
             }
             f32x4 v;
-            srp_layer<KQ, GQ>(act, w4, red, v, tid, timing && i == 5 ? stamps + 88 : nullptr);
+            srp_layer<KQ, GQ>(act, w4, red, v, tid, SRP_FINE(88));
             if (tid < QC) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lb[fin_q] = v + bias4;
             }
+#ifdef SRP_FINE_TIMERS
             if (timing && i == 5) stamps[92] = srp_clock();
+#endif
         }
 
         // ---- pick (every CU of the team, identical result): argmax with lowest-index ties, or the seeded draw
@@ -287,6 +302,15 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
         __syncthreads();
         stamp(i, 7);
     }
+    // ---- the carry for the next launch (see the prologue): this team's last FS samples and, per CU, the table part of
+    // the next launch's first gather -- requested here, stored at the very end
+    const bool leave = gfast && a.FS <= SRP_CARRY_HIST;
+    if (leave && gwave) gather_rows(a.nsteps);
+    if (leave && cu == 0) {
+        carry[16 + hr * SRP_CARRY_HIST + min(hpos, SRP_CARRY_HIST - 1)] = sh->hist[hr][a.nsteps + hpos];
+        if (tid == 0) carry[0] = t0 + a.nsteps;
+    }
+    if (!leave && cu == 0 && tid == 0) carry[0] = -1;
     // ---- the next frame's frame-tier input for this team's streams (saves the launch that would compute it).  All
     // operands of an item are requested in one batch (unconditional loads, dummy addresses where an operand is absent).
     if (timing) stamps[82] = srp_clock();
@@ -342,6 +366,10 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
             }
         }
     }
+    if (leave && gwave) {
+        const float acc = rows_sum(a.nsteps, 0.f);
+        if (glane) carry_sum[gu] = acc;
+    }
     if (timing) stamps[83] = srp_clock();
 }
 
@@ -365,13 +393,15 @@ bool srp_eligible(int B, int D, int Q, int FS) {
     return D == 256 || D == 512 || D == 1024;
 }
 
-long long srp_ws_floats(int D, int Q) { return SRP_SYNC_WORDS + (long long)SRP_NTEAMS * srp_team_vecs(D, Q) * 4; }
+long long srp_ws_floats(int D, int Q) { return srp_carry_base(D, Q) + (long long)SRP_NTEAMS * SRP_CARRY_WORDS; }
 
 int srp_init_ws(float* ws, int D, int Q) {
     // barrier / census / abort words zero, every hand-off slot EMPTY
     PH_CHECK(hipMemset(ws, 0, SRP_SYNC_WORDS * sizeof(float)));
     PH_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ws + SRP_SYNC_WORDS), (int)SRP_EMPTY,
                           (size_t)SRP_NTEAMS * srp_team_vecs(D, Q) * 4));
+    // no carry yet: the sample index it is for can never match
+    PH_CHECK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(ws + srp_carry_base(D, Q)), -1, (size_t)SRP_NTEAMS * SRP_CARRY_WORDS));
     return (int)hipDeviceSynchronize();
 }
 

@@ -197,7 +197,8 @@ def _greedy_follows_oracle(out, ref, ref_logits, B, slack_rows):
 def test_persistent_sample_kernel_matches_oracle_and_launch_path(dev, dim, B, T, monkeypatch):
     """sr_persist.hip (one launch per 10 sample steps, XCD-local teams) vs the fp64 oracle and vs the five-launches-per-
     sample path (three_tier.py:452-515, 809-832): greedy indices, graph replay and eager launches, partial teams
-    (B not a multiple of 4), two calls on one plan (barrier generations carry over)."""
+    (B not a multiple of 4), two calls on one plan and a second utterance on it (what a launch leaves for the next one --
+    slot states, the carried history and gather -- is either valid or recognised as stale)."""
     from oracle import samplernn_ref as S
     from parrot_amd.sampleRNN import lib
     from parrot_amd.sampleRNN.models.conditional import three_tier as tt
@@ -223,7 +224,14 @@ def test_persistent_sample_kernel_matches_oracle_and_launch_path(dev, dim, B, T,
                 last = gen.ws['logits'].detach().cpu().double()
                 assert_close(last[exact], ref_logits[exact, -1], 1e-4, "last-step logits")
             outs[use_graph] = out
+            # another utterance on the same plan: the carry the last launch left behind (history + first gather of a
+            # launch that never comes) must not leak into it -- same samples as a fresh plan produces
+            feats2 = torch.randn(T, B, 63, generator=torch.Generator().manual_seed(7)).numpy()
+            again = gen.generate(feats2).cpu().numpy().copy()
             gen.close()
+            fresh = tt.DeviceGenerator(B, T, temperature=0.0, use_graph=use_graph)
+            assert np.array_equal(again, fresh.generate(feats2).cpu().numpy())
+            fresh.close()
         assert np.array_equal(outs[True], outs[False])
         monkeypatch.setenv("PARROT_SR_PERSIST", "0")
         gen = tt.DeviceGenerator(B, T, temperature=0.0)
