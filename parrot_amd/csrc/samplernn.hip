@@ -21,6 +21,7 @@
 
 namespace {
 
+
 // xf[b][i] = (s / (Q/2) - 1) * 2 for the `n` samples before t (three_tier.py:309-310, 398-399);
 // optionally copies the conditioning frame of the current big frame.
 __global__ __launch_bounds__(256) void sr_prep_kernel(const int* __restrict__ samples, int len, const int* __restrict__ tbase,
@@ -219,11 +220,14 @@ struct SrPlan {
         }
         return 0;
     }
-    hipGraphExec_t exec = nullptr;
+    enum { SR_CHUNK = 8 };
+    hipGraphExec_t exec = nullptr, exec_chunk = nullptr;
+    int periods_left_single = 0;
     hipStream_t cap = nullptr;
     int last_error = 0;
     ~SrPlan() {
         if (exec) hipGraphExecDestroy(exec);
+        if (exec_chunk) hipGraphExecDestroy(exec_chunk);
         if (cap) hipStreamDestroy(cap);
         if (tiled_slab) (void)hipFree(tiled_slab);
         if (t2tbl) (void)hipFree(t2tbl);
@@ -356,19 +360,22 @@ struct SrPlan {
             if (winu) {  // the big tier's share of every frame's pre-activations: pbig[(b, f)] = big_out[b, f*D : (f+1)*D] . U +
                          // (bin . U + bU), one step-kernel launch with one job per frame (the LDS-tiled GEMM would put the
                          // [B nfr, 3D] product on 48 workgroups of 128 x 128 x K: measured 75 us per period)
+                // big_out [B, nfr D] is a [B nfr, D] matrix of (stream, frame) rows and pbig [B nfr, 3D] likewise: jobs of up
+                // to 64 consecutive rows each (the step kernel's tallest tile), every job streaming U once -- 12 MB x
+                // B nfr / 64 per period where one job per frame (32 rows) read it nfr times
                 SkJob jobs[SK_MAXJOB];
-                const int blk = (D >> 4) * 256;
-                for (int f0 = 0; f0 < nfr; f0 += SK_MAXJOB) {
+                const int blk = (D >> 4) * 256, rows = B * nfr, RJ = 64;
+                for (int r0 = 0; r0 < rows; r0 += RJ * SK_MAXJOB) {
                     int nj = 0;
-                    for (int f = f0; f < nfr && nj < SK_MAXJOB; ++f, ++nj) {
+                    for (int r = r0; r < rows && nj < SK_MAXJOB; r += RJ, ++nj) {
                         SkJob& j = jobs[nj];
                         sk_job_init(j);
                         j.nseg = 1;
-                        j.seg[0] = t_frm.U ? sk_seg(d.big_out + (size_t)f * D, nfr * D, t_frm.U, blk, D, 2)
-                                           : sk_seg(d.big_out + (size_t)f * D, nfr * D, d.frm_U, 3 * D, D, 0);
-                        j.M = B; j.N = 3 * D; j.H = 3 * D; j.epi = SK_EPI_LINEAR;
+                        j.seg[0] = t_frm.U ? sk_seg(d.big_out + (size_t)r * D, D, t_frm.U, blk, D, 2)
+                                           : sk_seg(d.big_out + (size_t)r * D, D, d.frm_U, 3 * D, D, 0);
+                        j.M = rows - r < RJ ? rows - r : RJ; j.N = 3 * D; j.H = 3 * D; j.epi = SK_EPI_LINEAR;
                         j.bias = pbias;
-                        j.out = pbig + (size_t)f * 3 * D; j.ldo = nfr * 3 * D;
+                        j.out = pbig + (size_t)r * 3 * D; j.ldo = 3 * D;
                     }
                     SkLaunch L;
                     SR_TRY(sk_make_launch(L, jobs, nj));
@@ -465,23 +472,35 @@ struct SrPlan {
             for (int p = 0; p < periods; ++p) SR_TRY(period(st));
             return 0;
         }
-        if (!exec) {
+        // Two graphs: one period, and SR_CHUNK periods back to back (a graph launch costs ~9 us of idle GPU between two
+        // periods -- 0.1 us per sample; the chunk graph pays it once per SR_CHUNK periods).  tbase advances on the device.
+        auto capture = [&](int n, hipGraphExec_t* out) -> int {
             if (!cap) {
-                e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
-                if (e != hipSuccess) return (int)e;
+                hipError_t ce = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
+                if (ce != hipSuccess) return (int)ce;
             }
-            e = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
-            if (e != hipSuccess) return (int)e;
-            const int rc = period(cap);
+            hipError_t ce = hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed);
+            if (ce != hipSuccess) return (int)ce;
+            int rc = 0;
+            for (int q = 0; q < n && rc == 0; ++q) rc = period(cap);
             hipGraph_t graph = nullptr;
-            e = hipStreamEndCapture(cap, &graph);
+            ce = hipStreamEndCapture(cap, &graph);
             if (rc != 0) { if (graph) hipGraphDestroy(graph); return rc; }
-            if (e != hipSuccess) return (int)e;
-            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (ce != hipSuccess) return (int)ce;
+            ce = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
-            if (e != hipSuccess) { exec = nullptr; return (int)e; }
+            if (ce != hipSuccess) { *out = nullptr; return (int)ce; }
+            return 0;
+        };
+        if (!exec) SR_TRY(capture(1, &exec));
+        if (periods >= SR_CHUNK && !exec_chunk) SR_TRY(capture(SR_CHUNK, &exec_chunk));
+        int left = periods;
+        for (; exec_chunk && left >= SR_CHUNK; left -= SR_CHUNK) {
+            e = hipGraphLaunch(exec_chunk, st);
+            if (e != hipSuccess) return (int)e;
         }
-        for (int p = 0; p < periods; ++p) {
+        periods_left_single = left;
+        for (int p = 0; p < periods_left_single; ++p) {
             e = hipGraphLaunch(exec, st);
             if (e != hipSuccess) return (int)e;
         }
