@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void sr_pick_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void sr_frame_in_kernel(const int* __restrict__ samples, int len, const int* __restrict__ tbase,
                                                           int toff, int FS, float half_q, const float* __restrict__ Win,
                                                           const float* __restrict__ bias, const float* __restrict__ add,
-                                                          int ld_add, float* __restrict__ out, int D) {
+                                                          int ld_add, float* __restrict__ out, int D,
+                                                          const float* __restrict__ gpre = nullptr, const float* __restrict__ h = nullptr,
+                                                          float* __restrict__ z = nullptr, float* __restrict__ rh = nullptr, int Dh = 0) {
     const int t = tbase[0] + toff;
     const int b = blockIdx.y, dd = blockIdx.x * 256 + threadIdx.x;
     if (dd >= D) return;
@@ -121,7 +123,17 @@ __global__ __launch_bounds__(256) void sr_frame_in_kernel(const int* __restrict_
         const float xf = ((float)samples[(size_t)b * len + t - FS + i] / half_q - 1.0f) * 2.0f;
         acc = fmaf(xf, Win[(size_t)i * D + dd], acc);
     }
-    out[(size_t)b * D + dd] = acc + (bias ? bias[dd] : 0.f) + add[(size_t)b * ld_add + dd];
+    acc += (bias ? bias[dd] : 0.f) + add[(size_t)b * ld_add + dd];
+    if (gpre && dd < 2 * Dh) {
+        // (D = 3 Dh: gates | candidate) the recurrent product h . Wg of this frame's gates is there already (the previous
+        // frame's projection launch made it): the gates are finished here, as the sample kernel's tail does for the frames
+        // inside a period -- the frame costs one launch less
+        const float gt = ph_sigmoid(gpre[(size_t)b * 2 * Dh + dd] + acc);
+        if (dd < Dh) z[(size_t)b * Dh + dd] = gt;
+        else rh[(size_t)b * Dh + dd - Dh] = gt * h[(size_t)b * Dh + dd - Dh];
+        return;
+    }
+    out[(size_t)b * D + dd] = acc;
 }
 
 __global__ void sr_tick_kernel(int* tbase, int inc, int set) {
@@ -389,11 +401,18 @@ struct SrPlan {
             // (on the persistent path the previous frame's sample kernel has already left this frame's input in gru_in)
             const float* ftop = nullptr;
             if (winu) {  // composed input: pin = xf . (Win . U) + pbig[f]  ([B, 3D]); the step GEMMs walk K = D
-                if (!persist || f == 0)
+                // (persistent path: h . Wg of this frame's gates was made beside the previous frame's projection -- the last
+                // frame of the previous period, or run()'s launch in front of the first one -- so the input kernel of a
+                // period's first frame finishes the gates as the sample kernel does for the other frames)
+                if (!persist)
                     hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(3 * D, 256), B), dim3(256), 0, st, d.samples, len,
                                        d.tbase, toff, FS, half_q, winu, (const float*)nullptr, pbig + (size_t)f * 3 * D,
                                        nfr * 3 * D, pin, 3 * D);
-                SR_TRY(gru(nullptr, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st, &t_frm, pin, persist && f > 0));
+                else if (f == 0)
+                    hipLaunchKernelGGL(sr_frame_in_kernel, dim3(ceil_div(3 * D, 256), B), dim3(256), 0, st, d.samples, len,
+                                       d.tbase, toff, FS, half_q, winu, (const float*)nullptr, pbig + (size_t)f * 3 * D,
+                                       nfr * 3 * D, pin, 3 * D, (const float*)gpre, (const float*)d.frm_h, d.z, d.rh, D);
+                SR_TRY(gru(nullptr, d.frm_U, d.frm_bU, d.frm_Wg, d.frm_Wc, d.frm_h, st, &t_frm, pin, persist));
                 ftop = d.frm_h;
             } else {
                 if (!persist || f == 0)
@@ -401,7 +420,7 @@ struct SrPlan {
                                        toff, FS, half_q, d.frm_Win, d.frm_bin, d.big_out + (size_t)f * D, nfr * D, d.gru_in, D);
                 SR_TRY(stack_step(false, d.gru_in, &ftop, st));
             }
-            if (persist && winu && f + 1 < nfr) {
+            if (persist && winu) {  // (last frame of the period: the gates' product of the next period's first frame)
                 // the projection and, beside it, the recurrent product of the NEXT frame's gates (h' . Wg: it does not wait for
                 // the frame's samples); the sample kernel finishes those gates at its end
                 SkJob jobs[2];
@@ -468,6 +487,9 @@ struct SrPlan {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         const int periods = d.T - 1;
+        if (persist && winu)  // h0 . Wg: the gates' recurrent product of the very first frame (see period())
+            SR_TRY(linear(d.frm_h, d.D, d.frm_Wg, 2 * d.D, d.D, 2 * d.D, nullptr, nullptr, 0, gpre, 2 * d.D, 0, st, nullptr, 0,
+                          nullptr, 0, t_frm.Wg));
         if (!d.use_graph) {
             for (int p = 0; p < periods; ++p) SR_TRY(period(st));
             return 0;

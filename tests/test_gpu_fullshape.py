@@ -6,7 +6,7 @@ window state AND every parameter gradient -- at the real widths, on windows shor
   cfg2  configs[1]: L=2 GRU, H=R=1024, B=64, U=200, ragged masks, kappa bias -1.5 (window stays inside the text)
   cfg4  configs[3]: L=3 LSTM, H=R=1536, B=64 per GPU
   cfg3  configs[2]: decode N=16, H=1024, feedback on, 60 steps
-  cfg5  configs[4]: SampleRNN generator DIM=1024, B=32, 1600 samples, greedy
+  cfg5  configs[4]: SampleRNN generator DIM=1024, B=32, 2000 samples (bench.py's utterance), greedy
 
 Reference lines: model.py:651-824 (training scan + cost), :882-1057 (decode scan), three_tier.py:795-832."""
 import numpy as np
@@ -562,7 +562,8 @@ def test_cfg3_decode_width(dev):
 
 
 def test_cfg5_generator_full_width_greedy(dev, capsys):
-    """BASELINE configs[4]: three-tier GRU DIM=1024, batch 32, 20 frames = 1600 samples, temperature 0.
+    """BASELINE configs[4]: three-tier GRU DIM=1024, batch 32, 25 frames = 2000 samples (the utterance bench.py times),
+    temperature 0.
     Greedy indices must equal the fp64 oracle's; a row may only leave the oracle's trajectory at a position where the
     oracle's own top-2 logits are closer than fp32 can resolve (gap < 2e-5 * |logit|max), which is then reported.
     The logits of the last sample step are compared at 1e-4."""
@@ -577,7 +578,7 @@ def test_cfg5_generator_full_width_greedy(dev, capsys):
         p = S.init_params(c, seed=5, perturb=0.2)
         lib.set_params(p)
         g = torch.Generator().manual_seed(2)
-        T, B = 20, 32
+        T, B = 25, 32
         feats = torch.randn(T, B, 63, generator=g, dtype=torch.float64)
         with torch.no_grad():
             ref, ref_logits = S.generate(p, c, feats, return_logits=True)
