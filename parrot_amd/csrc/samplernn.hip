@@ -437,6 +437,9 @@ struct SrPlan {
                 jobs[1].out = gpre; jobs[1].ldo = 2 * D;
                 SkLaunch L;
                 SR_TRY(sk_make_launch(L, jobs, 2));
+                // (FS + 2) D columns = 768 column tiles at D = 1024: 16-column workgroups are three per CU; the heuristic's
+                // 32-column ones (384) leave half the CUs with two streams and half with one (8.17 vs 8.07 us per sample)
+                L.force_tile = 21;
                 SR_TRY(sk_launch(L, st));
             } else {
                 SR_TRY(linear(ftop, D, persist ? Pout : d.frm_Wout, FS * D, D, FS * D, persist ? cb : d.frm_bout, nullptr, 0,
