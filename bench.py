@@ -491,7 +491,7 @@ def secondary_leg(a):
     gen = tt.DeviceGenerator(B, T, temperature=0.0)
     feats = torch.randn(T, B, 63, generator=g).numpy()
     best = None
-    for rep in range(3):
+    for rep in range(6):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         gen.generate(feats)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
