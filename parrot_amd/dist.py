@@ -30,9 +30,16 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _force_one_rank():
+    """PARROT_DIST_FORCE=1: a ONE-rank process group counts as distributed -- every collective of the training step is issued
+    (and is the identity).  The only way to drive the RCCL path of Trainer.step on a box with a single GPU
+    (tests/test_gpu_dp.py::test_one_rank_rccl_trainer_step_equals_plain_step)."""
+    return os.environ.get("PARROT_DIST_FORCE", "0") == "1"
+
+
 def init_process_group(backend=None):
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force_one_rank()) and not dist.is_initialized():
         if backend is None:
             # PARROT_DIST_BACKEND=gloo: plumbing test of the N > 1 path on a box with fewer GPUs than ranks
             backend = os.environ.get("PARROT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -65,7 +72,7 @@ class local_only:
 def is_distributed():
     if _LOCAL_ONLY:
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force_one_rank())
 
 
 def shard_batch(batch_size, rank, world):

@@ -69,6 +69,35 @@ def test_two_rank_trainer_step_equals_single_process(dev):
     assert torch.equal(ret[0][0], ret[1][0]), "replicas stay bit-identical"
 
 
+def _worker_rccl(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      PARROT_DIST_BACKEND="nccl", PARROT_DIST_FORCE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from parrot_amd import dist as pdist
+    pdist.init_process_group()
+    assert pdist.is_distributed() and dist.get_backend() == "nccl"
+    flat, costs, gn = _step(torch.device("cuda:0"), 0, B)
+    ret[0] = (flat, costs, gn)
+    pdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_one_rank_rccl_trainer_step_equals_plain_step(dev):
+    """Trainer.step through the distributed path on RCCL itself (backend "nccl", a one-rank group is
+    what one GPU allows): the mask-count all-reduce, the early bucket handed over by the backward pass while the scan's
+    hipGraph replays, every deferred weight-gradient matrix handed over by mark_ready, the gaps in finish(), the cost
+    reduction -- asynchronous RCCL collectives on their own stream beside the compute stream.  With one rank every sum is
+    the identity, so the parameters after two clip + Adam steps must equal the non-distributed step's bit for bit."""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_rccl, args=(29541, ret), nprocs=1, join=True)
+    flat1, costs1, gn1 = _step(dev, 0, B)
+    flat, costs, gn = ret[0]
+    assert costs == costs1 and gn == gn1
+    assert torch.equal(flat, flat1), "one-rank RCCL step differs from the plain step"
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(which_cost='GMM', k_gmm=3), dict(layer_norm=True), dict(use_speaker=True, num_speakers=4),
                                 dict(cell_type='lstm', num_layers=3), dict(num_layers=1, weak_feedback=False)])
 def test_early_gradient_bucket_is_final_when_the_hook_fires(dev, kw):
