@@ -651,13 +651,13 @@ struct DecoderPlan : PlanBase {
     int nticks5() const { return d.T + lag5(d.L - 1); }
     // part 0: the whole projection; 1: the rows of w and h_0 .. h_{l-2} (ready a tick earlier); 2: the rows of h_{l-1},
     // accumulated onto part 1 (LSTM stacks with l >= 2: two jobs of about the recurrent K instead of one of K = E + l H)
-    void input_job(SkJob& j, int l, int t, int g, int part = 0) const {
+    void input_job(SkJob& j, int l, int t, int g, int part = 0, bool no_w = false) const {
         const size_t BH = (size_t)d.B * d.H, BE = (size_t)d.B * d.E;
         const int wd = d.cell == 1 ? 4 * d.H : (g == 0 ? 2 * d.H : d.H);  // LSTM layers: one 4H-wide matrix (g = 0)
         sk_job_init(j);
         j.colmode = d.cell == 1 && tiled ? 1 : 0;  // (the tiled copies of LSTM matrices keep the gate-interleaved tile order)
         int n = 0;
-        if (part != 2) j.seg[n++] = fseg(d.w + (size_t)(t + 1) * BE, d.E, l, g, d.H, d.E, wd);
+        if (part != 2 && !no_w) j.seg[n++] = fseg(d.w + (size_t)(t + 1) * BE, d.E, l, g, d.H, d.E, wd);
         for (int q = 0; q < l; ++q) {
             if ((part == 1 && q == l - 1) || (part == 2 && q != l - 1)) continue;
             j.seg[n++] = fseg(d.h[q] + (size_t)(t + 1) * BH, d.H, l, g, d.H + d.E + q * d.H, d.H, wd);
@@ -675,6 +675,13 @@ struct DecoderPlan : PlanBase {
     // the tick in between -- both are 1.5 rounds there and take the extra half round for nothing --, part 2 = the rows of
     // h_{l-1} stays in the attention launch and accumulates.  No job of a tick walks more than K = H + E.
     bool s5_gru_split = true;
+    // Round 6: the rows of w of an upper layer's input projection (K = E) ride in that layer's OWN gate / candidate job (a
+    // second segment behind the recurrent block: w_{t+1} is two ticks old by then) instead of the attention launch's
+    // projection jobs.  At two layers the gate launch holds K = H + E (layer 0) beside K = H (layer 1) workgroups, one per
+    // CU, and the candidate launch likewise: the upper layers' workgroups walk the extra E rows while layer 0's are still
+    // busy, and the attention launch -- bound by its GEMM workgroups since the attention chain shrank -- walks K = l H
+    // instead of E + l H.
+    bool s5_w_in_step = getenv("PARROT_S5_WSTEP") ? atoi(getenv("PARROT_S5_WSTEP")) != 0 : true;
     int fwd5(hipStream_t st) {
         const int Q = nticks5();
         const int cfull = 160;  // workgroup count at which the heterogeneous launch keeps 32 x 32 tiles (measured)
@@ -682,6 +689,7 @@ struct DecoderPlan : PlanBase {
         // of the candidate projections), <= 3 input-projection jobs per upper layer
         static_assert(3 * (PARROT_MAX_LAYERS - 1) <= SK_MAXJOB && 2 * PARROT_MAX_LAYERS - 2 <= SK_MAXJOB, "fwd5: jobs[] too short");
         const bool gsplit = d.cell == 0 && s5_gru_split && d.L >= 3;
+        const bool wstep = s5_w_in_step;
         for (int q = 0; q < Q; ++q) {
             SkJob jobs[SK_MAXJOB];
             int n = 0;
@@ -691,12 +699,12 @@ struct DecoderPlan : PlanBase {
                 SkJob& j = jobs[n++];
                 if (d.cell == 1) lstm_job(j, l, t);  // LSTM layers: one fused product + cell update per layer-step
                 else gates_job(j, l, t);
-                if (l > 0) j.nseg = 1;  // recurrent block only; the rest arrives through seq_g (has_seq)
+                if (l > 0) j.nseg = wstep ? 2 : 1;  // recurrent block (+ the rows of w); the rest arrives through seq_g (has_seq)
             }
             if (gsplit)
                 for (int l = 2; l < d.L; ++l) {  // part 1 of the step whose part 2 the attention launch of THIS tick adds
                     const int tp = q - lag5(l) + 1;
-                    if (tp >= 0 && tp < d.T) input_job(jobs[n++], l, tp, 0, 1);
+                    if (tp >= 0 && tp < d.T) input_job(jobs[n++], l, tp, 0, 1, wstep);
                 }
             if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             n = 0;
@@ -706,12 +714,12 @@ struct DecoderPlan : PlanBase {
                     if (t < 0 || t >= d.T) continue;
                     SkJob& j = jobs[n++];
                     cand_job(j, l, t);
-                    if (l > 0) j.nseg = 1;
+                    if (l > 0) j.nseg = wstep ? 2 : 1;
                 }
                 if (gsplit)
                     for (int l = 2; l < d.L; ++l) {
                         const int tp = q - lag5(l) + 1;
-                        if (tp >= 0 && tp < d.T) input_job(jobs[n++], l, tp, 1, 1);
+                        if (tp >= 0 && tp < d.T) input_job(jobs[n++], l, tp, 1, 1, wstep);
                     }
                 if (n > 0) PL_TRY(launch_jobs(jobs, n, st, full_wgs));
             }
@@ -721,12 +729,12 @@ struct DecoderPlan : PlanBase {
                 const bool split = d.cell == 1 && l >= 2 && s5_split;
                 const bool gs = gsplit && l >= 2;  // (part 1 was written by the gate / candidate launches of this tick)
                 if (t >= 0 && t < d.T) {
-                    input_job(jobs[n++], l, t, 0, (split || gs) ? 2 : 0);
-                    if (d.cell == 0) input_job(jobs[n++], l, t, 1, gs ? 2 : 0);
+                    input_job(jobs[n++], l, t, 0, (split || gs) ? 2 : 0, wstep);
+                    if (d.cell == 0) input_job(jobs[n++], l, t, 1, gs ? 2 : 0, wstep);
                 }
                 if (split) {  // the rows that were ready a tick earlier
                     const int ta = t + 1;
-                    if (ta >= 0 && ta < d.T) input_job(jobs[n++], l, ta, 0, 1);
+                    if (ta >= 0 && ta < d.T) input_job(jobs[n++], l, ta, 0, 1, wstep);
                 }
             }
             if (q < d.T) {
