@@ -61,9 +61,13 @@ __global__ __launch_bounds__(SRP_THREADS) void srp_kernel(const SrpArgs a) {
     unsigned* abort_ = sync + 512;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(sync + 600);
     // Team = the XCD this workgroup runs on; rank = its place among the XCD's 32 workgroups.  The dispatcher deals
-    // workgroups to the XCDs round-robin, so blockIdx / 8 numbers the workgroups of one XCD 0 .. 31 without the census
-    // atomic (a cold L2 round trip in front of every load of the prologue); the census word is still counted, without
-    // waiting for it.  A placement that breaks the rule leaves a team incomplete: its polls time out and raise abort.
+    // workgroups to the XCDs round-robin -- workgroup i runs on XCD (i + c) % 8 with one c per launch --, so the workgroups
+    // with equal blockIdx % 8 share an XCD and blockIdx / 8 numbers them 0 .. 31 without the census atomic of round 5 (a
+    // cold L2 round trip in front of every load of the prologue; the census word is still counted, without waiting for
+    // it).  c is NOT always 0: tools/xcc_map_probe.hip saw c = 0 in 5200 launches (eager, graphs, odd grids in front), but
+    // a check `XCC_ID == blockIdx % 8` placed here aborted 9 of the 28 generation tests that this numbering passes (session
+    // r06bv) -- so the team is read from the hardware register, never computed.  A placement that splits a blockIdx % 8
+    // class over XCDs leaves a team incomplete: its polls time out and raise abort (the caller falls back to launches).
     const int team = srp_xcc();
     const int cu = (int)(blockIdx.x / SRP_NTEAMS);
     const bool timing = a.pad && blockIdx.x == 0 && tid == 0;
