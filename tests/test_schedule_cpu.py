@@ -250,6 +250,48 @@ def test_schedule_keeps_the_scan_orderings(monkeypatch, sched, cell, nl, seq_ini
         lib.parrot_decoder_destroy(plan)
 
 
+@pytest.mark.parametrize("cell,nl", [(0, 2), (0, 3), (1, 2), (1, 3)])
+def test_schedule5_w_rows_ride_in_the_step_jobs(monkeypatch, cell, nl):
+    """Round 6 (plans.hip fwd5, s5_w_in_step): the rows of w of an upper layer's input projection (K = E) are a second segment
+    of that layer's own gate / candidate job; the attention launch's projection jobs walk the h rows only.  Both placements
+    (PARROT_S5_WSTEP=0: the round-5 one) keep every read-after-write ordering; with the new one no projection job walks
+    K = E + l H any more and the upper layers' step jobs walk K = H + E."""
+    L, lib = _lib()
+    T, B, H, E, A, U = 6, 20, 32, 16, 4, 7
+    ks = {}
+    for wstep in ("1", "0"):
+        monkeypatch.setenv("PARROT_S5_WSTEP", wstep)
+        plan, ar, d = _make_plan(L, lib, 5, cell, nl, 0, monkeypatch, T, B, H, E, A, U)
+        try:
+            assert lib.parrot_decoder_schedule(plan) == 5
+            f = 4
+            slot = {"w": B * E * f, "kappa": B * A * f}
+            fwd_once = {"w", "kappa", "a", "b", "phi", "att_sup"}
+            for l in range(nl):
+                slot[f"h{l}"] = B * H * f
+                fwd_once |= {f"h{l}"}
+                if cell == 0:
+                    fwd_once |= {f"z{l}", f"r{l}", f"rh{l}", f"c{l}"}
+                else:
+                    slot[f"cst{l}"] = B * H * f
+                    fwd_once |= {f"cst{l}", f"gate4{l}"}
+                if l >= 1:
+                    fwd_once |= {f"seq_g{l}"} | ({f"seq_c{l}"} if cell == 0 else set())
+            _check(_trace(lib, plan, 0), ar, fwd_once, set(), T, slot)
+            n = lib.parrot_decoder_trace_jobs(plan, 0, None, 0)
+            buf = (C.c_longlong * (6 * n))()
+            lib.parrot_decoder_trace_jobs(plan, 0, buf, n)
+            jobs = [tuple(buf[6 * i:6 * i + 6]) for i in range(n)]  # (launch, job, M, N, Ksum, epi)
+            ks[wstep] = (sorted({j[4] for j in jobs if j[5] == 0}), sorted({j[4] for j in jobs if j[5] > 0}))
+        finally:
+            lib.parrot_decoder_destroy(plan)
+    lin_new, step_new = ks["1"]
+    lin_old, step_old = ks["0"]
+    assert max(lin_old) == E + (nl - 1) * H or (nl == 3 and max(lin_old) >= E + H)  # the round-5 projections walk the w rows
+    assert all(k % H == 0 for k in lin_new), lin_new  # ... the new ones the h rows only
+    assert H + E in step_new and H in step_old and H not in step_new, (step_new, step_old)
+
+
 @pytest.mark.parametrize("nl", [1, 2, 3])
 def test_fused_lstm_ticks_keep_the_scan_orderings(monkeypatch, nl):
     """bf16 LSTM stacks the wide kernel takes run schedule 7 by default, with BOTH ticks as one launch: forward, the
