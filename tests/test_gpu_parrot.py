@@ -302,12 +302,15 @@ def test_scan_schedules_agree_with_oracle(dev, monkeypatch, sched, chunk, cell):
                           use_graph=True)
 
 
+@pytest.mark.parametrize("wstep", ["1", "0"])
 @pytest.mark.parametrize("sched", [5])
-def test_balanced_wavefront_schedules(dev, monkeypatch, sched):
+def test_balanced_wavefront_schedules(dev, monkeypatch, sched, wstep):
     """Schedule 5 (attention in one heterogeneous launch with the upper layers' input projections) on the shapes the
     other schedules are tested on, plus: one layer (falls back to 0), more rows than one row tile, the softmax window,
-    ragged masks, a window of one step, eager and graph."""
+    ragged masks, a window of one step, eager and graph.  Both placements of the upper layers' w rows (round 6: in the
+    layers' own step jobs; PARROT_S5_WSTEP=0: in the attention launch's projection jobs)."""
     monkeypatch.setenv("PARROT_SCHEDULE", str(sched))
+    monkeypatch.setenv("PARROT_S5_WSTEP", wstep)
     for use_graph in (False, True):
         _check_cost_and_grads(dev, T=9, B=40, U=9, num_layers=2, encoder_type='bidirectional', use_graph=use_graph,
                               expect_schedule=sched)
