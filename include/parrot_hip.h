@@ -535,6 +535,19 @@ int parrot_softmax_ce_bwd(const float* logits, int ld, const int* target, const 
                           long long rows, int Q, float* dlogits, int ldd, void* stream);
 int parrot_relu_gate(const float* dy, const float* gate, float* out, long long n, void* stream);
 
+/* Weight-norm fold of a SampleRNN Linear (sampleRNN/lib/ops.py:101-110: `W * (g / W.norm(2, axis=0))`), SURVEY 8b's K9:
+ *   samplernn_weightnorm_fold:      W_eff[k][n] = W[k][n] * g[n] / ||W[:, n]||_2;  norm[n] = ||W[:, n]||_2 (may be NULL)
+ *   samplernn_weightnorm_fold_bwd:  dg[n] (+)= sum_k dW_eff[k][n] W[k][n] / norm[n]
+ *                                   dW[k][n] (+)= g[n] / norm[n] * (dW_eff[k][n] - W[k][n] * sum_k' dW_eff[k'][n] W[k'][n] / norm[n]^2)
+ * Row-major [K, N] matrices with leading dimensions ld / ldo / ldd / lddw >= N; ws: samplernn_weightnorm_ws_floats(N)
+ * floats of scratch (partial column sums, added in a fixed order: no atomics). */
+long long samplernn_weightnorm_ws_floats(int N);
+int samplernn_weightnorm_fold(const float* W, int ld, const float* g, float* W_eff, int ldo, float* norm, float* ws, int K, int N,
+                              void* stream);
+int samplernn_weightnorm_fold_bwd(const float* W, int ld, const float* g, const float* norm, const float* dW_eff, int ldd,
+                                  float* dW, int lddw, float* dg, float* ws, int K, int N, int accumulate_w, int accumulate_g,
+                                  void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Conditional three-tier SampleRNN generation: the per-sample loop of generate_and_save_samples
  * (sampleRNN/models/conditional/three_tier.py:794-832) and the three Theano functions it calls

@@ -148,6 +148,9 @@ SIGNATURES = {
     "parrot_softmax_ce_fwd": (_i, [_vp, _i, _vp, _ll, _i, _vp, _vp, _vp]),
     "parrot_softmax_ce_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _vp, _i, _vp]),
     "parrot_relu_gate": (_i, [_vp, _vp, _vp, _ll, _vp]),
+    "samplernn_weightnorm_ws_floats": (_ll, [_i]),
+    "samplernn_weightnorm_fold": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "samplernn_weightnorm_fold_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "parrot_colsum": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp]),
     "parrot_gru_step_fwd": (_i, [_vp] * 11 + [_i, _i, _vp]),
     "parrot_gru_step_bwd": (_i, [_vp] * 11 + [_i, _i, _vp]),

@@ -167,6 +167,83 @@ __global__ __launch_bounds__(256) void relu_gate_kernel(const float* __restrict_
     reinterpret_cast<f32x4*>(out)[i] = o;
 }
 
+
+// Weight-norm fold (sampleRNN/lib/ops.py:101-110): W_eff[k][n] = W[k][n] * g[n] / ||W[:, n]||_2.
+// Two launches each way, both chip-wide: (1) column sums of W^2 (backward: of dW_eff W) over WN_KS row slices -- workgroup
+// (column block of 64, slice): lane = column (256-byte row segments), 4 waves x 4 rows in flight, added across the waves
+// through LDS in wave order -> ws[slice][n]; (2) workgroup (column block, 64-row chunk): every lane adds its column's WN_KS partial sums in slice
+// order once (L2 hits) and scales its rows.  No atomics: the sums have one order.
+// Backward: dg[n] = dot[n] / ||W_n||,  dW[k][n] = (g[n] / ||W_n||) * (dW_eff[k][n] - W[k][n] * dot[n] / ||W_n||^2).
+constexpr int WN_KS = 16;
+
+template <bool DOT>
+__global__ __launch_bounds__(256) void wn_colsum_kernel(const float* __restrict__ W, int ld, const float* __restrict__ D, int ldd,
+                                                       float* __restrict__ ws, int K, int N) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane, nc = n < N ? n : N - 1;
+    const int rows = (K + WN_KS - 1) / WN_KS, k0 = blockIdx.y * rows, k1 = min(K, k0 + rows);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = k0 + wave;
+    for (; k + 12 < k1; k += 16) {
+        const float a = W[(size_t)k * ld + nc], b = W[(size_t)(k + 4) * ld + nc], c = W[(size_t)(k + 8) * ld + nc],
+                    d = W[(size_t)(k + 12) * ld + nc];
+        if (DOT) {
+            s0 = fmaf(D[(size_t)k * ldd + nc], a, s0); s1 = fmaf(D[(size_t)(k + 4) * ldd + nc], b, s1);
+            s2 = fmaf(D[(size_t)(k + 8) * ldd + nc], c, s2); s3 = fmaf(D[(size_t)(k + 12) * ldd + nc], d, s3);
+        } else {
+            s0 = fmaf(a, a, s0); s1 = fmaf(b, b, s1); s2 = fmaf(c, c, s2); s3 = fmaf(d, d, s3);
+        }
+    }
+    for (; k < k1; k += 4) {
+        const float a = W[(size_t)k * ld + nc];
+        s0 = fmaf(DOT ? D[(size_t)k * ldd + nc] : a, a, s0);
+    }
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && n < N) ws[(size_t)blockIdx.y * N + n] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+__device__ __forceinline__ float wn_total(const float* __restrict__ ws, int N, int n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < WN_KS; ++q) t += ws[(size_t)q * N + n];
+    return t;
+}
+
+// workgroup (column block of 64, chunk of WN_RC rows): lane = column -- its total once --, the four waves deal the rows
+constexpr int WN_RC = 64;
+__global__ __launch_bounds__(256) void wn_scale_fwd_kernel(const float* __restrict__ W, int ld, const float* __restrict__ g,
+                                                          const float* __restrict__ ws, float* __restrict__ out, int ldo,
+                                                          float* __restrict__ norm, int K, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    if (n >= N) return;
+    const float nrm = sqrtf(wn_total(ws, N, n));
+    if (blockIdx.y == 0 && wave == 0 && norm) norm[n] = nrm;
+    const float sc = g[n] / nrm;
+    const int k0 = blockIdx.y * WN_RC, k1 = min(K, k0 + WN_RC);
+    for (int k = k0 + wave; k < k1; k += 4) out[(size_t)k * ldo + n] = W[(size_t)k * ld + n] * sc;
+}
+
+__global__ __launch_bounds__(256) void wn_scale_bwd_kernel(const float* __restrict__ W, int ld, const float* __restrict__ g,
+                                                          const float* __restrict__ norm, const float* __restrict__ ws,
+                                                          const float* __restrict__ dWe, int ldd, float* __restrict__ dW, int lddw,
+                                                          float* __restrict__ dg, int K, int N, int acc_w, int acc_g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    if (n >= N) return;
+    const float dot = wn_total(ws, N, n), nrm = norm[n];
+    if (blockIdx.y == 0 && wave == 0) dg[n] = acc_g ? dg[n] + dot / nrm : dot / nrm;
+    const float sc = g[n] / nrm, q = dot / (nrm * nrm);
+    const int k0 = blockIdx.y * WN_RC, k1 = min(K, k0 + WN_RC);
+    for (int k = k0 + wave; k < k1; k += 4) {
+        const float v = sc * (dWe[(size_t)k * ldd + n] - W[(size_t)k * ld + n] * q);
+        float* o = dW + (size_t)k * lddw + n;
+        *o = acc_w ? *o + v : v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -234,6 +311,30 @@ int parrot_relu_gate(const float* dy, const float* gate, float* out, long long n
     const long long n4 = n >> 2, blocks = (n4 + 255) / 256;
     if (blocks > 0x7fffffffll) return PH_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(relu_gate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, gate, out, n4);
+    return (int)hipGetLastError();
+}
+
+long long samplernn_weightnorm_ws_floats(int N) { PH_ENTRY(); return N > 0 ? (long long)WN_KS * N : 0; }
+
+int samplernn_weightnorm_fold(const float* W, int ld, const float* g, float* W_eff, int ldo, float* norm, float* ws, int K, int N,
+                              void* stream) { PH_ENTRY();
+    if (!W || !g || !W_eff || !ws || K < 1 || N < 1 || ld < N || ldo < N) return PH_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wn_colsum_kernel<false>, dim3((unsigned)((N + 63) / 64), WN_KS), dim3(256), 0, st, W, ld,
+                       (const float*)nullptr, 0, ws, K, N);
+    hipLaunchKernelGGL(wn_scale_fwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((K + WN_RC - 1) / WN_RC)), dim3(256), 0, st,
+                       W, ld, g, ws, W_eff, ldo, norm, K, N);
+    return (int)hipGetLastError();
+}
+
+int samplernn_weightnorm_fold_bwd(const float* W, int ld, const float* g, const float* norm, const float* dW_eff, int ldd,
+                                  float* dW, int lddw, float* dg, float* ws, int K, int N, int accumulate_w, int accumulate_g,
+                                  void* stream) { PH_ENTRY();
+    if (!W || !g || !norm || !dW_eff || !dW || !dg || !ws || K < 1 || N < 1 || ld < N || ldd < N || lddw < N) return PH_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wn_colsum_kernel<true>, dim3((unsigned)((N + 63) / 64), WN_KS), dim3(256), 0, st, W, ld, dW_eff, ldd, ws, K, N);
+    hipLaunchKernelGGL(wn_scale_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((K + WN_RC - 1) / WN_RC)), dim3(256), 0, st,
+                       W, ld, g, norm, ws, dW_eff, ldd, dW, lddw, dg, K, N, accumulate_w, accumulate_g);
     return (int)hipGetLastError();
 }
 

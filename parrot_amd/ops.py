@@ -428,6 +428,45 @@ def softmax_ce(logits, target):
     return _SoftmaxCeFn.apply(logits, target)
 
 
+class _WeightNormFn(torch.autograd.Function):
+    """W_eff = W * (g / ||W||_2 per output column) (sampleRNN/lib/ops.py:101-110): one HIP pass each way."""
+
+    @staticmethod
+    def forward(ctx, W, g):
+        _chk(W, "W"); _chk(g, "g")
+        if W.dim() != 2 or g.dim() != 1 or g.shape[0] != W.shape[1]:
+            raise ValueError("weightnorm_fold: W [K, N], g [N] expected")
+        Wc = W if W.stride(1) == 1 else W.contiguous()
+        gc = g.contiguous()
+        K, N = Wc.shape
+        out = torch.empty(K, N, device=W.device, dtype=torch.float32)
+        norm = torch.empty(N, device=W.device, dtype=torch.float32)
+        ws = torch.empty(int(_lib.load().samplernn_weightnorm_ws_floats(N)), device=W.device, dtype=torch.float32)
+        _lib.call("samplernn_weightnorm_fold", Wc.data_ptr(), Wc.stride(0), gc.data_ptr(), out.data_ptr(), N, norm.data_ptr(),
+                  ws.data_ptr(), K, N, _stream())
+        ctx.save_for_backward(Wc, gc, norm)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        Wc, gc, norm = ctx.saved_tensors
+        K, N = Wc.shape
+        d = d.to(torch.float32)
+        if d.stride(1) != 1:
+            d = d.contiguous()
+        dW = torch.empty(K, N, device=Wc.device, dtype=torch.float32)
+        dg = torch.empty(N, device=Wc.device, dtype=torch.float32)
+        ws = torch.empty(int(_lib.load().samplernn_weightnorm_ws_floats(N)), device=Wc.device, dtype=torch.float32)
+        _lib.call("samplernn_weightnorm_fold_bwd", Wc.data_ptr(), Wc.stride(0), gc.data_ptr(), norm.data_ptr(), d.data_ptr(),
+                  d.stride(0), dW.data_ptr(), N, dg.data_ptr(), ws.data_ptr(), K, N, 0, 0, _stream())
+        return dW, dg
+
+
+def weightnorm_fold(W, g):
+    """Effective weight of a weight-normalised Linear: W * (g / ||W||_2 per column), differentiable in W and g."""
+    return _WeightNormFn.apply(W, g)
+
+
 # ----------------------------------------------------------------------------- GRU step / scan
 def gru_step_fwd(h, inputs, gate_inputs, Wg, Wc, mask=None):
     """One GatedRecurrent step; returns (h_new, saved) with saved = (z, r, rh, c)."""

@@ -54,6 +54,8 @@ def effective_weight(name, i, weightnorm=True):
     if not weightnorm:
         return w
     g = lib.param(name + '.g' + str(i))
+    if w.is_cuda:  # one HIP pass each way (include/parrot_hip.h: samplernn_weightnorm_fold)
+        return hip.weightnorm_fold(w, g)
     return w * (g / w.norm(2, dim=0)).unsqueeze(0)
 
 

@@ -116,3 +116,48 @@ def test_bad_sample_codes_raise(dev):
     logits = torch.randn(40, 16, device=dev)
     with pytest.raises(IndexError):
         ops.softmax_ce(logits, torch.full((40,), -1, device=dev))
+
+
+@pytest.mark.parametrize("K,N", [(1024, 1024), (2560, 1024), (63, 3072), (1024, 10240), (7, 5), (130, 65)])
+def test_weightnorm_fold_matches_torch(dev, K, N):
+    """samplernn_weightnorm_fold (sampleRNN/lib/ops.py:101-110: W * (g / W.norm(2, axis=0))) and its backward against the
+    float64 expression and torch autograd; a strided (column-sliced) W; the SampleRNN Linear built on it."""
+    from parrot_amd import ops
+    g0 = torch.Generator().manual_seed(K * 31 + N)
+    W = torch.randn(K, N, generator=g0, dtype=torch.float64) * 0.3
+    gg = torch.rand(N, generator=g0, dtype=torch.float64) + 0.5
+    d = torch.randn(K, N, generator=g0, dtype=torch.float64)
+    Wr, gr = W.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+    ref = Wr * (gr / Wr.norm(2, dim=0)).unsqueeze(0)
+    ref.backward(d)
+    Wh, gh = W.float().to(dev).requires_grad_(True), gg.float().to(dev).requires_grad_(True)
+    out = ops.weightnorm_fold(Wh, gh)
+    out.backward(d.float().to(dev))
+    assert_close(out.detach().cpu().double(), ref.detach(), 2e-6, "W_eff")
+    assert_close(Wh.grad.cpu().double(), Wr.grad, 1e-5, "dW")
+    assert_close(gh.grad.cpu().double(), gr.grad, 1e-5, "dg")
+    if N >= 64:  # a column slice of a wider matrix: leading dimension > N
+        wide = torch.randn(K, N + 40, generator=g0).to(dev)
+        sl = wide[:, 8:8 + N]
+        o2 = ops.weightnorm_fold(sl, gh.detach())
+        r2 = sl.double().cpu() * (gg / sl.double().cpu().norm(2, dim=0)).unsqueeze(0)
+        assert_close(o2.cpu().double(), r2, 2e-6, "W_eff of a strided W")
+
+
+def test_weightnorm_linear_uses_the_fold(dev):
+    """lib.ops.effective_weight on device parameters goes through the HIP fold and stays differentiable in W and g."""
+    from parrot_amd.sampleRNN import lib
+    from parrot_amd.sampleRNN.lib import ops as sops
+    lib.delete_all_params()
+    lib.set_device(dev)
+    try:
+        x = torch.randn(6, 48, device=dev)
+        y = sops.Linear('wn_test', 48, 80, x, weightnorm=True)
+        W, g = lib.param('wn_test.W0'), lib.param('wn_test.g0')
+        ref = x.double().cpu() @ (W.detach().double().cpu() * (g.detach().double().cpu() / W.detach().double().cpu().norm(2, dim=0)))
+        ref = ref + lib.param('wn_test.b').detach().double().cpu()
+        assert_close(y.detach().cpu().double(), ref, 1e-5, "weight-normalised Linear")
+        y.sum().backward()
+        assert W.grad is not None and g.grad is not None and float(g.grad.abs().max()) > 0
+    finally:
+        lib.delete_all_params()
