@@ -611,12 +611,19 @@ def test_cfg5_generator_full_width_greedy(dev, capsys):
         tt.configure(DIM=1024, EMB_SIZE=256, RNN_TYPE='GRU', N_RNN=1)
 
 
-def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
+@pytest.mark.parametrize("B,S_len", [(4, 320), (32, 4000)])
+def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys, B, S_len):
     """BASELINE configs[4] widths in TRAINING (three-tier GRU, DIM = 1024, EMB_SIZE = 256, Q = 256; three_tier.py:534-636) on the
     round-5 operators -- gather-sum / segmented-sum embedding, ReLU MLP with gated dx products, softmax-CE kernels, 1024-wide
     tier GEMMs and scans: cost, ip_cost, the carried states and EVERY parameter gradient vs the fp64 oracle, on mu-law-like
     (peaked) sample codes with a ragged mask, a fresh window (reset) and a carried one.  B = 4, 320 samples: 1280 rows of the
-    sample-level tier, ten 128-position chunks per embedding position in the segmented sum, most of the 256 codes unused."""
+    sample-level tier, ten 128-position chunks per embedding position in the segmented sum, most of the 256 codes unused.
+    B = 32, 4000 samples: the window bench.py times (`secondary.samplernn_train`), 128 000 rows, a fresh window only (the
+    float64 oracle of it takes a few minutes of CPU and ~20 GB: skipped on a host with less than 64 GB free)."""
+    if B * S_len > 100000:
+        import psutil
+        if psutil.virtual_memory().available < 64 << 30:
+            pytest.skip("the float64 oracle of the benchmarked window needs ~20 GB of host memory")
     from oracle import samplernn_ref as S
     from parrot_amd.sampleRNN import lib
     from parrot_amd.sampleRNN.models.conditional import three_tier as tt
@@ -645,15 +652,14 @@ def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
         p = S.init_params(c, seed=8, perturb=0.1)
         lib.set_params(p)
         g = torch.Generator().manual_seed(3)
-        B, S_len = 4, 320
         seq = (torch.randn(B, S_len + 80, generator=g) * 12 + 128).round().clamp(0, 255).long()
         seq[:, ::9] = 128
         feats = torch.randn(B, S_len // 80, 63, generator=g, dtype=torch.float64)
         mask = torch.ones(B, S_len + 80, dtype=torch.float64)
-        mask[1, 250:] = 0
-        mask[3, 333:] = 0
+        mask[1, S_len - 70:] = 0
+        mask[3, S_len + 13:] = 0
         rep = []
-        for reset in (1, 0):
+        for reset in ((1, 0) if B * S_len < 100000 else (1,)):
             h0 = torch.randn(B, 1, 1024, generator=g, dtype=torch.float64) * 0.3
             bh0 = torch.randn(B, 1, 1024, generator=g, dtype=torch.float64) * 0.3
             for t in lib.named_params().values():
@@ -669,7 +675,7 @@ def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
                                                 tie_tol=1e-6, tie_report=ties)
             (rc + rip).backward()
             near, taken = sum(t_[0] for t_ in ties), sum(t_[1] for t_ in ties)
-            assert near <= 64, f"{near} pre-activations within 1e-6 of the kink: not a handful"
+            assert near <= 64 * max(1, B * S_len // 1280), f"{near} pre-activations within 1e-6 of the kink: not a handful"
             assert_close(cost, rc, 1e-4, "cost")
             assert_close(ip_cost, rip, 1e-4, "ip_cost")
             assert_close(nh0, rh0, 1e-4, "new_h0")
@@ -687,7 +693,7 @@ def test_cfg5_training_full_width_cost_and_every_gradient(dev, capsys):
                 n += 1
             assert n >= 20
             rep.append(f"reset={reset}: cost {float(cost.detach()):.5f} (oracle {float(rc.detach()):.5f}), ip_cost {float(ip_cost.detach()):.5f}; {n} gradients, "
-                       f"worst {worst[0]}: {worst[1]:.2e}; ReLU pre-activations within 1e-6 of 0: {near} of 2.6 M, branch taken from the HIP run: {taken}")
+                       f"worst {worst[0]}: {worst[1]:.2e}; ReLU pre-activations within 1e-6 of 0: {near} of {2048 * B * S_len / 1e6:.1f} M, branch taken from the HIP run: {taken}")
         with capsys.disabled():
             print("\n[cfg5 training parity] " + "\n[cfg5 training parity] ".join(rep))
     finally:
