@@ -6,7 +6,8 @@
 namespace {
 
 constexpr int SRP_THREADS = 512, SRP_TEAM = 32, SRP_NTEAMS = 8, SRP_ROWS = 4, SRP_Q = 256;
-constexpr int SRP_SYNC_WORDS = 1024;  // [0..255] arrive (32 words per team), [256..511] census, [512] abort, [513] fault code
+constexpr int SRP_SYNC_WORDS = 1024;  // [256 + 32 team] arrivals per team (counted, not waited for), [512] abort, [513] fault code,
+                                      // [600 ..) phase stamps of a timed launch (PARROT_SR_TIMING)
 constexpr int SRP_MAXHIST = 64;       // FS + nsteps
 constexpr int SRP_GMAX = 12;          // table rows of the gather requested in one batch (FS - 1 <= SRP_GMAX; else a loop)
 // f32x4 hand-off slots per team in the workspace: x1, x2 [D] and the logits [Q]
@@ -23,12 +24,6 @@ __device__ __forceinline__ int srp_xcc() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return (int)(v & 7);
-}
-// RMW executed in the issuing XCD's L2 (no sc1: the line never leaves this XCD), returns the previous value
-__device__ __forceinline__ unsigned srp_l2_add(unsigned* p, unsigned v) {
-    unsigned old;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(old) : "v"(p), "v"(v) : "memory");
-    return old;
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t srp_rsrc(const void* p) {
     const unsigned long long a = (unsigned long long)p;
@@ -63,7 +58,7 @@ __device__ __forceinline__ unsigned long long srp_clock() {
 }
 
 struct SrpShared {
-    int rank, ok, gen;
+    int ok;
     int hist[SRP_ROWS][SRP_MAXHIST];
     float mx[SRP_ROWS];
 };
