@@ -900,12 +900,12 @@ class Parrot(Brick):
                               for l in leafs]
             gscale = torch.ones((), device=gscale.device)
         # output layer
-        dread = torch.zeros(T * B, R, device=readouts.device, dtype=torch.float32)
+        dread = torch.empty(T * B, R, device=readouts.device, dtype=torch.float32)  # (the first head's product stores: no fill)
         for i, (wn, bn, dim) in enumerate(self._out_names):
             dp = save['dpreds'][i] * gscale
             ops.gemm(readouts.t(), dp, out=self.store.grad(wn), accumulate=True)
             ops.colsum(dp, out=self.store.grad(bn), accumulate=True)
-            ops.gemm(dp, self.store.param(wn).t(), out=dread, accumulate=True)
+            ops.gemm(dp, self.store.param(wn).t(), out=dread, accumulate=i > 0)
             if self.use_speaker:
                 swn, sbn, _ = self._spk_out_names[i]
                 dsum = dp.view(T, B, dim).sum(0)
