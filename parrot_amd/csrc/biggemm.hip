@@ -889,7 +889,15 @@ __global__ __launch_bounds__(256) void bg_reduce_kernel(const BgArgs a) {
         float v = a.accumulate ? *c : 0.f;
         if (a.bias) v += a.bias[n];
         const float* w = a.ws + ((long long)batch * a.splitk) * mn + r;
-        for (int ks = 0; ks < a.splitk; ++ks) v += w[(long long)ks * mn];
+        int ks = 0;  // (eight slices requested per round, added in slice order)
+        for (; ks + 8 <= a.splitk; ks += 8) {
+            float p[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) p[q] = w[(long long)(ks + q) * mn];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += p[q];
+        }
+        for (; ks < a.splitk; ++ks) v += w[(long long)ks * mn];
         if (a.gate && !(a.gate[(long long)m * a.ldg + n] > 0.f)) v = 0.f;
         *c = v;
     }
